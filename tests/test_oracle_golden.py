@@ -162,8 +162,9 @@ def test_pe_against_float64():
     div = np.exp(np.arange(0, 512, 2, dtype=np.float64) * -(np.log(10000.0) / 512))
     assert np.abs(pe[:, 0::2] - np.sin(pos * div)).max() < 1e-4      # fp32 argument rounding at p~300
     assert np.abs(pe[:, 1::2] - np.cos(pos * div)).max() < 1e-4
-    arg32 = (pos.astype(np.float32) * np.exp(np.arange(0, 512, 2, dtype=np.float32)
-                                             * np.float32(-(np.log(10000.0) / 512)))).astype(np.float64)
+    import math
+    div32 = torch.exp(torch.arange(0, 512, 2, dtype=torch.float) * -(math.log(10000.0) / 512))
+    arg32 = (torch.arange(0, 300).unsqueeze(1).float() * div32).double().numpy()    # the fp32 argument, exactly
     assert np.abs(pe[:, 0::2] - np.sin(arg32)).max() < 2e-6
     assert pe[0, 0] == 0.0 and pe[0, 1] == 1.0
 
