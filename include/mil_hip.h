@@ -1,0 +1,119 @@
+/*
+ * mil_hip.h - C ABI of the MI355X (gfx950) hot-path library `libmil_hip.so`.
+ *
+ * The reference (KyleKWKim/LLM-guided-Multimodal-MIL) has no native layer, plugin registry
+ * or FFI: its boundary is the Python class `aggregator(args).forward(x_list, x_CI)`
+ * (model/aggregator.py:9-209) whose device work is implicit ATen launches.  This header
+ * defines the native boundary the build adds underneath that class.  Each entry point
+ * names the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (fp32 unless the name says otherwise); sizes are
+ *    host scalars; `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *    nothing synchronises, allocates or frees: capture-safe.
+ *  - outputs and workspaces are caller-allocated; ownership never moves.
+ *  - return value: 0 on success, a negative MIL_E* code on a rejected argument, or the
+ *    positive hipError_t of a failed launch.  No exceptions cross the ABI; no global state.
+ *  - bags are concatenated along the row axis: x is [R, L] row-major and bag b owns rows
+ *    [bag_off[b], bag_off[b+1]).  One softmax per bag (the reference runs one bag per
+ *    forward: model/dim1/ABMIL.py:48,57; test_ddp.py:73).
+ */
+#ifndef MIL_HIP_H
+#define MIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIL_OK 0
+#define MIL_EINVAL (-22)   /* unsupported shape / null pointer */
+#define MIL_ENOSPC (-28)   /* workspace too small */
+
+#define MIL_GATE_D 192     /* gate width D of ABMIL (model/dim1/ABMIL.py:7), fixed by the reference */
+#define MIL_POOL_TILE 32   /* rows per attention-pool tile (tile map granularity) */
+
+/* Library/ABI version, for the host mirror's load-time check. */
+int mil_abi_version(void);
+
+/* ---- tile map ---------------------------------------------------------------------------
+ * The attention-pool kernels split every bag into tiles of MIL_POOL_TILE rows.
+ * tile_map is int32 [T][4] = {bag, row0, nrows, 0}; bag_tile_off is int32 [B+1] (first tile
+ * of each bag).  The host mirror builds both from the bag lengths. */
+
+/* ---- K1a: gate scores -------------------------------------------------------------------
+ * s[i] = w . (tanh(Wv x_i + bv) * sigmoid(Wu x_i + bu)) + b      for all R rows.
+ * Replaces ABMIL.forward lines 52-54 (model/dim1/ABMIL.py).  fp32 MFMA (v_mfma_f32_32x32x2),
+ * exact f32 products/accumulation.  Wv, Wu: [192, L]; bv, bu: [192]; w: [192]; b: [1].
+ * gates (nullable): [R, 384] = {V | U} post-activation, saved for the backward.
+ * Requires L % 32 == 0, D == 192. */
+int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu,
+                        const float* bu, const float* w, const float* b, float* scores,
+                        float* gates, int R, int L, int D, void* stream);
+
+/* ---- K1b: attention pool ----------------------------------------------------------------
+ * A = softmax over the rows of each bag of s; M[b] = sum_i A_i x_i; lse[b] = logsumexp(s).
+ * Replaces ABMIL.forward lines 56-59.  Split-N: one workgroup per tile writes an online-
+ * softmax partial (max, sum, weighted row sum), a per-bag workgroup merges them.
+ * partials workspace: [T, L + 2] floats.  M: [B, L]; lse: [B]. */
+int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_map,
+                      const int32_t* bag_tile_off, int T, int B, int L, float* partials,
+                      float* M, float* lse, void* stream);
+
+/* ---- K3b: per-bag head ------------------------------------------------------------------
+ * z = M Wf^T + bf (logits), p = sigmoid(z).  model/aggregator.py:128-131,200 (eval: the
+ * Dropout(0.25) is the identity).  Wf: [C, L]; z, p: [B, C]; C <= 32. */
+int mil_head_fwd(const float* M, const float* Wf, const float* bf, float* z, float* p, int B,
+                 int L, int C, void* stream);
+
+/* BCELoss(mean) on p vs one-hot float labels y, and its gradient through the sigmoid:
+ * loss_sum[0] += sum_bc -[y log p + (1-y) log(1-p)] * scale   (log clamped at -100 as torch),
+ * dz = (p - y) * scale.  train_ddp.py:99,323-324.  scale = 1 / (C * global_bags).
+ * loss_sum must be zeroed by the caller (it is accumulated so ranks/steps can share it). */
+int mil_bce_fwd_bwd(const float* p, const float* y, float* loss_sum, float* dz, int B, int C,
+                    float scale, void* stream);
+
+/* Head backward: given dz (or dp when p != NULL: dz = dp * p * (1 - p)),
+ * dM = dz Wf, dWf = dz^T M, dbf = sum_b dz, cdot[b] = M[b] . dM[b]. */
+int mil_head_bwd(const float* dz_or_dp, const float* p, const float* M, const float* Wf, float* dM,
+                 float* dWf, float* dbf, float* cdot, int B, int L, int C, void* stream);
+
+/* out[b] = a[b] . c[b] for two [B, L] matrices (cdot = M . dM when dM comes from autograd). */
+int mil_rowdot(const float* a, const float* c, float* out, int B, int L, void* stream);
+
+/* ---- K1 backward ------------------------------------------------------------------------
+ * ds_i = A_i (x_i . dM[bag] - cdot[bag]),  A_i = exp(s_i - lse[bag]).
+ * If dx != NULL also writes the pool term dx_i = A_i dM[bag] (overwrites dx). */
+int mil_attn_pool_bwd(const float* x, const float* scores, const float* lse, const float* dM,
+                      const float* cdot, const int32_t* tile_map, int T, int L, float* ds,
+                      float* dx, void* stream);
+
+/* Gate parameter gradients from the saved gates and ds:
+ * dWv = dPreV^T x, dWu = dPreU^T x, dbv, dbu, dw = sum_i ds_i V_i U_i, db = sum_i ds_i,
+ * with dPreV = ds w U (1 - V^2), dPreU = ds w V U (1 - U).  Split-K fp32 MFMA GEMM over the
+ * rows + a reduce kernel.  workspace: mil_gate_bwd_workspace_floats(R, L) floats.
+ * If accumulate != 0 the results are added to the outputs, else they overwrite them. */
+size_t mil_gate_bwd_workspace_floats(int R, int L);
+int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, const float* w,
+                        int R, int L, int D, float* workspace, size_t workspace_floats,
+                        float* dWv, float* dbv, float* dWu, float* dbu, float* dw, float* db,
+                        int accumulate, void* stream);
+
+/* Input gradient through the gate (needed when the bag is itself a computed tensor, i.e.
+ * the fused text+image path): dx += dPreV Wv + dPreU Wu. */
+int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,
+                       const float* Wu, int R, int L, int D, float* dx, void* stream);
+
+/* ---- optimizer --------------------------------------------------------------------------
+ * torch.optim.Adam step with L2 weight decay folded into the gradient (train_ddp.py:115-118)
+ * over a flat fp32 buffer; grad is multiplied by grad_scale first (1/world after all-reduce). */
+int mil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                  int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIL_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of ``libmil_hip.so`` (C ABI: include/mil_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  ``lib()`` raises
+if the shared object has not been built (``python -c 'import __graft_entry__ as g; g.build()'``
+or ``make -C llm-guided-multimodal-mil_amd/csrc``)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_float, c_int, c_size_t, c_void_p
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mil_hip.h")
+ABI_VERSION = 1
+
+_P = c_void_p
+# name -> (restype, argtypes); mirrors include/mil_hip.h one to one
+SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
+    "mil_abi_version": (c_int, []),
+    "mil_gate_scores_fwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
+    "mil_attn_pool_fwd": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, _P, _P]),
+    "mil_head_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P]),
+    "mil_bce_fwd_bwd": (c_int, [_P] * 4 + [c_int, c_int, c_float, _P]),
+    "mil_head_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
+    "mil_rowdot": (c_int, [_P] * 3 + [c_int, c_int, _P]),
+    "mil_attn_pool_bwd": (c_int, [_P] * 6 + [c_int, c_int, _P, _P, _P]),
+    "mil_gate_bwd_workspace_floats": (c_size_t, [c_int, c_int]),
+    "mil_gate_bwd_params": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),
+    "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P]),
+    "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
+}
+
+_lib = None
+
+
+class MilHipError(RuntimeError):
+    pass
+
+
+def header_symbols() -> List[str]:
+    """Function names declared in include/mil_hip.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mil_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MilHipError(
+                f"{LIB_PATH} is missing: the HIP library is not built and there is no fallback path. "
+                "Run __graft_entry__.build() or `make -C llm-guided-multimodal-mil_amd/csrc`.")
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so the kernels share its runtime/streams)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.mil_abi_version()
+        if got != ABI_VERSION:
+            raise MilHipError(f"libmil_hip.so ABI {got} != expected {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-22: "invalid argument (MIL_EINVAL)", -28: "workspace too small (MIL_ENOSPC)"}.get(
+            rc, f"hipError {rc}" if rc > 0 else f"error {rc}")
+        raise MilHipError(f"{what}: {kind}")

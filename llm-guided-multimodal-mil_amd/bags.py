@@ -1,0 +1,65 @@
+"""Ragged bag batches: bags concatenated along the patch axis plus the tile map the
+attention-pool kernels iterate over (include/mil_hip.h, "tile map")."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+POOL_TILE = 32
+
+
+def build_tile_map(lengths: Sequence[int], tile: int = POOL_TILE):
+    """(tile_map int32 [T, 4] = {bag, row0, nrows, 0}, bag_tile_off int32 [B+1], bag_off int32 [B+1])."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    B = len(lengths)
+    bag_off = np.zeros(B + 1, dtype=np.int64)
+    bag_off[1:] = np.cumsum(lengths)
+    ntiles = (lengths + tile - 1) // tile
+    bag_tile_off = np.zeros(B + 1, dtype=np.int64)
+    bag_tile_off[1:] = np.cumsum(ntiles)
+    T = int(bag_tile_off[-1])
+    tm = np.zeros((T, 4), dtype=np.int32)
+    if T:
+        bag = np.repeat(np.arange(B), ntiles)
+        local = np.arange(T) - bag_tile_off[bag]
+        row0 = bag_off[bag] + local * tile
+        tm[:, 0] = bag
+        tm[:, 1] = row0
+        tm[:, 2] = np.minimum(tile, bag_off[bag + 1] - row0)
+    return tm, bag_tile_off.astype(np.int32), bag_off.astype(np.int32)
+
+
+@dataclass
+class BagLayout:
+    """Device-resident description of how R rows split into B bags."""
+    lengths: List[int]
+    R: int
+    B: int
+    T: int
+    tile_map: torch.Tensor       # int32 [T, 4]
+    bag_tile_off: torch.Tensor   # int32 [B+1]
+    bag_off: torch.Tensor        # int32 [B+1]
+
+    _cache = {}
+
+    @classmethod
+    def make(cls, lengths: Sequence[int], device) -> "BagLayout":
+        key = (tuple(int(v) for v in lengths), str(device))
+        hit = cls._cache.get(key)
+        if hit is not None:
+            return hit
+        tm, bto, bo = build_tile_map(lengths)
+        lay = cls(lengths=list(key[0]), R=int(bo[-1]), B=len(key[0]), T=int(tm.shape[0]),
+                  tile_map=torch.from_numpy(tm).to(device), bag_tile_off=torch.from_numpy(bto).to(device),
+                  bag_off=torch.from_numpy(bo).to(device))
+        if len(cls._cache) > 64:
+            cls._cache.clear()
+        cls._cache[key] = lay
+        return lay
+
+    @classmethod
+    def uniform(cls, B: int, N: int, device) -> "BagLayout":
+        return cls.make([N] * B, device)

@@ -1,0 +1,682 @@
+// K1: gated-attention MIL pooling (ABMIL) forward and backward for gfx950.
+//
+// Reference arithmetic: model/dim1/ABMIL.py:47-59 (forward), torch autograd of the same
+// ops (backward).  Two regimes:
+//   * gate GEMMs  x[R,L] . [Wv;Wu]^T -> [R,384] and its transpose-product in the backward are
+//     dense fp32 contractions: v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s roof).
+//   * scores -> softmax over the bag -> A.x (and ds in the backward) stream x once: HBM-bound.
+#include "mil_common.h"
+
+// ================================================================================ K1a gate forward
+// Workgroup: 512 threads = 8 waves, tile = 128 rows x all 384 gate columns, K-slices of 32.
+//   wave (wr, wc): rows 32*wr..+31, d-chunks {3wc, 3wc+1, 3wc+2} for both V and U  -> 6 accumulators.
+// LDS image: row-major [rows][32 k] padded to 36 words: ds_read_b128 conflict-free (36*r mod 64
+// covers all 16 four-bank slots over each 16-lane group).
+// k permutation: lane (r, h) reads 4 consecutive k = 8t+4h..+3 and feeds element j to the j-th of
+// 4 MFMAs, so MFMA (t, j) contracts k in {8t+j, 8t+4+j}: A and B use the same map, the sum over a
+// slice is complete.
+#define GF_TM 128
+#define GF_BK 32
+#define GF_S 36
+#define GF_NG 384
+
+__global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, const float* __restrict__ Wv,
+                                                  const float* __restrict__ bv, const float* __restrict__ Wu,
+                                                  const float* __restrict__ bu, const float* __restrict__ wvec,
+                                                  const float* __restrict__ battn, float* __restrict__ scores,
+                                                  float* __restrict__ gates, int R, int L) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * GF_S];
+    float* xs = smem;                       // [2][128][36]
+    float* ws = smem + 2 * GF_TM * GF_S;    // [2][384][36]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * GF_TM;
+
+    const int srow = tid >> 3, sch = tid & 7;   // staging: row (+64 i), 16-byte chunk within the 32-k slice
+    f32x4 rx[2], rw[6];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gr = row0 + srow + 64 * i;
+            rx[i] = gr < R ? *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + k0 + 4 * sch) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int wrow = srow + 64 * i;     // 0..383; rows 0..191 = Wv, 192..383 = Wu (i < 3 <=> Wv)
+            const float* base = (i < 3) ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L;
+            rw[i] = *reinterpret_cast<const f32x4*>(base + k0 + 4 * sch);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<f32x4*>(xs + (buf * GF_TM + srow + 64 * i) * GF_S + 4 * sch) = rx[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            *reinterpret_cast<f32x4*>(ws + (buf * GF_NG + srow + 64 * i) * GF_S + 4 * sch) = rw[i];
+    };
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][u][i] = 0.f;
+
+    const int nslice = L / GF_BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int s = 0; s < nslice; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslice) gload((s + 1) * GF_BK);
+        const float* xa = xs + (buf * GF_TM + 32 * wr + r) * GF_S + 4 * h;
+        const float* wb = ws + (buf * GF_NG + 32 * 3 * wc + r) * GF_S + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 8 * t);
+            f32x4 b[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    b[c][u] = *reinterpret_cast<const f32x4*>(wb + (u * 192 + 32 * c) * GF_S + 8 * t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[c][u][j], acc[c][u], 0, 0, 0);
+        }
+        if (s + 1 < nslice) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue: lane holds column d = 32*(3wc+c) + r of both V and U for 16 rows.
+    float part[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int d = 32 * (3 * wc + c) + r;
+        const float bvd = bv[d], bud = bu[d], wd = wvec[d];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = tanhf(acc[c][0][i] + bvd);
+            const float u = 1.0f / (1.0f + expf(-(acc[c][1][i] + bud)));
+            part[i] += wd * v * u;
+            if (gates != nullptr) {
+                const int gr = row0 + 32 * wr + mfma32_row(i, h);
+                if (gr < R) {
+                    gates[(size_t)gr * GF_NG + d] = v;
+                    gates[(size_t)gr * GF_NG + 192 + d] = u;
+                }
+            }
+        }
+    }
+    float* sred = smem;    // [2][128], main loop is done (last __syncthreads passed)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = half_allsum(part[i]);
+        if (r == 0) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
+    }
+    __syncthreads();
+    if (tid < GF_TM) {
+        const int gr = row0 + tid;
+        if (gr < R) scores[gr] = sred[tid] + sred[GF_TM + tid] + battn[0];
+    }
+}
+
+// ================================================================================ K1b attention pool forward
+// One workgroup (256 threads) per tile of <= 32 rows of one bag.  Wave w streams rows w, w+4, ...;
+// lane l owns columns 4l + 256q (16-byte loads, 1 KiB per wave instruction).
+// Output partial: acc[t][L] weighted row sum with weights exp(s_i - m_tile) in partials[0 .. T*L),
+// then (m_tile, l_tile) pairs in partials[T*L + 2t ..].
+template <int NQ>
+__global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ x, const float* __restrict__ scores,
+                                                      const int32_t* __restrict__ tile_map, float* __restrict__ partials,
+                                                      int L) {
+    __shared__ float p_lds[MIL_POOL_TILE];
+    __shared__ float ml_lds[2];
+    __shared__ __attribute__((aligned(16))) float red[3 * NQ * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x;
+    const int row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
+
+    if (wave == 0) {
+        const float s = lane < nrows ? scores[row0 + lane] : -INFINITY;
+        const float m = wave_allmax(s);
+        const float p = lane < nrows ? expf(s - m) : 0.f;
+        const float l = wave_allsum(p);
+        if (lane < MIL_POOL_TILE) p_lds[lane] = p;
+        if (lane == 0) { ml_lds[0] = m; ml_lds[1] = l; }
+    }
+    __syncthreads();
+
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+        const int rr = wave + 4 * i;
+        if (rr < nrows) {
+            const float p = p_lds[rr];
+            const float* xr = x + (size_t)(row0 + rr) * L + 4 * lane;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+                acc[q] += p * v;
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            *reinterpret_cast<f32x4*>(red + ((wave - 1) * NQ + q) * 256 + 4 * lane) = acc[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = partials + (size_t)t * L;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 v = acc[q];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * NQ + q) * 256 + 4 * lane);
+            *reinterpret_cast<f32x4*>(out + 256 * q + 4 * lane) = v;
+        }
+        if (lane == 0) {
+            float* ml = partials + (size_t)gridDim.x * L + 2 * t;
+            ml[0] = ml_lds[0];
+            ml[1] = ml_lds[1];
+        }
+    }
+}
+
+// Merge the tile partials of one bag: M = sum_t e^{m_t - m} acc_t / sum_t e^{m_t - m} l_t.
+__global__ __launch_bounds__(256) void k_pool_merge(const float* __restrict__ partials,
+                                                    const int32_t* __restrict__ bag_tile_off, float* __restrict__ M,
+                                                    float* __restrict__ lse, int L, int T) {
+    __shared__ float red[256];
+    __shared__ float scale_lds[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1];
+    const float* ml = partials + (size_t)T * L;
+    float m = -INFINITY;
+    for (int t = t0 + tid; t < t1; t += 256) m = fmaxf(m, ml[2 * t]);
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float l = 0.f;
+    for (int t = t0 + tid; t < t1; t += 256) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
+    red[tid] = l;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    l = red[0];
+    const float inv = (t1 > t0) ? 1.0f / l : 0.f;
+    float accum[8];   // L <= 2048 columns: 8 per thread
+    const int ncol = (L + 255) / 256;
+    for (int c = 0; c < 8; ++c) accum[c] = 0.f;
+    for (int tb = t0; tb < t1; tb += 256) {
+        __syncthreads();
+        const int t = tb + tid;
+        scale_lds[tid] = (t < t1) ? expf(ml[2 * t] - m) : 0.f;
+        __syncthreads();
+        const int cnt = min(256, t1 - tb);
+        for (int k = 0; k < cnt; ++k) {
+            const float sc = scale_lds[k];
+            const float* pr = partials + (size_t)(tb + k) * L;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < ncol) {
+                    const int col = tid + 256 * c;
+                    if (col < L) accum[c] += sc * pr[col];
+                }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < ncol) {
+            const int col = tid + 256 * c;
+            if (col < L) M[(size_t)b * L + col] = accum[c] * inv;
+        }
+    if (tid == 0) lse[b] = (t1 > t0) ? m + logf(l) : -INFINITY;
+}
+
+// ================================================================================ K1 backward: ds (HBM-bound)
+// ds_i = A_i (x_i . dM - cdot),  A_i = exp(s_i - lse).  Optionally dx_i = A_i dM (the pool term).
+template <int NQ>
+__global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x, const float* __restrict__ scores,
+                                                     const float* __restrict__ lse, const float* __restrict__ dM,
+                                                     const float* __restrict__ cdot,
+                                                     const int32_t* __restrict__ tile_map, float* __restrict__ ds,
+                                                     float* __restrict__ dx, int L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x;
+    const int bag = tile_map[4 * t], row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
+    f32x4 g[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) g[q] = *reinterpret_cast<const f32x4*>(dM + (size_t)bag * L + 256 * q + 4 * lane);
+    const float lse_b = lse[bag], c_b = cdot[bag];
+#pragma unroll
+    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+        const int rr = wave + 4 * i;
+        if (rr < nrows) {
+            const size_t row = (size_t)(row0 + rr);
+            const float* xr = x + row * L + 4 * lane;
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+                dot += v[0] * g[q][0] + v[1] * g[q][1] + v[2] * g[q][2] + v[3] * g[q][3];
+            }
+            dot = wave_allsum(dot);
+            const float a = expf(scores[row] - lse_b);
+            if (lane == 0) ds[row] = a * (dot - c_b);
+            if (dx != nullptr) {
+                float* dr = dx + row * L + 4 * lane;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dr + 256 * q) = a * g[q];
+            }
+        }
+    }
+}
+
+// ================================================================================ K1 backward: gate dW (MFMA)
+// dW[gi][j] = sum_rows dPre[row][gi] x[row][j], gi = permuted gate index: block m (0..2) holds
+// d in [64m, 64m+64): local 0..63 -> dPreV_d, 64..127 -> dPreU_d, so one (V, U) load pair yields both.
+// Workgroup 256 threads = 4 waves, output tile 128 (gi) x 128 (j), wave (wi, wj) owns 64 x 64.
+// Split-K over row chunks of KC rows; partials [S][384][L] are summed by k_gate_bwd_reduce.
+// Both operands are "k-major" in LDS ([row][i] and [row][j]): lane (i = l & 31, k = l >> 5) reads
+// word row*128 + i: consecutive lanes -> consecutive banks, no conflicts, no padding.
+#define GB_BKR 32
+
+__global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x, const float* __restrict__ gates,
+                                                     const float* __restrict__ ds, const float* __restrict__ wvec,
+                                                     float* __restrict__ part, float* __restrict__ pbias, int R, int L,
+                                                     int KC, int NJ) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GB_BKR * 128];
+    float* ab = smem;                         // [2][32][128] dPre
+    float* xb = smem + 2 * GB_BKR * 128;      // [2][32][128] x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int bid = blockIdx.x;
+    const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
+    const int j0 = jt * 128;
+    const int rbeg = s * KC, rend = min(R, rbeg + KC);
+    const int nslice = (rend - rbeg + GB_BKR - 1) / GB_BKR;
+
+    // staging maps
+    const int xrow = tid >> 5, xc4 = tid & 31;    // x: rows xrow + 8i (i < 4), 16-byte chunk xc4
+    const int arow = tid >> 4, ad4 = tid & 15;    // gates: rows arow + 16i (i < 2), d = 64m + 4*ad4
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
+    f32x4 rx[4], rv[2], ru[2];
+    float rds[2];
+    f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
+    float acc_ds = 0.f;
+
+    auto gload = [&](int rs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr = rs + xrow + 8 * i;
+            rx[i] = gr < rend ? *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gr = rs + arow + 16 * i;
+            if (gr < rend) {
+                const float* gp = gates + (size_t)gr * GF_NG + 64 * m + 4 * ad4;
+                rv[i] = *reinterpret_cast<const f32x4*>(gp);
+                ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
+                rds[i] = ds[gr];
+            } else {
+                rv[i] = f32x4{0, 0, 0, 0};
+                ru[i] = f32x4{0, 0, 0, 0};
+                rds[i] = 0.f;
+            }
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = rx[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 v = rv[i], u = ru[i];
+            const f32x4 dsw = rds[i] * w4;
+            const f32x4 pv = dsw * u * (1.0f - v * v);          // ds w U (1 - V^2)
+            const f32x4 pu = dsw * v * u * (1.0f - u);          // ds w V U (1 - U)
+            float* dst = ab + (buf * GB_BKR + arow + 16 * i) * 128 + 4 * ad4;
+            *reinterpret_cast<f32x4*>(dst) = pv;
+            *reinterpret_cast<f32x4*>(dst + 64) = pu;
+            acc_bv += pv;
+            acc_bu += pu;
+            acc_w += rds[i] * v * u;
+            if (ad4 == 0) acc_ds += rds[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    if (nslice > 0) {
+        gload(rbeg);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int buf = sl & 1;
+        if (sl + 1 < nslice) gload(rbeg + (sl + 1) * GB_BKR);
+        const float* ap = ab + buf * GB_BKR * 128 + h * 128 + 64 * wi + r;
+        const float* bp = xb + buf * GB_BKR * 128 + h * 128 + 64 * wj + r;
+#pragma unroll
+        for (int ks = 0; ks < GB_BKR / 2; ++ks) {
+            const float a0 = ap[ks * 256], a1 = ap[ks * 256 + 32];
+            const float b0 = bp[ks * 256], b1 = bp[ks * 256 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (sl + 1 < nslice) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial tile -> part[s][128m + 64wi + 32a + row][j0 + 64wj + 32b + r]
+    float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
+
+    // bias / w partials (only the j-tile-0 workgroups publish them)
+    if (jt == 0) {
+        float* redf = smem;   // [16 row groups][3][64]
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            redf[(arow * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
+            redf[(arow * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
+            redf[(arow * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid / 64, d = tid % 64;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += redf[(g * 3 + which) * 64 + d];
+            pbias[((size_t)s * 4 + which) * 192 + 64 * m + d] = v;
+        }
+        if (m == 0) {
+            __syncthreads();
+            redf[tid] = acc_ds;
+            __syncthreads();
+            if (tid == 0) {
+                float v = 0.f;
+                for (int g = 0; g < 256; g += 16) v += redf[g];
+                pbias[((size_t)s * 4 + 3) * 192] = v;
+            }
+        }
+    }
+}
+
+// Sum the split-K partials and un-permute the gate index.  One thread per output float4.
+__global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __restrict__ part, const float* __restrict__ pbias,
+                                                         int S, int L, float* __restrict__ dWv, float* __restrict__ dbv,
+                                                         float* __restrict__ dWu, float* __restrict__ dbu,
+                                                         float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const int L4 = L / 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nW = GF_NG * L4;
+    if (idx < nW) {
+        const int gi = idx / L4, c4 = idx % L4;
+        f32x4 v = {0, 0, 0, 0};
+        for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + ((size_t)s * GF_NG + gi) * L + 4 * c4);
+        const int m = gi >> 7, ii = gi & 127;
+        float* dst = (ii < 64 ? dWv + (size_t)(64 * m + ii) * L : dWu + (size_t)(64 * m + ii - 64) * L) + 4 * c4;
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+    } else if (idx < nW + 3 * 192 + 1) {
+        const int k = idx - nW;
+        const int which = k / 192, d = k % 192;
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += pbias[((size_t)s * 4 + which) * 192 + d];
+        float* dst = which == 0 ? dbv + d : which == 1 ? dbu + d : which == 2 ? dw + d : db;
+        if (accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+// ================================================================================ host entry points
+static inline int split_plan(int R, int L, int* KC_out) {
+    const int NJ = L / 128;
+    int smax = (2 * MIL_NUM_CU) / (3 * NJ);
+    if (smax < 1) smax = 1;
+    int kc = ((R + smax - 1) / smax + GB_BKR - 1) / GB_BKR * GB_BKR;
+    if (kc < GB_BKR) kc = GB_BKR;
+    *KC_out = kc;
+    return (R + kc - 1) / kc;
+}
+
+extern "C" int mil_abi_version(void) { return 1; }
+
+extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                   const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
+                                   void* stream) {
+    if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
+    if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
+    if (R == 0) return MIL_OK;
+    const int grid = (R + GF_TM - 1) / GF_TM;
+    hipLaunchKernelGGL(k_gate_fwd, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores, gates,
+                       R, L);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_map,
+                                 const int32_t* bag_tile_off, int T, int B, int L, float* partials, float* M,
+                                 float* lse, void* stream) {
+    if (!x || !scores || !tile_map || !bag_tile_off || !partials || !M || !lse) return MIL_EINVAL;
+    if (L <= 0 || (L % 256) != 0 || L > 1024 || B < 0 || T < 0) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (T > 0) {
+        switch (L / 256) {
+            case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+            case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+            case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+            default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+        }
+        MIL_CHECK_LAUNCH();
+    }
+    if (B > 0) {
+        hipLaunchKernelGGL(k_pool_merge, dim3(B), dim3(256), 0, st, partials, bag_tile_off, M, lse, L, T);
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_bwd(const float* x, const float* scores, const float* lse, const float* dM,
+                                 const float* cdot, const int32_t* tile_map, int T, int L, float* ds, float* dx,
+                                 void* stream) {
+    if (!x || !scores || !lse || !dM || !cdot || !tile_map || !ds) return MIL_EINVAL;
+    if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
+    if (T == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (L / 256) {
+        case 1: hipLaunchKernelGGL(k_pool_bwd_ds<1>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
+        case 2: hipLaunchKernelGGL(k_pool_bwd_ds<2>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
+        case 3: hipLaunchKernelGGL(k_pool_bwd_ds<3>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
+        default: hipLaunchKernelGGL(k_pool_bwd_ds<4>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
+    }
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" size_t mil_gate_bwd_workspace_floats(int R, int L) {
+    if (R <= 0 || L <= 0 || (L % 128) != 0) return 0;
+    int kc;
+    const int S = split_plan(R, L, &kc);
+    return (size_t)S * GF_NG * L + (size_t)S * 4 * 192;
+}
+
+extern "C" int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                                   int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
+                                   float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
+    if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
+    if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
+    int kc;
+    const int S = split_plan(R, L, &kc);
+    const size_t need = (size_t)S * GF_NG * L + (size_t)S * 4 * 192;
+    if (workspace_floats < need) return MIL_ENOSPC;
+    float* part = workspace;
+    float* pbias = workspace + (size_t)S * GF_NG * L;
+    const int NJ = L / 128;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gate_bwd_dw, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
+    MIL_CHECK_LAUNCH();
+    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
+                       dbu, dw, db, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// ================================================================================ K1 backward: gate dx (MFMA)
+// dx[row][j] += sum_d dPreV[row][d] Wv[d][j] + dPreU[row][d] Wu[d][j]     (M = R, N = L, K = 384).
+// K-slices of 32 = 16 d's x {V, U} so one (V, U) load pair yields both dPre terms.
+// Workgroup 256 threads, tile 128 rows x 128 cols, wave (wi, wj) owns 64 x 64.
+// LDS: A [128][32] padded to 33 words (lane i reads word 33 i + k: conflict-free), B [32][128].
+#define GX_AS 33
+__global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ gates, const float* __restrict__ ds,
+                                                     const float* __restrict__ wvec, const float* __restrict__ Wv,
+                                                     const float* __restrict__ Wu, float* __restrict__ dx, int R, int L) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (128 * GX_AS + 32 * 128)];
+    float* as = smem;                       // [2][128][33]
+    float* bs = smem + 2 * 128 * GX_AS;     // [2][32][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int NJ = L / 128;
+    const int jt = blockIdx.x % NJ, rt = blockIdx.x / NJ;
+    const int row0 = rt * 128, j0 = jt * 128;
+
+    // staging: A: thread -> row (tid >> 1), 8 d's: (tid & 1) * 8 .. +7 ; B: k row (tid >> 5) + 8 i, chunk (tid & 31)
+    const int arow = tid >> 1, ad0 = (tid & 1) * 8;
+    const int brow = tid >> 5, bc4 = tid & 31;
+    const int garow = row0 + arow;
+    const float dsr = garow < R ? ds[garow] : 0.f;
+    f32x4 rv[2], ru[2], rb[4];
+
+    auto gload = [&](int kk) {   // kk: slice index, d0 = 16 kk
+        const int d0 = 16 * kk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (garow < R) {
+                const float* gp = gates + (size_t)garow * GF_NG + d0 + ad0 + 4 * i;
+                rv[i] = *reinterpret_cast<const f32x4*>(gp);
+                ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
+            } else {
+                rv[i] = f32x4{0, 0, 0, 0};
+                ru[i] = f32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = brow + 8 * i;    // 0..31: k < 16 -> Wv[d0 + k], else Wu[d0 + k - 16]
+            const float* base = (i < 2) ? Wv + (size_t)(d0 + k) * L : Wu + (size_t)(d0 + k - 16) * L;
+            rb[i] = *reinterpret_cast<const f32x4*>(base + j0 + 4 * bc4);
+        }
+    };
+    auto swrite = [&](int buf, int kk) {
+        const int d0 = 16 * kk;
+        float* ad = as + (buf * 128 + arow) * GX_AS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + d0 + ad0 + 4 * i);
+            const f32x4 v = rv[i], u = ru[i];
+            const f32x4 dsw = dsr * w4;
+            const f32x4 pv = dsw * u * (1.0f - v * v);
+            const f32x4 pu = dsw * v * u * (1.0f - u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ad[ad0 + 4 * i + e] = pv[e];
+                ad[16 + ad0 + 4 * i + e] = pu[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(bs + (buf * 32 + brow + 8 * i) * 128 + 4 * bc4) = rb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int nslice = MIL_GATE_D / 16;   // 12
+    gload(0);
+    swrite(0, 0);
+    __syncthreads();
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int buf = sl & 1;
+        if (sl + 1 < nslice) gload(sl + 1);
+        const float* ap = as + (buf * 128 + 64 * wi + r) * GX_AS + h;
+        const float* bp = bs + (buf * 32 + h) * 128 + 64 * wj + r;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float a0 = ap[2 * ks], a1 = ap[32 * GX_AS + 2 * ks];
+            const float b0 = bp[ks * 256], b1 = bp[ks * 256 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (sl + 1 < nslice) swrite(buf ^ 1, sl + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gr = row0 + 64 * wi + 32 * a + mfma32_row(i, h);
+            if (gr < R) {
+                float* o = dx + (size_t)gr * L + j0 + 64 * wj + r;
+                o[0] += acc[a][0][i];
+                o[32] += acc[a][1][i];
+            }
+        }
+}
+
+extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu,
+                                  int R, int L, int D, float* dx, void* stream) {
+    if (!gates || !ds || !w || !Wv || !Wu || !dx) return MIL_EINVAL;
+    if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R < 0) return MIL_EINVAL;
+    if (R == 0) return MIL_OK;
+    const int grid = ((R + 127) / 128) * (L / 128);
+    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, (hipStream_t)stream, gates, ds, w, Wv, Wu, dx, R, L);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

@@ -1,0 +1,179 @@
+// K3b: per-bag classifier head, sigmoid, BCE loss and their backward; Adam step.
+// Reference: model/aggregator.py:128-131,200 (fc = Dropout(.25) + Linear(512, C), sigmoid),
+// train_ddp.py:99,323-324 (BCELoss), train_ddp.py:115-118 (Adam).  All tiny, latency-bound kernels.
+#include "mil_common.h"
+
+__device__ __forceinline__ float block_allsum_256(float v, float* red) {
+    const int tid = threadIdx.x;
+    v = wave_allsum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// z[b][c] = M[b] . Wf[c] + bf[c];  p = sigmoid(z).   grid = B, 256 threads.
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ M, const float* __restrict__ Wf,
+                                                  const float* __restrict__ bf, float* __restrict__ z,
+                                                  float* __restrict__ p, int L, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+        for (int j = tid; j < L; j += 256) v += M[(size_t)b * L + j] * Wf[(size_t)c * L + j];
+        v = block_allsum_256(v, red);
+        if (tid == 0) {
+            const float zz = v + bf[c];
+            z[b * C + c] = zz;
+            p[b * C + c] = 1.0f / (1.0f + expf(-zz));
+        }
+    }
+}
+
+// BCE(mean) forward + gradient through the sigmoid.  One workgroup.
+__global__ __launch_bounds__(256) void k_bce_fwd_bwd(const float* __restrict__ p, const float* __restrict__ y,
+                                                     float* __restrict__ loss_sum, float* __restrict__ dz, int n,
+                                                     float scale) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float pi = p[i], yi = y[i];
+        const float lp = fmaxf(logf(pi), -100.0f);
+        const float l1p = fmaxf(logf(1.0f - pi), -100.0f);
+        acc += -(yi * lp + (1.0f - yi) * l1p);
+        dz[i] = (pi - yi) * scale;
+    }
+    acc = block_allsum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, acc * scale);
+}
+
+// dM[b] = dz[b] Wf;  cdot[b] = M[b] . dM[b].   grid = B, 256 threads.
+__global__ __launch_bounds__(256) void k_head_bwd_dm(const float* __restrict__ dz_or_dp, const float* __restrict__ p,
+                                                     const float* __restrict__ M, const float* __restrict__ Wf,
+                                                     float* __restrict__ dM, float* __restrict__ cdot, int L, int C) {
+    __shared__ float red[4];
+    __shared__ float dzs[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < C) {
+        float g = dz_or_dp[b * C + tid];
+        if (p != nullptr) { const float pp = p[b * C + tid]; g = g * pp * (1.0f - pp); }
+        dzs[tid] = g;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int j = tid; j < L; j += 256) {
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += dzs[c] * Wf[(size_t)c * L + j];
+        dM[(size_t)b * L + j] = v;
+        dot += v * M[(size_t)b * L + j];
+    }
+    dot = block_allsum_256(dot, red);
+    if (tid == 0) cdot[b] = dot;
+}
+
+// dWf[c][j] = sum_b dz[b][c] M[b][j];  dbf[c] = sum_b dz[b][c].   one thread per (c, j) (+ C for the bias).
+__global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict__ dz_or_dp, const float* __restrict__ p,
+                                                         const float* __restrict__ M, float* __restrict__ dWf,
+                                                         float* __restrict__ dbf, int B, int L, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < C * L) {
+        const int c = idx / L, j = idx % L;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float g = dz_or_dp[b * C + c];
+            if (p != nullptr) { const float pp = p[b * C + c]; g = g * pp * (1.0f - pp); }
+            v += g * M[(size_t)b * L + j];
+        }
+        dWf[idx] = v;
+    } else if (idx < C * L + C) {
+        const int c = idx - C * L;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float g = dz_or_dp[b * C + c];
+            if (p != nullptr) { const float pp = p[b * C + c]; g = g * pp * (1.0f - pp); }
+            v += g;
+        }
+        dbf[c] = v;
+    }
+}
+
+// torch.optim.Adam, weight decay folded into the gradient (L2), bias-corrected.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,
+                                              float* __restrict__ m, float* __restrict__ v, size_t n, float lr, float b1,
+                                              float b2, float eps, float wd, float gscale, float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float pi = param[i];
+    const float g = grad[i] * gscale + wd * pi;
+    const float mi = b1 * m[i] + (1.0f - b1) * g;
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    // torch: denom = sqrt(v)/sqrt(bc2) + eps; param -= (lr / bc1) * m / denom
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    param[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+extern "C" int mil_head_fwd(const float* M, const float* Wf, const float* bf, float* z, float* p, int B, int L, int C,
+                            void* stream) {
+    if (!M || !Wf || !bf || !z || !p) return MIL_EINVAL;
+    if (B < 0 || L <= 0 || C <= 0 || C > 32) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_head_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, M, Wf, bf, z, p, L, C);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_bce_fwd_bwd(const float* p, const float* y, float* loss_sum, float* dz, int B, int C, float scale,
+                               void* stream) {
+    if (!p || !y || !loss_sum || !dz) return MIL_EINVAL;
+    if (B <= 0 || C <= 0) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_bce_fwd_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, p, y, loss_sum, dz, B * C, scale);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_head_bwd(const float* dz_or_dp, const float* p, const float* M, const float* Wf, float* dM,
+                            float* dWf, float* dbf, float* cdot, int B, int L, int C, void* stream) {
+    if (!dz_or_dp || !M || !Wf || !dM || !dWf || !dbf || !cdot) return MIL_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C > 32) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_head_bwd_dm, dim3(B), dim3(256), 0, st, dz_or_dp, p, M, Wf, dM, cdot, L, C);
+    MIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_head_bwd_params, dim3((C * L + C + 255) / 256), dim3(256), 0, st, dz_or_dp, p, M, dWf, dbf, B, L,
+                       C);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                             void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2));
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// out[b] = a[b] . c[b]   (row-wise dot of two [B, L] matrices; cdot for the pool backward).
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ a, const float* __restrict__ c,
+                                                float* __restrict__ out, int L) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float v = 0.f;
+    for (int j = threadIdx.x; j < L; j += 256) v += a[(size_t)b * L + j] * c[(size_t)b * L + j];
+    v = block_allsum_256(v, red);
+    if (threadIdx.x == 0) out[b] = v;
+}
+
+extern "C" int mil_rowdot(const float* a, const float* c, float* out, int B, int L, void* stream) {
+    if (!a || !c || !out || B < 0 || L <= 0) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_rowdot, dim3(B), dim3(256), 0, (hipStream_t)stream, a, c, out, L);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

@@ -1,0 +1,43 @@
+// Shared device helpers for the gfx950 kernels.  CDNA4 only: 64-lane waves, MFMA, LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/mil_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MIL_WAVE 64
+#define MIL_NUM_CU 256
+
+#define MIL_CHECK_LAUNCH()                               \
+    do {                                                 \
+        hipError_t e_ = hipGetLastError();               \
+        if (e_ != hipSuccess) return (int)e_;            \
+    } while (0)
+
+// Butterfly all-reduce over the 64 lanes of a wave: every lane ends with the result.
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_allmax(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+// All-reduce inside each 32-lane half (lanes l and l^32 stay separate).
+__device__ __forceinline__ float half_allsum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Row of a 32x32 MFMA accumulator register: C/D layout col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (dtype independent on gfx950).
+__device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }

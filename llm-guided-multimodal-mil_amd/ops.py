@@ -1,0 +1,210 @@
+"""Host-side operators over the C ABI (include/mil_hip.h).
+
+Two layers:
+  * plain functions, one per C entry point: torch tensors in, torch tensors out, all work
+    enqueued on the current HIP stream, no host sync;
+  * ``torch.autograd.Function`` wrappers (``gated_attention_pool``, ``head_sigmoid``) so the
+    ``aggregator`` module composes with autograd/DDP exactly like the reference's
+    ABMIL (model/dim1/ABMIL.py:47-64) and ``fc`` + sigmoid (model/aggregator.py:128-131,200).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .bags import BagLayout
+
+GATE_D = 192
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.MilHipError(f"{name}: expected a tensor on the MI355X (cuda) device; there is no CPU path")
+    if t.dtype != torch.float32:
+        raise _lib.MilHipError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- plain operators
+def gate_scores_fwd(x, Wv, bv, Wu, bu, w, b, save_gates: bool = True):
+    """scores [R], gates [R, 384] (or None).  ABMIL.py:52-54."""
+    x = _f32c(x, "x")
+    R, L = x.shape
+    scores = torch.empty(R, device=x.device, dtype=torch.float32)
+    gates = torch.empty((R, 2 * GATE_D), device=x.device, dtype=torch.float32) if save_gates else None
+    rc = _lib.lib().mil_gate_scores_fwd(_p(x), _p(_f32c(Wv, "Wv")), _p(_f32c(bv, "bv")), _p(_f32c(Wu, "Wu")),
+                                        _p(_f32c(bu, "bu")), _p(_f32c(w, "w")), _p(_f32c(b, "b")), _p(scores),
+                                        _p(gates), R, L, Wv.shape[0], _stream())
+    _lib.check(rc, "mil_gate_scores_fwd")
+    return scores, gates
+
+
+def attn_pool_fwd(x, scores, layout: BagLayout):
+    """M [B, L], lse [B].  ABMIL.py:56-59 per bag."""
+    x = _f32c(x, "x")
+    R, L = x.shape
+    if R != layout.R:
+        raise _lib.MilHipError(f"attn_pool_fwd: x has {R} rows but the bag layout covers {layout.R}")
+    partials = torch.empty(layout.T * (L + 2), device=x.device, dtype=torch.float32)
+    M = torch.empty((layout.B, L), device=x.device, dtype=torch.float32)
+    lse = torch.empty(layout.B, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_fwd(_p(x), _p(scores), _p(layout.tile_map), _p(layout.bag_tile_off), layout.T,
+                                      layout.B, L, _p(partials), _p(M), _p(lse), _stream())
+    _lib.check(rc, "mil_attn_pool_fwd")
+    return M, lse
+
+
+def head_fwd(M, Wf, bf):
+    """logits z [B, C], p = sigmoid(z).  aggregator.py:128-131,200 (eval)."""
+    M = _f32c(M, "M")
+    B, L = M.shape
+    C = Wf.shape[0]
+    z = torch.empty((B, C), device=M.device, dtype=torch.float32)
+    p = torch.empty_like(z)
+    rc = _lib.lib().mil_head_fwd(_p(M), _p(_f32c(Wf, "Wf")), _p(_f32c(bf, "bf")), _p(z), _p(p), B, L, C, _stream())
+    _lib.check(rc, "mil_head_fwd")
+    return z, p
+
+
+def bce_fwd_bwd(p, y, scale: float, loss_sum: Optional[torch.Tensor] = None):
+    """Adds sum(BCE) * scale into loss_sum [1] and returns (loss_sum, dz = (p - y) * scale)."""
+    B, C = p.shape
+    if loss_sum is None:
+        loss_sum = torch.zeros(1, device=p.device, dtype=torch.float32)
+    dz = torch.empty_like(p)
+    rc = _lib.lib().mil_bce_fwd_bwd(_p(_f32c(p, "p")), _p(_f32c(y, "y")), _p(loss_sum), _p(dz), B, C, float(scale),
+                                    _stream())
+    _lib.check(rc, "mil_bce_fwd_bwd")
+    return loss_sum, dz
+
+
+def head_bwd(dz_or_dp, p, M, Wf):
+    """(dM [B, L], dWf [C, L], dbf [C], cdot [B]).  If p is given the first argument is dL/dp."""
+    B, L = M.shape
+    C = Wf.shape[0]
+    dM = torch.empty_like(M)
+    dWf = torch.empty((C, L), device=M.device, dtype=torch.float32)
+    dbf = torch.empty(C, device=M.device, dtype=torch.float32)
+    cdot = torch.empty(B, device=M.device, dtype=torch.float32)
+    rc = _lib.lib().mil_head_bwd(_p(_f32c(dz_or_dp, "dz")), _p(p), _p(_f32c(M, "M")), _p(_f32c(Wf, "Wf")), _p(dM),
+                                 _p(dWf), _p(dbf), _p(cdot), B, L, C, _stream())
+    _lib.check(rc, "mil_head_bwd")
+    return dM, dWf, dbf, cdot
+
+
+def rowdot(a, c):
+    B, L = a.shape
+    out = torch.empty(B, device=a.device, dtype=torch.float32)
+    rc = _lib.lib().mil_rowdot(_p(_f32c(a, "a")), _p(_f32c(c, "c")), _p(out), B, L, _stream())
+    _lib.check(rc, "mil_rowdot")
+    return out
+
+
+def attn_pool_bwd(x, scores, lse, dM, cdot, layout: BagLayout, want_dx: bool):
+    """ds [R] and, if requested, the pool term of dx ([R, L] = A_i dM)."""
+    x = _f32c(x, "x")
+    R, L = x.shape
+    ds = torch.empty(R, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if want_dx else None
+    rc = _lib.lib().mil_attn_pool_bwd(_p(x), _p(scores), _p(lse), _p(_f32c(dM, "dM")), _p(cdot), _p(layout.tile_map),
+                                      layout.T, L, _p(ds), _p(dx), _stream())
+    _lib.check(rc, "mil_attn_pool_bwd")
+    return ds, dx
+
+
+def gate_bwd_params(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False,
+                    workspace: Optional[torch.Tensor] = None):
+    x = _f32c(x, "x")
+    R, L = x.shape
+    need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_gate_bwd_params(_p(x), _p(gates), _p(ds), _p(_f32c(w, "w")), R, L, GATE_D, _p(workspace),
+                                        workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
+                                        1 if accumulate else 0, _stream())
+    _lib.check(rc, "mil_gate_bwd_params")
+    return workspace
+
+
+def gate_bwd_input(gates, ds, w, Wv, Wu, dx):
+    R, L = dx.shape
+    rc = _lib.lib().mil_gate_bwd_input(_p(gates), _p(ds), _p(_f32c(w, "w")), _p(_f32c(Wv, "Wv")), _p(_f32c(Wu, "Wu")),
+                                       R, L, GATE_D, _p(dx), _stream())
+    _lib.check(rc, "mil_gate_bwd_input")
+    return dx
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+              weight_decay: float = 1e-7, grad_scale: float = 1.0):
+    rc = _lib.lib().mil_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step), lr,
+                                  betas[0], betas[1], eps, weight_decay, grad_scale, _stream())
+    _lib.check(rc, "mil_adam_step")
+
+
+# --------------------------------------------------------------------------- autograd wrappers
+class _GatedAttentionPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Wv, bv, Wu, bu, w, b, layout: BagLayout):
+        x = _f32c(x, "x")
+        need_grad = any(ctx.needs_input_grad[:7])
+        scores, gates = gate_scores_fwd(x, Wv, bv, Wu, bu, w.reshape(-1), b, save_gates=need_grad)
+        M, lse = attn_pool_fwd(x, scores, layout)
+        ctx.layout = layout
+        ctx.save_for_backward(x, Wv, Wu, w, scores, gates if gates is not None else torch.empty(0, device=x.device), lse, M)
+        ctx.mark_non_differentiable(scores)
+        return M, scores
+
+    @staticmethod
+    def backward(ctx, dM, _dscores):
+        x, Wv, Wu, w, scores, gates, lse, M = ctx.saved_tensors
+        dM = _f32c(dM, "dM")
+        cdot = rowdot(M, dM)
+        want_dx = ctx.needs_input_grad[0]
+        ds, dx = attn_pool_bwd(x, scores, lse, dM, cdot, ctx.layout, want_dx)
+        dWv = torch.empty_like(Wv)
+        dWu = torch.empty_like(Wu)
+        dbv = torch.empty(GATE_D, device=x.device, dtype=torch.float32)
+        dbu = torch.empty_like(dbv)
+        dw = torch.empty_like(dbv)
+        db = torch.empty(1, device=x.device, dtype=torch.float32)
+        wflat = w.reshape(-1)
+        gate_bwd_params(x, gates, ds, wflat, dWv, dbv, dWu, dbu, dw, db)
+        if want_dx:
+            gate_bwd_input(gates, ds, wflat, Wv, Wu, dx)
+        return dx, dWv, dbv, dWu, dbu, dw.reshape(w.shape), db, None
+
+
+def gated_attention_pool(x, Wv, bv, Wu, bu, w, b, layout: BagLayout) -> Tuple[torch.Tensor, torch.Tensor]:
+    """M [B, L] (differentiable) and the raw attention scores [R] (not differentiable)."""
+    return _GatedAttentionPool.apply(x, Wv, bv, Wu, bu, w, b, layout)
+
+
+class _HeadSigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, M, Wf, bf):
+        z, p = head_fwd(M, Wf, bf)
+        ctx.save_for_backward(M, Wf, p)
+        ctx.mark_non_differentiable(z)
+        return p, z
+
+    @staticmethod
+    def backward(ctx, dp, _dz):
+        M, Wf, p = ctx.saved_tensors
+        dM, dWf, dbf, _ = head_bwd(_f32c(dp, "dp"), p, M, Wf)
+        return dM, dWf, dbf
+
+
+def head_sigmoid(M, Wf, bf):
+    """(p = sigmoid(fc(M)) [B, C] differentiable, logits z [B, C])."""
+    return _HeadSigmoid.apply(M, Wf, bf)

@@ -1,0 +1,132 @@
+"""Fused training step for the image-only branch (BASELINE config 2/4): one bag batch ->
+gate scores -> attention pool -> head -> BCE -> backward -> one flat-gradient all-reduce ->
+Adam, with every buffer preallocated and every kernel enqueued through the C ABI (no autograd
+graph, no host sync inside a step).
+
+Replaces, for this branch, the reference's per-step sequence train_ddp.py:295-348
+(generator(...) / criterion / zero_grad / backward / optimizer.step) and DDP's implicit bucketed
+all-reduce (train_ddp.py:79): the live gradients (198 211 floats) are one contiguous buffer, so
+the exchange is a single RCCL all-reduce per step."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .bags import BagLayout
+
+PARAM_ORDER = [
+    "aggregator.attention_V.0.weight", "aggregator.attention_V.0.bias",
+    "aggregator.attention_U.0.weight", "aggregator.attention_U.0.bias",
+    "aggregator.attention_weights.weight", "aggregator.attention_weights.bias",
+    "fc.1.weight", "fc.1.bias",
+]
+
+
+class FlatParams:
+    """Canonical reference-named parameters as views into one flat fp32 buffer (and the same for
+    gradients / Adam moments), so the optimizer and the all-reduce are single launches."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], device, order=None):
+        self.order = list(order or params.keys())
+        self.shapes = {k: tuple(params[k].shape) for k in self.order}
+        sizes = [int(params[k].numel()) for k in self.order]
+        # keep every view 16-byte aligned for float4 kernels
+        self.offsets = {}
+        off = 0
+        for k, n in zip(self.order, sizes):
+            self.offsets[k] = off
+            off += (n + 3) // 4 * 4
+        self.numel = off
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        for k in self.order:
+            self.view(self.flat, k).copy_(params[k])
+
+    def view(self, buf: torch.Tensor, k: str) -> torch.Tensor:
+        o = self.offsets[k]
+        n = 1
+        for s in self.shapes[k]:
+            n *= s
+        return buf[o:o + n].view(self.shapes[k])
+
+    def p(self, k):
+        return self.view(self.flat, k)
+
+    def g(self, k):
+        return self.view(self.grad, k)
+
+    def state_dict(self):
+        return {k: self.p(k).clone() for k in self.order}
+
+
+class ImageOnlyTrainer:
+    def __init__(self, params: Dict[str, torch.Tensor], device, lr: float = 1e-5, betas=(0.9, 0.999),
+                 weight_decay: float = 1e-7, eps: float = 1e-8, world_size: int = 1):
+        self.device = device
+        self.fp = FlatParams(params, device, PARAM_ORDER)
+        self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
+        self.world = world_size
+        self.step_count = 0
+        self.loss_sum = torch.zeros(1, device=device, dtype=torch.float32)
+        self._ws: Optional[torch.Tensor] = None
+        self.last = {}
+        if self.world > 1:      # DDP broadcasts rank 0's parameters at wrap time (train_ddp.py:79)
+            dist.broadcast(self.fp.flat, src=0)
+
+    # ------------------------------------------------------------------ pieces (also timed one by one by bench.py)
+    def forward(self, x: torch.Tensor, layout: BagLayout, save_gates: bool = True):
+        fp = self.fp
+        scores, gates = ops.gate_scores_fwd(
+            x, fp.p("aggregator.attention_V.0.weight"), fp.p("aggregator.attention_V.0.bias"),
+            fp.p("aggregator.attention_U.0.weight"), fp.p("aggregator.attention_U.0.bias"),
+            fp.p("aggregator.attention_weights.weight").view(-1), fp.p("aggregator.attention_weights.bias"),
+            save_gates=save_gates)
+        M, lse = ops.attn_pool_fwd(x, scores, layout)
+        z, prob = ops.head_fwd(M, fp.p("fc.1.weight"), fp.p("fc.1.bias"))
+        self.last = dict(x=x, layout=layout, scores=scores, gates=gates, M=M, lse=lse, logits=z, prob=prob)
+        return prob, z
+
+    def backward(self, y: torch.Tensor, global_bags: Optional[int] = None):
+        """BCE(mean over the GLOBAL batch) + gradients into the flat grad buffer (overwrites it)."""
+        c, fp = self.last, self.fp
+        B, C = c["prob"].shape
+        nb = global_bags if global_bags is not None else B * self.world
+        self.loss_sum.zero_()
+        _, dz = ops.bce_fwd_bwd(c["prob"], y, 1.0 / (nb * C), self.loss_sum)
+        Wf = fp.p("fc.1.weight")
+        B_, L = c["M"].shape
+        lib = ops._lib.lib()
+        dM = torch.empty_like(c["M"])
+        cdot = torch.empty(B_, device=self.device, dtype=torch.float32)
+        rc = lib.mil_head_bwd(ops._p(dz), None, ops._p(c["M"]), ops._p(Wf), ops._p(dM), ops._p(fp.g("fc.1.weight")),
+                              ops._p(fp.g("fc.1.bias")), ops._p(cdot), B_, L, C, ops._stream())
+        ops._lib.check(rc, "mil_head_bwd")
+        ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], dM, cdot, c["layout"], want_dx=False)
+        self._ws = ops.gate_bwd_params(
+            c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
+            fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
+            fp.g("aggregator.attention_U.0.weight"), fp.g("aggregator.attention_U.0.bias"),
+            fp.g("aggregator.attention_weights.weight").view(-1), fp.g("aggregator.attention_weights.bias"),
+            accumulate=False, workspace=self._ws)
+        return self.loss_sum
+
+    def reduce_and_step(self):
+        """One all-reduce(sum) of the flat gradient over RCCL, then Adam.  The local loss was already
+        normalised by the global bag count, so the sum IS DDP's mean-of-ranks gradient."""
+        if self.world > 1:
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.loss_sum, op=dist.ReduceOp.SUM)
+        self.step_count += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, self.step_count, self.lr,
+                      self.betas, self.eps, self.wd, 1.0)
+
+    def train_step(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
+        prob, z = self.forward(x, layout, save_gates=True)
+        self.backward(y)
+        self.reduce_and_step()
+        return self.loss_sum, prob

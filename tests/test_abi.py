@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mil_hip.h declares (no compute
+calls without a GPU), and the host-side bag/tile bookkeeping is right."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from mil_amd import _lib
+from mil_amd.bags import build_tile_map
+
+
+def test_library_exports_header_symbols():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    names = _lib.header_symbols()
+    assert "mil_gate_scores_fwd" in names and "mil_attn_pool_fwd" in names
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/mil_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
+    handle.mil_abi_version.restype = ctypes.c_int
+    assert handle.mil_abi_version() == _lib.ABI_VERSION
+
+
+def test_missing_library_is_a_hard_error(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmil_hip.so")
+    with pytest.raises(_lib.MilHipError):
+        _lib.lib()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from mil_amd import ops
+    with pytest.raises(_lib.MilHipError):
+        ops.gate_scores_fwd(torch.zeros(4, 512), *[torch.zeros(1)] * 6)
+
+
+def test_tile_map_ragged():
+    lengths = [1, 63, 64, 130, 0, 257]
+    tm, bto, bo = build_tile_map(lengths)
+    assert bo.tolist() == [0, 1, 64, 128, 258, 258, 515]
+    assert bto.tolist() == [0, 1, 3, 5, 10, 10, 19]
+    covered = np.zeros(515, dtype=int)
+    for bag, row0, n, _ in tm:
+        assert 1 <= n <= 32 and bo[bag] <= row0 and row0 + n <= bo[bag + 1]
+        covered[row0:row0 + n] += 1
+    assert (covered == 1).all()
+    for b in range(len(lengths)):
+        assert (tm[bto[b]:bto[b + 1], 0] == b).all()
