@@ -62,6 +62,20 @@ int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_m
                       const int32_t* bag_tile_off, int T, int B, int L, float* partials,
                       float* M, float* lse, void* stream);
 
+/* The two halves of mil_attn_pool_fwd as separate entry points, so a training step can replace
+ * the plain merge by the fused tail below.  mil_attn_pool_partial writes the tile partials only. */
+int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
+                          float* partials, void* stream);
+
+/* Fused per-bag tail (one workgroup per bag): merge the partials -> M, lse; head z, p; and, when
+ * labels y are given, BCE loss (accumulated into loss_sum, see mil_bce_fwd_bwd), dz, dM = dz Wf and
+ * cdot = M . dM, i.e. everything between the pool's partial pass and the pool's backward.
+ * ABMIL.py:57-59 + aggregator.py:128-131,200 + train_ddp.py:99,323-324.  L in {256, 512, 1024}. */
+int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
+                        const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
+                        float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
+                        void* stream);
+
 /* ---- K3b: per-bag head ------------------------------------------------------------------
  * z = M Wf^T + bf (logits), p = sigmoid(z).  model/aggregator.py:128-131,200 (eval: the
  * Dropout(0.25) is the identity).  Wf: [C, L]; z, p: [B, C]; C <= 32. */
@@ -79,6 +93,10 @@ int mil_bce_fwd_bwd(const float* p, const float* y, float* loss_sum, float* dz, 
  * dM = dz Wf, dWf = dz^T M, dbf = sum_b dz, cdot[b] = M[b] . dM[b]. */
 int mil_head_bwd(const float* dz_or_dp, const float* p, const float* M, const float* Wf, float* dM,
                  float* dWf, float* dbf, float* cdot, int B, int L, int C, void* stream);
+
+/* Parameter half of mil_head_bwd alone (dWf = dz^T M, dbf = sum_b dz), for use after the fused tail. */
+int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
+                        void* stream);
 
 /* out[b] = a[b] . c[b] for two [B, L] matrices (cdot = M . dM when dM comes from autograd). */
 int mil_rowdot(const float* a, const float* c, float* out, int B, int L, void* stream);

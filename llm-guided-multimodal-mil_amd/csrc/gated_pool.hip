@@ -15,6 +15,9 @@
 // k permutation: lane (r, h) reads 4 consecutive k = 8t+4h..+3 and feeds element j to the j-th of
 // 4 MFMAs, so MFMA (t, j) contracts k in {8t+j, 8t+4+j}: A and B use the same map, the sum over a
 // slice is complete.
+#ifndef GF_VARIANT
+#define GF_VARIANT 0
+#endif
 #define GF_TM 128
 #define GF_BK 32
 #define GF_S 36
@@ -35,28 +38,27 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
     const int row0 = blockIdx.x * GF_TM;
 
     const int srow = tid >> 3, sch = tid & 7;   // staging: row (+64 i), 16-byte chunk within the 32-k slice
-    f32x4 rx[2], rw[6];
-
-    auto gload = [&](int k0) {
+    // 8 staging pieces per slice: pieces 0,1 = x rows srow, srow+64; pieces 2..7 = gate-weight rows
+    // srow + 64 (i-2) (0..191 = Wv, 192..383 = Wu).  Rows past R are clamped (their results are never stored),
+    // so the loop body is branch-free and can be interleaved with the MFMAs.
+    f32x4 rs[8];
+    const float* gsrc[8];
+    float* ldst[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gr = row0 + srow + 64 * i;
-            rx[i] = gr < R ? *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + k0 + 4 * sch) : f32x4{0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) {
+        if (i < 2) {
+            const int gr = min(row0 + srow + 64 * i, R - 1);
+            gsrc[i] = x + (size_t)gr * L + 4 * sch;
+            ldst[i] = xs + (srow + 64 * i) * GF_S + 4 * sch;
+        } else {
+            const int wrow = srow + 64 * (i - 2);
+            gsrc[i] = ((i - 2) < 3 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 4 * sch;
+            ldst[i] = ws + wrow * GF_S + 4 * sch;
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int wrow = srow + 64 * i;     // 0..383; rows 0..191 = Wv, 192..383 = Wu (i < 3 <=> Wv)
-            const float* base = (i < 3) ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L;
-            rw[i] = *reinterpret_cast<const f32x4*>(base + k0 + 4 * sch);
-        }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<f32x4*>(xs + (buf * GF_TM + srow + 64 * i) * GF_S + 4 * sch) = rx[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            *reinterpret_cast<f32x4*>(ws + (buf * GF_NG + srow + 64 * i) * GF_S + 4 * sch) = rw[i];
+    }
+    auto gload_piece = [&](int i, int k0) { rs[i] = *reinterpret_cast<const f32x4*>(gsrc[i] + k0); };
+    auto swrite_piece = [&](int i, int buf) {
+        *reinterpret_cast<f32x4*>(ldst[i] + buf * (i < 2 ? GF_TM : GF_NG) * GF_S) = rs[i];
     };
 
     f32x16 acc[3][2];
@@ -68,32 +70,55 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
             for (int i = 0; i < 16; ++i) acc[c][u][i] = 0.f;
 
     const int nslice = L / GF_BK;
-    gload(0);
-    swrite(0);
+    // Pipeline: registers hold slice s+1 (loaded one iteration ago); during iteration s they are written to
+    // the other LDS buffer (free since the barrier that ended iteration s-1) and reloaded with slice s+2,
+    // one piece per MFMA group.  One barrier per slice, nothing drains in front of it.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gload_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) swrite_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gload_piece(i, min(1, nslice - 1) * GF_BK);
     __syncthreads();
     for (int s = 0; s < nslice; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nslice) gload((s + 1) * GF_BK);
+        const int k2 = min(s + 2, nslice - 1) * GF_BK;     // tail iterations reload the last slice (harmless)
         const float* xa = xs + (buf * GF_TM + 32 * wr + r) * GF_S + 4 * h;
         const float* wb = ws + (buf * GF_NG + 32 * 3 * wc + r) * GF_S + 4 * h;
+        f32x4 a[2], b[2][3][2];
+        // fragment piece p (0..6) of k-group t into register set q: p == 0 -> A, else B tile (c, u)
+        auto frag_piece = [&](int t, int q, int p) {
+            if (p == 0) {
+                a[q] = *reinterpret_cast<const f32x4*>(xa + 8 * t);
+            } else {
+                const int c = (p - 1) >> 1, u = (p - 1) & 1;
+                b[q][c][u] = *reinterpret_cast<const f32x4*>(wb + (u * 192 + 32 * c) * GF_S + 8 * t);
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < 7; ++p) frag_piece(0, 0, p);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 8 * t);
-            f32x4 b[3][2];
+            const int q = t & 1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    b[c][u] = *reinterpret_cast<const f32x4*>(wb + (u * 192 + 32 * c) * GF_S + 8 * t);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const int g = 4 * t + j;
+                if (g >= 4 && g < 12) {          // staging piece g-4: LDS write of slice s+1, reload with slice s+2
+                    swrite_piece(g - 4, buf ^ 1);
+                    gload_piece(g - 4, k2);
+                }
+                if (t < 3) {                      // prefetch the next k-group's fragments, 2 reads per MFMA group
+                    frag_piece(t + 1, q ^ 1, 2 * j);
+                    if (2 * j + 1 < 7) frag_piece(t + 1, q ^ 1, 2 * j + 1);
+                }
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
-                        acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[c][u][j], acc[c][u], 0, 0, 0);
+                        acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b[q][c][u][j], acc[c][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (s + 1 < nslice) swrite(buf ^ 1);
         __syncthreads();
     }
 
@@ -107,10 +132,18 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
         const float bvd = bv[d], bud = bu[d], wd = wvec[d];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+#if GF_VARIANT == 2 || GF_VARIANT == 4
+            const float v = acc[c][0][i] + bvd;
+            const float u = acc[c][1][i] + bud;
+#elif GF_VARIANT == 1 || GF_VARIANT == 3
+            const float v = fast_tanh(acc[c][0][i] + bvd);
+            const float u = fast_sigmoid(acc[c][1][i] + bud);
+#else
             const float v = tanhf(acc[c][0][i] + bvd);
             const float u = 1.0f / (1.0f + expf(-(acc[c][1][i] + bud)));
+#endif
             part[i] += wd * v * u;
-            if (gates != nullptr) {
+            if (gates != nullptr && GF_VARIANT != 3 && GF_VARIANT != 4) {
                 const int gr = row0 + 32 * wr + mfma32_row(i, h);
                 if (gr < R) {
                     gates[(size_t)gr * GF_NG + d] = v;
@@ -161,18 +194,21 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
     f32x4 acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0, 0, 0, 0};
+    // Rows past the tile end are clamped to its last row and carry weight 0 (p_lds is 0 there): the
+    // loop is branch-free, so all 8 x NQ 16-byte loads of a wave are in flight together.
+    f32x4 v[MIL_POOL_TILE / 4][NQ];
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const int rr = wave + 4 * i;
-        if (rr < nrows) {
-            const float p = p_lds[rr];
-            const float* xr = x + (size_t)(row0 + rr) * L + 4 * lane;
+        const int rr = min(wave + 4 * i, nrows - 1);
+        const float* xr = x + (size_t)(row0 + rr) * L + 4 * lane;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 256 * q);
-                acc[q] += p * v;
-            }
-        }
+        for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+        const float p = p_lds[wave + 4 * i];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] += p * v[i][q];
     }
     if (wave > 0) {
 #pragma unroll
@@ -270,20 +306,28 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
 #pragma unroll
     for (int q = 0; q < NQ; ++q) g[q] = *reinterpret_cast<const f32x4*>(dM + (size_t)bag * L + 256 * q + 4 * lane);
     const float lse_b = lse[bag], c_b = cdot[bag];
+    // branch-free loads (rows past the tile end clamp to its last row), guarded stores
+    f32x4 v[MIL_POOL_TILE / 4][NQ];
+    float sc[MIL_POOL_TILE / 4];
+#pragma unroll
+    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+        const size_t row = (size_t)(row0 + min(wave + 4 * i, nrows - 1));
+        const float* xr = x + row * L + 4 * lane;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+        sc[i] = scores[row];
+    }
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
         const int rr = wave + 4 * i;
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            dot += v[i][q][0] * g[q][0] + v[i][q][1] * g[q][1] + v[i][q][2] * g[q][2] + v[i][q][3] * g[q][3];
+        dot = wave_allsum(dot);
+        const float a = expf(sc[i] - lse_b);
         if (rr < nrows) {
             const size_t row = (size_t)(row0 + rr);
-            const float* xr = x + row * L + 4 * lane;
-            float dot = 0.f;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 256 * q);
-                dot += v[0] * g[q][0] + v[1] * g[q][1] + v[2] * g[q][2] + v[3] * g[q][3];
-            }
-            dot = wave_allsum(dot);
-            const float a = expf(scores[row] - lse_b);
             if (lane == 0) ds[row] = a * (dot - c_b);
             if (dx != nullptr) {
                 float* dr = dx + row * L + 4 * lane;
@@ -313,7 +357,16 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int bid = blockIdx.x;
+    // XCD-aware order: hardware deals workgroup ids round-robin over the 8 XCDs (id % 8 shares an L2).
+    // The 3*NJ workgroups of one row chunk re-read the same x / gate rows, so give them consecutive
+    // slots of ONE XCD: logical = (id % 8) * ceil-share + id / 8 (bijective form for any grid size).
+    int bid = blockIdx.x;
+#if !defined(GB_NOXCD)
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+#endif
     const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
     const int j0 = jt * 128;
     const int rbeg = s * KC, rend = min(R, rbeg + KC);
@@ -324,49 +377,42 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
     const int arow = tid >> 4, ad4 = tid & 15;    // gates: rows arow + 16i (i < 2), d = 64m + 4*ad4
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
     f32x4 rx[4], rv[2], ru[2];
-    float rds[2];
+    float rds[2], rmask[2];      // raw ds value and its validity mask (applied at use, never at load)
     f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
     float acc_ds = 0.f;
 
-    auto gload = [&](int rs) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr = rs + xrow + 8 * i;
-            rx[i] = gr < rend ? *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4) : f32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gr = rs + arow + 16 * i;
-            if (gr < rend) {
-                const float* gp = gates + (size_t)gr * GF_NG + 64 * m + 4 * ad4;
-                rv[i] = *reinterpret_cast<const f32x4*>(gp);
-                ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
-                rds[i] = ds[gr];
-            } else {
-                rv[i] = f32x4{0, 0, 0, 0};
-                ru[i] = f32x4{0, 0, 0, 0};
-                rds[i] = 0.f;
-            }
-        }
+    // Branch-free staging pieces (rows past the chunk end are clamped to its last row and get ds = 0, so they
+    // add nothing): the loop body is one basic block and every piece sits between two MFMA groups.
+    auto xload = [&](int i, int rs) {
+        const int gr = min(rs + xrow + 8 * i, rend - 1);
+        rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4);
     };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = rx[i];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x4 v = rv[i], u = ru[i];
-            const f32x4 dsw = rds[i] * w4;
-            const f32x4 pv = dsw * u * (1.0f - v * v);          // ds w U (1 - V^2)
-            const f32x4 pu = dsw * v * u * (1.0f - u);          // ds w V U (1 - U)
-            float* dst = ab + (buf * GB_BKR + arow + 16 * i) * 128 + 4 * ad4;
-            *reinterpret_cast<f32x4*>(dst) = pv;
-            *reinterpret_cast<f32x4*>(dst + 64) = pu;
-            acc_bv += pv;
-            acc_bu += pu;
-            acc_w += rds[i] * v * u;
-            if (ad4 == 0) acc_ds += rds[i];
-        }
+    auto xwrite = [&](int i, int buf) {
+        *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = rx[i];
+    };
+    auto aload = [&](int i, int rs, bool live) {
+        const int gr = rs + arow + 16 * i;
+        const int gc = min(gr, rend - 1);
+        const float* gp = gates + (size_t)gc * GF_NG + 64 * m + 4 * ad4;
+        rv[i] = *reinterpret_cast<const f32x4*>(gp);
+        ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
+        rds[i] = ds[gc];                                  // unconditional load: keeps the body branch-free
+        rmask[i] = (live && gr < rend) ? 1.f : 0.f;
+    };
+    auto awrite_v = [&](int i, int buf) {           // dPreV = ds w U (1 - V^2)
+        const f32x4 v = rv[i], u = ru[i];
+        const f32x4 pv = (rds[i] * rmask[i] * w4) * u * (1.0f - v * v);
+        *reinterpret_cast<f32x4*>(ab + (buf * GB_BKR + arow + 16 * i) * 128 + 4 * ad4) = pv;
+        acc_bv += pv;
+    };
+    auto awrite_u = [&](int i, int buf) {           // dPreU = ds w V U (1 - U)
+        const f32x4 v = rv[i], u = ru[i];
+        const float dsv = rds[i] * rmask[i];
+        const f32x4 pu = (dsv * w4) * v * u * (1.0f - u);
+        *reinterpret_cast<f32x4*>(ab + (buf * GB_BKR + arow + 16 * i) * 128 + 64 + 4 * ad4) = pu;
+        acc_bu += pu;
+        acc_w += dsv * v * u;
+        if (ad4 == 0) acc_ds += dsv;
     };
 
     f32x16 acc[2][2];
@@ -378,25 +424,49 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     if (nslice > 0) {
-        gload(rbeg);
-        swrite(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xload(i, rbeg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aload(i, rbeg, true);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xwrite(i, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { awrite_v(i, 0); awrite_u(i, 0); }
+        const int rs1 = rbeg + min(1, nslice - 1) * GB_BKR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xload(i, rs1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aload(i, rs1, nslice > 1);   // a single-slice chunk must not count slice 0 twice
     }
     __syncthreads();
     for (int sl = 0; sl < nslice; ++sl) {
         const int buf = sl & 1;
-        if (sl + 1 < nslice) gload(rbeg + (sl + 1) * GB_BKR);
+        // registers hold slice sl+1 (or, in the last iteration, a dead copy with ds forced to 0)
+        const bool live2 = sl + 2 < nslice;
+        const int rs2 = rbeg + min(sl + 2, nslice - 1) * GB_BKR;
         const float* ap = ab + buf * GB_BKR * 128 + h * 128 + 64 * wi + r;
         const float* bp = xb + buf * GB_BKR * 128 + h * 128 + 64 * wj + r;
+        float fa[2][2], fb[2][2];
+        fa[0][0] = ap[0]; fa[0][1] = ap[32]; fb[0][0] = bp[0]; fb[0][1] = bp[32];
 #pragma unroll
         for (int ks = 0; ks < GB_BKR / 2; ++ks) {
-            const float a0 = ap[ks * 256], a1 = ap[ks * 256 + 32];
-            const float b0 = bp[ks * 256], b1 = bp[ks * 256 + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const int q = ks & 1;
+            if (ks + 1 < GB_BKR / 2) {
+                fa[q ^ 1][0] = ap[(ks + 1) * 256]; fa[q ^ 1][1] = ap[(ks + 1) * 256 + 32];
+                fb[q ^ 1][0] = bp[(ks + 1) * 256]; fb[q ^ 1][1] = bp[(ks + 1) * 256 + 32];
+            }
+            // one staging piece per k-step: LDS image of slice sl+1, then reload the registers with slice sl+2
+            if (ks >= 1 && ks <= 4) { xwrite(ks - 1, buf ^ 1); xload(ks - 1, rs2); }
+            if (ks == 5) awrite_v(0, buf ^ 1);
+            if (ks == 6) { awrite_u(0, buf ^ 1); aload(0, rs2, live2); }
+            if (ks == 7) awrite_v(1, buf ^ 1);
+            if (ks == 8) { awrite_u(1, buf ^ 1); aload(1, rs2, live2); }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (sl + 1 < nslice) swrite(buf ^ 1);
         __syncthreads();
     }
 
@@ -407,7 +477,12 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
+            for (int i = 0; i < 16; ++i) {
+#if defined(GB_VARIANT) && GB_VARIANT == 1
+                if (acc[a][b][i] == 12345.678f)
+#endif
+                pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
+            }
 
     // bias / w partials (only the j-tile-0 workgroups publish them)
     if (jt == 0) {
@@ -493,21 +568,34 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
     return MIL_OK;
 }
 
+static int launch_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
+                               float* partials, hipStream_t st) {
+    if (T <= 0) return MIL_OK;
+    switch (L / 256) {
+        case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+        case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+        case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+        default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+    }
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
+                                     float* partials, void* stream) {
+    if (!x || !scores || !tile_map || !partials) return MIL_EINVAL;
+    if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
+    return launch_pool_partial(x, scores, tile_map, T, L, partials, (hipStream_t)stream);
+}
+
 extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_map,
                                  const int32_t* bag_tile_off, int T, int B, int L, float* partials, float* M,
                                  float* lse, void* stream) {
     if (!x || !scores || !tile_map || !bag_tile_off || !partials || !M || !lse) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || B < 0 || T < 0) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (T > 0) {
-        switch (L / 256) {
-            case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-            case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-            case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-            default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-        }
-        MIL_CHECK_LAUNCH();
-    }
+    const int rc = launch_pool_partial(x, scores, tile_map, T, L, partials, st);
+    if (rc != MIL_OK) return rc;
     if (B > 0) {
         hipLaunchKernelGGL(k_pool_merge, dim3(B), dim3(256), 0, st, partials, bag_tile_off, M, lse, L, T);
         MIL_CHECK_LAUNCH();

@@ -114,6 +114,121 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const f
     param[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused per-bag tail of the forward and head of the backward (one workgroup per bag):
+//   merge the attention-pool tile partials -> M, lse        (ABMIL.py:57-59)
+//   z = M Wf^T + bf, p = sigmoid(z)                         (aggregator.py:128-131,200)
+//   if labels: loss += BCE(p, y) * scale, dz = (p - y) * scale, dM = dz Wf, cdot = M . dM
+// Thread (g, c4): column float4 c4 < L/4, tile group g < 256/(L/4); tile loads are unrolled 8 deep
+// so one workgroup keeps ~8 x 4 KiB in flight (the kernel is latency-bound: B workgroups only).
+__global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict__ partials,
+                                                         const int32_t* __restrict__ bag_tile_off, int T, int L,
+                                                         const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                         int C, const float* __restrict__ y, float scale,
+                                                         float* __restrict__ M, float* __restrict__ lse,
+                                                         float* __restrict__ z, float* __restrict__ p,
+                                                         float* __restrict__ loss_sum, float* __restrict__ dz,
+                                                         float* __restrict__ dM, float* __restrict__ cdot) {
+    __shared__ float red[4];
+    __shared__ float scale_lds[1024];
+    __shared__ __attribute__((aligned(16))) float m_lds[1024];
+    __shared__ __attribute__((aligned(16))) float part_lds[4 * 1024];
+    __shared__ float dzs[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
+    const float* ml = partials + (size_t)T * L;
+    // global max / normaliser over the bag's tiles
+    float m = -INFINITY;
+    for (int t = t0 + tid; t < t1; t += 256) m = fmaxf(m, ml[2 * t]);
+    m = wave_allmax(m);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int t = t0 + tid; t < t1; t += 256) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
+    l = block_allsum_256(l, red);
+    const float inv = nt > 0 ? 1.0f / l : 0.f;
+
+    const int L4 = L >> 2, NG = 256 / L4;          // L in {256, 512, 1024} -> NG in {4, 2, 1}
+    const int c4 = tid % L4, g = tid / L4;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int tb = 0; tb < nt; tb += 1024) {
+        __syncthreads();
+        for (int k = tid; k < 1024; k += 256) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
+        __syncthreads();
+        const int cnt = min(1024, nt - tb);
+        int k = g;
+        for (; k + 7 * NG < cnt; k += 8 * NG) {
+            f32x4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + tb + k + e * NG) * L + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += scale_lds[k + e * NG] * v[e];
+        }
+        for (; k < cnt; k += NG)
+            acc += scale_lds[k] * *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + tb + k) * L + 4 * c4);
+    }
+    *reinterpret_cast<f32x4*>(part_lds + g * L + 4 * c4) = acc;
+    __syncthreads();
+    for (int j = tid; j < L; j += 256) {
+        float v = 0.f;
+        for (int gg = 0; gg < NG; ++gg) v += part_lds[gg * L + j];
+        v *= inv;
+        m_lds[j] = v;
+        M[(size_t)b * L + j] = v;
+    }
+    if (tid == 0) lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
+    __syncthreads();
+    // head
+    float lossacc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+        for (int j = tid; j < L; j += 256) v += m_lds[j] * Wf[(size_t)c * L + j];
+        v = block_allsum_256(v, red);
+        if (tid == 0) {
+            const float zz = v + bf[c];
+            const float pp = 1.0f / (1.0f + expf(-zz));
+            z[b * C + c] = zz;
+            p[b * C + c] = pp;
+            if (y != nullptr) {
+                const float yy = y[b * C + c];
+                lossacc += -(yy * fmaxf(logf(pp), -100.0f) + (1.0f - yy) * fmaxf(logf(1.0f - pp), -100.0f));
+                const float d = (pp - yy) * scale;
+                dz[b * C + c] = d;
+                dzs[c] = d;
+            }
+        }
+    }
+    if (y == nullptr) return;
+    if (tid == 0) atomicAdd(loss_sum, lossacc * scale);
+    __syncthreads();
+    float dot = 0.f;
+    for (int j = tid; j < L; j += 256) {
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += dzs[c] * Wf[(size_t)c * L + j];
+        dM[(size_t)b * L + j] = v;
+        dot += v * m_lds[j];
+    }
+    dot = block_allsum_256(dot, red);
+    if (tid == 0) cdot[b] = dot;
+}
+
+extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
+                                   const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
+                                   float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
+                                   void* stream) {
+    if (!partials || !bag_tile_off || !Wf || !bf || !M || !lse || !z || !p) return MIL_EINVAL;
+    if (y && (!loss_sum || !dz || !dM || !cdot)) return MIL_EINVAL;
+    if (!(L == 256 || L == 512 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_pool_merge_head, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
+                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_head_fwd(const float* M, const float* Wf, const float* bf, float* z, float* p, int B, int L, int C,
                             void* stream) {
     if (!M || !Wf || !bf || !z || !p) return MIL_EINVAL;
@@ -142,6 +257,16 @@ extern "C" int mil_head_bwd(const float* dz_or_dp, const float* p, const float* 
     MIL_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_head_bwd_params, dim3((C * L + C + 255) / 256), dim3(256), 0, st, dz_or_dp, p, M, dWf, dbf, B, L,
                        C);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
+                                   void* stream) {
+    if (!dz || !M || !dWf || !dbf) return MIL_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C > 32) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_head_bwd_params, dim3((C * L + C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz,
+                       (const float*)nullptr, M, dWf, dbf, B, L, C);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

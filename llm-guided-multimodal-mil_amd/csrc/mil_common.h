@@ -38,6 +38,10 @@ __device__ __forceinline__ float half_allsum(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// exp2-based forms: v_exp_f32 + v_rcp_f32, abs error ~1e-7 on outputs in [-1, 1].
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
 // Row of a 32x32 MFMA accumulator register: C/D layout col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (dtype independent on gfx950).
 __device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }

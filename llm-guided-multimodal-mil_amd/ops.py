@@ -65,6 +65,45 @@ def attn_pool_fwd(x, scores, layout: BagLayout):
     return M, lse
 
 
+def attn_pool_partial(x, scores, layout: BagLayout):
+    """Tile partials only ([T*L] weighted sums then [T*2] (max, sum) pairs); merged by pool_merge_head."""
+    x = _f32c(x, "x")
+    R, L = x.shape
+    if R != layout.R:
+        raise _lib.MilHipError(f"attn_pool_partial: x has {R} rows but the bag layout covers {layout.R}")
+    partials = torch.empty(layout.T * (L + 2), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_partial(_p(x), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials), _stream())
+    _lib.check(rc, "mil_attn_pool_partial")
+    return partials
+
+
+def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0, loss_sum=None,
+                    dM=None):
+    """Fused per-bag tail: returns dict(M, lse, logits, prob[, dz, dM, cdot]); with labels it also adds the
+    BCE loss into loss_sum and produces the head's backward inputs for the pool."""
+    B, C, dev = layout.B, Wf.shape[0], partials.device
+    out = dict(M=torch.empty((B, L), device=dev), lse=torch.empty(B, device=dev),
+               logits=torch.empty((B, C), device=dev), prob=torch.empty((B, C), device=dev))
+    if y is not None:
+        out.update(dz=torch.empty((B, C), device=dev), dM=dM if dM is not None else torch.empty((B, L), device=dev),
+                   cdot=torch.empty(B, device=dev))
+        if loss_sum is None:
+            loss_sum = torch.zeros(1, device=dev)
+        out["loss_sum"] = loss_sum
+    rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
+                                        _p(_f32c(bf, "bf")), C, _p(y), float(scale), _p(out["M"]), _p(out["lse"]),
+                                        _p(out["logits"]), _p(out["prob"]), _p(loss_sum), _p(out.get("dz")),
+                                        _p(out.get("dM")), _p(out.get("cdot")), _stream())
+    _lib.check(rc, "mil_pool_merge_head")
+    return out
+
+
+def head_bwd_params(dz, M, dWf, dbf):
+    B, L = M.shape
+    rc = _lib.lib().mil_head_bwd_params(_p(dz), _p(M), _p(dWf), _p(dbf), B, L, dz.shape[1], _stream())
+    _lib.check(rc, "mil_head_bwd_params")
+
+
 def head_fwd(M, Wf, bf):
     """logits z [B, C], p = sigmoid(z).  aggregator.py:128-131,200 (eval)."""
     M = _f32c(M, "M")

@@ -79,34 +79,35 @@ class ImageOnlyTrainer:
             dist.broadcast(self.fp.flat, src=0)
 
     # ------------------------------------------------------------------ pieces (also timed one by one by bench.py)
-    def forward(self, x: torch.Tensor, layout: BagLayout, save_gates: bool = True):
+    def _gate_fwd(self, x, save_gates=True):
         fp = self.fp
-        scores, gates = ops.gate_scores_fwd(
+        return ops.gate_scores_fwd(
             x, fp.p("aggregator.attention_V.0.weight"), fp.p("aggregator.attention_V.0.bias"),
             fp.p("aggregator.attention_U.0.weight"), fp.p("aggregator.attention_U.0.bias"),
             fp.p("aggregator.attention_weights.weight").view(-1), fp.p("aggregator.attention_weights.bias"),
             save_gates=save_gates)
-        M, lse = ops.attn_pool_fwd(x, scores, layout)
-        z, prob = ops.head_fwd(M, fp.p("fc.1.weight"), fp.p("fc.1.bias"))
-        self.last = dict(x=x, layout=layout, scores=scores, gates=gates, M=M, lse=lse, logits=z, prob=prob)
-        return prob, z
 
-    def backward(self, y: torch.Tensor, global_bags: Optional[int] = None):
-        """BCE(mean over the GLOBAL batch) + gradients into the flat grad buffer (overwrites it)."""
+    def forward(self, x: torch.Tensor, layout: BagLayout, y: Optional[torch.Tensor] = None,
+                global_bags: Optional[int] = None):
+        """Inference when y is None; with labels the fused tail also produces loss, dz, dM, cdot."""
+        fp = self.fp
+        scores, gates = self._gate_fwd(x, save_gates=y is not None)
+        partials = ops.attn_pool_partial(x, scores, layout)
+        scale = 1.0
+        if y is not None:
+            nb = global_bags if global_bags is not None else layout.B * self.world
+            scale = 1.0 / (nb * fp.p("fc.1.weight").shape[0])
+            self.loss_sum.zero_()
+        t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale,
+                                self.loss_sum if y is not None else None)
+        self.last = dict(x=x, layout=layout, scores=scores, gates=gates, **t)
+        return t["prob"], t["logits"]
+
+    def backward(self):
+        """Gradients of the (globally normalised) BCE loss into the flat grad buffer (overwrites it)."""
         c, fp = self.last, self.fp
-        B, C = c["prob"].shape
-        nb = global_bags if global_bags is not None else B * self.world
-        self.loss_sum.zero_()
-        _, dz = ops.bce_fwd_bwd(c["prob"], y, 1.0 / (nb * C), self.loss_sum)
-        Wf = fp.p("fc.1.weight")
-        B_, L = c["M"].shape
-        lib = ops._lib.lib()
-        dM = torch.empty_like(c["M"])
-        cdot = torch.empty(B_, device=self.device, dtype=torch.float32)
-        rc = lib.mil_head_bwd(ops._p(dz), None, ops._p(c["M"]), ops._p(Wf), ops._p(dM), ops._p(fp.g("fc.1.weight")),
-                              ops._p(fp.g("fc.1.bias")), ops._p(cdot), B_, L, C, ops._stream())
-        ops._lib.check(rc, "mil_head_bwd")
-        ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], dM, cdot, c["layout"], want_dx=False)
+        ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"))
+        ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
         self._ws = ops.gate_bwd_params(
             c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
             fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
@@ -126,7 +127,7 @@ class ImageOnlyTrainer:
                       self.betas, self.eps, self.wd, 1.0)
 
     def train_step(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
-        prob, z = self.forward(x, layout, save_gates=True)
-        self.backward(y)
+        prob, z = self.forward(x, layout, y)
+        self.backward()
         self.reduce_and_step()
         return self.loss_sum, prob
