@@ -234,61 +234,60 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
 }
 
 // Merge the tile partials of one bag: M = sum_t e^{m_t - m} acc_t / sum_t e^{m_t - m} l_t.
+// grid = (B, L / 128): workgroup (b, cb) owns 128 columns of bag b; thread (g, c4): float4 column c4 < 32,
+// tile group g < 8, tile loads unrolled 4 deep (the kernel is latency-bound, so many loads in flight
+// and 4x more workgroups than bags).
 __global__ __launch_bounds__(256) void k_pool_merge(const float* __restrict__ partials,
                                                     const int32_t* __restrict__ bag_tile_off, float* __restrict__ M,
                                                     float* __restrict__ lse, int L, int T) {
-    __shared__ float red[256];
-    __shared__ float scale_lds[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1];
+    __shared__ float red[4];
+    __shared__ float scale_lds[1024];
+    __shared__ __attribute__((aligned(16))) float part_lds[8 * 128];
+    const int b = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x;
+    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
     const float* ml = partials + (size_t)T * L;
     float m = -INFINITY;
     for (int t = t0 + tid; t < t1; t += 256) m = fmaxf(m, ml[2 * t]);
-    red[tid] = m;
+    m = wave_allmax(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-        __syncthreads();
-    }
-    m = red[0];
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float l = 0.f;
     for (int t = t0 + tid; t < t1; t += 256) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
-    red[tid] = l;
+    l = wave_allsum(l);
+    if ((tid & 63) == 0) red[tid >> 6] = l;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+    l = red[0] + red[1] + red[2] + red[3];
+    const float inv = nt > 0 ? 1.0f / l : 0.f;
+
+    const int c4 = tid & 31, g = tid >> 5;
+    const float* base = partials + 128 * cb + 4 * c4;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int tb = 0; tb < nt; tb += 1024) {
         __syncthreads();
-    }
-    l = red[0];
-    const float inv = (t1 > t0) ? 1.0f / l : 0.f;
-    float accum[8];   // L <= 2048 columns: 8 per thread
-    const int ncol = (L + 255) / 256;
-    for (int c = 0; c < 8; ++c) accum[c] = 0.f;
-    for (int tb = t0; tb < t1; tb += 256) {
+        for (int k = tid; k < 1024; k += 256) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
         __syncthreads();
-        const int t = tb + tid;
-        scale_lds[tid] = (t < t1) ? expf(ml[2 * t] - m) : 0.f;
-        __syncthreads();
-        const int cnt = min(256, t1 - tb);
-        for (int k = 0; k < cnt; ++k) {
-            const float sc = scale_lds[k];
-            const float* pr = partials + (size_t)(tb + k) * L;
+        const int cnt = min(1024, nt - tb);
+        int k = g;
+        for (; k + 24 < cnt; k += 32) {
+            f32x4 v[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < ncol) {
-                    const int col = tid + 256 * c;
-                    if (col < L) accum[c] += sc * pr[col];
-                }
-        }
-    }
+            for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const f32x4*>(base + (size_t)(t0 + tb + k + 8 * e) * L);
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-        if (c < ncol) {
-            const int col = tid + 256 * c;
-            if (col < L) M[(size_t)b * L + col] = accum[c] * inv;
+            for (int e = 0; e < 4; ++e) acc += scale_lds[k + 8 * e] * v[e];
         }
-    if (tid == 0) lse[b] = (t1 > t0) ? m + logf(l) : -INFINITY;
+        for (; k < cnt; k += 8) acc += scale_lds[k] * *reinterpret_cast<const f32x4*>(base + (size_t)(t0 + tb + k) * L);
+    }
+    *reinterpret_cast<f32x4*>(part_lds + g * 128 + 4 * c4) = acc;
+    __syncthreads();
+    if (tid < 128) {
+        float v = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) v += part_lds[gg * 128 + tid];
+        M[(size_t)b * L + 128 * cb + tid] = v * inv;
+    }
+    if (tid == 0 && cb == 0) lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
 }
 
 // ================================================================================ K1 backward: ds (HBM-bound)
@@ -597,7 +596,7 @@ extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int3
     const int rc = launch_pool_partial(x, scores, tile_map, T, L, partials, st);
     if (rc != MIL_OK) return rc;
     if (B > 0) {
-        hipLaunchKernelGGL(k_pool_merge, dim3(B), dim3(256), 0, st, partials, bag_tile_off, M, lse, L, T);
+        hipLaunchKernelGGL(k_pool_merge, dim3(B, L / 128), dim3(256), 0, st, partials, bag_tile_off, M, lse, L, T);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;

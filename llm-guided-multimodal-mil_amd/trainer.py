@@ -131,3 +131,26 @@ class ImageOnlyTrainer:
         self.backward()
         self.reduce_and_step()
         return self.loss_sum, prob
+
+    # ------------------------------------------------------------------ hipGraph replay of the launch-bound part
+    def capture(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
+        """Capture forward+backward (8 launches on static buffers) into one hipGraph.  ``x`` and ``y`` become
+        the static input buffers: copy new bags into them, then call ``replay_step()``.  The all-reduce and the
+        Adam launch stay eager (Adam's bias corrections are per-step host scalars)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward(x, layout, y)
+                self.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.forward(x, layout, y)
+            self.backward()
+        return self
+
+    def replay_step(self):
+        self._graph.replay()
+        self.reduce_and_step()
+        return self.loss_sum, self.last["prob"]
