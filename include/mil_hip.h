@@ -124,6 +124,25 @@ int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, con
 int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,
                        const float* Wu, int R, int L, int D, float* dx, void* stream);
 
+/* ---- K3a: generic fp32-MFMA GEMM with fused epilogue -----------------------------------------
+ * C[M,N] (+)= act(A_op[M,K] . B_op[K,N] + bias) + residual
+ *   a_mode 0: A_op[i][k] = A[i*lda + k];   a_mode 1: A_op[i][k] = A[k*lda + i]
+ *   b_mode 0: B_op[k][j] = B[j*ldb + k] (nn.Linear weight [N,K]);   b_mode 1: B_op[k][j] = B[k*ldb + j]
+ * Forms used: y = x W^T (0,0)  [fc_pathology aggregator.py:47, Attention projections sam/transformer.py:413-416,
+ * MLPBlock sam/common.py:21-26, CLIP blocks clip/model.py:171-178];  dx = dy W (0,1);  dW = dy^T x (1,1).
+ * act: 0 none, 1 tanh, 2 relu, 3 QuickGELU x*sigmoid(1.702x) (clip/model.py:162-164).  bias [N] / residual
+ * [M, ldr] may be NULL.  k-contiguous operands need K % 32 == 0; all leading dimensions % 4 == 0.
+ * The (1,1) form splits K across workgroups when a workspace of mil_gemm_workspace_floats() floats is
+ * given (bias/act/residual must then be unset) and reduces the partials in a second launch. */
+size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
+int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+             int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
+             int accumulate, float* workspace, size_t workspace_floats, void* stream);
+/* out[j] (+)= sum_i Y[i][j]  (bias gradients). */
+int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, void* stream);
+/* dpre = dy * act'(y) from the post-activation output y (act 0 none, 1 tanh, 2 relu). */
+int mil_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, void* stream);
+
 /* ---- optimizer --------------------------------------------------------------------------
  * torch.optim.Adam step with L2 weight decay folded into the gradient (train_ddp.py:115-118)
  * over a flat fp32 buffer; grad is multiplied by grad_scale first (1/world after all-reduce). */

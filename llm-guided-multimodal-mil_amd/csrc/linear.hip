@@ -1,0 +1,294 @@
+// K3a: generic fp32-MFMA GEMM with fused epilogue, used for every dense projection of the path:
+//   fc_pathology / fc_CI2* (model/aggregator.py:44-68), the q/k/v/out projections and MLP of the SAM
+//   two-way transformer (model/sam/transformer.py:413-416, common.py:21-26), the CLIP text blocks
+//   (clip/model.py:171-178) and their backward products.
+//
+//   C[M,N] (+)= epilogue( A_op[M,K] . B_op[K,N] )
+//     a_mode 0: A_op[i][k] = A[i*lda + k]   (row-major activations)
+//     a_mode 1: A_op[i][k] = A[k*lda + i]   (transposed use: dW = dY^T X)
+//     b_mode 0: B_op[k][j] = B[j*ldb + k]   (nn.Linear weight [N, K]:  y = x W^T)
+//     b_mode 1: B_op[k][j] = B[k*ldb + j]   (dx = dy W,  dW = dY^T X)
+//   instantiated: NT (0,0), NN (0,1), TN (1,1).
+//
+// Workgroup 256 threads = 4 waves, tile 128 x 128 x 32, wave (wi, wj) owns 64 x 64 = 2 x 2 MFMA
+// 32x32x2 f32 tiles.  k-contiguous operands live in LDS as [128][36] and are read with ds_read_b128
+// (lane (r, h) takes k = 8t+4h..+3, one element per MFMA of the group); k-major operands as [32][128]
+// read with ds_read_b32 at row 8t+4h+jj: both use the same k order, so modes mix freely.
+// Staging is branch-free (indices clamped, out-of-range k zeroed by a mask applied at LDS-write
+// time) and issued as 8 pieces between MFMA groups; registers hold the slice after next.
+#include "mil_common.h"
+
+#define LG_BK 32
+#define LG_KS 36       // k-contiguous image row stride (words)
+
+enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_QUICKGELU = 3 };
+
+template <int MODE>
+struct OperandTile {
+    // MODE 0: [128 rows][32 k] from row-major src (k contiguous);  MODE 1: [32 k][128 cols] from k-major src.
+    const float* src[4];
+    int lds_off[4];
+    float kmask_k[4];     // MODE 1: local k row of each piece (mask is recomputed per slice)
+    f32x4 reg[4];
+    float mask[4];
+    int ld, K, tid;
+
+    __device__ __forceinline__ void init(const float* base, int ld_, int origin, int extent, int K_, int tid_) {
+        ld = ld_; K = K_; tid = tid_;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (MODE == 0) {
+                const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+                const int gr = min(origin + row, extent - 1);
+                src[i] = base + (size_t)gr * ld + 4 * ch;
+                lds_off[i] = row * LG_KS + 4 * ch;
+            } else {
+                const int kr = (tid >> 5) + 8 * i, c4 = tid & 31;
+                const int gc = min(origin + 4 * c4, max(extent - 4, 0));
+                src[i] = base + gc;
+                lds_off[i] = kr * 128 + 4 * c4;
+                kmask_k[i] = (float)kr;
+            }
+            mask[i] = 1.f;
+        }
+    }
+    __device__ __forceinline__ void load(int i, int k0) {
+        if (MODE == 0) {
+            reg[i] = *reinterpret_cast<const f32x4*>(src[i] + k0);   // K % 32 == 0 here: k0 <= K - 32
+        } else {
+            const int kr = k0 + (tid >> 5) + 8 * i;
+            reg[i] = *reinterpret_cast<const f32x4*>(src[i] + (size_t)min(kr, K - 1) * ld);
+            mask[i] = kr < K ? 1.f : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(int i, float* lds) const {
+        if (MODE == 0) *reinterpret_cast<f32x4*>(lds + lds_off[i]) = reg[i];
+        else *reinterpret_cast<f32x4*>(lds + lds_off[i]) = reg[i] * mask[i];
+    }
+};
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              float* __restrict__ C, int ldc, int M, int N, int K, int kchunk,
+                                              const float* __restrict__ bias, int act, const float* __restrict__ residual,
+                                              int ldr, int accumulate, float* __restrict__ partial) {
+    constexpr int ASZ = AMODE == 0 ? 128 * LG_KS : LG_BK * 128;
+    constexpr int BSZ = BMODE == 0 ? 128 * LG_KS : LG_BK * 128;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
+    float* as = smem;
+    float* bs = smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int nslice = (kend - kbeg + LG_BK - 1) / LG_BK;
+
+    OperandTile<AMODE> ta;
+    OperandTile<BMODE> tb;
+    // the K seen by the loaders is this block's chunk end (so the zero mask also cuts the split-K chunk)
+    ta.init(A, lda, i0, M, kend, tid);
+    tb.init(B, ldb, j0, N, kend, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    if (nslice > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ta.load(i, kbeg); tb.load(i, kbeg); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ta.store(i, as); tb.store(i, bs); }
+        const int k1 = kbeg + min(1, nslice - 1) * LG_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ta.load(i, k1); tb.load(i, k1); }
+    }
+    __syncthreads();
+    for (int s = 0; s < nslice; ++s) {
+        const int buf = s & 1;
+        const int k2 = kbeg + min(s + 2, nslice - 1) * LG_BK;
+        const float* ab = as + buf * ASZ;
+        const float* bb = bs + buf * BSZ;
+        float* an = as + (buf ^ 1) * ASZ;
+        float* bn = bs + (buf ^ 1) * BSZ;
+        f32x4 fa[2][2], fb[2][2];     // [register set][tile]
+        auto frag_a = [&](int t, int q, int a) {
+            if (AMODE == 0) {
+                fa[q][a] = *reinterpret_cast<const f32x4*>(ab + (64 * wi + 32 * a + r) * LG_KS + 8 * t + 4 * h);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fa[q][a][jj] = ab[(8 * t + 4 * h + jj) * 128 + 64 * wi + 32 * a + r];
+            }
+        };
+        auto frag_b = [&](int t, int q, int b) {
+            if (BMODE == 0) {
+                fb[q][b] = *reinterpret_cast<const f32x4*>(bb + (64 * wj + 32 * b + r) * LG_KS + 8 * t + 4 * h);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fb[q][b][jj] = bb[(8 * t + 4 * h + jj) * 128 + 64 * wj + 32 * b + r];
+            }
+        };
+        frag_a(0, 0, 0); frag_a(0, 0, 1); frag_b(0, 0, 0); frag_b(0, 0, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = t & 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int g = 4 * t + jj;
+                if (g >= 2 && g < 10) {            // staging piece g-2: next slice into LDS, reload with the slice after
+                    const int pc = g - 2;
+                    if (pc < 4) { ta.store(pc, an); ta.load(pc, k2); }
+                    else { tb.store(pc - 4, bn); tb.load(pc - 4, k2); }
+                }
+                if (t < 3) {                        // next k-group's fragments: one tile per MFMA group
+                    if (jj == 0) frag_a(t + 1, q ^ 1, 0);
+                    if (jj == 1) frag_a(t + 1, q ^ 1, 1);
+                    if (jj == 2) frag_b(t + 1, q ^ 1, 0);
+                    if (jj == 3) frag_b(t + 1, q ^ 1, 1);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0][jj], fb[q][0][jj], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0][jj], fb[q][1][jj], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1][jj], fb[q][0][jj], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1][jj], fb[q][1][jj], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column j, 16 rows per tile
+    const bool split = partial != nullptr;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + 64 * wj + 32 * b + r;
+        if (j >= N) continue;
+        const float bj = (!split && bias != nullptr) ? bias[j] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + 64 * wi + 32 * a + mfma32_row(i, h);
+                if (row >= M) continue;
+                float v = acc[a][b][i];
+                if (split) {
+                    partial[((size_t)blockIdx.z * M + row) * N + j] = v;
+                    continue;
+                }
+                v += bj;
+                if (act == ACT_TANH) v = tanhf(v);
+                else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (act == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
+                if (residual != nullptr) v += residual[(size_t)row * ldr + j];
+                float* o = C + (size_t)row * ldc + j;
+                if (accumulate) v += *o;
+                *o = v;
+            }
+    }
+}
+
+// split-K reduce: C (+)= sum_s partial[s]  (+ bias etc. are not used on the split path: weight gradients only)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int S, float* __restrict__ C,
+                                                       int ldc, int M, int N, int accumulate) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    const int row = (int)(idx / N), j = (int)(idx % N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += partial[((size_t)s * M + row) * N + j];
+    float* o = C + (size_t)row * ldc + j;
+    if (accumulate) v += *o;
+    *o = v;
+}
+
+// out[j] (+)= sum_i Y[i][j]       (bias gradients).  grid = ceil(N / 64), 256 threads = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int ldy, int M, int N, float* __restrict__ out,
+                                                int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float v = 0.f;
+    if (c < N)
+        for (int i = g; i < M; i += 4) v += Y[(size_t)i * ldy + c];
+    red[g][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (accumulate) v += out[c];
+        out[c] = v;
+    }
+}
+
+// dpre = dy * act'(y) elementwise (y = post-activation output).  n multiple of 4 not required.
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                 float* __restrict__ dpre, size_t n, int act) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float yy = y[i], g = dy[i];
+    dpre[i] = act == ACT_TANH ? g * (1.0f - yy * yy) : act == ACT_RELU ? (yy > 0.f ? g : 0.f) : g;
+}
+
+extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
+    // split-K is only used for the transposed-A form (weight gradients: K = number of rows)
+    if (a_mode != 1) return 0;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
+    const int maxS = (K + LG_BK - 1) / LG_BK;
+    if (S > maxS) S = maxS;
+    if (S < 2) return 0;
+    return (size_t)S * M * N;
+}
+
+extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                        int M, int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
+                        float* workspace, size_t workspace_floats, void* stream) {
+    if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return MIL_EINVAL;
+    if (M == 0 || N == 0) return MIL_OK;
+    if ((lda & 3) || (ldb & 3) || act < 0 || act > 3) return MIL_EINVAL;
+    if (a_mode == 0 && (K % LG_BK) != 0) return MIL_EINVAL;        // k-contiguous operands: whole slices only
+    if (b_mode == 0 && (K % LG_BK) != 0) return MIL_EINVAL;
+    if (a_mode == 1 && (M < 4 || (M & 3))) return MIL_EINVAL;      // k-major operands: 16-byte columns
+    if (b_mode == 1 && (N < 4 || (N & 3))) return MIL_EINVAL;
+    if (a_mode == 1 && b_mode == 0) return MIL_EINVAL;             // TT form is never needed
+    hipStream_t st = (hipStream_t)stream;
+    int S = 1, kchunk = K;
+    float* partial = nullptr;
+    const size_t need = mil_gemm_workspace_floats(M, N, K, a_mode);
+    if (need > 0 && workspace != nullptr && workspace_floats >= need && bias == nullptr && act == 0 && residual == nullptr) {
+        S = (int)(need / ((size_t)M * N));
+        kchunk = ((K + S - 1) / S + LG_BK - 1) / LG_BK * LG_BK;
+        S = (K + kchunk - 1) / kchunk;
+        partial = S > 1 ? workspace : nullptr;
+        if (S == 1) kchunk = K;
+    }
+    dim3 grid((N + 127) / 128, (M + 127) / 128, S);
+    if (a_mode == 0 && b_mode == 0)
+        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial);
+    else if (a_mode == 0 && b_mode == 1)
+        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial);
+    else
+        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial);
+    MIL_CHECK_LAUNCH();
+    if (partial != nullptr) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, S, C, ldc, M, N, accumulate);
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+extern "C" int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, void* stream) {
+    if (!Y || !out || M < 0 || N <= 0) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, Y, ldy, M, N, out, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, void* stream) {
+    if (!dy || !y || !dpre || act < 0 || act > 2) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n, act);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

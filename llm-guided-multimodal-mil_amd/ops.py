@@ -247,3 +247,86 @@ class _HeadSigmoid(torch.autograd.Function):
 def head_sigmoid(M, Wf, bf):
     """(p = sigmoid(fc(M)) [B, C] differentiable, logits z [B, C])."""
     return _HeadSigmoid.apply(M, Wf, bf)
+
+
+# --------------------------------------------------------------------------- generic fp32-MFMA linear (K3a)
+ACT = {"none": 0, "tanh": 1, "relu": 2, "quickgelu": 3}
+
+
+def gemm(A, a_mode: int, B, b_mode: int, M: int, N: int, K: int, out=None, bias=None, act: int = 0, residual=None,
+         accumulate: bool = False, split_k: bool = False):
+    """C[M,N] (+)= act(A_op . B_op + bias) + residual  (include/mil_hip.h: mil_gemm)."""
+    A = _f32c(A, "A")
+    B = _f32c(B, "B")
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    ws, nws = None, 0
+    if split_k:
+        nws = _lib.lib().mil_gemm_workspace_floats(M, N, K, a_mode)
+        if nws:
+            ws = torch.empty(nws, device=A.device, dtype=torch.float32)
+    rc = _lib.lib().mil_gemm(_p(A), A.stride(0), a_mode, _p(B), B.stride(0), b_mode, _p(out), out.stride(0), M, N, K,
+                             _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
+                             1 if accumulate else 0, _p(ws), nws, _stream())
+    _lib.check(rc, "mil_gemm")
+    return out
+
+
+def colsum(Y, out=None, accumulate: bool = False):
+    M, N = Y.shape
+    if out is None:
+        out = torch.empty(N, device=Y.device, dtype=torch.float32)
+    rc = _lib.lib().mil_colsum(_p(Y), Y.stride(0), M, N, _p(out), 1 if accumulate else 0, _stream())
+    _lib.check(rc, "mil_colsum")
+    return out
+
+
+def act_bwd(dy, y, act: int):
+    if act == 0:
+        return dy
+    dpre = torch.empty_like(dy)
+    rc = _lib.lib().mil_act_bwd(_p(dy), _p(y), _p(dpre), dy.numel(), act, _stream())
+    _lib.check(rc, "mil_act_bwd")
+    return dpre
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual): nn.Linear (+Tanh/ReLU) of aggregator.py:44-68, sam/transformer.py:413-416,
+    sam/common.py:21-26.  x [M, K], W [N, K]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act: int, residual):
+        x = _f32c(x, "x")
+        W = _f32c(W, "W")
+        M, K = x.shape
+        N = W.shape[0]
+        res = _f32c(residual, "residual") if residual is not None else None
+        y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res)
+        ctx.act = act
+        ctx.has_b = b is not None
+        ctx.has_res = residual is not None
+        # with a residual the saved y is not the activation output; only act == none is used with residuals
+        if ctx.has_res and act != 0:
+            raise _lib.MilHipError("linear_act: residual is only supported with act='none'")
+        ctx.save_for_backward(x, W, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        M, K = x.shape
+        N = W.shape[0]
+        dpre = act_bwd(dy, y, ctx.act)
+        dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
+        dW = gemm(dpre, 1, x, 1, N, K, M, split_k=True) if ctx.needs_input_grad[1] else None
+        db = colsum(dpre) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dres = dy if ctx.has_res else None
+        return dx, dW, db, None, dres
+
+
+def linear_act(x, W, b=None, act: str = "none", residual=None):
+    lead = x.shape[:-1]
+    y = _LinearAct.apply(x.reshape(-1, x.shape[-1]), W, b, ACT[act],
+                         residual.reshape(-1, residual.shape[-1]) if residual is not None else None)
+    return y.reshape(*lead, W.shape[0])
