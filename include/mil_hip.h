@@ -143,6 +143,54 @@ int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate
 /* dpre = dy * act'(y) from the post-activation output y (act 0 none, 1 tanh, 2 relu). */
 int mil_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, void* stream);
 
+/* ---- K2: attention cores, LayerNorm, positional encoding ---------------------------------------
+ * softmax(q k^T / sqrt(C)) v per head and per bag, AFTER the q/k/v projections and BEFORE out_proj of
+ * model/sam/transformer.py:428-450 (and clip/model.py:171-184 with causal = 1).  q [Tq, H*C], k, v [Tk, H*C]
+ * row-major; query rows [q_off[b], q_off[b+1]) attend to key rows [k_off[b], k_off[b+1]).  C in {32, 64}.
+ *
+ * "rows" form: one thread per (query row, head), keys looped (image->token attention, token self-attention,
+ * CLIP).  q_bag [Tq] = bag of each query row.  lse [Tq, H] (nullable) is saved for the backward.
+ * The backward needs <= 16 keys per bag; blk_map int32 [nblk][3] = {bag, row0, nrows <= 32} tiles the query
+ * rows, bag_blk_off [B+1]; workspace nblk * 2 * 16 * H*C floats. */
+int mil_attn_rows_fwd(const float* q, const float* k, const float* v, const int32_t* q_off,
+                      const int32_t* k_off, const int32_t* q_bag, int Tq, int H, int C, int causal, float* o,
+                      float* lse, void* stream);
+int mil_attn_rows_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                      const float* lse, const int32_t* k_off, const int32_t* blk_map,
+                      const int32_t* bag_blk_off, int nblk, int B, int H, int C, float* dq, float* dk, float* dv,
+                      float* workspace, void* stream);
+/* "pool" form: <= 16 queries per bag over many keys (token->image attention: an H-head attention pool over
+ * the patches).  tile_map int32 [ntiles][3] = {bag, key0, nkeys <= 64}, bag_tile_off [B+1].
+ * forward workspace: ntiles * 16 * (H*C + 2*H) floats; backward workspace: ntiles * 16 * H*C floats. */
+int mil_attn_pool_fwd_mh(const float* q, const float* k, const float* v, const int32_t* q_off,
+                         const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int Tmax, int H,
+                         int C, float* o, float* lse, float* workspace, void* stream);
+int mil_attn_pool_bwd_mh(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                         const float* lse, const int32_t* q_off, const int32_t* tile_map,
+                         const int32_t* bag_tile_off, int ntiles, int B, int Tmax, int H, int C, float* dq, float* dk,
+                         float* dv, float* workspace, void* stream);
+/* nn.LayerNorm over the last dim E (multiple of 64, <= 512), eps inside the sqrt.  stats [rows, 2] =
+ * (mean, rstd), saved for the backward.  backward workspace: mil_layernorm_bwd_blocks(rows) * 2 * E floats. */
+int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
+                      float* stats, void* stream);
+int mil_layernorm_bwd_blocks(int rows);
+int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* stats, int rows, int E,
+                      float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+/* out[row] = x[row] + pe[row - row_off[row_bag[row]]]: keys + key_pe (sam/transformer.py:292,304) with the
+ * table rows indexed by the position inside the bag (aggregator.py:190 passes pe[:, :N]). */
+int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,
+               float* out, void* stream);
+/* The sinusoidal table of model/aggregator.py:99-106 built on the device: pe [n, E]. */
+int mil_sinusoid_pe(float* pe, int n, int E, void* stream);
+
+/* ---- K4: CLIP text tower front/back ends (clip/model.py:339-352; the blocks in between are
+ * mil_layernorm_fwd + mil_gemm + mil_attn_rows_fwd(causal)) -------------------------------------
+ * x[s][p] = token_embedding[ids[s][p]] + positional_embedding[p];  ids int64 [nseq, ctx]. */
+int mil_embed_tokens(const int64_t* ids, const float* table, const float* pos, int nseq, int ctx, int W,
+                     float* out, void* stream);
+/* out[s] = x[s][argmax_p ids[s][p]]: the row at the EOT token (largest id), x [nseq, ctx, W]. */
+int mil_gather_eot(const int64_t* ids, const float* x, int nseq, int ctx, int W, float* out, void* stream);
+
 /* ---- optimizer --------------------------------------------------------------------------
  * torch.optim.Adam step with L2 weight decay folded into the gradient (train_ddp.py:115-118)
  * over a flat fp32 buffer; grad is multiplied by grad_scale first (1/world after all-reduce). */

@@ -38,6 +38,17 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                          _P, c_size_t, _P]),
     "mil_colsum": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     "mil_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    "mil_attn_rows_fwd": (c_int, [_P] * 6 + [c_int] * 4 + [_P, _P, _P]),
+    "mil_attn_rows_bwd": (c_int, [_P] * 9 + [c_int] * 4 + [_P] * 4 + [_P]),
+    "mil_attn_pool_fwd_mh": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
+    "mil_attn_pool_bwd_mh": (c_int, [_P] * 9 + [c_int] * 5 + [_P] * 4 + [_P]),
+    "mil_layernorm_fwd": (c_int, [_P] * 3 + [c_int, c_int, c_float, _P, _P, _P]),
+    "mil_layernorm_bwd_blocks": (c_int, [c_int]),
+    "mil_layernorm_bwd": (c_int, [_P] * 4 + [c_int, c_int] + [_P] * 4 + [_P]),
+    "mil_add_pe": (c_int, [_P] * 4 + [c_int, c_int, _P, _P]),
+    "mil_sinusoid_pe": (c_int, [_P, c_int, c_int, _P]),
+    "mil_embed_tokens": (c_int, [_P] * 3 + [c_int] * 3 + [_P, _P]),
+    "mil_gather_eot": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
 }
 

@@ -1,0 +1,116 @@
+"""CLIP text tower (reference: clip/model.py, text side only: encode_text :339-352, Transformer /
+ResidualAttentionBlock :167-199, LayerNorm :153-159, QuickGELU :162-164, causal mask :324-330).
+
+Forward-only (the tower is frozen: model/dim1/CLIP.py:71-75 runs it under no_grad).  Parameter names match
+the reference state_dict (token_embedding.weight, positional_embedding, transformer.resblocks.N.{attn.in_proj_*,
+attn.out_proj.*, ln_1.*, mlp.c_fc.*, mlp.c_proj.*, ln_2.*}, ln_final.*, text_projection).  The visual tower is
+never run on this path and is not instantiated (its keys are ignored when loading a full CLIP state_dict)."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..segments import AttnSegs
+
+
+class _Attn(nn.Module):          # parameter container with nn.MultiheadAttention's names
+    def __init__(self, width: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = nn.Linear(width, width)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model: int, n_head: int):
+        super().__init__()
+        self.attn = _Attn(d_model)
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)),
+                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = nn.LayerNorm(d_model)
+        self.n_head = n_head
+
+    def flat(self, x, segs):
+        W = x.shape[1]
+        h = ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        q = ops.linear_act(h, w[:W], b[:W])
+        k = ops.linear_act(h, w[W:2 * W], b[W:2 * W])
+        v = ops.linear_act(h, w[2 * W:], b[2 * W:])
+        o = ops.attention_rows(q, k, v, segs, self.n_head, causal=True)
+        x = ops.linear_act(o, self.attn.out_proj.weight, self.attn.out_proj.bias, "none", residual=x)
+        h = ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+        h = ops.linear_act(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "quickgelu")
+        return ops.linear_act(h, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "none", residual=x)
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class CLIPText(nn.Module):
+    def __init__(self, embed_dim: int = 512, context_length: int = 77, vocab_size: int = 49408,
+                 transformer_width: int = 512, transformer_heads: int = 8, transformer_layers: int = 12):
+        super().__init__()
+        self.context_length = context_length
+        self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads)
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = nn.LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * 2.6592600369327779)      # ln(1/0.07), clip/model.py:291
+        self._proj_t = None
+        self.initialize_parameters()
+
+    def initialize_parameters(self):
+        w, n = self.transformer.width, self.transformer.layers
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        for blk in self.transformer.resblocks:
+            nn.init.normal_(blk.attn.in_proj_weight, std=w ** -0.5)
+            nn.init.normal_(blk.attn.out_proj.weight, std=(w ** -0.5) * ((2 * n) ** -0.5))
+            nn.init.normal_(blk.mlp.c_fc.weight, std=(2 * w) ** -0.5)
+            nn.init.normal_(blk.mlp.c_proj.weight, std=(w ** -0.5) * ((2 * n) ** -0.5))
+        nn.init.normal_(self.text_projection, std=w ** -0.5)
+
+    @property
+    def dtype(self):
+        return self.positional_embedding.dtype
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        # a full CLIP checkpoint also carries the (unused) visual tower
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("visual.")}
+        self._proj_t = None
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    @torch.no_grad()
+    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+        """text int64 [P, ctx] -> [P, embed_dim]."""
+        P, ctx = text.shape
+        x = ops.embed_tokens(text, self.token_embedding.weight, self.positional_embedding)     # [P*ctx, W]
+        segs = AttnSegs.make([ctx] * P, [ctx] * P, text.device)
+        for blk in self.transformer.resblocks:
+            x = blk.flat(x, segs)
+        x = ops.layer_norm(x, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
+        eot = ops.gather_eot(text, x)                                                          # [P, W]
+        if self._proj_t is None or self._proj_t.device != eot.device:
+            self._proj_t = self.text_projection.t().contiguous()        # frozen: [embed, W] = nn.Linear layout
+        return ops.linear_act(eot, self._proj_t)
+
+
+def build_text_model(state_dict: dict) -> CLIPText:
+    """Text-side counterpart of clip/model.py:395-432 build_model: sizes are read off the state_dict."""
+    embed_dim = state_dict["text_projection"].shape[1]
+    ctx = state_dict["positional_embedding"].shape[0]
+    vocab = state_dict["token_embedding.weight"].shape[0]
+    width = state_dict["ln_final.weight"].shape[0]
+    layers = len({k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")})
+    m = CLIPText(embed_dim, ctx, vocab, width, width // 64, layers)
+    m.load_state_dict(state_dict, strict=False)
+    return m.eval()

@@ -1,0 +1,603 @@
+// K2: multi-head attention cores of the SAM two-way transformer (model/sam/transformer.py:428-450,
+// after the q/k/v projections and before out_proj) and of the CLIP text blocks (clip/model.py:171-184),
+// plus LayerNorm and the positional-encoding add.  Softmax(q k^T / sqrt(c)) v per head, per bag.
+//
+// Segments: query rows [q_off[b], q_off[b+1]) attend to key rows [k_off[b], k_off[b+1]) of the same bag b.
+// Two regimes, both HBM/latency-bound (head dim c = 32 or 64, so no MFMA: the contraction is over c):
+//   "rows":  one thread per (query row, head), keys looped with an online softmax.  Used when a bag has
+//            few keys per query: image->token attention (N queries x T<=16 text tokens), token self
+//            attention, CLIP's causal 77 x 77.
+//   "pool":  few queries (T <= 16) over many keys (token->image attention: an 8-head attention POOL over
+//            the patches).  Split over 64-key tiles like the MIL pool: thread = channel j of the internal
+//            width I (head = j / c), scores by a c-lane shuffle reduction, online-softmax partials, merge.
+#include "mil_common.h"
+
+#define AT_MAXT 16
+#define AT_KT 64
+
+template <int C>
+__device__ __forceinline__ float head_allsum(float v) {
+    if (C == 64) return wave_allsum(v);
+    return half_allsum(v);          // C == 32: the 32-lane half that holds this head
+}
+
+// ================================================================================ rows: forward
+// grid = ceil(total query rows * H / 256).  q, k, v: [rows, I] row-major; o: [Tq, I]; lse: [Tq, H].
+template <int C>
+__global__ __launch_bounds__(256) void k_attn_rows_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const int32_t* __restrict__ q_off,
+                                                       const int32_t* __restrict__ k_off, const int32_t* __restrict__ q_bag,
+                                                       int Tq, int H, int causal, float scale, float* __restrict__ o,
+                                                       float* __restrict__ lse) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tq * H) return;
+    const int row = idx / H, h = idx % H, I = H * C;
+    const int b = q_bag[row];
+    const int kb = k_off[b];
+    int nk = k_off[b + 1] - kb;
+    if (causal) nk = min(nk, row - q_off[b] + 1);
+    float qr[C];
+#pragma unroll
+    for (int e = 0; e < C; e += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(q + (size_t)row * I + h * C + e);
+        qr[e] = t[0] * scale; qr[e + 1] = t[1] * scale; qr[e + 2] = t[2] * scale; qr[e + 3] = t[3] * scale;
+    }
+    float m = -INFINITY, l = 0.f, acc[C];
+#pragma unroll
+    for (int e = 0; e < C; ++e) acc[e] = 0.f;
+    for (int j = 0; j < nk; ++j) {
+        const float* kr = k + (size_t)(kb + j) * I + h * C;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < C; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(kr + e);
+            s += qr[e] * t[0] + qr[e + 1] * t[1] + qr[e + 2] * t[2] + qr[e + 3] * t[3];
+        }
+        const float mn = fmaxf(m, s);
+        const float alpha = expf(m - mn), p = expf(s - mn);
+        l = l * alpha + p;
+        const float* vr = v + (size_t)(kb + j) * I + h * C;
+#pragma unroll
+        for (int e = 0; e < C; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(vr + e);
+            acc[e] = acc[e] * alpha + p * t[0];
+            acc[e + 1] = acc[e + 1] * alpha + p * t[1];
+            acc[e + 2] = acc[e + 2] * alpha + p * t[2];
+            acc[e + 3] = acc[e + 3] * alpha + p * t[3];
+        }
+        m = mn;
+    }
+    const float inv = nk > 0 ? 1.0f / l : 0.f;
+#pragma unroll
+    for (int e = 0; e < C; e += 4) {
+        f32x4 t = {acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv};
+        *reinterpret_cast<f32x4*>(o + (size_t)row * I + h * C + e) = t;
+    }
+    if (lse != nullptr) lse[(size_t)row * H + h] = nk > 0 ? m + logf(l) : -INFINITY;
+}
+
+// ================================================================================ rows: backward (Tk <= 16 per bag)
+// Phase 1 (thread = (row, head) of a 32-row block): recompute p_t, ds_t; dq row.  Phase 2 (thread = channel):
+// per-workgroup partial dk[t][j] = sum_rows ds[row,h,t] q[row][j] scale, dv[t][j] = sum_rows p[row,h,t] do[row][j].
+// Workgroups never straddle bags (host pads the block map): blk_map[g] = {bag, row0, nrows}.
+// Partials: [nblk][2][AT_MAXT][I] summed per bag by k_attn_rows_bwd_reduce.
+template <int C>
+__global__ __launch_bounds__(256) void k_attn_rows_bwd(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                const float* __restrict__ o, const float* __restrict__ dout,
+                                const float* __restrict__ lse, const int32_t* __restrict__ k_off,
+                                const int32_t* __restrict__ blk_map, int H, float scale, float* __restrict__ dq,
+                                float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // p [32][H][16], ds [32][H][16]
+    const int tid = threadIdx.x, I = H * C;
+    const int b = blk_map[3 * blockIdx.x], row0 = blk_map[3 * blockIdx.x + 1], nrows = blk_map[3 * blockIdx.x + 2];
+    const int kb = k_off[b], nk = k_off[b + 1] - kb;
+    float* p_l = lds;
+    float* ds_l = lds + 32 * H * AT_MAXT;
+    for (int idx = tid; idx < 32 * H; idx += blockDim.x) {
+        const int rr = idx / H, h = idx % H;
+        float pt[AT_MAXT], dst[AT_MAXT];
+#pragma unroll
+        for (int t = 0; t < AT_MAXT; ++t) { pt[t] = 0.f; dst[t] = 0.f; }
+        if (rr < nrows) {
+            const size_t row = (size_t)(row0 + rr);
+            float qr[C], dor[C];
+            float delta = 0.f;
+#pragma unroll
+            for (int e = 0; e < C; ++e) {
+                qr[e] = q[row * I + h * C + e];
+                dor[e] = dout[row * I + h * C + e];
+                delta += dor[e] * o[row * I + h * C + e];
+            }
+            const float ls = lse[row * H + h];
+            float dqr[C];
+#pragma unroll
+            for (int e = 0; e < C; ++e) dqr[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < AT_MAXT; ++t) {
+                if (t < nk) {
+                    const float* kr = k + (size_t)(kb + t) * I + h * C;
+                    const float* vr = v + (size_t)(kb + t) * I + h * C;
+                    float s = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int e = 0; e < C; ++e) { s += qr[e] * kr[e]; dp += dor[e] * vr[e]; }
+                    const float p = expf(s * scale - ls);
+                    // one key: softmax == 1 identically, its score gradient is exactly 0 (the T=1 degeneracy)
+                    const float d = nk == 1 ? 0.f : p * (dp - delta);
+                    pt[t] = p;
+                    dst[t] = d * scale;
+#pragma unroll
+                    for (int e = 0; e < C; ++e) dqr[e] += d * scale * kr[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < C; ++e) dq[row * I + h * C + e] = dqr[e];
+        }
+#pragma unroll
+        for (int t = 0; t < AT_MAXT; ++t) {
+            p_l[(rr * H + h) * AT_MAXT + t] = pt[t];
+            ds_l[(rr * H + h) * AT_MAXT + t] = dst[t];
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < I; j += blockDim.x) {
+        const int h = j / C;
+        float dk[AT_MAXT], dv[AT_MAXT];
+#pragma unroll
+        for (int t = 0; t < AT_MAXT; ++t) { dk[t] = 0.f; dv[t] = 0.f; }
+        for (int rr = 0; rr < nrows; ++rr) {
+            const float qv = q[(size_t)(row0 + rr) * I + j], dov = dout[(size_t)(row0 + rr) * I + j];
+#pragma unroll
+            for (int t = 0; t < AT_MAXT; ++t) {
+                dk[t] += ds_l[(rr * H + h) * AT_MAXT + t] * qv;
+                dv[t] += p_l[(rr * H + h) * AT_MAXT + t] * dov;
+            }
+        }
+        float* pp = part + (size_t)blockIdx.x * 2 * AT_MAXT * I;
+#pragma unroll
+        for (int t = 0; t < AT_MAXT; ++t) {
+            pp[t * I + j] = dk[t];
+            pp[(AT_MAXT + t) * I + j] = dv[t];
+        }
+    }
+}
+
+// dk[kb + t][j] = sum over the bag's blocks of part[g][0][t][j]; same for dv.  grid = (B, 2 * AT_MAXT), block = I threads
+__global__ void k_attn_rows_bwd_reduce(const float* __restrict__ part, const int32_t* __restrict__ bag_blk_off,
+                                       const int32_t* __restrict__ k_off, int I, float* __restrict__ dk,
+                                       float* __restrict__ dv) {
+    const int b = blockIdx.x, which = blockIdx.y / AT_MAXT, t = blockIdx.y % AT_MAXT;
+    const int kb = k_off[b], nk = k_off[b + 1] - kb;
+    if (t >= nk) return;
+    for (int j = threadIdx.x; j < I; j += blockDim.x) {
+        float vsum = 0.f;
+        for (int g = bag_blk_off[b]; g < bag_blk_off[b + 1]; ++g)
+            vsum += part[((size_t)g * 2 + which) * AT_MAXT * I + (size_t)t * I + j];
+        (which == 0 ? dk : dv)[(size_t)(kb + t) * I + j] = vsum;
+    }
+}
+
+// ================================================================================ pool: forward (T <= 16 queries, many keys)
+// One workgroup (I threads) per 64-key tile of one bag: tile_map[g] = {bag, key0, nkeys}.  Thread j = channel.
+// Partials per tile: acc [T][I], (m, l) [T][H][2].  TM = compile-time bound on the queries per bag; slots
+// t >= T run on zero queries (harmless, never stored) so the key loop has no data-dependent branches.
+template <int C, int TM>
+__global__ __launch_bounds__(512) void k_attn_pool_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const int32_t* __restrict__ q_off,
+                                                       const int32_t* __restrict__ tile_map, int H, float scale,
+                                                       float* __restrict__ pacc, float* __restrict__ pml) {
+    const int j = threadIdx.x, I = H * C, h = j / C;
+    const int b = tile_map[3 * blockIdx.x], key0 = tile_map[3 * blockIdx.x + 1], nkeys = tile_map[3 * blockIdx.x + 2];
+    const int qb = q_off[b], T = q_off[b + 1] - qb;
+    float qv[TM], m[TM], l[TM], acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        qv[t] = t < T ? q[(size_t)(qb + t) * I + j] * scale : 0.f;
+        m[t] = -INFINITY; l[t] = 0.f; acc[t] = 0.f;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < nkeys; ++kk) {
+        const float kv = k[(size_t)(key0 + kk) * I + j], vv = v[(size_t)(key0 + kk) * I + j];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float s = head_allsum<C>(qv[t] * kv);
+            const float mn = fmaxf(m[t], s);
+            const float alpha = expf(m[t] - mn), p = expf(s - mn);
+            l[t] = l[t] * alpha + p;
+            acc[t] = acc[t] * alpha + p * vv;
+            m[t] = mn;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        if (t < T) {
+            pacc[((size_t)blockIdx.x * AT_MAXT + t) * I + j] = acc[t];
+            if ((j % C) == 0) {
+                pml[(((size_t)blockIdx.x * AT_MAXT + t) * H + h) * 2] = m[t];
+                pml[(((size_t)blockIdx.x * AT_MAXT + t) * H + h) * 2 + 1] = l[t];
+            }
+        }
+    }
+}
+
+// merge: grid = (B, T_max), block = I threads.  o[qb + t][j], lse[qb + t][h]
+template <int C>
+__global__ __launch_bounds__(512) void k_attn_pool_merge(const float* __restrict__ pacc, const float* __restrict__ pml,
+                                  const int32_t* __restrict__ q_off, const int32_t* __restrict__ bag_tile_off, int H,
+                                  float* __restrict__ o, float* __restrict__ lse) {
+    const int b = blockIdx.x, t = blockIdx.y, j = threadIdx.x, I = H * C, h = j / C;
+    const int qb = q_off[b], T = q_off[b + 1] - qb;
+    if (t >= T) return;
+    const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
+    float m = -INFINITY;
+    for (int g = g0; g < g1; ++g) m = fmaxf(m, pml[(((size_t)g * AT_MAXT + t) * H + h) * 2]);
+    float l = 0.f, acc = 0.f;
+    for (int g = g0; g < g1; ++g) {
+        const float sc = expf(pml[(((size_t)g * AT_MAXT + t) * H + h) * 2] - m);
+        l += sc * pml[(((size_t)g * AT_MAXT + t) * H + h) * 2 + 1];
+        acc += sc * pacc[((size_t)g * AT_MAXT + t) * I + j];
+    }
+    o[(size_t)(qb + t) * I + j] = g1 > g0 ? acc / l : 0.f;
+    if ((j % C) == 0) lse[(size_t)(qb + t) * H + h] = g1 > g0 ? m + logf(l) : -INFINITY;
+}
+
+// ================================================================================ pool: backward
+// Same tiling.  Per key: dv = sum_t p do_t, dk = sum_t ds q_t scale; per tile partial dq[t][j] = sum_keys ds k scale.
+// Slots t >= T carry q = do = 0, lse = delta = 0: p = 1, dp = 0, ds = 0, so they add nothing.
+template <int C, int TM>
+__global__ __launch_bounds__(512) void k_attn_pool_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const float* __restrict__ o,
+                                                       const float* __restrict__ dout, const float* __restrict__ lse,
+                                                       const int32_t* __restrict__ q_off,
+                                                       const int32_t* __restrict__ tile_map, int H, float scale,
+                                                       float* __restrict__ dk, float* __restrict__ dv,
+                                                       float* __restrict__ pdq) {
+    const int j = threadIdx.x, I = H * C, h = j / C;
+    const int b = tile_map[3 * blockIdx.x], key0 = tile_map[3 * blockIdx.x + 1], nkeys = tile_map[3 * blockIdx.x + 2];
+    const int qb = q_off[b], T = q_off[b + 1] - qb;
+    float qv[TM], dov[TM], ls[TM], delta[TM], dq[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const bool live = t < T;
+        const size_t qr = (size_t)(qb + (live ? t : 0)) * I + j;
+        qv[t] = live ? q[qr] : 0.f;
+        dov[t] = live ? dout[qr] : 0.f;
+        ls[t] = live ? lse[(size_t)(qb + t) * H + h] : 0.f;
+        delta[t] = head_allsum<C>(dov[t] * (live ? o[qr] : 0.f));
+        dq[t] = 0.f;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < nkeys; ++kk) {
+        const size_t kr = (size_t)(key0 + kk) * I + j;
+        const float kv = k[kr], vv = v[kr];
+        float dkv = 0.f, dvv = 0.f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float s = head_allsum<C>(qv[t] * kv) * scale;
+            const float dp = head_allsum<C>(dov[t] * vv);
+            const float p = expf(s - ls[t]);
+            const float d = p * (dp - delta[t]) * scale;
+            dvv += p * dov[t];
+            dkv += d * qv[t];
+            dq[t] += d * kv;
+        }
+        dk[kr] = dkv;
+        dv[kr] = dvv;
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+        if (t < T) pdq[((size_t)blockIdx.x * AT_MAXT + t) * I + j] = dq[t];
+}
+
+// dq[qb + t][j] = sum over the bag's tiles.  grid = (B, T_max), block = I
+__global__ void k_attn_pool_bwd_reduce(const float* __restrict__ pdq, const int32_t* __restrict__ q_off,
+                                       const int32_t* __restrict__ bag_tile_off, int I, float* __restrict__ dq) {
+    const int b = blockIdx.x, t = blockIdx.y, j = threadIdx.x;
+    const int qb = q_off[b], T = q_off[b + 1] - qb;
+    if (t >= T) return;
+    float acc = 0.f;
+    for (int g = bag_tile_off[b]; g < bag_tile_off[b + 1]; ++g) acc += pdq[((size_t)g * AT_MAXT + t) * I + j];
+    dq[(size_t)(qb + t) * I + j] = acc;
+}
+
+// ================================================================================ LayerNorm (rows x E), one wave per row
+// y = (x - mean) * rstd * gamma + beta, biased variance, eps inside the sqrt (nn.LayerNorm, eps 1e-5).
+template <int NE>     // E = 64 * NE
+__global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int rows, float eps,
+                                                       float* __restrict__ y, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), E = 64 * NE;
+    if (row >= rows) return;
+    float v[NE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { v[e] = x[(size_t)row * E + lane + 64 * e]; s += v[e]; }
+    const float mean = wave_allsum(s) / E;
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const float d = v[e] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_allsum(ss) / E + eps);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int c = lane + 64 * e;
+        y[(size_t)row * E + c] = (v[e] - mean) * rstd * gamma[c] + beta[c];
+    }
+    if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  per-workgroup partial dgamma/dbeta [nblk][2][E]
+template <int NE>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ dy, const float* __restrict__ stats,
+                                                       int rows, int rows_per_blk, float* __restrict__ dx,
+                                                       float* __restrict__ part) {
+    __shared__ float red[4][2][64 * NE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, E = 64 * NE;
+    float dg[NE], db[NE], gm[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[lane + 64 * e]; }
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+    for (int row = r0 + w; row < r1; row += 4) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float xh[NE], g[NE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int c = lane + 64 * e;
+            const float d = dy[(size_t)row * E + c];
+            xh[e] = (x[(size_t)row * E + c] - mean) * rstd;
+            g[e] = d * gm[e];
+            s1 += g[e];
+            s2 += g[e] * xh[e];
+            dg[e] += d * xh[e];
+            db[e] += d;
+        }
+        s1 = wave_allsum(s1) / E;
+        s2 = wave_allsum(s2) / E;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd * (g[e] - s1 - xh[e] * s2);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { red[w][0][lane + 64 * e] = dg[e]; red[w][1][lane + 64 * e] = db[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * E; c += 256) {
+        const int which = c / E, cc = c % E;
+        part[((size_t)blockIdx.x * 2 + which) * E + cc] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+    }
+}
+
+// ================================================================================ keys + pe (positional table row = index within the bag)
+// out[row] = x[row] + pe[row - row_off[bag]]   (model/sam/transformer.py:292,304: k = keys + key_pe with
+// key_pe = self.pe[:, :N] of model/aggregator.py:99-106,190).  One float4 per thread.
+__global__ __launch_bounds__(256) void k_add_pe(const float* __restrict__ x, const float* __restrict__ pe,
+                                                const int32_t* __restrict__ row_bag, const int32_t* __restrict__ row_off,
+                                                size_t n4, int E4, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int row = (int)(i / E4), c4 = (int)(i % E4);
+    const int pos = row - row_off[row_bag[row]];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pe + ((size_t)pos * E4 + c4) * 4);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = a + p;
+}
+
+// Sinusoidal table of model/aggregator.py:99-106, built on the device once: pe[p][2i] = sin(p * w_i),
+// pe[p][2i+1] = cos(p * w_i), w_i = exp(2i * -(ln 1e4 / E)).  fp32 argument as in the reference.
+__global__ __launch_bounds__(256) void k_sinusoid_pe(float* __restrict__ pe, int n, int E) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * (E / 2)) return;
+    const int p = (int)(idx / (E / 2)), i = (int)(idx % (E / 2));
+    const float w = expf((float)(2 * i) * -(logf(10000.0f) / (float)E));
+    const float a = (float)p * w;
+    pe[(size_t)p * E + 2 * i] = sinf(a);
+    pe[(size_t)p * E + 2 * i + 1] = cosf(a);
+}
+
+// ================================================================================ host entry points
+#define DISPATCH_C(C_, ...)                      \
+    do {                                         \
+        if ((C_) == 32) { constexpr int CC = 32; __VA_ARGS__; } \
+        else { constexpr int CC = 64; __VA_ARGS__; }            \
+    } while (0)
+#define DISPATCH_CT(C_, T_, ...)                                                     \
+    do {                                                                             \
+        if ((T_) <= 1) { constexpr int TT = 1; DISPATCH_C(C_, __VA_ARGS__); }         \
+        else if ((T_) <= 4) { constexpr int TT = 4; DISPATCH_C(C_, __VA_ARGS__); }    \
+        else if ((T_) <= 8) { constexpr int TT = 8; DISPATCH_C(C_, __VA_ARGS__); }    \
+        else { constexpr int TT = 16; DISPATCH_C(C_, __VA_ARGS__); }                  \
+    } while (0)
+
+extern "C" int mil_attn_rows_fwd(const float* q, const float* k, const float* v, const int32_t* q_off,
+                                 const int32_t* k_off, const int32_t* q_bag, int Tq, int H, int C, int causal,
+                                 float* o, float* lse, void* stream) {
+    if (!q || !k || !v || !q_off || !k_off || !q_bag || !o) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || Tq < 0) return MIL_EINVAL;
+    if (Tq == 0) return MIL_OK;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int grid = (Tq * H + 255) / 256;
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_rows_fwd<CC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, q, k, v, q_off,
+                                     k_off, q_bag, Tq, H, causal, scale, o, lse));
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_rows_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                 const float* lse, const int32_t* k_off, const int32_t* blk_map,
+                                 const int32_t* bag_blk_off, int nblk, int B, int H, int C, float* dq, float* dk,
+                                 float* dv, float* workspace, void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !k_off || !blk_map || !bag_blk_off || !dq || !dk || !dv || !workspace)
+        return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || nblk < 0 || B < 0) return MIL_EINVAL;
+    if (nblk == 0) return MIL_OK;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int I = H * C;
+    const size_t shm = (size_t)2 * 32 * H * AT_MAXT * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_rows_bwd<CC>), dim3(nblk), dim3(256), shm, st, q, k, v, o, dout, lse, k_off,
+                                     blk_map, H, scale, dq, workspace));
+    MIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_attn_rows_bwd_reduce, dim3(B, 2 * AT_MAXT), dim3(min(I, 256)), 0, st, workspace, bag_blk_off,
+                       k_off, I, dk, dv);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_fwd_mh(const float* q, const float* k, const float* v, const int32_t* q_off,
+                                    const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int Tmax,
+                                    int H, int C, float* o, float* lse, float* workspace, void* stream) {
+    if (!q || !k || !v || !q_off || !tile_map || !bag_tile_off || !o || !lse || !workspace) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || H * C > 512 || Tmax <= 0 || Tmax > AT_MAXT) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int I = H * C;
+    float* pacc = workspace;
+    float* pml = workspace + (size_t)ntiles * AT_MAXT * I;
+    hipStream_t st = (hipStream_t)stream;
+    if (ntiles > 0) {
+        DISPATCH_CT(C, Tmax, hipLaunchKernelGGL((k_attn_pool_fwd<CC, TT>), dim3(ntiles), dim3(I), 0, st, q, k, v, q_off,
+                                                tile_map, H, scale, pacc, pml));
+        MIL_CHECK_LAUNCH();
+    }
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_pool_merge<CC>), dim3(B, Tmax), dim3(I), 0, st, pacc, pml, q_off, bag_tile_off,
+                                     H, o, lse));
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_bwd_mh(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                    const float* lse, const int32_t* q_off, const int32_t* tile_map,
+                                    const int32_t* bag_tile_off, int ntiles, int B, int Tmax, int H, int C, float* dq,
+                                    float* dk, float* dv, float* workspace, void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !q_off || !tile_map || !bag_tile_off || !dq || !dk || !dv || !workspace)
+        return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || H * C > 512 || Tmax <= 0 || Tmax > AT_MAXT) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int I = H * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (ntiles > 0) {
+        DISPATCH_CT(C, Tmax, hipLaunchKernelGGL((k_attn_pool_bwd<CC, TT>), dim3(ntiles), dim3(I), 0, st, q, k, v, o, dout,
+                                                lse, q_off, tile_map, H, scale, dk, dv, workspace));
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_attn_pool_bwd_reduce, dim3(B, Tmax), dim3(I), 0, st, workspace, q_off, bag_tile_off, I, dq);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps,
+                                 float* y, float* stats, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || E <= 0 || (E % 64) != 0 || E > 512) return MIL_EINVAL;
+    if (rows == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((rows + 3) / 4), blk(256);
+    switch (E / 64) {
+        case 1: hipLaunchKernelGGL(k_layernorm_fwd<1>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
+        case 2: hipLaunchKernelGGL(k_layernorm_fwd<2>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
+        case 4: hipLaunchKernelGGL(k_layernorm_fwd<4>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
+        case 8: hipLaunchKernelGGL(k_layernorm_fwd<8>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
+        default: return MIL_EINVAL;
+    }
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_layernorm_bwd_blocks(int rows) {
+    int nb = (rows + 63) / 64;
+    if (nb > 1024) nb = 1024;
+    return nb < 1 ? 1 : nb;
+}
+
+extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* stats, int rows, int E,
+                                 float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
+    if (!x || !gamma || !dy || !stats || !dx || !dgamma || !dbeta || !workspace) return MIL_EINVAL;
+    if (rows <= 0 || (E % 64) != 0 || E > 512) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = mil_layernorm_bwd_blocks(rows);
+    const int rpb = (rows + nb - 1) / nb;
+    const dim3 grid(nb), blk(256);
+    switch (E / 64) {
+        case 1: hipLaunchKernelGGL(k_layernorm_bwd<1>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 2: hipLaunchKernelGGL(k_layernorm_bwd<2>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 4: hipLaunchKernelGGL(k_layernorm_bwd<4>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 8: hipLaunchKernelGGL(k_layernorm_bwd<8>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        default: return MIL_EINVAL;
+    }
+    MIL_CHECK_LAUNCH();
+    // partials are [nb][2][E]: two strided column sums
+    int rc = mil_colsum(workspace, 2 * E, nb, E, dgamma, 0, stream);
+    if (rc) return rc;
+    return mil_colsum(workspace + E, 2 * E, nb, E, dbeta, 0, stream);
+}
+
+extern "C" int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,
+                          float* out, void* stream) {
+    if (!x || !pe || !row_bag || !row_off || !out || rows < 0 || E <= 0 || (E & 3)) return MIL_EINVAL;
+    if (rows == 0) return MIL_OK;
+    const size_t n4 = (size_t)rows * (E / 4);
+    hipLaunchKernelGGL(k_add_pe, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, pe, row_bag,
+                       row_off, n4, E / 4, out);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_sinusoid_pe(float* pe, int n, int E, void* stream) {
+    if (!pe || n < 0 || E <= 0 || (E & 1)) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    const size_t cnt = (size_t)n * (E / 2);
+    hipLaunchKernelGGL(k_sinusoid_pe, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pe, n, E);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// ================================================================================ CLIP text front/back ends
+// x[s][p] = token_embedding[ids[s][p]] + positional_embedding[p]      (clip/model.py:340-342)
+__global__ __launch_bounds__(256) void k_embed_tokens(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                      const float* __restrict__ pos, size_t n4, int ctx, int W4,
+                                                      float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t tok = i / W4;
+    const int c4 = (int)(i % W4), p = (int)(tok % ctx);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(table + ((size_t)ids[tok] * W4 + c4) * 4);
+    const f32x4 q = *reinterpret_cast<const f32x4*>(pos + ((size_t)p * W4 + c4) * 4);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = e + q;
+}
+
+// out[s] = x[s][argmax_p ids[s][p]]  (the EOT token has the largest id, clip/model.py:348-350; first maximum
+// on ties, as torch.argmax).  One workgroup (64 threads) per sequence.
+__global__ __launch_bounds__(64) void k_gather_eot(const int64_t* __restrict__ ids, const float* __restrict__ x, int ctx, int W,
+                                                   float* __restrict__ out) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    long long best = -1;
+    int bi = 0;
+    for (int p = lane; p < ctx; p += 64) {
+        const long long v = ids[(size_t)s * ctx + p];
+        if (v > best) { best = v; bi = p; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const long long ob = __shfl_xor(best, m);
+        const int oi = __shfl_xor(bi, m);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    for (int c = lane; c < W; c += 64) out[(size_t)s * W + c] = x[((size_t)s * ctx + bi) * W + c];
+}
+
+extern "C" int mil_embed_tokens(const int64_t* ids, const float* table, const float* pos, int nseq, int ctx, int W,
+                                float* out, void* stream) {
+    if (!ids || !table || !pos || !out || nseq < 0 || ctx <= 0 || W <= 0 || (W & 3)) return MIL_EINVAL;
+    if (nseq == 0) return MIL_OK;
+    const size_t n4 = (size_t)nseq * ctx * (W / 4);
+    hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, table,
+                       pos, n4, ctx, W / 4, out);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_gather_eot(const int64_t* ids, const float* x, int nseq, int ctx, int W, float* out, void* stream) {
+    if (!ids || !x || !out || nseq < 0 || ctx <= 0 || W <= 0) return MIL_EINVAL;
+    if (nseq == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_gather_eot, dim3(nseq), dim3(64), 0, (hipStream_t)stream, ids, x, ctx, W, out);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

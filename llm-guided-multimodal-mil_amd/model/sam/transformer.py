@@ -1,0 +1,136 @@
+"""Two-way (text <-> image) cross-attention transformer, MI355X path.
+
+Same module tree / parameter names / forward signature as the reference's
+model/sam/transformer.py (TwoWayTransformer :10-120, TwoWayAttentionBlock :236-309, Attention :395-450),
+so state_dicts interchange; the arithmetic runs on the HIP library: projections on the fp32-MFMA GEMM
+(residual adds fused in the out_proj epilogue), the attention cores on the "pool" kernel (text tokens
+over the patches of a bag) or the "rows" kernel (patches over the few text tokens), LayerNorm and the
+positional add as streaming kernels.  Internally every tensor is flat [rows, E] with per-bag segments,
+so a batch of ragged bags is one launch sequence (the reference runs one bag per forward)."""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...segments import AttnSegs
+from .common import MLPBlock
+
+
+class Attention(nn.Module):
+    """q/k/v projections to internal_dim = embedding_dim // downsample_rate, H-head attention, out projection."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.internal_dim = embedding_dim // downsample_rate
+        self.num_heads = num_heads
+        assert self.internal_dim % num_heads == 0, "num_heads must divide embedding_dim."
+        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.k_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
+
+    def flat(self, q, k, v, segs: AttnSegs, form: str, residual=None):
+        """q [Tq, E], k/v [Tk, E] flat rows; form 'pool' (few queries, many keys) or 'rows'."""
+        qp = ops.linear_act(q, self.q_proj.weight, self.q_proj.bias)
+        kp = ops.linear_act(k, self.k_proj.weight, self.k_proj.bias)
+        vp = ops.linear_act(v, self.v_proj.weight, self.v_proj.bias)
+        core = ops.attention_pool if form == "pool" else ops.attention_rows
+        o = core(qp, kp, vp, segs, self.num_heads)
+        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
+
+    def forward(self, q, k, v):
+        """Reference signature: q [B, Tq, E], k, v [B, Tk, E] -> [B, Tq, E]."""
+        B, Tq, E = q.shape
+        Tk = k.shape[1]
+        segs = AttnSegs.make([Tq] * B, [Tk] * B, q.device)
+        form = "pool" if (Tq <= 16 and Tk > 16) else "rows"
+        return self.flat(q.reshape(B * Tq, E), k.reshape(B * Tk, E), v.reshape(B * Tk, E), segs, form).reshape(B, Tq, E)
+
+
+class _LN(nn.LayerNorm):
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class TwoWayAttentionBlock(nn.Module):
+    def __init__(self, embedding_dim: int, num_heads: int, mlp_dim: int = 2048, activation: str = "relu",
+                 attention_downsample_rate: int = 2, skip_first_layer_pe: bool = False):
+        super().__init__()
+        self.self_attn = Attention(embedding_dim, num_heads)
+        self.norm1 = _LN(embedding_dim)
+        self.cross_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm2 = _LN(embedding_dim)
+        self.mlp = MLPBlock(embedding_dim, mlp_dim, activation)
+        self.norm3 = _LN(embedding_dim)
+        self.norm4 = _LN(embedding_dim)
+        self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.skip_first_layer_pe = skip_first_layer_pe
+
+    def flat(self, queries, keys, query_pe, keys_pe_fn, s_tt: AttnSegs, s_ti: AttnSegs, s_it: AttnSegs):
+        """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe."""
+        if self.skip_first_layer_pe:                                            # :282-283 (replaces, no residual)
+            queries = self.self_attn.flat(queries, queries, queries, s_tt, "rows")
+        else:                                                                   # :285-287
+            q = queries + query_pe
+            queries = self.self_attn.flat(q, q, queries, s_tt, "rows", residual=queries)
+        queries = self.norm1(queries)
+        q = queries + query_pe                                                  # :291-295
+        k = keys_pe_fn(keys)
+        queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
+        queries = self.norm3(self.mlp(queries, residual=queries))               # :298-300
+        q = queries + query_pe                                                  # :303-307
+        keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys))
+        return queries, keys
+
+    def forward(self, queries, keys, query_pe, key_pe):
+        B, T, E = queries.shape
+        N = keys.shape[1]
+        dev = queries.device
+        s_tt, s_ti, s_it = (AttnSegs.make([T] * B, [T] * B, dev), AttnSegs.make([T] * B, [N] * B, dev),
+                            AttnSegs.make([N] * B, [T] * B, dev))
+        kpe = key_pe.reshape(B * N, E)
+        q, k = self.flat(queries.reshape(B * T, E), keys.reshape(B * N, E), query_pe.reshape(B * T, E),
+                         lambda kk: kk + kpe, s_tt, s_ti, s_it)
+        return q.reshape(B, T, E), k.reshape(B, N, E)
+
+
+class TwoWayTransformer(nn.Module):
+    def __init__(self, args, depth: int, embedding_dim: int, num_heads: int, mlp_dim: int, activation: str = "relu",
+                 attention_downsample_rate: int = 2):
+        super().__init__()
+        self.args = args
+        self.depth, self.embedding_dim, self.num_heads, self.mlp_dim = depth, embedding_dim, num_heads, mlp_dim
+        self.layers = nn.ModuleList([
+            TwoWayAttentionBlock(embedding_dim, num_heads, mlp_dim, activation, attention_downsample_rate,
+                                 skip_first_layer_pe=(i == 0)) for i in range(depth)])
+        self.final_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm_final_attn = _LN(embedding_dim)
+
+    def flat(self, image, point, pe_table, n_lengths, t_lengths) -> Tuple[torch.Tensor, torch.Tensor]:
+        """image [sum N_b, E] patch tokens, point [sum T_b, E] text tokens, pe_table [>= max N_b, E].
+        Returns (queries [sum T_b, E], keys [sum N_b, E])  (sam/transformer.py:100-120)."""
+        dev = image.device
+        s_tt = AttnSegs.make(t_lengths, t_lengths, dev)
+        s_ti = AttnSegs.make(t_lengths, n_lengths, dev)
+        s_it = AttnSegs.make(n_lengths, t_lengths, dev)
+        keys_pe = lambda kk: ops.add_pe(kk, pe_table, s_ti.k_bag, s_ti.k_off)      # noqa: E731
+        queries, keys = point, image
+        for layer in self.layers:
+            queries, keys = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it)
+        q = queries + point                                                      # :114-118
+        k = keys_pe(keys)
+        queries = self.norm_final_attn(self.final_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
+        return queries, keys
+
+    def forward(self, image_embedding, image_pe, point_embedding):
+        """Reference signature (sam/transformer.py:58-63): image_embedding [B, N, E], image_pe [B or 1, N, E],
+        point_embedding [B, T, E] -> (queries [B, T, E], keys [B, N, E]).  5-D CT maps are out of scope."""
+        if image_embedding.dim() != 3:
+            raise NotImplementedError("CT feature maps (5-D image_embedding) are outside the MIL hot path")
+        B, N, E = image_embedding.shape
+        T = point_embedding.shape[1]
+        pe = image_pe.reshape(-1, E)[:N].contiguous()
+        q, k = self.flat(image_embedding.reshape(B * N, E), point_embedding.reshape(B * T, E), pe, [N] * B, [T] * B)
+        return q.reshape(B, T, E), k.reshape(B, N, E)

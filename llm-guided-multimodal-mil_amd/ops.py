@@ -330,3 +330,174 @@ def linear_act(x, W, b=None, act: str = "none", residual=None):
     y = _LinearAct.apply(x.reshape(-1, x.shape[-1]), W, b, ACT[act],
                          residual.reshape(-1, residual.shape[-1]) if residual is not None else None)
     return y.reshape(*lead, W.shape[0])
+
+
+# --------------------------------------------------------------------------- K2: attention cores, LayerNorm, PE
+def _head_dim(I: int, H: int) -> int:
+    c = I // H
+    if c * H != I or c not in (32, 64):
+        raise _lib.MilHipError(f"attention: internal dim {I} / {H} heads = head dim {c}; kernels support 32 and 64")
+    return c
+
+
+class _AttnRows(torch.autograd.Function):
+    """softmax(q k^T / sqrt(c)) v, one thread per (query row, head): sam/transformer.py:441-446 for
+    image->token / token self attention, clip/model.py:183 with causal=True."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, segs, H: int, causal: bool):
+        q, k, v = _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
+        Tq, I = q.shape
+        C = _head_dim(I, H)
+        o = torch.empty_like(q)
+        lse = torch.empty((Tq, H), device=q.device, dtype=torch.float32)
+        rc = _lib.lib().mil_attn_rows_fwd(_p(q), _p(k), _p(v), _p(segs.q_off), _p(segs.k_off), _p(segs.q_bag), Tq, H, C,
+                                          1 if causal else 0, _p(o), _p(lse), _stream())
+        _lib.check(rc, "mil_attn_rows_fwd")
+        ctx.segs, ctx.H, ctx.C, ctx.causal = segs, H, C, causal
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        segs, H, C = ctx.segs, ctx.H, ctx.C
+        if ctx.causal or segs.Tk_max > 16:
+            raise _lib.MilHipError("attention rows backward supports <= 16 keys per bag, non-causal (the CLIP tower is frozen)")
+        I = H * C
+        do = _f32c(do, "do")
+        dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        ws = torch.empty(max(1, segs.nblk) * 2 * 16 * I, device=q.device, dtype=torch.float32)
+        rc = _lib.lib().mil_attn_rows_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.k_off), _p(segs.blk_map),
+                                          _p(segs.bag_blk_off), segs.nblk, segs.B, H, C, _p(dq), _p(dk), _p(dv), _p(ws),
+                                          _stream())
+        _lib.check(rc, "mil_attn_rows_bwd")
+        return dq, dk, dv, None, None, None
+
+
+def attention_rows(q, k, v, segs, H: int, causal: bool = False):
+    return _AttnRows.apply(q, k, v, segs, H, causal)
+
+
+class _AttnPool(torch.autograd.Function):
+    """<= 16 queries per bag over many keys (token->image attention, sam/transformer.py:293,116)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, segs, H: int):
+        q, k, v = _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
+        Tq, I = q.shape
+        C = _head_dim(I, H)
+        if segs.Tq_max > 16:
+            raise _lib.MilHipError("attention pool form supports <= 16 queries per bag")
+        o = torch.empty_like(q)
+        lse = torch.empty((Tq, H), device=q.device, dtype=torch.float32)
+        ws = torch.empty(max(1, segs.ntiles) * 16 * (I + 2 * H), device=q.device, dtype=torch.float32)
+        rc = _lib.lib().mil_attn_pool_fwd_mh(_p(q), _p(k), _p(v), _p(segs.q_off), _p(segs.tile_map), _p(segs.bag_tile_off),
+                                             segs.ntiles, segs.B, max(1, segs.Tq_max), H, C, _p(o), _p(lse), _p(ws), _stream())
+        _lib.check(rc, "mil_attn_pool_fwd_mh")
+        ctx.segs, ctx.H, ctx.C = segs, H, C
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        segs, H, C = ctx.segs, ctx.H, ctx.C
+        I = H * C
+        do = _f32c(do, "do")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty(max(1, segs.ntiles) * 16 * I, device=q.device, dtype=torch.float32)
+        rc = _lib.lib().mil_attn_pool_bwd_mh(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.q_off), _p(segs.tile_map),
+                                             _p(segs.bag_tile_off), segs.ntiles, segs.B, max(1, segs.Tq_max), H, C, _p(dq),
+                                             _p(dk), _p(dv), _p(ws), _stream())
+        _lib.check(rc, "mil_attn_pool_bwd_mh")
+        return dq, dk, dv, None, None
+
+
+def attention_pool(q, k, v, segs, H: int):
+    return _AttnPool.apply(q, k, v, segs, H)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        x = _f32c(x, "x")
+        rows, E = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_layernorm_fwd(_p(x), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), rows, E, eps, _p(y),
+                                          _p(stats), _stream())
+        _lib.check(rc, "mil_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        rows, E = x.shape
+        dy = _f32c(dy, "dy")
+        dx = torch.empty_like(x)
+        dg = torch.empty(E, device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        nb = _lib.lib().mil_layernorm_bwd_blocks(rows)
+        ws = torch.empty(nb * 2 * E, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_layernorm_bwd(_p(x), _p(gamma), _p(dy), _p(stats), rows, E, _p(dx), _p(dg), _p(db), _p(ws),
+                                          _stream())
+        _lib.check(rc, "mil_layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps: float = 1e-5):
+    lead = x.shape[:-1]
+    return _LayerNorm.apply(x.reshape(-1, x.shape[-1]), gamma, beta, eps).reshape(*lead, x.shape[-1])
+
+
+class _AddPE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pe, row_bag, row_off):
+        x = _f32c(x, "x")
+        rows, E = x.shape
+        out = torch.empty_like(x)
+        rc = _lib.lib().mil_add_pe(_p(x), _p(pe), _p(row_bag), _p(row_off), rows, E, _p(out), _stream())
+        _lib.check(rc, "mil_add_pe")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+def add_pe(x, pe, row_bag, row_off):
+    """x[row] + pe[position of the row inside its bag]."""
+    return _AddPE.apply(x, pe, row_bag, row_off)
+
+
+def sinusoid_pe(n: int, E: int, device):
+    pe = torch.empty((n, E), device=device, dtype=torch.float32)
+    rc = _lib.lib().mil_sinusoid_pe(_p(pe), n, E, _stream())
+    _lib.check(rc, "mil_sinusoid_pe")
+    return pe
+
+
+# --------------------------------------------------------------------------- K4: CLIP text front/back ends
+def embed_tokens(ids, table, pos):
+    """token_embedding[ids] + positional_embedding  ->  [nseq * ctx, W]  (clip/model.py:340-342)."""
+    nseq, ctx = ids.shape
+    W = table.shape[1]
+    if ids.dtype != torch.int64 or not ids.is_cuda:
+        raise _lib.MilHipError("embed_tokens: ids must be int64 on the GPU")
+    out = torch.empty((nseq * ctx, W), device=ids.device, dtype=torch.float32)
+    rc = _lib.lib().mil_embed_tokens(_p(ids.contiguous()), _p(_f32c(table, "table")), _p(_f32c(pos, "pos")), nseq, ctx, W,
+                                     _p(out), _stream())
+    _lib.check(rc, "mil_embed_tokens")
+    return out
+
+
+def gather_eot(ids, x):
+    """Rows of x [nseq*ctx, W] at each sequence's EOT position (argmax of the ids)."""
+    nseq, ctx = ids.shape
+    W = x.shape[1]
+    out = torch.empty((nseq, W), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_gather_eot(_p(ids.contiguous()), _p(_f32c(x, "x")), nseq, ctx, W, _p(out), _stream())
+    _lib.check(rc, "mil_gather_eot")
+    return out

@@ -38,6 +38,11 @@ def rel_err(a, b):
 def check_grad(name, got, gold, tol):
     """Compare a gradient tensor with its golden norm + strided sample (and full tensor if stored)."""
     g = got.detach().cpu().float()
+    if name.endswith("k_proj.bias"):
+        # softmax is invariant to a constant added to every key's score, so d/d(k_proj.bias) == 0 exactly;
+        # both sides only hold rounding noise (1e-7 .. 1e-5 here)
+        assert float(g.abs().max()) < 5e-5, name
+        return
     if float(gold[name + ".norm"]) < 1e-7:       # mathematically-zero gradient (softmax bias): rounding noise only
         assert float(g.abs().max()) < 1e-6, name
         return
