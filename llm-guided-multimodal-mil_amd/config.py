@@ -1,0 +1,65 @@
+"""Flag system of the entry points.  Flag names and defaults follow the reference's config.py:10-142 for
+everything the hot path reads (modality / model_* / aggregator / num_classes / learnablePrompt / n_ctx /
+clinical_features / lr / b1 / b2 / batch_size / seed / dist_* ...), list flags are parsed with
+ast.literal_eval as upstream (config.py:4-8).  Hospital-data flags are dropped; synthetic-data flags are new."""
+import argparse
+import ast
+
+
+def arg_as_list(s):
+    v = ast.literal_eval(s)
+    if not isinstance(v, list):
+        raise argparse.ArgumentTypeError(f'Argument "{s}" is not a list')
+    return v
+
+
+def create_arg_parser(argv=None):
+    p = argparse.ArgumentParser(description="MI355X-native LLM-guided multi-modal MIL (hot path)")
+    # ---- model (reference names; defaults chosen so the built path runs: upstream defaults select CT + TransMIL)
+    p.add_argument("--modality", default=["pathology"], type=arg_as_list, help="subset of ['pathology', 'CI']")
+    p.add_argument("--alignment_base", default="CI", type=str)
+    p.add_argument("--model_CT", default="resnetMC3_18", type=str)
+    p.add_argument("--model_pathology", default="ABMIL", type=str)
+    p.add_argument("--model_CI", default="CLIP", type=str)
+    p.add_argument("--aggregator", default="ABMIL", type=str)
+    p.add_argument("--CI_prompt_version", default="single", type=str, help="single (1 note) | devided (10 prompts)")
+    p.add_argument("--clinical_features", type=arg_as_list,
+                   default=["sex", "age", "sm", "locationcancer", "cancerimaging", "cancerimagingT", "cancerimagingN",
+                            "cancerimagingM", "classification_cancer"])
+    p.add_argument("--learnablePrompt", default=0, type=int)
+    p.add_argument("--n_ctx", default=8, type=int)
+    p.add_argument("--prompt_len", default=0, type=int)
+    p.add_argument("--num_classes", type=int, default=2)
+    p.add_argument("--variant", default="fusion", choices=["fusion", "image_only"],
+                   help="fusion: model/aggregator.py path; image_only: model/aggregator_clip.py path")
+    # ---- optimisation (train_ddp.py:104-118 forces lr 1e-5 for Adam with 2 classes)
+    p.add_argument("--start_epoch", type=int, default=0)
+    p.add_argument("--n_epochs", type=int, default=2)
+    p.add_argument("--resume", default="", type=str)
+    p.add_argument("--lr", type=float, default=1e-5)
+    p.add_argument("--loss", type=str, default="BCE")
+    p.add_argument("--loss_point", type=str, default="Last")
+    p.add_argument("--schedule", default=[500], nargs="*", type=int)
+    p.add_argument("--cos", action="store_true")
+    p.add_argument("--b1", type=float, default=0.9)
+    p.add_argument("--b2", type=float, default=0.999)
+    p.add_argument("--seed", default=1234, type=int)
+    p.add_argument("--batch_size", default=8, type=int, help="global mini-batch (divided by the number of GPUs)")
+    p.add_argument("--iter_per_epoch", type=int, default=20)
+    p.add_argument("--save_dir", type=str, default="")
+    p.add_argument("--test_pth", type=str, default=None)
+    p.add_argument("--best_thres", type=float, default=0.5)
+    # ---- distributed (one process per GPU; torchrun env or mp.spawn as upstream train_ddp.py:622-624)
+    p.add_argument("--gpu", default="0", type=str, help="comma-separated GPU ids when spawning")
+    p.add_argument("--multiprocessing_distributed", action="store_true")
+    p.add_argument("--dist_url", type=str, default="tcp://127.0.0.1:4444")
+    p.add_argument("--dist_backend", type=str, default="nccl")
+    p.add_argument("--world_size", type=int, default=1)
+    p.add_argument("--rank", type=int, default=0)
+    # ---- synthetic data (no hospital data offline)
+    p.add_argument("--synthetic", default=[1024, 768, 64], type=arg_as_list,
+                   help="[patches per bag, patch feature dim, bags in the synthetic cohort]")
+    p.add_argument("--ragged", action="store_true", help="draw a different patch count per bag")
+    p.add_argument("--clip_layers", type=int, default=12)
+    p.add_argument("--fused_step", action="store_true", help="image_only: fused trainer instead of autograd + DDP")
+    return p.parse_args(argv)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Evaluation entry point (reference: test_ddp.py): load `checkpoint_best.pth.tar` strictly, eval mode, batch 1,
+per-sample inference time, predictions = output[:, 1] (test_ddp.py:73,187,214-253).  The ROC / Excel reporting
+of the reference is out of scope; accuracy at `--best_thres` and mean latency are printed instead."""
+import os
+import sys
+import time
+
+import torch
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mil_amd  # noqa: F401
+    __package__ = "mil_amd"
+
+from .config import create_arg_parser  # noqa: E402
+from .dataset import SyntheticBags, collate_bags  # noqa: E402
+from .train_ddp import build_model  # noqa: E402
+
+
+def test(args):
+    if not torch.cuda.is_available():
+        raise NotImplementedError("the MIL hot path runs on MI355X only: no GPU is visible")
+    dev = torch.device("cuda", int(args.gpu.split(",")[0]))
+    torch.cuda.set_device(dev)
+    model = build_model(args).to(dev)
+    if args.test_pth:
+        ck = torch.load(os.path.join(args.test_pth, "checkpoint_best.pth.tar"), map_location=dev, weights_only=True)
+        model.load_state_dict(ck["state_dict"])                       # strict, as test_ddp.py:99
+    model.eval()
+    n_patch, feat, n_bags = [int(v) for v in args.synthetic]
+    prompts = 10 if args.CI_prompt_version == "devided" else 1
+    data = SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, args.seed + 1, args.ragged)
+    preds, labels, times = [], [], []
+    with torch.no_grad():
+        for i in range(len(data)):                                     # batch_size = 1 (test_ddp.py:73)
+            b = collate_bags([data[i]])
+            x = b["pathology"].to(dev)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            if args.variant == "image_only":
+                _, out = model([x])
+            else:
+                out, _ = model([x], b["CI"].to(dev))
+            torch.cuda.synchronize()
+            times.append(time.time() - t0)
+            preds.append(float(out[0, 1]))
+            labels.append(int(b["label"][0].argmax()))
+    hard = [1 if p >= args.best_thres else 0 for p in preds]
+    acc = sum(int(a == b) for a, b in zip(hard, labels)) / len(labels)
+    print(f"bags {len(labels)}  ACC@{args.best_thres:.4f} {acc:.4f}  Time for inference {1e3 * sum(times[1:]) / max(1, len(times) - 1):.3f} ms/bag")
+    return preds, labels
+
+
+if __name__ == "__main__":
+    test(create_arg_parser())

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Training entry point (reference: train_ddp.py): one process per GPU, seeded model, sharded bags, BCE on the
+sigmoid outputs vs one-hot labels, Adam, rank-0 checkpoints with the reference's state_dict schema.
+
+Launch either like upstream (`--multiprocessing_distributed --gpu 0,1`: mp.spawn, tcp rendezvous,
+train_ddp.py:587-624) or under torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the env).  Data is synthetic
+(`--synthetic [N, F, bags]`): the hospital cohort is private.
+
+Two step implementations:
+  * default: `generator = DDP(get_model(args))`, autograd through the HIP operators - the reference's loop
+    (train_ddp.py:295-348) with `loss_point='Last'` semantics (:323-324);
+  * `--variant image_only --fused_step`: `trainer.ImageOnlyTrainer`, no autograd graph, one flat all-reduce."""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mil_amd  # noqa: F401
+    __package__ = "mil_amd"
+
+from .bags import BagLayout  # noqa: E402
+from .config import create_arg_parser  # noqa: E402
+from .dataset import SyntheticBags, collate_bags  # noqa: E402
+from .dist_utils import env_world, init_process_group, shard_indices  # noqa: E402
+from .utils import AverageMeter, ProgressMeter, calculate_accuracy, save_checkpoint, scheduled_lr  # noqa: E402
+
+
+def build_model(args):
+    if args.variant == "image_only":
+        from .model.utils_clip import get_model
+        args.patch_dim = int(args.synthetic[1])
+    else:
+        from .model.utils import get_model
+    return get_model(args)
+
+
+def main_worker(local_rank: int, nprocs: int, args):
+    if args.multiprocessing_distributed:
+        world, rank = nprocs * args.world_size, args.rank * nprocs + local_rank          # train_ddp.py:58
+        gpu = int(args.gpu.split(",")[local_rank])
+    else:
+        world, rank, gpu = env_world()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    if world > 1:
+        init_process_group(args.dist_backend, args.dist_url if args.multiprocessing_distributed else "env://", world,
+                           rank, dev)
+    if rank != 0:
+        import builtins
+        builtins.print = lambda *a, **k: None                                            # train_ddp.py:45-48
+    torch.manual_seed(args.seed)
+    n_patch, feat, n_bags = [int(v) for v in args.synthetic]
+    prompts = 10 if args.CI_prompt_version == "devided" else 1
+    data = SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, args.seed, args.ragged)
+    per_gpu = max(1, args.batch_size // world)                                           # train_ddp.py:75
+    model = build_model(args).to(dev)
+    lr0 = 1e-3 if args.num_classes > 2 else 1e-5                                         # train_ddp.py:110-113
+    args.lr = lr0
+
+    fused = args.fused_step and args.variant == "image_only"
+    if fused:
+        from .trainer import ImageOnlyTrainer
+        sd = model.state_dict()
+        params = {k.replace("extractor_pathology.", "aggregator."): v for k, v in sd.items()}
+        tr = ImageOnlyTrainer(params, dev, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
+    else:
+        generator = model
+        if world > 1:
+            generator = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)
+        criterion = torch.nn.BCELoss()
+        optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr0,
+                                     betas=(args.b1, args.b2), weight_decay=1e-7)        # train_ddp.py:115-118
+        if args.resume:
+            ck = torch.load(args.resume, map_location=dev, weights_only=True)
+            model.load_state_dict(ck["state_dict"])
+            optimizer.load_state_dict(ck["optimizer"])
+            args.start_epoch = ck["epoch"]
+
+    for epoch in range(args.start_epoch, args.n_epochs):
+        idx = shard_indices(len(data), world, rank, epoch)                               # sampler.set_epoch(epoch)
+        lr = scheduled_lr(lr0, epoch, args.n_epochs, args.schedule, args.cos)
+        losses, accs, bt = AverageMeter("Loss", ":.4e"), AverageMeter("Acc", ":6.3f"), AverageMeter("Time", ":6.3f")
+        steps = min(args.iter_per_epoch, len(idx) // per_gpu)
+        progress = ProgressMeter(steps, [bt, losses, accs], prefix=f"Epoch: [{epoch}]")
+        model.train()
+        end = time.time()
+        for it in range(steps):
+            batch = collate_bags([data[j] for j in idx[it * per_gpu:(it + 1) * per_gpu]])
+            x = batch["pathology"].to(dev, non_blocking=True)
+            y = batch["label"].to(dev, non_blocking=True)
+            if fused:
+                tr.lr = lr
+                flat = torch.cat([x[b, :n] for b, n in enumerate(batch["lengths"])], 0)
+                loss, prob = tr.train_step(flat, BagLayout.make(batch["lengths"], dev), y)
+            else:
+                for g in optimizer.param_groups:
+                    g["lr"] = lr
+                if args.variant == "image_only":
+                    _, prob = generator([x], batch["lengths"])
+                else:
+                    prob, _ = generator([x], batch["CI"].to(dev), batch["lengths"])
+                loss = criterion(prob, y)                                                # loss_point 'Last'
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+            if it % 10 == 0 or it == steps - 1:
+                losses.update(float(loss), x.shape[0])                                   # host sync only when logging
+                accs.update(float(calculate_accuracy(prob.detach(), y)), x.shape[0])
+                bt.update(time.time() - end)
+                progress.display(it)
+            end = time.time()
+        if rank == 0 and args.save_dir:
+            os.makedirs(args.save_dir, exist_ok=True)
+            sd = tr.fp.state_dict() if fused else model.state_dict()
+            state = {"epoch": epoch + 1, "state_dict": sd}
+            if not fused:
+                state["optimizer"] = optimizer.state_dict()
+            save_checkpoint(state, True, args.save_dir, f"checkpoint_{epoch:04d}.pth.tar")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = create_arg_parser(argv)
+    if not torch.cuda.is_available():
+        raise NotImplementedError("the MIL hot path runs on MI355X only: no GPU is visible")   # train_ddp.py:83-88
+    if args.multiprocessing_distributed:
+        n = len(args.gpu.split(","))
+        mp.spawn(main_worker, nprocs=n, args=(n, args))
+    else:
+        main_worker(0, 1, args)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ import torch.distributed as dist
 
 from . import ops
 from .bags import BagLayout
+from .dist_utils import allreduce_flat, broadcast_flat
 
 PARAM_ORDER = [
     "aggregator.attention_V.0.weight", "aggregator.attention_V.0.bias",
@@ -76,7 +77,7 @@ class ImageOnlyTrainer:
         self._ws: Optional[torch.Tensor] = None
         self.last = {}
         if self.world > 1:      # DDP broadcasts rank 0's parameters at wrap time (train_ddp.py:79)
-            dist.broadcast(self.fp.flat, src=0)
+            broadcast_flat(self.fp.flat, src=0)
 
     # ------------------------------------------------------------------ pieces (also timed one by one by bench.py)
     def _gate_fwd(self, x, save_gates=True):
@@ -120,8 +121,8 @@ class ImageOnlyTrainer:
         """One all-reduce(sum) of the flat gradient over RCCL, then Adam.  The local loss was already
         normalised by the global bag count, so the sum IS DDP's mean-of-ranks gradient."""
         if self.world > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.loss_sum, op=dist.ReduceOp.SUM)
+            allreduce_flat(self.fp.grad)
+            allreduce_flat(self.loss_sum)
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, self.step_count, self.lr,
                       self.betas, self.eps, self.wd, 1.0)
