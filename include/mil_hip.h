@@ -138,8 +138,11 @@ size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
              int accumulate, float* workspace, size_t workspace_floats, void* stream);
-/* out[j] (+)= sum_i Y[i][j]  (bias gradients). */
-int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, void* stream);
+/* out[j] (+)= sum_i Y[i][j]  (bias gradients).  With a workspace of mil_colsum_workspace_floats(M, N) floats
+ * a tall matrix is summed in 256-row chunks by many workgroups and folded in a second launch (fixed order). */
+size_t mil_colsum_workspace_floats(int M, int N);
+int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, float* workspace,
+               void* stream);
 /* dpre = dy * act'(y) from the post-activation output y (act 0 none, 1 tanh, 2 relu). */
 int mil_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, void* stream);
 

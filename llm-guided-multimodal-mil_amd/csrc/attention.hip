@@ -524,9 +524,9 @@ extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float
     }
     MIL_CHECK_LAUNCH();
     // partials are [nb][2][E]: two strided column sums
-    int rc = mil_colsum(workspace, 2 * E, nb, E, dgamma, 0, stream);
+    int rc = mil_colsum(workspace, 2 * E, nb, E, dgamma, 0, nullptr, stream);
     if (rc) return rc;
-    return mil_colsum(workspace + E, 2 * E, nb, E, dbeta, 0, stream);
+    return mil_colsum(workspace + E, 2 * E, nb, E, dbeta, 0, nullptr, stream);
 }
 
 extern "C" int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,

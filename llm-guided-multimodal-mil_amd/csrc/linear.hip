@@ -203,20 +203,33 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     *o = v;
 }
 
-// out[j] (+)= sum_i Y[i][j]       (bias gradients).  grid = ceil(N / 64), 256 threads = 64 columns x 4 row lanes
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int ldy, int M, int N, float* __restrict__ out,
-                                                int accumulate) {
+// out[j] (+)= sum_i Y[i][j]   (bias gradients, LayerNorm parameter gradients).
+// grid = (ceil(N / 64), nchunk): workgroup (cb, ch) sums rows [ch*rpc, (ch+1)*rpc) of 64 columns with 4 row lanes;
+// with nchunk > 1 the result goes to part[ch][N] and a second launch (nchunk = 1) folds the chunks, so the sum
+// order is fixed (no atomics) and a tall matrix still fills the chip.
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int ldy, int M, int N, int rpc,
+                                                float* __restrict__ out, int ldo, int accumulate) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    float v = 0.f;
-    if (c < N)
-        for (int i = g; i < M; i += 4) v += Y[(size_t)i * ldy + c];
-    red[g][threadIdx.x & 63] = v;
+    const int r0 = blockIdx.y * rpc, r1 = min(M, r0 + rpc);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (c < N) {
+        int i = r0 + g;
+        for (; i + 12 < r1; i += 16) {
+            v0 += Y[(size_t)i * ldy + c];
+            v1 += Y[(size_t)(i + 4) * ldy + c];
+            v2 += Y[(size_t)(i + 8) * ldy + c];
+            v3 += Y[(size_t)(i + 12) * ldy + c];
+        }
+        for (; i < r1; i += 4) v0 += Y[(size_t)i * ldy + c];
+    }
+    red[g][threadIdx.x & 63] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (g == 0 && c < N) {
-        v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (accumulate) v += out[c];
-        out[c] = v;
+        float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float* o = out + (size_t)blockIdx.y * ldo + c;
+        if (accumulate) v += *o;
+        *o = v;
     }
 }
 
@@ -278,9 +291,23 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
     return MIL_OK;
 }
 
-extern "C" int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, void* stream) {
+extern "C" size_t mil_colsum_workspace_floats(int M, int N) {
+    const int nch = (M + 255) / 256;
+    return nch > 1 ? (size_t)nch * N : 0;
+}
+
+extern "C" int mil_colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, float* workspace,
+                          void* stream) {
     if (!Y || !out || M < 0 || N <= 0) return MIL_EINVAL;
-    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, Y, ldy, M, N, out, accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (M + 255) / 256;
+    if (nch > 1 && workspace != nullptr) {
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, nch), dim3(256), 0, st, Y, ldy, M, N, 256, workspace, N, 0);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, N, nch, N, nch, out, 0, accumulate);
+    } else {
+        hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64, 1), dim3(256), 0, st, Y, ldy, M, N, M > 0 ? M : 1, out, 0, accumulate);
+    }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

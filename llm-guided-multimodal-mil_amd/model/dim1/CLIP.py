@@ -25,6 +25,23 @@ class CLIP(nn.Module):
         """x int64 [B, P, ctx] tokenised notes -> [B, P, 512]  (dim1/CLIP.py:71-77, one encode_text over all B*P
         prompts instead of a Python loop over the batch)."""
         B, P, ctx = x.shape
-        with torch.no_grad():
-            feats = self.model.encode_text(x.reshape(B * P, ctx))
-        return feats.reshape(B, P, -1)
+        flat = x.reshape(B * P, ctx)
+        if not getattr(self.args, "cache_text", 0):
+            with torch.no_grad():
+                feats = self.model.encode_text(flat)
+            return feats.reshape(B, P, -1)
+        # The tower is frozen, so a note's embedding never changes: encode each distinct token row once
+        # (keyed by its bytes; costs one small device->host copy of the ids per call) and replay it afterwards.
+        host = flat.cpu().numpy()
+        keys = [row.tobytes() for row in host]
+        todo = sorted({i for i, k in enumerate(keys) if k not in self._cache}, key=lambda i: i)
+        first = {}
+        for i in todo:
+            first.setdefault(keys[i], i)
+        if first:
+            idx = torch.tensor(list(first.values()), device=x.device)
+            with torch.no_grad():
+                new = self.model.encode_text(flat.index_select(0, idx))
+            for j, k in enumerate(first.keys()):
+                self._cache[k] = new[j].clone()
+        return torch.stack([self._cache[k] for k in keys], 0).reshape(B, P, -1)

@@ -276,7 +276,9 @@ def colsum(Y, out=None, accumulate: bool = False):
     M, N = Y.shape
     if out is None:
         out = torch.empty(N, device=Y.device, dtype=torch.float32)
-    rc = _lib.lib().mil_colsum(_p(Y), Y.stride(0), M, N, _p(out), 1 if accumulate else 0, _stream())
+    nws = _lib.lib().mil_colsum_workspace_floats(M, N)
+    ws = torch.empty(nws, device=Y.device, dtype=torch.float32) if nws else None
+    rc = _lib.lib().mil_colsum(_p(Y), Y.stride(0), M, N, _p(out), 1 if accumulate else 0, _p(ws), _stream())
     _lib.check(rc, "mil_colsum")
     return out
 
