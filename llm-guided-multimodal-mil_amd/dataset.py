@@ -34,6 +34,47 @@ def collate_bags(items):
     n_max = max(it["length"] for it in items)
     x = torch.zeros((len(items), n_max, items[0]["pathology"].shape[1]))
     for b, it in enumerate(items):
-        x[b, :it["length"]] = it["pathology"]
+        x[b, :it["length"]] = it["pathology"][:it["length"]]
     return {"pathology": x, "CI": torch.stack([it["CI"] for it in items]),
             "label": torch.stack([it["label"] for it in items]), "lengths": [it["length"] for it in items]}
+
+
+class NpyBagDataset(Dataset):
+    """On-disk pathology bags as the reference stores them: one `<patientid>.npy` per patient holding the
+    CTransPath features [n, 768] fp32 (dataset.py:366-367).  Mirrors the train-time patch-drop augmentation
+    (a sorted random subset of 90 % of the patches for biopsies, 80 % for resections, dataset.py:374-381) and the
+    zero-padding to a fixed row count used when batch_size > 1 (:383-391).  Labels/notes come from a small JSON
+    index {"id": {"label": 0|1, "kind": "Biopsy"|"Resection", "ids": [[...77 ints...], ...]}} instead of the
+    private Excel sheets."""
+
+    def __init__(self, root: str, index: dict, mode: str = "train", augmentation: bool = True, pad_to: int = 0,
+                 num_classes: int = 2, seed: int = 1234):
+        import random
+        self.root, self.mode, self.aug, self.pad_to, self.C = root, mode, augmentation, pad_to, num_classes
+        self.keys = sorted(index.keys())
+        self.index = index
+        self.rng = random.Random(seed)
+
+    def __len__(self):
+        return len(self.keys)
+
+    def __getitem__(self, i: int):
+        import os
+        import numpy as np
+        key = self.keys[i]
+        meta = self.index[key]
+        feat = np.load(os.path.join(self.root, key + ".npy"))               # allow_pickle stays False
+        n = feat.shape[0]
+        if self.mode == "train" and self.aug:
+            keep = 0.9 if meta.get("kind", "Biopsy") == "Biopsy" else 0.8
+            sel = sorted(self.rng.sample(range(n), int(n * keep)))
+            feat = feat[sel, :]
+        length = feat.shape[0]
+        if self.pad_to:
+            out = np.zeros((self.pad_to, feat.shape[1]), dtype=np.float32)
+            out[:length] = feat
+            feat = out
+        label = torch.nn.functional.one_hot(torch.tensor(int(meta["label"])), self.C).float()
+        ids = torch.tensor(meta.get("ids", [[0] * 77]), dtype=torch.int64)
+        return {"pathology": torch.from_numpy(np.ascontiguousarray(feat)).float(), "CI": ids, "label": label,
+                "length": length, "index": i}
