@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--bags-per-gpu", type=int, default=32)
     ap.add_argument("--patches", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: BASELINE config 5 variant (x and gate weights stored bf16, fp32 accumulate); use with "
+                         "--patches 4096 --dim 1024.  The headline metric is f32.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (default: eager; "
@@ -156,20 +159,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MIL_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo - a one-GPU rehearsal of the N>1 code path
+    # (RCCL refuses two ranks on one device); never used for reported numbers.
+    rehearsal = os.environ.get("MIL_BENCH_REHEARSAL") == "1"
+    gpu = 0 if rehearsal else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     B, N, L, C = args.bags_per_gpu, args.patches, args.dim, 2
     params = syn.image_only_params(1234, L=L)
     tr = ImageOnlyTrainer(params, dev, world_size=world)
     x = syn.make_bags(4321 + rank, B, N, L).reshape(B * N, L).to(dev)       # resident in HBM before timing
+    if args.dtype == "bf16":
+        x = x.to(torch.bfloat16)
     y = syn.make_labels(99 + rank, B, C).to(dev)
     lay = BagLayout.uniform(B, N, dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -199,14 +212,26 @@ def main():
         line = {
             "metric": "bags/sec fwd+bwd, N=1024 patches D=512", "value": round(value, 1), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{B} bags/GPU x {N} patches x {L} dims, image-only gated-attention MIL "
                                    f"fwd+BCE+bwd+allreduce+Adam (BASELINE config 2; x{world} GPUs = {world * B} bags)",
                        "bags_per_gpu": B, "patches": N, "dim": L, "global_bags": world * B,
                        "parallelism": f"dp{world}", "loss": round(loss, 6),
                        "launch": "eager" if not args.graph else "hipGraph(fwd+bwd)+eager(allreduce,adam)"},
         }
-        if not args.no_breakdown:
+        if not args.no_breakdown and args.dtype == "bf16":
+            sb = 2                                    # bytes per stored x element
+            fwd_ms = timed(lambda: tr._gate_fwd(x, True), 20)
+            sc, _ = tr._gate_fwd(x, True)
+            pp_ms = timed(lambda: ops.attn_pool_partial_bf16(x, sc, lay), 20)
+            R = B * N
+            line["roofline"] = {"bound": "hbm", "kernel": "k_gate_fwd_bf16", "achieved": round(R * L * sb / (fwd_ms * 1e-3) / 1e9, 1),
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(R * L * sb / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                "traffic": None, "ms_per_launch": round(fwd_ms, 4),
+                                "mfma_tflops": round(4.0 * R * L * D_GATE / (fwd_ms * 1e-3) / 1e12, 1)}
+            line["kernels_ms"] = {"gate_fwd_bf16": round(fwd_ms, 4), "pool_partial_bf16": round(pp_ms, 4)}
+            line["kernels_gbs"] = {"pool_partial_bf16": round(R * L * sb / (pp_ms * 1e-3) / 1e9, 1)}
+        elif not args.no_breakdown:
             kb = kernel_breakdown(tr, x, lay, y)
             R = B * N
             flops = {"gate_fwd": 4.0 * R * L * D_GATE, "gate_bwd_dw": 4.0 * R * L * D_GATE}

@@ -124,6 +124,23 @@ int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, con
 int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,
                        const float* Wu, int R, int L, int D, float* dx, void* stream);
 
+/* ---- K1, bf16-storage variant (BASELINE config 5: N=4096, D=1024) -------------------------------
+ * x and the gate weights are stored as bf16 (uint16_t bit patterns); all accumulation is fp32.  Same
+ * arithmetic as the fp32 entry points on rounded inputs (model/dim1/ABMIL.py:47-59); the deviation from
+ * the fp32 oracle is reported, the 1e-3 bar applies to the fp32 path.  L % 64 == 0 (gate), L in {512,1024} (pool). */
+int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
+int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu,
+                             const float* bu, const float* w, const float* b, float* scores, float* gates,
+                             int R, int L, int D, void* stream);
+int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
+                               float* partials, void* stream);
+int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, const float* lse, const float* dM,
+                           const float* cdot, const int32_t* tile_map, int T, int L, float* ds, void* stream);
+/* mil_gate_bwd_params with x stored as bf16 (widened while staged; fp32 MFMA product). */
+int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R, int L,
+                            int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,
+                            float* dbu, float* dw, float* db, int accumulate, void* stream);
+
 /* ---- K3a: generic fp32-MFMA GEMM with fused epilogue -----------------------------------------
  * C[M,N] (+)= act(A_op[M,K] . B_op[K,N] + bias) + residual
  *   a_mode 0: A_op[i][k] = A[i*lda + k];   a_mode 1: A_op[i][k] = A[k*lda + i]

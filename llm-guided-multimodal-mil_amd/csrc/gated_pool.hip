@@ -103,11 +103,21 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int g = 4 * t + j;
+#if !defined(GF_ABL_NOSTAGE)
                 if (g >= 4 && g < 12) {          // staging piece g-4: LDS write of slice s+1, reload with slice s+2
+#if !defined(GF_ABL_NOSWRITE)
                     swrite_piece(g - 4, buf ^ 1);
+#endif
+#if !defined(GF_ABL_NOGLOAD)
                     gload_piece(g - 4, k2);
+#endif
                 }
+#endif
+#if defined(GF_ABL_NOFRAG)
+                if (0) {
+#else
                 if (t < 3) {                      // prefetch the next k-group's fragments, 2 reads per MFMA group
+#endif
                     frag_piece(t + 1, q ^ 1, 2 * j);
                     if (2 * j + 1 < 7) frag_piece(t + 1, q ^ 1, 2 * j + 1);
                 }
@@ -119,7 +129,9 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if !defined(GF_ABL_NOBARRIER)
         __syncthreads();
+#endif
     }
 
     // Epilogue: lane holds column d = 32*(3wc+c) + r of both V and U for 16 rows.
@@ -345,8 +357,11 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
 // Both operands are "k-major" in LDS ([row][i] and [row][j]): lane (i = l & 31, k = l >> 5) reads
 // word row*128 + i: consecutive lanes -> consecutive banks, no conflicts, no padding.
 #define GB_BKR 32
+typedef unsigned short gb_u16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x, const float* __restrict__ gates,
+// XB16: x is stored as bf16 and widened to fp32 while it is staged (config-5 path; the product stays fp32 MFMA).
+template <bool XB16>
+__global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv, const float* __restrict__ gates,
                                                      const float* __restrict__ ds, const float* __restrict__ wvec,
                                                      float* __restrict__ part, float* __restrict__ pbias, int R, int L,
                                                      int KC, int NJ) {
@@ -371,8 +386,12 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
     const int rbeg = s * KC, rend = min(R, rbeg + KC);
     const int nslice = (rend - rbeg + GB_BKR - 1) / GB_BKR;
 
+    const float* x = static_cast<const float*>(xv);
+    const unsigned short* xh = static_cast<const unsigned short*>(xv);
     // staging maps
     const int xrow = tid >> 5, xc4 = tid & 31;    // x: rows xrow + 8i (i < 4), 16-byte chunk xc4
+    const int hrow = tid >> 4, hc8 = tid & 15;    // bf16 x: rows hrow + 16i (i < 2), 16-byte chunk (8 columns) hc8
+    gb_u16x8 rh[2];
     const int arow = tid >> 4, ad4 = tid & 15;    // gates: rows arow + 16i (i < 2), d = 64m + 4*ad4
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
     f32x4 rx[4], rv[2], ru[2];
@@ -383,11 +402,32 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
     // Branch-free staging pieces (rows past the chunk end are clamped to its last row and get ds = 0, so they
     // add nothing): the loop body is one basic block and every piece sits between two MFMA groups.
     auto xload = [&](int i, int rs) {
-        const int gr = min(rs + xrow + 8 * i, rend - 1);
-        rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4);
+        if (XB16) {
+            if (i < 2) {
+                const int gr = min(rs + hrow + 16 * i, rend - 1);
+                rh[i] = *reinterpret_cast<const gb_u16x8*>(xh + (size_t)gr * L + j0 + 8 * hc8);
+            }
+        } else {
+            const int gr = min(rs + xrow + 8 * i, rend - 1);
+            rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4);
+        }
     };
     auto xwrite = [&](int i, int buf) {
-        *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = rx[i];
+        if (XB16) {
+            if (i < 2) {
+                float* dst = xb + (buf * GB_BKR + hrow + 16 * i) * 128 + 8 * hc8;
+                f32x4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __uint_as_float(((unsigned)rh[i][e]) << 16);
+                    hi[e] = __uint_as_float(((unsigned)rh[i][4 + e]) << 16);
+                }
+                *reinterpret_cast<f32x4*>(dst) = lo;
+                *reinterpret_cast<f32x4*>(dst + 4) = hi;
+            }
+        } else {
+            *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = rx[i];
+        }
     };
     auto aload = [&](int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
@@ -455,11 +495,15 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const float* __restrict__ x
                 fb[q ^ 1][0] = bp[(ks + 1) * 256]; fb[q ^ 1][1] = bp[(ks + 1) * 256 + 32];
             }
             // one staging piece per k-step: LDS image of slice sl+1, then reload the registers with slice sl+2
+#if !defined(GB_ABL_NOX)
             if (ks >= 1 && ks <= 4) { xwrite(ks - 1, buf ^ 1); xload(ks - 1, rs2); }
+#endif
+#if !defined(GB_ABL_NOA)
             if (ks == 5) awrite_v(0, buf ^ 1);
             if (ks == 6) { awrite_u(0, buf ^ 1); aload(0, rs2, live2); }
             if (ks == 7) awrite_v(1, buf ^ 1);
             if (ks == 8) { awrite_u(1, buf ^ 1); aload(1, rs2, live2); }
+#endif
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
@@ -525,7 +569,17 @@ __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __restrict
     if (idx < nW) {
         const int gi = idx / L4, c4 = idx % L4;
         f32x4 v = {0, 0, 0, 0};
-        for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + ((size_t)s * GF_NG + gi) * L + 4 * c4);
+        const float* src = part + (size_t)gi * L + 4 * c4;
+        const size_t stride = (size_t)GF_NG * L;
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {          // 8 independent 16-byte loads in flight (the kernel is latency-bound)
+            f32x4 t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + e) * stride);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v += t[e];
+        }
+        for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
         const int m = gi >> 7, ii = gi & 127;
         float* dst = (ii < 64 ? dWv + (size_t)(64 * m + ii) * L : dWu + (size_t)(64 * m + ii - 64) * L) + 4 * c4;
         if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
@@ -639,7 +693,30 @@ extern "C" int mil_gate_bwd_params(const float* x, const float* gates, const flo
     float* pbias = workspace + (size_t)S * GF_NG * L;
     const int NJ = L / 128;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gate_bwd_dw, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
+    hipLaunchKernelGGL(k_gate_bwd_dw<false>, dim3(S * 3 * NJ), dim3(256), 0, st, (const void*)x, gates, ds, w, part, pbias, R, L, kc, NJ);
+    MIL_CHECK_LAUNCH();
+    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
+                       dbu, dw, db, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R,
+                                       int L, int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
+                                       float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
+    if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
+    if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
+    int kc;
+    const int S = split_plan(R, L, &kc);
+    const size_t need = (size_t)S * GF_NG * L + (size_t)S * 4 * 192;
+    if (workspace_floats < need) return MIL_ENOSPC;
+    float* part = workspace;
+    float* pbias = workspace + (size_t)S * GF_NG * L;
+    const int NJ = L / 128;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gate_bwd_dw<true>, dim3(S * 3 * NJ), dim3(256), 0, st, (const void*)x, gates, ds, w, part, pbias,
+                       R, L, kc, NJ);
     MIL_CHECK_LAUNCH();
     const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,

@@ -503,3 +503,62 @@ def gather_eot(ids, x):
     rc = _lib.lib().mil_gather_eot(_p(ids.contiguous()), _p(_f32c(x, "x")), nseq, ctx, W, _p(out), _stream())
     _lib.check(rc, "mil_gather_eot")
     return out
+
+
+# --------------------------------------------------------------------------- K1 bf16-storage variant (config 5)
+def _bf16c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.bfloat16:
+        raise _lib.MilHipError(f"{name}: expected a bfloat16 tensor on the GPU")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    src = _f32c(src, "src")
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    rc = _lib.lib().mil_cast_bf16(_p(src), _p(out), src.numel(), _stream())
+    _lib.check(rc, "mil_cast_bf16")
+    return out
+
+
+def gate_scores_fwd_bf16(x16, Wv16, bv, Wu16, bu, w, b, save_gates: bool = True):
+    x16 = _bf16c(x16, "x")
+    R, L = x16.shape
+    scores = torch.empty(R, device=x16.device, dtype=torch.float32)
+    gates = torch.empty((R, 2 * GATE_D), device=x16.device, dtype=torch.float32) if save_gates else None
+    rc = _lib.lib().mil_gate_scores_fwd_bf16(_p(x16), _p(_bf16c(Wv16, "Wv")), _p(bv), _p(_bf16c(Wu16, "Wu")), _p(bu), _p(w),
+                                             _p(b), _p(scores), _p(gates), R, L, Wv16.shape[0], _stream())
+    _lib.check(rc, "mil_gate_scores_fwd_bf16")
+    return scores, gates
+
+
+def attn_pool_partial_bf16(x16, scores, layout: BagLayout):
+    x16 = _bf16c(x16, "x")
+    R, L = x16.shape
+    partials = torch.empty(layout.T * (L + 2), device=x16.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_partial_bf16(_p(x16), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials), _stream())
+    _lib.check(rc, "mil_attn_pool_partial_bf16")
+    return partials
+
+
+def attn_pool_bwd_bf16(x16, scores, lse, dM, cdot, layout: BagLayout):
+    x16 = _bf16c(x16, "x")
+    R, L = x16.shape
+    ds = torch.empty(R, device=x16.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_bwd_bf16(_p(x16), _p(scores), _p(lse), _p(dM), _p(cdot), _p(layout.tile_map), layout.T, L,
+                                           _p(ds), _stream())
+    _lib.check(rc, "mil_attn_pool_bwd_bf16")
+    return ds
+
+
+def gate_bwd_params_x16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None):
+    x16 = _bf16c(x16, "x")
+    R, L = x16.shape
+    need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x16.device, dtype=torch.float32)
+    rc = _lib.lib().mil_gate_bwd_params_x16(_p(x16), _p(gates), _p(ds), _p(w), R, L, GATE_D, _p(workspace),
+                                            workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
+                                            1 if accumulate else 0, _stream())
+    _lib.check(rc, "mil_gate_bwd_params_x16")
+    return workspace

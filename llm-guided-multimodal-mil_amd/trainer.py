@@ -42,7 +42,11 @@ class FlatParams:
             off += (n + 3) // 4 * 4
         self.numel = off
         self.flat = torch.zeros(off, device=device, dtype=torch.float32)
-        self.grad = torch.zeros_like(self.flat)
+        # the gradient buffer carries 4 extra floats: slot 0 of the tail holds the step's loss, so the ONE
+        # all-reduce of the step also sums the loss over the ranks
+        self.grad_ext = torch.zeros(off + 4, device=device, dtype=torch.float32)
+        self.grad = self.grad_ext[:off]
+        self.loss_slot = self.grad_ext[off:off + 1]
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         for k in self.order:
@@ -73,7 +77,7 @@ class ImageOnlyTrainer:
         self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
         self.world = world_size
         self.step_count = 0
-        self.loss_sum = torch.zeros(1, device=device, dtype=torch.float32)
+        self.loss_sum = self.fp.loss_slot
         self._ws: Optional[torch.Tensor] = None
         self.last = {}
         if self.world > 1:      # DDP broadcasts rank 0's parameters at wrap time (train_ddp.py:79)
@@ -82,6 +86,13 @@ class ImageOnlyTrainer:
     # ------------------------------------------------------------------ pieces (also timed one by one by bench.py)
     def _gate_fwd(self, x, save_gates=True):
         fp = self.fp
+        if x.dtype == torch.bfloat16:       # config-5 path: bf16 storage of x and of the gate weights, fp32 accumulate
+            Wv16 = ops.cast_bf16(fp.p("aggregator.attention_V.0.weight"))
+            Wu16 = ops.cast_bf16(fp.p("aggregator.attention_U.0.weight"))
+            return ops.gate_scores_fwd_bf16(x, Wv16, fp.p("aggregator.attention_V.0.bias"), Wu16,
+                                            fp.p("aggregator.attention_U.0.bias"),
+                                            fp.p("aggregator.attention_weights.weight").view(-1),
+                                            fp.p("aggregator.attention_weights.bias"), save_gates=save_gates)
         return ops.gate_scores_fwd(
             x, fp.p("aggregator.attention_V.0.weight"), fp.p("aggregator.attention_V.0.bias"),
             fp.p("aggregator.attention_U.0.weight"), fp.p("aggregator.attention_U.0.bias"),
@@ -93,7 +104,7 @@ class ImageOnlyTrainer:
         """Inference when y is None; with labels the fused tail also produces loss, dz, dM, cdot."""
         fp = self.fp
         scores, gates = self._gate_fwd(x, save_gates=y is not None)
-        partials = ops.attn_pool_partial(x, scores, layout)
+        partials = (ops.attn_pool_partial_bf16 if x.dtype == torch.bfloat16 else ops.attn_pool_partial)(x, scores, layout)
         scale = 1.0
         if y is not None:
             nb = global_bags if global_bags is not None else layout.B * self.world
@@ -108,8 +119,12 @@ class ImageOnlyTrainer:
         """Gradients of the (globally normalised) BCE loss into the flat grad buffer (overwrites it)."""
         c, fp = self.last, self.fp
         ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"))
-        ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
-        self._ws = ops.gate_bwd_params(
+        b16 = c["x"].dtype == torch.bfloat16
+        if b16:
+            ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
+        else:
+            ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
+        self._ws = (ops.gate_bwd_params_x16 if b16 else ops.gate_bwd_params)(
             c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
             fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
             fp.g("aggregator.attention_U.0.weight"), fp.g("aggregator.attention_U.0.bias"),
@@ -121,8 +136,7 @@ class ImageOnlyTrainer:
         """One all-reduce(sum) of the flat gradient over RCCL, then Adam.  The local loss was already
         normalised by the global bag count, so the sum IS DDP's mean-of-ranks gradient."""
         if self.world > 1:
-            allreduce_flat(self.fp.grad)
-            allreduce_flat(self.loss_sum)
+            allreduce_flat(self.fp.grad_ext)        # gradients + loss in one collective
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, self.step_count, self.lr,
                       self.betas, self.eps, self.wd, 1.0)

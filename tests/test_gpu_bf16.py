@@ -1,0 +1,54 @@
+"""GPU: the bf16-storage variant of K1 (BASELINE config 5).  Exactness reference: the fp32 oracle evaluated on the
+SAME bf16-rounded inputs (x and gate weights rounded to bf16, everything else fp32) - against that the kernels must
+match to fp32 accuracy.  Against the unrounded fp32 oracle the deviation is reported and bounded loosely."""
+import pytest
+import torch
+
+from conftest import rel_err
+from mil_amd import ops, synthetic as syn
+from mil_amd.bags import BagLayout
+from mil_amd.trainer import ImageOnlyTrainer
+from oracle import mil_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _round(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("lengths,L", [([300, 77], 512), ([1000], 1024), ([33, 1, 129], 1024)])
+def test_bf16_step_matches_oracle_on_rounded_inputs(lengths, L):
+    p = syn.image_only_params(55, L=L)
+    bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(800 + i)) for i, n in enumerate(lengths)]
+    y = syn.make_labels(56, len(lengths))
+    tr = ImageOnlyTrainer(p, torch.device(DEV), lr=1e-3)
+    x16 = torch.cat(bags, 0).to(DEV).to(torch.bfloat16)
+    lay = BagLayout.make(lengths, torch.device(DEV))
+    prob, z = tr.forward(x16, lay, y.to(DEV))
+    tr.backward()
+    # oracle on rounded x; the gate weights are rounded only inside the gate (the pool and dW use fp32 masters... the
+    # gradient flows to the fp32 master through the identity, as in mixed-precision training)
+    pr = dict(p)
+    pr["aggregator.attention_V.0.weight"] = _round(p["aggregator.attention_V.0.weight"])
+    pr["aggregator.attention_U.0.weight"] = _round(p["aggregator.attention_U.0.weight"])
+    rb = [_round(b) for b in bags]
+    loss, logits, rprob, grads = orc.batch_loss_and_grads(rb, y, pr)
+    assert float((z.cpu() - logits).abs().max()) <= 5e-5
+    assert torch.equal(prob.cpu().argmax(-1), rprob.argmax(-1))
+    assert abs(float(tr.loss_sum.item()) - float(loss)) <= 1e-5
+    for k in grads:
+        if float(grads[k].norm()) > 1e-7:
+            assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= 5e-4, k
+    # deviation from the UNROUNDED fp32 oracle (reported in DESIGN.md; loose bound here)
+    _, logits32, _, _ = orc.batch_loss_and_grads(bags, y, p)
+    dev = float((z.cpu() - logits32).abs().max())
+    print(f"bf16 vs fp32 oracle: max |dlogit| = {dev:.2e}")
+    assert dev <= 5e-3
+
+
+def test_cast_bf16_round_to_nearest_even():
+    x = torch.tensor([1.0, 1.00390625, 1.005859375, -2.5, 3.0e38, 1e-40, float("inf")] + [0.1 * i for i in range(25)])
+    got = ops.cast_bf16(x.to(DEV)).cpu()
+    assert torch.equal(got, x.to(torch.bfloat16))

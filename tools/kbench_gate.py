@@ -35,6 +35,10 @@ for rnd in range(3):
         _lib._lib = h
         t_f = timed(lambda: ops.gate_scores_fwd(*args, save_gates=True))
         scores, gates = ops.gate_scores_fwd(*args, save_gates=True)
+        if rnd == 0:
+            ref_scores = globals().setdefault("REF_SCORES", scores.clone())
+            ref_gates = globals().setdefault("REF_GATES", gates.clone())
+            print(f"   {name}: max|dscore| vs first lib {float((scores - ref_scores).abs().max()):.2e}  max|dgates| {float((gates - ref_gates).abs().max()):.2e}")
         ds = torch.randn(B * N, device=dev) * 1e-3
         g = [torch.empty_like(p[k]) for k in ("aggregator.attention_V.0.weight", "aggregator.attention_V.0.bias",
              "aggregator.attention_U.0.weight", "aggregator.attention_U.0.bias")] + [torch.empty(192, device=dev), torch.empty(1, device=dev)]
