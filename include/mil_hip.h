@@ -200,6 +200,14 @@ int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
  * table rows indexed by the position inside the bag (aggregator.py:190 passes pe[:, :N]). */
 int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,
                float* out, void* stream);
+/* One-text-token fast path of the image->token attention (sam/transformer.py:303-307): with a single key the
+ * softmax is 1, so every patch of bag b receives the same row o[b]:  out[row] = x[row] + o[row_bag[row]].
+ * mil_segment_colsum is its backward w.r.t. o: out[b] = sum of Y over the rows [row_off[b], row_off[b+1]);
+ * workspace (nullable) ceil(max_rows / 256) * B * E floats lets long bags be summed by many workgroups. */
+int mil_add_bag_row(const float* x, const float* o, const int32_t* row_bag, int rows, int E, float* out,
+                    void* stream);
+int mil_segment_colsum(const float* Y, const int32_t* row_off, int B, int max_rows, int E, float* out,
+                       float* workspace, void* stream);
 /* The sinusoidal table of model/aggregator.py:99-106 built on the device: pe [n, E]. */
 int mil_sinusoid_pe(float* pe, int n, int E, void* stream);
 

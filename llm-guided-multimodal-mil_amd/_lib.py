@@ -52,6 +52,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_layernorm_bwd_blocks": (c_int, [c_int]),
     "mil_layernorm_bwd": (c_int, [_P] * 4 + [c_int, c_int] + [_P] * 4 + [_P]),
     "mil_add_pe": (c_int, [_P] * 4 + [c_int, c_int, _P, _P]),
+    "mil_add_bag_row": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "mil_segment_colsum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "mil_sinusoid_pe": (c_int, [_P, c_int, c_int, _P]),
     "mil_embed_tokens": (c_int, [_P] * 3 + [c_int] * 3 + [_P, _P]),
     "mil_gather_eot": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),

@@ -380,6 +380,43 @@ __global__ __launch_bounds__(256) void k_add_pe(const float* __restrict__ x, con
     *reinterpret_cast<f32x4*>(out + 4 * i) = a + p;
 }
 
+// out[row] = x[row] + o[row_bag[row]]: a per-bag row broadcast over the bag's rows.  With ONE text token per bag
+// the image->token attention (sam/transformer.py:303-307) has softmax == 1, so its output is the same projected
+// token for every patch of the bag: this add replaces the q projection, the attention core and the per-patch
+// out projection.  One float4 per thread.
+__global__ __launch_bounds__(256) void k_add_bag_row(const float* __restrict__ x, const float* __restrict__ o,
+                                                     const int32_t* __restrict__ row_bag, size_t n4, int E4,
+                                                     float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int row = (int)(i / E4), c4 = (int)(i % E4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(o + ((size_t)row_bag[row] * E4 + c4) * 4);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = a + b;
+}
+
+// out[b][j] = sum over the rows of bag b of Y[row][j]   (backward of k_add_bag_row w.r.t. o).
+// grid = (ceil(E / 64), B, nchunk): chunk ch sums rows ch, ch + nchunk, ... of 4-row lanes into part[ch][b][E];
+// a second launch with nchunk = 1 over the partials folds them (fixed order, no atomics).
+__global__ __launch_bounds__(256) void k_segment_colsum(const float* __restrict__ Y, const int32_t* __restrict__ row_off,
+                                                        int E, int nchunk, int rows_per_chunk, float* __restrict__ out,
+                                                        int B) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int b = blockIdx.y, ch = blockIdx.z;
+    const int r0 = row_off[b] + ch * rows_per_chunk, r1 = min(row_off[b + 1], r0 + rows_per_chunk);
+    float v0 = 0.f, v1 = 0.f;
+    if (c < E) {
+        int i = r0 + g;
+        for (; i + 4 < r1; i += 8) { v0 += Y[(size_t)i * E + c]; v1 += Y[(size_t)(i + 4) * E + c]; }
+        for (; i < r1; i += 4) v0 += Y[(size_t)i * E + c];
+    }
+    red[g][threadIdx.x & 63] = v0 + v1;
+    __syncthreads();
+    if (g == 0 && c < E)
+        out[((size_t)ch * B + b) * E + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // Sinusoidal table of model/aggregator.py:99-106, built on the device once: pe[p][2i] = sin(p * w_i),
 // pe[p][2i+1] = cos(p * w_i), w_i = exp(2i * -(ln 1e4 / E)).  fp32 argument as in the reference.
 __global__ __launch_bounds__(256) void k_sinusoid_pe(float* __restrict__ pe, int n, int E) {
@@ -600,4 +637,36 @@ extern "C" int mil_gather_eot(const int64_t* ids, const float* x, int nseq, int 
     hipLaunchKernelGGL(k_gather_eot, dim3(nseq), dim3(64), 0, (hipStream_t)stream, ids, x, ctx, W, out);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_add_bag_row(const float* x, const float* o, const int32_t* row_bag, int rows, int E, float* out,
+                               void* stream) {
+    if (!x || !o || !row_bag || !out || rows < 0 || E <= 0 || (E & 3)) return MIL_EINVAL;
+    if (rows == 0) return MIL_OK;
+    const size_t n4 = (size_t)rows * (E / 4);
+    hipLaunchKernelGGL(k_add_bag_row, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, o, row_bag,
+                       n4, E / 4, out);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_segment_colsum(const float* Y, const int32_t* row_off, int B, int max_rows, int E, float* out,
+                                  float* workspace, void* stream) {
+    if (!Y || !row_off || !out || B < 0 || E <= 0 || max_rows < 0) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int nchunk = (max_rows + 255) / 256;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 1 && workspace == nullptr) nchunk = 1;
+    const int rpc = nchunk > 1 ? 256 : (max_rows > 0 ? max_rows : 1);
+    if (nchunk == 1) {
+        hipLaunchKernelGGL(k_segment_colsum, dim3((E + 63) / 64, B, 1), dim3(256), 0, st, Y, row_off, E, 1, rpc, out, B);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
+    hipLaunchKernelGGL(k_segment_colsum, dim3((E + 63) / 64, B, nchunk), dim3(256), 0, st, Y, row_off, E, nchunk, rpc,
+                       workspace, B);
+    MIL_CHECK_LAUNCH();
+    // fold: view the partials [nchunk][B*E] as a matrix with nchunk rows
+    return mil_colsum(workspace, B * E, nchunk, B * E, out, 0, nullptr, stream);
 }

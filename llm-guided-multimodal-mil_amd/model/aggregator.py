@@ -93,12 +93,15 @@ class aggregator(nn.Module):
         return p
 
     # ------------------------------------------------------------------ forward (aggregator.py:134-209)
-    def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None):
+    def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
+                text_features: Optional[torch.Tensor] = None):
         """x_list = [x_pathology [B, N, 768]] (or [] for CI only); x_CI int64 [B, P, ctx] token ids.
         `lengths` (optional) gives the true patch count of each zero-padded bag (dataset.py:386-391 pads to a
         fixed length when batch > 1); padded rows are then dropped instead of being attended to."""
         modality = self.args.modality
-        t = self.clinic_extractor(x_CI)                                                   # :151  [B, P, 512]
+        # text_features [B, P, 512] (optional): embeddings of the frozen text tower computed earlier by
+        # `self.clinic_extractor(x_CI)`; lets a captured hipGraph replay the trainable part only
+        t = text_features if text_features is not None else self.clinic_extractor(x_CI)   # :151  [B, P, 512]
         B, P, _ = t.shape
         if "pathology" in modality:
             x = x_list[0]

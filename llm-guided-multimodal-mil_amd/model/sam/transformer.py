@@ -81,7 +81,15 @@ class TwoWayAttentionBlock(nn.Module):
         queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
         queries = self.norm3(self.mlp(queries, residual=queries))               # :298-300
         q = queries + query_pe                                                  # :303-307
-        keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys))
+        if s_it.Tk_max == 1 and min(s_it.k_lengths, default=1) == 1:
+            # One text token per bag: the softmax over a single key is exactly 1, every patch receives the same
+            # out_proj(v_proj(token)) and q_proj / k_proj get exactly zero gradient (as upstream).  Skips two
+            # [N, 512] projections and the attention core; bit-for-bit the general path's result up to rounding.
+            a = self.cross_attn_image_to_token
+            o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
+            keys = self.norm4(ops.add_bag_row(keys, o, s_it))
+        else:
+            keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys))
         return queries, keys
 
     def forward(self, queries, keys, query_pe, key_pe):

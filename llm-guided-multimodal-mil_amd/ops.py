@@ -562,3 +562,34 @@ def gate_bwd_params_x16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulat
                                             1 if accumulate else 0, _stream())
     _lib.check(rc, "mil_gate_bwd_params_x16")
     return workspace
+
+
+class _AddBagRow(torch.autograd.Function):
+    """x[row] + o[bag of row]  (one-text-token fast path of the image->token attention)."""
+
+    @staticmethod
+    def forward(ctx, x, o, segs):
+        x, o = _f32c(x, "x"), _f32c(o, "o")
+        rows, E = x.shape
+        out = torch.empty_like(x)
+        rc = _lib.lib().mil_add_bag_row(_p(x), _p(o), _p(segs.q_bag), rows, E, _p(out), _stream())
+        _lib.check(rc, "mil_add_bag_row")
+        ctx.segs = segs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        segs = ctx.segs
+        g = _f32c(g, "g")
+        rows, E = g.shape
+        do = torch.empty((segs.B, E), device=g.device, dtype=torch.float32)
+        nch = (segs.Tq_max + 255) // 256
+        ws = torch.empty(nch * segs.B * E, device=g.device, dtype=torch.float32) if nch > 1 else None
+        rc = _lib.lib().mil_segment_colsum(_p(g), _p(segs.q_off), segs.B, segs.Tq_max, E, _p(do), _p(ws), _stream())
+        _lib.check(rc, "mil_segment_colsum")
+        return g, do, None
+
+
+def add_bag_row(x, o, segs):
+    """segs: AttnSegs whose QUERY side are the rows of x (q_bag / q_off)."""
+    return _AddBagRow.apply(x, o, segs)

@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--clip_layers", type=int, default=12)
 ap.add_argument("--cache_text", action="store_true")
+ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
 dev = torch.device("cuda")
 args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
@@ -24,7 +25,8 @@ model = get_model(args).to(dev).eval()      # eval: parity mode (dropout off), g
 x = syn.make_bags(1, a.bags, a.patches, 768).to(dev)
 ids = syn.make_token_ids(2, a.bags, a.prompts).to(dev)
 y = syn.make_labels(3, a.bags).to(dev)
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7)
+opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7,
+                       capturable=a.graph)
 crit = torch.nn.BCELoss()
 
 def step():
@@ -35,6 +37,30 @@ def step():
     opt.step()
     return loss
 
+if a.graph:
+    with torch.no_grad():
+        tfeat = model.clinic_extractor(ids)          # frozen tower: outside the graph (cached per note in training)
+    def gstep():
+        prob, _ = model([x], ids, text_features=tfeat)
+        loss = crit(prob, y)
+        loss.backward()
+        opt.step()
+        return loss
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            gstep()
+    torch.cuda.current_stream().wait_stream(side)
+    # grads are None at capture time: backward() allocates them from the graph's pool and every replay
+    # overwrites them in place (no per-parameter fill / accumulate kernels)
+    opt.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = gstep()
+    def step():
+        g.replay()
+        return static_loss
 for _ in range(a.warmup): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): loss = step()
