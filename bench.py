@@ -66,8 +66,9 @@ def kernel_breakdown(tr, x, lay, y, iters=20):
     partials = ops.attn_pool_partial(x, c["scores"], lay)
     scale = 1.0 / c["prob"].numel()
     out["merge_head_loss"] = timed(lambda: ops.pool_merge_head(partials, lay, L, fp.p("fc.1.weight"), fp.p("fc.1.bias"),
-                                                               y, scale, tr.loss_sum), iters)
-    out["head_bwd_params"] = timed(lambda: ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias")), iters)
+                                                               y, scale), iters)
+    out["head_bwd_params"] = timed(lambda: ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"),
+                                                               c["loss_bag"], tr.loss_sum), iters)
     ds, _ = ops.attn_pool_bwd(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay, False)
     out["pool_bwd_ds"] = timed(lambda: ops.attn_pool_bwd(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay, False), iters)
     g = {k: torch.empty_like(fp.p(k)) for k in fp.order}

@@ -68,12 +68,13 @@ int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* ti
                           float* partials, void* stream);
 
 /* Fused per-bag tail (one workgroup per bag): merge the partials -> M, lse; head z, p; and, when
- * labels y are given, BCE loss (accumulated into loss_sum, see mil_bce_fwd_bwd), dz, dM = dz Wf and
- * cdot = M . dM, i.e. everything between the pool's partial pass and the pool's backward.
+ * labels y are given, the bag's BCE loss loss_bag[b] = scale * sum_c BCE(p_bc, y_bc) (log clamped at -100;
+ * summed in fixed order by mil_head_bwd_params), dz, dM = dz Wf and cdot = M . dM, i.e. everything
+ * between the pool's partial pass and the pool's backward.
  * ABMIL.py:57-59 + aggregator.py:128-131,200 + train_ddp.py:99,323-324.  L in {256, 512, 1024}. */
 int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
                         const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
-                        float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
+                        float* lse, float* z, float* p, float* loss_bag, float* dz, float* dM, float* cdot,
                         void* stream);
 
 /* ---- K3b: per-bag head ------------------------------------------------------------------
@@ -94,9 +95,10 @@ int mil_bce_fwd_bwd(const float* p, const float* y, float* loss_sum, float* dz, 
 int mil_head_bwd(const float* dz_or_dp, const float* p, const float* M, const float* Wf, float* dM,
                  float* dWf, float* dbf, float* cdot, int B, int L, int C, void* stream);
 
-/* Parameter half of mil_head_bwd alone (dWf = dz^T M, dbf = sum_b dz), for use after the fused tail. */
+/* Parameter half of mil_head_bwd alone (dWf = dz^T M, dbf = sum_b dz), for use after the fused tail; if
+ * loss_bag [B] is given it also writes loss_out[0] = sum_b loss_bag[b] (overwrite: no memset, no atomics). */
 int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
-                        void* stream);
+                        const float* loss_bag, float* loss_out, void* stream);
 
 /* out[b] = a[b] . c[b] for two [B, L] matrices (cdot = M . dM when dM comes from autograd). */
 int mil_rowdot(const float* a, const float* c, float* out, int B, int L, void* stream);

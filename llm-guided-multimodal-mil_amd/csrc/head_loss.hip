@@ -71,29 +71,46 @@ __global__ __launch_bounds__(256) void k_head_bwd_dm(const float* __restrict__ d
     if (tid == 0) cdot[b] = dot;
 }
 
-// dWf[c][j] = sum_b dz[b][c] M[b][j];  dbf[c] = sum_b dz[b][c].   one thread per (c, j) (+ C for the bias).
+// dWf[c][j] = sum_b dz[b][c] M[b][j];  dbf[c] = sum_b dz[b][c];  loss_out[0] = sum_b loss_bag[b].
+// grid = C * ceil(L / 64) + 1 workgroups of 256 threads = 64 columns x 4 bag lanes; the last workgroup does the
+// bias gradient and the loss.  dz_or_dp / p as in mil_head_bwd.
 __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict__ dz_or_dp, const float* __restrict__ p,
                                                          const float* __restrict__ M, float* __restrict__ dWf,
-                                                         float* __restrict__ dbf, int B, int L, int C) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < C * L) {
-        const int c = idx / L, j = idx % L;
+                                                         float* __restrict__ dbf, int B, int L, int C,
+                                                         const float* __restrict__ loss_bag, float* __restrict__ loss_out) {
+    __shared__ float red[4][64];
+    const int nlb = (L + 63) / 64;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if ((int)blockIdx.x < C * nlb) {
+        const int c = blockIdx.x / nlb, j = (blockIdx.x % nlb) * 64 + lane;
         float v = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float g = dz_or_dp[b * C + c];
-            if (p != nullptr) { const float pp = p[b * C + c]; g = g * pp * (1.0f - pp); }
-            v += g * M[(size_t)b * L + j];
+        if (j < L)
+            for (int b = g; b < B; b += 4) {
+                float gz = dz_or_dp[b * C + c];
+                if (p != nullptr) { const float pp = p[b * C + c]; gz = gz * pp * (1.0f - pp); }
+                v += gz * M[(size_t)b * L + j];
+            }
+        red[g][lane] = v;
+        __syncthreads();
+        if (g == 0 && j < L) dWf[(size_t)c * L + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    } else {
+        // bias gradients: thread t < C sums over the bags; the loss: wave 1 sums loss_bag
+        if ((int)threadIdx.x < C) {
+            const int c = threadIdx.x;
+            float v = 0.f;
+            for (int b = 0; b < B; ++b) {
+                float gz = dz_or_dp[b * C + c];
+                if (p != nullptr) { const float pp = p[b * C + c]; gz = gz * pp * (1.0f - pp); }
+                v += gz;
+            }
+            dbf[c] = v;
         }
-        dWf[idx] = v;
-    } else if (idx < C * L + C) {
-        const int c = idx - C * L;
-        float v = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float g = dz_or_dp[b * C + c];
-            if (p != nullptr) { const float pp = p[b * C + c]; g = g * pp * (1.0f - pp); }
-            v += g;
+        if (loss_bag != nullptr && g == 1) {
+            float v = 0.f;
+            for (int b = lane; b < B; b += 64) v += loss_bag[b];
+            v = wave_allsum(v);
+            if (lane == 0) loss_out[0] = v;
         }
-        dbf[c] = v;
     }
 }
 
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const f
 // Fused per-bag tail of the forward and head of the backward (one workgroup per bag):
 //   merge the attention-pool tile partials -> M, lse        (ABMIL.py:57-59)
 //   z = M Wf^T + bf, p = sigmoid(z)                         (aggregator.py:128-131,200)
-//   if labels: loss += BCE(p, y) * scale, dz = (p - y) * scale, dM = dz Wf, cdot = M . dM
+//   if labels: loss_bag[b] = BCE(p_b, y_b) * scale, dz = (p - y) * scale, dM = dz Wf, cdot = M . dM
 // Thread (g, c4): column float4 c4 < L/4, tile group g < 256/(L/4); tile loads are unrolled 8 deep
 // so one workgroup keeps ~8 x 4 KiB in flight (the kernel is latency-bound: B workgroups only).
 __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict__ partials,
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
         }
     }
     if (y == nullptr) return;
-    if (tid == 0) atomicAdd(loss_sum, lossacc * scale);
+    if (tid == 0) loss_sum[b] = lossacc * scale;      // per-bag loss; summed (fixed order) by k_head_bwd_params
     __syncthreads();
     float dot = 0.f;
     for (int j = tid; j < L; j += 256) {
@@ -255,18 +272,18 @@ extern "C" int mil_head_bwd(const float* dz_or_dp, const float* p, const float* 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_head_bwd_dm, dim3(B), dim3(256), 0, st, dz_or_dp, p, M, Wf, dM, cdot, L, C);
     MIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_head_bwd_params, dim3((C * L + C + 255) / 256), dim3(256), 0, st, dz_or_dp, p, M, dWf, dbf, B, L,
-                       C);
+    hipLaunchKernelGGL(k_head_bwd_params, dim3(C * ((L + 63) / 64) + 1), dim3(256), 0, st, dz_or_dp, p, M, dWf, dbf, B, L,
+                       C, (const float*)nullptr, (float*)nullptr);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
-                                   void* stream) {
+                                   const float* loss_bag, float* loss_out, void* stream) {
     if (!dz || !M || !dWf || !dbf) return MIL_EINVAL;
-    if (B <= 0 || L <= 0 || C <= 0 || C > 32) return MIL_EINVAL;
-    hipLaunchKernelGGL(k_head_bwd_params, dim3((C * L + C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz,
-                       (const float*)nullptr, M, dWf, dbf, B, L, C);
+    if (B <= 0 || L <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_head_bwd_params, dim3(C * ((L + 63) / 64) + 1), dim3(256), 0, (hipStream_t)stream, dz,
+                       (const float*)nullptr, M, dWf, dbf, B, L, C, loss_bag, loss_out);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

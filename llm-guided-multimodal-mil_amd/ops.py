@@ -77,30 +77,27 @@ def attn_pool_partial(x, scores, layout: BagLayout):
     return partials
 
 
-def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0, loss_sum=None,
-                    dM=None):
-    """Fused per-bag tail: returns dict(M, lse, logits, prob[, dz, dM, cdot]); with labels it also adds the
-    BCE loss into loss_sum and produces the head's backward inputs for the pool."""
+def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0):
+    """Fused per-bag tail: returns dict(M, lse, logits, prob[, loss_bag, dz, dM, cdot]); with labels it also
+    produces each bag's scaled BCE loss and the head's backward inputs for the pool."""
     B, C, dev = layout.B, Wf.shape[0], partials.device
     out = dict(M=torch.empty((B, L), device=dev), lse=torch.empty(B, device=dev),
                logits=torch.empty((B, C), device=dev), prob=torch.empty((B, C), device=dev))
     if y is not None:
-        out.update(dz=torch.empty((B, C), device=dev), dM=dM if dM is not None else torch.empty((B, L), device=dev),
-                   cdot=torch.empty(B, device=dev))
-        if loss_sum is None:
-            loss_sum = torch.zeros(1, device=dev)
-        out["loss_sum"] = loss_sum
+        out.update(dz=torch.empty((B, C), device=dev), dM=torch.empty((B, L), device=dev),
+                   cdot=torch.empty(B, device=dev), loss_bag=torch.empty(B, device=dev))
     rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
                                         _p(_f32c(bf, "bf")), C, _p(y), float(scale), _p(out["M"]), _p(out["lse"]),
-                                        _p(out["logits"]), _p(out["prob"]), _p(loss_sum), _p(out.get("dz")),
+                                        _p(out["logits"]), _p(out["prob"]), _p(out.get("loss_bag")), _p(out.get("dz")),
                                         _p(out.get("dM")), _p(out.get("cdot")), _stream())
     _lib.check(rc, "mil_pool_merge_head")
     return out
 
 
-def head_bwd_params(dz, M, dWf, dbf):
+def head_bwd_params(dz, M, dWf, dbf, loss_bag=None, loss_out=None):
     B, L = M.shape
-    rc = _lib.lib().mil_head_bwd_params(_p(dz), _p(M), _p(dWf), _p(dbf), B, L, dz.shape[1], _stream())
+    rc = _lib.lib().mil_head_bwd_params(_p(dz), _p(M), _p(dWf), _p(dbf), B, L, dz.shape[1], _p(loss_bag), _p(loss_out),
+                                        _stream())
     _lib.check(rc, "mil_head_bwd_params")
 
 

@@ -109,16 +109,14 @@ class ImageOnlyTrainer:
         if y is not None:
             nb = global_bags if global_bags is not None else layout.B * self.world
             scale = 1.0 / (nb * fp.p("fc.1.weight").shape[0])
-            self.loss_sum.zero_()
-        t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale,
-                                self.loss_sum if y is not None else None)
+        t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale)
         self.last = dict(x=x, layout=layout, scores=scores, gates=gates, **t)
         return t["prob"], t["logits"]
 
     def backward(self):
         """Gradients of the (globally normalised) BCE loss into the flat grad buffer (overwrites it)."""
         c, fp = self.last, self.fp
-        ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"))
+        ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum)
         b16 = c["x"].dtype == torch.bfloat16
         if b16:
             ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
