@@ -138,7 +138,13 @@ int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int
                                float* partials, void* stream);
 int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, const float* lse, const float* dM,
                            const float* cdot, const int32_t* tile_map, int T, int L, float* ds, void* stream);
-/* mil_gate_bwd_params with x stored as bf16 (widened while staged; fp32 MFMA product). */
+/* Gate parameter gradients on the bf16 MFMA: x and dPre rounded to bf16, fp32 accumulation, fp32 partials and
+ * outputs (same contract as mil_gate_bwd_params; L % 256 == 0; workspace mil_gate_bwd_workspace_floats_bf16). */
+size_t mil_gate_bwd_workspace_floats_bf16(int R, int L);
+int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R, int L,
+                             int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,
+                             float* dbu, float* dw, float* db, int accumulate, void* stream);
+/* mil_gate_bwd_params with x stored as bf16 (widened while staged; fp32 MFMA product: exact on the rounded x). */
 int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R, int L,
                             int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,
                             float* dbu, float* dw, float* db, int accumulate, void* stream);

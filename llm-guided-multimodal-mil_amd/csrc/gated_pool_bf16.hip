@@ -8,6 +8,7 @@
 //   k_gate_bwd_dw_x16 weight gradient with x read as bf16 and widened in staging (fp32 MFMA; a bf16-MFMA
 //                     version of the transposed product is the next step)
 #include "mil_common.h"
+#include "gate_reduce.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -269,6 +270,205 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds_bf16(const u16* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- gate dW, bf16 MFMA
+// dW[gi][j] = sum_rows dPre[row][gi] x[row][j] with both operands rounded to bf16 and fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16).  Same split-K / permuted-gate-index scheme and the same fp32 partial buffers and
+// reduce kernel as k_gate_bwd_dw.  Both operands are k-major in memory ([row][gi], [row][j]), so their LDS images stay
+// row-major and the fragments come from the hardware transpose read ds_read_b64_tr_b16: the lane with column r and half
+// h gets 4 consecutive rows of its column per read (probed on gfx950: lane l <- column (l & 31), rows q = 0..3 of the
+// block whose row q / columns 4p..4p+3 were addressed by lane 4q + p of its 16-lane group).
+// Workgroup 256 threads, output tile 128 (gi) x 256 (j): wave (wi, wj) = 64 x 128 = 2 x 4 MFMA tiles, so one staged
+// (and VALU-built) dPre slice feeds twice the MFMAs of a 128-wide tile.  Row stride 160 bf16 = 320 B: the four rows of
+// a transpose read start 80 words apart -> banks 0/16/32/48, conflict-free.
+#define WB_BKR 32
+#define WB_S 160
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ u16x8 tr_frag(const u16* img, int row, int col) {
+    // 8 consecutive rows [row, row + 8) of column (col + lane column), as one 32x32x16 operand fragment
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + row * WB_S + col));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (row + 4) * WB_S + col));
+    u16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
+    ushort4 o;
+    o.x = __builtin_bit_cast(u16, (__bf16)v[0]);
+    o.y = __builtin_bit_cast(u16, (__bf16)v[1]);
+    o.z = __builtin_bit_cast(u16, (__bf16)v[2]);
+    o.w = __builtin_bit_cast(u16, (__bf16)v[3]);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const float* __restrict__ gates,
+                                                          const float* __restrict__ ds, const float* __restrict__ wvec,
+                                                          float* __restrict__ part, float* __restrict__ pbias, int R, int L,
+                                                          int KC, int NJ) {
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (WB_BKR * WB_S + WB_BKR * 2 * WB_S)];
+    // per stage: A image [32][160] (128 gi used), B image [32][320] (256 j used, two 160-wide panels of 128 j)
+    constexpr int ASZ = WB_BKR * WB_S, BSZ = WB_BKR * 2 * WB_S;
+    u16* ab = smem;
+    u16* xb = smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int h = lane >> 5;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;     // transpose-read address roles
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
+    const int j0 = jt * 256;
+    const int rbeg = s * KC, rend = min(R, rbeg + KC);
+    const int nslice = (rend - rbeg + WB_BKR - 1) / WB_BKR;
+
+    // staging maps: x: 32 rows x 256 cols bf16 = 1024 16-byte chunks, 4 per thread: row (tid >> 5) + 8i, chunk tid & 31
+    //               gates: rows (tid >> 4) + 16i (i < 2), d = 64m + 4 (tid & 15)
+    const int xrow = tid >> 5, xc = tid & 31;
+    const int arow = tid >> 4, ad4 = tid & 15;
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
+    u16x8 rx[4];
+    f32x4 rv[2], ru[2];
+    float rds[2], rmask[2];
+    f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
+    float acc_ds = 0.f;
+
+    auto xload = [&](int i, int rs) {
+        const int gr = min(rs + xrow + 8 * i, rend - 1);
+        rx[i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
+    };
+    auto xwrite = [&](int i, int buf) {
+        // columns 0..127 -> panel 0, 128..255 -> panel 1 (each panel is its own 160-stride image)
+        u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
+        *reinterpret_cast<u16x8*>(dst) = rx[i];
+    };
+    auto aload = [&](int i, int rs, bool live) {
+        const int gr = rs + arow + 16 * i;
+        const int gc = min(gr, rend - 1);
+        const float* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
+        rv[i] = *reinterpret_cast<const f32x4*>(gp);
+        ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
+        rds[i] = ds[gc];
+        rmask[i] = (live && gr < rend) ? 1.f : 0.f;
+    };
+    auto awrite = [&](int i, int buf) {
+        const f32x4 v = rv[i], u = ru[i];
+        const float dsv = rds[i] * rmask[i];
+        const f32x4 pv = (dsv * w4) * u * (1.0f - v * v);
+        const f32x4 pu = (dsv * w4) * v * u * (1.0f - u);
+        u16* dst = ab + buf * ASZ + (arow + 16 * i) * WB_S + 4 * ad4;
+        *reinterpret_cast<ushort4*>(dst) = pack_bf16x4(pv);
+        *reinterpret_cast<ushort4*>(dst + 64) = pack_bf16x4(pu);
+        acc_bv += pv;
+        acc_bu += pu;
+        acc_w += dsv * v * u;
+        if (ad4 == 0) acc_ds += dsv;
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    if (nslice > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xload(i, rbeg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aload(i, rbeg, true);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xwrite(i, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) awrite(i, 0);
+        const int rs1 = rbeg + min(1, nslice - 1) * WB_BKR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xload(i, rs1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aload(i, rs1, nslice > 1);
+    }
+    __syncthreads();
+    // fragment column offsets inside an image: wave tile + 16-lane group + 4 p
+    const int acol = 64 * wi + 16 * tg + 4 * tp;                 // + 32 a
+    const int bcol = 16 * tg + 4 * tp;                           // + 32 b inside panel wj
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int buf = sl & 1;
+        const bool live2 = sl + 2 < nslice;
+        const int rs2 = rbeg + min(sl + 2, nslice - 1) * WB_BKR;
+        const u16* ai = ab + buf * ASZ;
+        const u16* bi = xb + buf * BSZ + wj * ASZ;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = 16 * ks + 8 * h + tq;
+            u16x8 fa[2], fb[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = tr_frag(ai, row, acol + 32 * a);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = tr_frag(bi, row, bcol + 32 * b);
+            // staging for the next slice rides between the two k-steps
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xwrite(i, buf ^ 1); xload(i, rs2); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { awrite(i, buf ^ 1); aload(i, rs2, live2); }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
+                                                                        __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // partial tile -> part[s][128m + 64wi + 32a + row][j0 + 128wj + 32b + r]
+    const int r = lane & 31;
+    float* pt = part + ((size_t)s * HB_NG + 128 * m + 64 * wi) * L + j0 + 128 * wj + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
+
+    if (jt == 0) {
+        float* redf = reinterpret_cast<float*>(smem);   // [16 row groups][3][64]
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            redf[(arow * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
+            redf[(arow * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
+            redf[(arow * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid / 64, d = tid % 64;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += redf[(g * 3 + which) * 64 + d];
+            pbias[((size_t)s * 4 + which) * 192 + 64 * m + d] = v;
+        }
+        if (m == 0) {
+            __syncthreads();
+            redf[tid] = acc_ds;
+            __syncthreads();
+            if (tid == 0) {
+                float v = 0.f;
+                for (int g = 0; g < 256; g += 16) v += redf[g];
+                pbias[((size_t)s * 4 + 3) * 192] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- host entry points
 extern "C" int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
     if (!src || !dst) return MIL_EINVAL;
@@ -310,6 +510,45 @@ extern "C" int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, co
     hipStream_t st = (hipStream_t)stream;
     if (L == 512) hipLaunchKernelGGL(k_pool_bwd_ds_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, L);
     else hipLaunchKernelGGL(k_pool_bwd_ds_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, L);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+static inline int split_plan_bf16(int R, int L, int* KC_out) {
+    const int NJ = L / 256;
+    int smax = MIL_NUM_CU / (3 * NJ);          // one 256-thread workgroup per CU (128 accumulator registers per lane)
+    if (smax < 1) smax = 1;
+    int kc = ((R + smax - 1) / smax + WB_BKR - 1) / WB_BKR * WB_BKR;
+    if (kc < WB_BKR) kc = WB_BKR;
+    *KC_out = kc;
+    return (R + kc - 1) / kc;
+}
+
+extern "C" size_t mil_gate_bwd_workspace_floats_bf16(int R, int L) {
+    if (R <= 0 || L <= 0 || (L % 256) != 0) return 0;
+    int kc;
+    const int S = split_plan_bf16(R, L, &kc);
+    return (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
+}
+
+extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R,
+                                        int L, int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
+                                        float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
+    if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
+    if (D != MIL_GATE_D || L <= 0 || (L % 256) != 0 || R <= 0) return MIL_EINVAL;
+    int kc;
+    const int S = split_plan_bf16(R, L, &kc);
+    const size_t need = (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
+    if (workspace_floats < need) return MIL_ENOSPC;
+    float* part = workspace;
+    float* pbias = workspace + (size_t)S * HB_NG * L;
+    const int NJ = L / 256;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gate_bwd_dw_bf16, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
+    MIL_CHECK_LAUNCH();
+    const int nthreads = HB_NG * (L / 4) + 3 * 192 + 1;
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
+                       dbu, dw, db, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -590,3 +590,17 @@ class _AddBagRow(torch.autograd.Function):
 def add_bag_row(x, o, segs):
     """segs: AttnSegs whose QUERY side are the rows of x (q_bag / q_off)."""
     return _AddBagRow.apply(x, o, segs)
+
+
+def gate_bwd_params_bf16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None):
+    """Weight gradients on the bf16 MFMA (dPre and x rounded to bf16, fp32 accumulate)."""
+    x16 = _bf16c(x16, "x")
+    R, L = x16.shape
+    need = _lib.lib().mil_gate_bwd_workspace_floats_bf16(R, L)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x16.device, dtype=torch.float32)
+    rc = _lib.lib().mil_gate_bwd_params_bf16(_p(x16), _p(gates), _p(ds), _p(w), R, L, GATE_D, _p(workspace),
+                                             workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
+                                             1 if accumulate else 0, _stream())
+    _lib.check(rc, "mil_gate_bwd_params_bf16")
+    return workspace

@@ -71,11 +71,13 @@ class FlatParams:
 
 class ImageOnlyTrainer:
     def __init__(self, params: Dict[str, torch.Tensor], device, lr: float = 1e-5, betas=(0.9, 0.999),
-                 weight_decay: float = 1e-7, eps: float = 1e-8, world_size: int = 1):
+                 weight_decay: float = 1e-7, eps: float = 1e-8, world_size: int = 1, bf16_grad_mfma: bool = True):
         self.device = device
         self.fp = FlatParams(params, device, PARAM_ORDER)
         self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
         self.world = world_size
+        # bf16 x only: weight gradient on the bf16 MFMA (dPre rounded to bf16) or on the fp32 MFMA (exact on the rounded x)
+        self.bf16_grad_mfma = bf16_grad_mfma
         self.step_count = 0
         self.loss_sum = self.fp.loss_slot
         self._ws: Optional[torch.Tensor] = None
@@ -122,7 +124,10 @@ class ImageOnlyTrainer:
             ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
         else:
             ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
-        self._ws = (ops.gate_bwd_params_x16 if b16 else ops.gate_bwd_params)(
+        dw_fn = ops.gate_bwd_params
+        if b16:
+            dw_fn = ops.gate_bwd_params_bf16 if (self.bf16_grad_mfma and c["x"].shape[1] % 256 == 0) else ops.gate_bwd_params_x16
+        self._ws = dw_fn(
             c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
             fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
             fp.g("aggregator.attention_U.0.weight"), fp.g("aggregator.attention_U.0.bias"),

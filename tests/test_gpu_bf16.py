@@ -18,12 +18,13 @@ def _round(t):
     return t.to(torch.bfloat16).float()
 
 
+@pytest.mark.parametrize("grad_mfma", [False, True])
 @pytest.mark.parametrize("lengths,L", [([300, 77], 512), ([1000], 1024), ([33, 1, 129], 1024)])
-def test_bf16_step_matches_oracle_on_rounded_inputs(lengths, L):
+def test_bf16_step_matches_oracle_on_rounded_inputs(lengths, L, grad_mfma):
     p = syn.image_only_params(55, L=L)
     bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(800 + i)) for i, n in enumerate(lengths)]
     y = syn.make_labels(56, len(lengths))
-    tr = ImageOnlyTrainer(p, torch.device(DEV), lr=1e-3)
+    tr = ImageOnlyTrainer(p, torch.device(DEV), lr=1e-3, bf16_grad_mfma=grad_mfma)
     x16 = torch.cat(bags, 0).to(DEV).to(torch.bfloat16)
     lay = BagLayout.make(lengths, torch.device(DEV))
     prob, z = tr.forward(x16, lay, y.to(DEV))
@@ -40,7 +41,10 @@ def test_bf16_step_matches_oracle_on_rounded_inputs(lengths, L):
     assert abs(float(tr.loss_sum.item()) - float(loss)) <= 1e-5
     for k in grads:
         if float(grads[k].norm()) > 1e-7:
-            assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= 5e-4, k
+            # fp32-MFMA gradient: exact on the rounded x.  bf16-MFMA gradient: dPre is rounded to bf16 too
+            # (relative 2^-9 per element), only the two weight matrices see it - biases / w / head stay fp32.
+            tol = 6e-3 if (grad_mfma and k.endswith(("attention_V.0.weight", "attention_U.0.weight"))) else 5e-4
+            assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= tol, (k, rel_err(tr.fp.g(k).cpu(), grads[k]))
     # deviation from the UNROUNDED fp32 oracle (reported in DESIGN.md; loose bound here)
     _, logits32, _, _ = orc.batch_loss_and_grads(bags, y, p)
     dev = float((z.cpu() - logits32).abs().max())
