@@ -230,8 +230,24 @@ def main():
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(R * L * sb / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                 "traffic": None, "ms_per_launch": round(fwd_ms, 4),
                                 "mfma_tflops": round(4.0 * R * L * D_GATE / (fwd_ms * 1e-3) / 1e12, 1)}
-            line["kernels_ms"] = {"gate_fwd_bf16": round(fwd_ms, 4), "pool_partial_bf16": round(pp_ms, 4)}
-            line["kernels_gbs"] = {"pool_partial_bf16": round(R * L * sb / (pp_ms * 1e-3) / 1e9, 1)}
+            tr.forward(x, lay, y)
+            c = dict(tr.last)
+            ds = ops.attn_pool_bwd_bf16(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay)
+            ds_ms = timed(lambda: ops.attn_pool_bwd_bf16(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay), 20)
+            fp = tr.fp
+            g = {k: torch.empty_like(fp.p(k)) for k in fp.order}
+            gargs = (g["aggregator.attention_V.0.weight"], g["aggregator.attention_V.0.bias"],
+                     g["aggregator.attention_U.0.weight"], g["aggregator.attention_U.0.bias"],
+                     g["aggregator.attention_weights.weight"].view(-1), g["aggregator.attention_weights.bias"])
+            wv = fp.p("aggregator.attention_weights.weight").view(-1)
+            ws = ops.gate_bwd_params_bf16(x, c["gates"], ds, wv, *gargs)
+            dw_ms = timed(lambda: ops.gate_bwd_params_bf16(x, c["gates"], ds, wv, *gargs, False, ws), 20)
+            line["kernels_ms"] = {"gate_fwd_bf16": round(fwd_ms, 4), "pool_partial_bf16": round(pp_ms, 4),
+                                  "pool_bwd_ds_bf16": round(ds_ms, 4), "gate_bwd_dw_bf16(+reduce)": round(dw_ms, 4)}
+            line["kernels_gbs"] = {"pool_partial_bf16": round(R * L * sb / (pp_ms * 1e-3) / 1e9, 1),
+                                   "pool_bwd_ds_bf16": round(R * L * sb / (ds_ms * 1e-3) / 1e9, 1)}
+            line["kernels_tflops"] = {"gate_fwd_bf16": round(4.0 * R * L * D_GATE / (fwd_ms * 1e-3) / 1e12, 1),
+                                      "gate_bwd_dw_bf16": round(4.0 * R * L * D_GATE / (dw_ms * 1e-3) / 1e12, 1)}
         elif not args.no_breakdown:
             kb = kernel_breakdown(tr, x, lay, y)
             R = B * N

@@ -1,6 +1,7 @@
-"""Model factory of the image-only variant (reference: model/utils_clip.py)."""
+"""`get_model(args)` for the image-only variant (the reference's model/utils_clip.py entry point)."""
+from ._registry import build
 
 
 def get_model(args):
-    from .aggregator_clip import aggregator
-    return aggregator(args)
+    model = build("image_only", args)
+    return model
