@@ -35,7 +35,7 @@ from mil_amd.trainer import ImageOnlyTrainer  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # HBM bytes per launch from rocprofv3 PMC passes of this same command at the default workload
 # (profiles/r01_bench_hbm_traffic_pmc.csv: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied)
-PMC_TRAFFIC_BYTES = {"gate_fwd": (70.5 + 48.1) * 2 ** 20, "gate_bwd_dw": (126.7 + 30.8 + 30.9 + 0.8) * 2 ** 20}
+PMC_TRAFFIC_BYTES = {"gate_fwd": (70.5 + 48.1) * 2 ** 20, "gate_bwd_dw": (126.7 + 30.8) * 2 ** 20}
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 D_GATE = 192
 
@@ -76,7 +76,11 @@ def kernel_breakdown(tr, x, lay, y, iters=20):
              g["aggregator.attention_U.0.bias"], g["aggregator.attention_weights.weight"].view(-1),
              g["aggregator.attention_weights.bias"])
     ws = ops.gate_bwd_params(x, c["gates"], ds, w, *gargs)
-    out["gate_bwd_dw"] = timed(lambda: ops.gate_bwd_params(x, c["gates"], ds, w, *gargs, False, ws), iters)
+    lib = ops._lib.lib()
+    out["gate_bwd_dw"] = timed(lambda: lib.mil_gate_bwd_partials(ops._p(x), ops._p(c["gates"]), ops._p(ds), ops._p(w), R, L,
+                                                                 D_GATE, ops._p(ws), ws.numel(), ops._stream()), iters)
+    out["gate_bwd_reduce"] = timed(lambda: lib.mil_gate_bwd_reduce(ops._p(ws), R, L, *[ops._p(t) for t in gargs], 0,
+                                                                   ops._stream()), iters)
     out["adam"] = timed(lambda: ops.adam_step(fp.flat, fp.grad, fp.exp_avg, fp.exp_avg_sq, 1), iters)
     return out
 
@@ -254,7 +258,7 @@ def main():
             flops = {"gate_fwd": 4.0 * R * L * D_GATE, "gate_bwd_dw": 4.0 * R * L * D_GATE}
             dom = max(("gate_fwd", "gate_bwd_dw"), key=lambda k: kb[k])
             ach = flops[dom] / (kb[dom] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd" if dom == "gate_fwd" else "k_gate_bwd_dw(+reduce)",
+            line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd" if dom == "gate_fwd" else "k_gate_bwd_dw",
                                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                                 "traffic": PMC_TRAFFIC_BYTES[dom] if (B, N, L) == (32, 1024, 512) else None,

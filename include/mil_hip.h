@@ -121,6 +121,13 @@ int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, con
                         float* dWv, float* dbv, float* dWu, float* dbu, float* dw, float* db,
                         int accumulate, void* stream);
 
+/* The two launches of mil_gate_bwd_params on their own: the split-K MFMA kernel (fills the workspace) and the
+ * reduce (workspace -> outputs). */
+int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                          int D, float* workspace, size_t workspace_floats, void* stream);
+int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                        float* dw, float* db, int accumulate, void* stream);
+
 /* Input gradient through the gate (needed when the bag is itself a computed tensor, i.e.
  * the fused text+image path): dx += dPreV Wv + dPreU Wu. */
 int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,
