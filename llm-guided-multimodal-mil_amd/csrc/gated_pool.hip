@@ -8,59 +8,58 @@
 #include "mil_common.h"
 
 // ================================================================================ K1a gate forward
-// Workgroup: 512 threads = 8 waves, tile = 128 rows x all 384 gate columns, K-slices of 32.
-//   wave (wr, wc): rows 32*wr..+31, d-chunks {3wc, 3wc+1, 3wc+2} for both V and U  -> 6 accumulators.
-// LDS image: row-major [rows][32 k] padded to 36 words: ds_read_b128 conflict-free (36*r mod 64
-// covers all 16 four-bank slots over each 16-lane group).
-// k permutation: lane (r, h) reads 4 consecutive k = 8t+4h..+3 and feeds element j to the j-th of
-// 4 MFMAs, so MFMA (t, j) contracts k in {8t+j, 8t+4+j}: A and B use the same map, the sum over a
-// slice is complete.
-#ifndef GF_VARIANT
-#define GF_VARIANT 0
-#endif
+// Workgroup: 512 threads = 8 waves, tile = 128 rows x all 384 gate columns, K-slices of 32, double-buffered in LDS.
+//   wave (wr, wc): rows 32*wr..+31, d-chunks {3wc, 3wc+1, 3wc+2} for both V and U  -> 6 accumulators, so V_d and
+//   U_d of a row land in the same lane and the gate product / score reduction never leave registers.
+// k permutation: lane (r, h) reads 4 consecutive k = 8t+4h..+3 (one ds_read_b128) and feeds element j to the j-th of
+// 4 MFMAs, so MFMA (t, j) contracts k in {8t+j, 8t+4+j}: A and B use the same map, the sum over a slice is complete.
+// Staging: global -> LDS directly (global_load_lds_dwordx4: no staging VGPRs, no ds_write).  An LDS-DMA
+// wave-instruction writes 64 x 16 B contiguously (8 rows of 128 B), so the image cannot be padded: rows are 32 words
+// and the 16-byte chunk c of row `row` sits at chunk c ^ ((row >> 1) & 7) (applied to the per-lane SOURCE address,
+// the same XOR on the fragment reads).  Over any 16-lane ds_read_b128 group (row >> 1) & 7 takes all 8 values for
+// both row parities -> conflict-free (SQ_LDS_BANK_CONFLICT = 0).
+// Schedule: the 8 DMA pieces of slice s+1 and the fragment reads of the next k-group are pinned between the MFMA
+// groups of slice s (sched_barrier); one barrier per slice, in front of which hipcc drains the DMA (vmcnt(0)).
+// Measured at 32 x 1024 x 512 (us): register-staged + padded image 109.4, this form 105.8, bit-identical results;
+// main loop alone 92.5 (bare MFMA stream), +staging, +6 for the epilogue (fast activations; ocml tanhf/expf +4).
 #define GF_TM 128
 #define GF_BK 32
-#define GF_S 36
 #define GF_NG 384
 
+typedef __attribute__((address_space(3))) void lds_void;
 __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, const float* __restrict__ Wv,
-                                                  const float* __restrict__ bv, const float* __restrict__ Wu,
-                                                  const float* __restrict__ bu, const float* __restrict__ wvec,
-                                                  const float* __restrict__ battn, float* __restrict__ scores,
-                                                  float* __restrict__ gates, int R, int L) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * GF_S];
-    float* xs = smem;                       // [2][128][36]
-    float* ws = smem + 2 * GF_TM * GF_S;    // [2][384][36]
-
+                                                       const float* __restrict__ bv, const float* __restrict__ Wu,
+                                                       const float* __restrict__ bu, const float* __restrict__ wvec,
+                                                       const float* __restrict__ battn, float* __restrict__ scores,
+                                                       float* __restrict__ gates, int R, int L) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * 32];
+    float* xs = smem;                      // [2][128][32]
+    float* ws = smem + 2 * GF_TM * 32;     // [2][384][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * GF_TM;
-
-    const int srow = tid >> 3, sch = tid & 7;   // staging: row (+64 i), 16-byte chunk within the 32-k slice
-    // 8 staging pieces per slice: pieces 0,1 = x rows srow, srow+64; pieces 2..7 = gate-weight rows
-    // srow + 64 (i-2) (0..191 = Wv, 192..383 = Wu).  Rows past R are clamped (their results are never stored),
-    // so the loop body is branch-free and can be interleaved with the MFMAs.
-    f32x4 rs[8];
+    // DMA pieces of this wave: 2 x-pieces (8 rows each) and 6 W-pieces; lane -> (row in piece, physical chunk)
+    const int prow = lane >> 3, pch = lane & 7;
     const float* gsrc[8];
-    float* ldst[8];
+    int ldst[8];                           // LDS float offset of the piece base (wave-uniform) inside one buffer
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (i < 2) {
-            const int gr = min(row0 + srow + 64 * i, R - 1);
-            gsrc[i] = x + (size_t)gr * L + 4 * sch;
-            ldst[i] = xs + (srow + 64 * i) * GF_S + 4 * sch;
+            const int lr = (2 * wave + i) * 8 + prow;                         // row inside the 128-row tile
+            const int gr = min(row0 + lr, R - 1);
+            gsrc[i] = x + (size_t)gr * L + 4 * (pch ^ ((lr >> 1) & 7));
+            ldst[i] = (2 * wave + i) * 8 * 32;
         } else {
-            const int wrow = srow + 64 * (i - 2);
-            gsrc[i] = ((i - 2) < 3 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 4 * sch;
-            ldst[i] = ws + wrow * GF_S + 4 * sch;
+            const int wrow = (6 * wave + (i - 2)) * 8 + prow;                 // 0..383
+            gsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 4 * (pch ^ ((wrow >> 1) & 7));
+            ldst[i] = (6 * wave + (i - 2)) * 8 * 32;
         }
     }
-    auto gload_piece = [&](int i, int k0) { rs[i] = *reinterpret_cast<const f32x4*>(gsrc[i] + k0); };
-    auto swrite_piece = [&](int i, int buf) {
-        *reinterpret_cast<f32x4*>(ldst[i] + buf * (i < 2 ? GF_TM : GF_NG) * GF_S) = rs[i];
+    auto dma_piece = [&](int i, int buf, int k0) {
+        float* dst = (i < 2 ? xs + buf * GF_TM * 32 : ws + buf * GF_NG * 32) + ldst[i];
+        __builtin_amdgcn_global_load_lds(gsrc[i] + k0, (lds_void*)dst, 16, 0, 0);
     };
-
     f32x16 acc[3][2];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -70,29 +69,25 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
             for (int i = 0; i < 16; ++i) acc[c][u][i] = 0.f;
 
     const int nslice = L / GF_BK;
-    // Pipeline: registers hold slice s+1 (loaded one iteration ago); during iteration s they are written to
-    // the other LDS buffer (free since the barrier that ended iteration s-1) and reloaded with slice s+2,
-    // one piece per MFMA group.  One barrier per slice, nothing drains in front of it.
+    // (starting each workgroup's K loop at a different slice, to de-correlate the L2 requests for the shared gate
+    //  weights, measured no gain: 107.4 vs 106.2 us fp32, 172 vs 171 us bf16 - the slices stay in natural order)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gload_piece(i, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) swrite_piece(i, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gload_piece(i, min(1, nslice - 1) * GF_BK);
-    __syncthreads();
+    for (int i = 0; i < 8; ++i) dma_piece(i, 0, 0);
+    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    const int fx = (r >> 1) & 7;                       // swizzle term of this lane's fragment rows (row % 32 == r)
     for (int s = 0; s < nslice; ++s) {
         const int buf = s & 1;
-        const int k2 = min(s + 2, nslice - 1) * GF_BK;     // tail iterations reload the last slice (harmless)
-        const float* xa = xs + (buf * GF_TM + 32 * wr + r) * GF_S + 4 * h;
-        const float* wb = ws + (buf * GF_NG + 32 * 3 * wc + r) * GF_S + 4 * h;
+        const int k1 = min(s + 1, nslice - 1) * GF_BK;
+        const float* xa = xs + (buf * GF_TM + 32 * wr + r) * 32;
+        const float* wb = ws + (buf * GF_NG + 32 * 3 * wc + r) * 32;
         f32x4 a[2], b[2][3][2];
-        // fragment piece p (0..6) of k-group t into register set q: p == 0 -> A, else B tile (c, u)
         auto frag_piece = [&](int t, int q, int p) {
+            const int ch = 4 * ((2 * t + h) ^ fx);
             if (p == 0) {
-                a[q] = *reinterpret_cast<const f32x4*>(xa + 8 * t);
+                a[q] = *reinterpret_cast<const f32x4*>(xa + ch);
             } else {
                 const int c = (p - 1) >> 1, u = (p - 1) & 1;
-                b[q][c][u] = *reinterpret_cast<const f32x4*>(wb + (u * 192 + 32 * c) * GF_S + 8 * t);
+                b[q][c][u] = *reinterpret_cast<const f32x4*>(wb + (u * 192 + 32 * c) * 32 + ch);
             }
         };
 #pragma unroll
@@ -103,21 +98,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int g = 4 * t + j;
-#if !defined(GF_ABL_NOSTAGE)
-                if (g >= 4 && g < 12) {          // staging piece g-4: LDS write of slice s+1, reload with slice s+2
-#if !defined(GF_ABL_NOSWRITE)
-                    swrite_piece(g - 4, buf ^ 1);
-#endif
-#if !defined(GF_ABL_NOGLOAD)
-                    gload_piece(g - 4, k2);
-#endif
-                }
-#endif
-#if defined(GF_ABL_NOFRAG)
-                if (0) {
-#else
-                if (t < 3) {                      // prefetch the next k-group's fragments, 2 reads per MFMA group
-#endif
+                if (g < 8) dma_piece(g, buf ^ 1, k1);     // next slice, one DMA piece per MFMA group
+                if (t < 3) {
                     frag_piece(t + 1, q ^ 1, 2 * j);
                     if (2 * j + 1 < 7) frag_piece(t + 1, q ^ 1, 2 * j + 1);
                 }
@@ -129,12 +111,9 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#if !defined(GF_ABL_NOBARRIER)
         __syncthreads();
-#endif
     }
 
-    // Epilogue: lane holds column d = 32*(3wc+c) + r of both V and U for 16 rows.
     float part[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) part[i] = 0.f;
@@ -144,17 +123,10 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
         const float bvd = bv[d], bud = bu[d], wd = wvec[d];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-#if GF_VARIANT == 2 || GF_VARIANT == 4      /* scratch ablations only: no activations */
-            const float v = acc[c][0][i] + bvd;
-            const float u = acc[c][1][i] + bud;
-#else
-            // v_exp_f32 / v_rcp_f32 forms (abs error ~1e-7 on (-1, 1) outputs): the ocml tanhf/expf cost 4 us per
-            // launch at 32 x 1024 x 512 for no measurable change in the logits (parity asserted at 2e-5)
             const float v = fast_tanh(acc[c][0][i] + bvd);
             const float u = fast_sigmoid(acc[c][1][i] + bud);
-#endif
             part[i] += wd * v * u;
-            if (gates != nullptr && GF_VARIANT != 3 && GF_VARIANT != 4) {
+            if (gates != nullptr) {
                 const int gr = row0 + 32 * wr + mfma32_row(i, h);
                 if (gr < R) {
                     gates[(size_t)gr * GF_NG + d] = v;
@@ -163,7 +135,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
             }
         }
     }
-    float* sred = smem;    // [2][128], main loop is done (last __syncthreads passed)
+    float* sred = smem;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const float v = half_allsum(part[i]);
