@@ -100,6 +100,13 @@ int mil_head_bwd(const float* dz_or_dp, const float* p, const float* M, const fl
 int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
                         const float* loss_bag, float* loss_out, void* stream);
 
+/* CLIP-as-loss of the image-only variant (reference utils.py:247-284 CLIPloss_v1, forward :261-284):
+ * out [b, E] bag embeddings, feat [b, F, E] frozen CLIP text features of the F per-feature prompts of each sample;
+ * logits_f = out feat_f^T [b, b], identity targets, cross entropy over the bag axis, mean over F*b.
+ * loss [1] and d_out [b, E] are overwritten.  b <= 64.  workspace: 4*ceil(F/4) + F*b*E floats. */
+int mil_clip_contrastive_loss(const float* out, const float* feat, int b, int F, int E, float* loss, float* d_out,
+                              float* workspace, void* stream);
+
 /* out[b] = a[b] . c[b] for two [B, L] matrices (cdot = M . dM when dM comes from autograd). */
 int mil_rowdot(const float* a, const float* c, float* out, int B, int L, void* stream);
 

@@ -319,3 +319,64 @@ extern "C" int mil_rowdot(const float* a, const float* c, float* out, int B, int
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// CLIP-as-loss of the image-only variant (reference utils.py:247-284 CLIPloss_v1): for each clinical feature f,
+// logits_f[i][j] = out[i] . feat[j][f]  (bag embedding i vs the CLIP text feature of sample j's prompt f), target =
+// identity, CrossEntropyLoss over dim 1 (softmax over the bags i for every text j), mean over F * b.
+//   loss = -(1 / (F b)) sum_f sum_j log softmax_i(logits_f[:, j])[j];  d_out[i] = sum_f sum_j (p_f[i][j] - [i==j]) feat[j][f] / (F b)
+// One workgroup (256 threads) per feature; b <= 64.  part_dout [F][b][E] is folded over F by mil_colsum.
+__global__ __launch_bounds__(256) void k_clip_contrastive(const float* __restrict__ out, const float* __restrict__ feat,
+                                                          int b, int F, int E, float* __restrict__ loss_f,
+                                                          float* __restrict__ part_dout) {
+    __shared__ float lg[64 * 64];       // logits -> d_logits, [i][j]
+    __shared__ float red[4];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    for (int idx = tid; idx < b * b; idx += 256) {
+        const int i = idx / b, j = idx % b;
+        const float* o = out + (size_t)i * E;
+        const float* t = feat + ((size_t)j * F + f) * E;
+        float v = 0.f;
+        for (int e = 0; e < E; e += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(o + e), c = *reinterpret_cast<const f32x4*>(t + e);
+            v += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+        lg[i * 64 + j] = v;
+    }
+    __syncthreads();
+    float lacc = 0.f;
+    const float inv = 1.0f / (float)(F * b);
+    if (tid < b) {                       // column j = tid: softmax over the bags i
+        const int j = tid;
+        float m = -INFINITY;
+        for (int i = 0; i < b; ++i) m = fmaxf(m, lg[i * 64 + j]);
+        float s = 0.f;
+        for (int i = 0; i < b; ++i) s += expf(lg[i * 64 + j] - m);
+        const float lse = m + logf(s);
+        lacc = -(lg[j * 64 + j] - lse);
+        for (int i = 0; i < b; ++i) lg[i * 64 + j] = (expf(lg[i * 64 + j] - lse) - (i == j ? 1.f : 0.f)) * inv;
+    }
+    lacc = block_allsum_256(lacc, red);
+    if (tid == 0) loss_f[f] = lacc * inv;
+    __syncthreads();
+    for (int idx = tid; idx < b * E; idx += 256) {
+        const int i = idx / E, e = idx % E;
+        float v = 0.f;
+        for (int j = 0; j < b; ++j) v += lg[i * 64 + j] * feat[((size_t)j * F + f) * E + e];
+        part_dout[((size_t)f * b + i) * E + e] = v;
+    }
+}
+
+extern "C" int mil_clip_contrastive_loss(const float* out, const float* feat, int b, int F, int E, float* loss,
+                                         float* d_out, float* workspace, void* stream) {
+    if (!out || !feat || !loss || !d_out || !workspace) return MIL_EINVAL;
+    if (b <= 0 || b > 64 || F <= 0 || E <= 0 || (E & 3)) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* loss_f = workspace;                      // [F]
+    float* part = workspace + ((F + 3) & ~3);       // [F][b][E]
+    hipLaunchKernelGGL(k_clip_contrastive, dim3(F), dim3(256), 0, st, out, feat, b, F, E, loss_f, part);
+    MIL_CHECK_LAUNCH();
+    int rc = mil_colsum(part, b * E, F, b * E, d_out, 0, nullptr, stream);
+    if (rc) return rc;
+    return mil_colsum(loss_f, 1, F, 1, loss, 0, nullptr, stream);
+}

@@ -604,3 +604,29 @@ def gate_bwd_params_bf16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumula
                                              1 if accumulate else 0, _stream())
     _lib.check(rc, "mil_gate_bwd_params_bf16")
     return workspace
+
+
+# --------------------------------------------------------------------------- CLIP-as-loss (aggregator_clip path)
+class _ClipContrastive(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, feat):
+        out, feat = _f32c(out, "out"), _f32c(feat, "feat")
+        b, E = out.shape
+        F_ = feat.shape[1]
+        loss = torch.empty(1, device=out.device, dtype=torch.float32)
+        d_out = torch.empty_like(out)
+        ws = torch.empty(((F_ + 3) // 4) * 4 + F_ * b * E, device=out.device, dtype=torch.float32)
+        rc = _lib.lib().mil_clip_contrastive_loss(_p(out), _p(feat), b, F_, E, _p(loss), _p(d_out), _p(ws), _stream())
+        _lib.check(rc, "mil_clip_contrastive_loss")
+        ctx.save_for_backward(d_out)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_out,) = ctx.saved_tensors
+        return d_out * g, None
+
+
+def clip_contrastive_loss(out, feat):
+    """CLIPloss_v1 (reference utils.py:261-284): out [b, E] bag embeddings vs frozen text features feat [b, F, E]."""
+    return _ClipContrastive.apply(out, feat)

@@ -64,3 +64,29 @@ def adjust_learning_rate(optimizer, epoch: int, args):
     for g in optimizer.param_groups:
         g["lr"] = lr
     return lr
+
+
+class CLIPloss_v1(torch.nn.Module):
+    """CLIP-as-loss of the image-only variant (reference utils.py:247-284): contrast every bag embedding with the
+    frozen CLIP text features of the per-feature prompts of every sample in the batch.
+
+    The reference builds the prompts as strings ("a lung cancer patient photo of <feature> <value>", :266-267) and
+    tokenises them; text handling is out of scope here, so forward takes the token ids int64 [b, F, 77] directly.
+    `clip.load` downloads weights: the tower is the ViT-B/32 text architecture with caller-loaded or random weights."""
+
+    def __init__(self, args, text_model=None):
+        super().__init__()
+        from .clip.model import CLIPText
+        self.args = args
+        self.model = text_model if text_model is not None else CLIPText(
+            512, 77, int(getattr(args, "clip_vocab", 49408)), int(getattr(args, "clip_width", 512)),
+            int(getattr(args, "clip_heads", 8)), int(getattr(args, "clip_layers", 12)))
+        for p in self.model.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, output: torch.Tensor, prompt_ids: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        b, F_, ctx = prompt_ids.shape
+        with torch.no_grad():
+            feat = self.model.encode_text(prompt_ids.reshape(b * F_, ctx)).reshape(b, F_, -1)
+        return ops.clip_contrastive_loss(output, feat)

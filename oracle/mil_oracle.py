@@ -269,6 +269,16 @@ def batch_loss_and_grads(bags: List[Tensor], labels: Tensor, p: Params, forward=
     return loss.detach(), logits.detach(), prob.detach(), grads
 
 
+# --------------------------------------------------------------------------- CLIP-as-loss
+def clip_contrastive_loss(out: Tensor, feat: Tensor) -> Tensor:
+    """utils.py:276-282 (CLIPloss_v1.forward after the text features are built): out [b, E], feat [b, F, E].
+    logits [F, b, b] = out[None] @ feat.permute(1, 2, 0); identity targets repeated over F; CrossEntropyLoss
+    with probability targets of shape [F, b, b] (class axis = dim 1)."""
+    logits = torch.matmul(out.unsqueeze(0), feat.permute(1, 2, 0))
+    labels = torch.eye(out.shape[0]).unsqueeze(0).repeat(logits.shape[0], 1, 1)
+    return F.cross_entropy(logits, labels)
+
+
 # --------------------------------------------------------------------------- data-parallel partition
 def distributed_sampler_indices(n: int, world: int, rank: int, epoch: int = 0, shuffle: bool = True,
                                 seed: int = 0) -> List[int]:
