@@ -211,6 +211,14 @@ int mil_attn_pool_bwd_mh(const float* q, const float* k, const float* v, const f
                          const float* lse, const int32_t* q_off, const int32_t* tile_map,
                          const int32_t* bag_tile_off, int ntiles, int B, int Tmax, int H, int C, float* dq, float* dk,
                          float* dv, float* workspace, void* stream);
+/* Backward of the rows form for self-attention over whole sequences of <= 80 tokens (q, k, v share q_off), with
+ * the causal mask of clip/model.py:324-330 if causal != 0: the text tower's backward for learnable prompts
+ * (model/dim1/CLIP.py:29-62).  One workgroup per (sequence, head). */
+int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                     const float* lse, const int32_t* q_off, int B, int Tmax, int H, int C, int causal, float* dq,
+                     float* dk, float* dv, void* stream);
+/* QuickGELU x*sigmoid(1.702x) (clip/model.py:162-164): out = act(x) if dy == NULL, else out = dy * act'(x). */
+int mil_quickgelu(const float* x, const float* dy, float* out, size_t n, void* stream);
 /* nn.LayerNorm over the last dim E (multiple of 64, <= 512), eps inside the sqrt.  stats [rows, 2] =
  * (mean, rstd), saved for the backward.  backward workspace: mil_layernorm_bwd_blocks(rows) * 2 * E floats. */
 int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,

@@ -89,6 +89,11 @@ class CLIPText(nn.Module):
         self._proj_t = None
         return super().load_state_dict(sd, strict=strict, **kw)
 
+    def _proj(self, device):
+        if self._proj_t is None or self._proj_t.device != device:
+            self._proj_t = self.text_projection.detach().t().contiguous()     # frozen: [embed, W] = nn.Linear layout
+        return self._proj_t
+
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:
         """text int64 [P, ctx] -> [P, embed_dim]."""
@@ -99,9 +104,20 @@ class CLIPText(nn.Module):
             x = blk.flat(x, segs)
         x = ops.layer_norm(x, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
         eot = ops.gather_eot(text, x)                                                          # [P, W]
-        if self._proj_t is None or self._proj_t.device != eot.device:
-            self._proj_t = self.text_projection.t().contiguous()        # frozen: [embed, W] = nn.Linear layout
-        return ops.linear_act(eot, self._proj_t)
+        return ops.linear_act(eot, self._proj(eot.device))
+
+    def encode_embedded(self, prompts: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
+        """Differentiable tower for already-embedded prompts (learnable context, model/dim1/CLIP.py:54-60):
+        prompts [P, ctx, W] = token embeddings with the context rows replaced (positional embedding NOT yet
+        added), text int64 [P, ctx] only locates the EOT row.  Gradients flow to `prompts`; the weights stay frozen."""
+        P, ctx, W = prompts.shape
+        x = (prompts + self.positional_embedding).reshape(P * ctx, W)
+        segs = AttnSegs.make([ctx] * P, [ctx] * P, prompts.device)
+        for blk in self.transformer.resblocks:
+            x = blk.flat(x, segs)
+        x = ops.layer_norm(x, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
+        eot = x.view(P, ctx, W)[torch.arange(P, device=x.device), text.argmax(dim=-1)]
+        return ops.linear_act(eot, self._proj(eot.device))
 
 
 def build_text_model(state_dict: dict) -> CLIPText:

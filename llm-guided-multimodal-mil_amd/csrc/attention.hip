@@ -670,3 +670,102 @@ extern "C" int mil_segment_colsum(const float* Y, const int32_t* row_off, int B,
     // fold: view the partials [nchunk][B*E] as a matrix with nchunk rows
     return mil_colsum(workspace, B * E, nchunk, B * E, out, 0, nullptr, stream);
 }
+
+// ================================================================================ full-sequence attention backward
+// Backward of the rows-form attention for sequences of up to 80 tokens per (bag, head) - the CLIP text blocks when the
+// prompt context is learnable (model/dim1/CLIP.py:29-62: CoOp trains ctx through the frozen tower).  One workgroup
+// per (bag, head): scores, probabilities and dS live in LDS ([T][T] floats), q/k/v/do rows are re-read from L2.
+//   p = softmax(q k^T scale (+ causal mask));  dv_j = sum_i p_ij do_i;  dS_ij = p_ij (do_i . v_j - delta_i);
+//   dq_i = scale sum_j dS_ij k_j;  dk_j = scale sum_i dS_ij q_i.
+#define AS_MAXT 80
+template <int C>
+__global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const float* __restrict__ o,
+                                                      const float* __restrict__ dout, const float* __restrict__ lse,
+                                                      const int32_t* __restrict__ q_off, int H, int causal, float scale,
+                                                      float* __restrict__ dq, float* __restrict__ dk,
+                                                      float* __restrict__ dv) {
+    __shared__ float P[AS_MAXT * AS_MAXT];      // p, then dS
+    __shared__ float delta[AS_MAXT];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, I = H * C;
+    const int r0 = q_off[b], T = q_off[b + 1] - r0;
+    for (int i = tid; i < T; i += 256) {
+        float d = 0.f;
+        for (int e = 0; e < C; ++e) d += dout[(size_t)(r0 + i) * I + h * C + e] * o[(size_t)(r0 + i) * I + h * C + e];
+        delta[i] = d;
+    }
+    for (int idx = tid; idx < T * T; idx += 256) {
+        const int i = idx / T, j = idx % T;
+        float p = 0.f;
+        if (!causal || j <= i) {
+            const float* qi = q + (size_t)(r0 + i) * I + h * C;
+            const float* kj = k + (size_t)(r0 + j) * I + h * C;
+            float s = 0.f;
+            for (int e = 0; e < C; ++e) s += qi[e] * kj[e];
+            p = expf(s * scale - lse[(size_t)(r0 + i) * H + h]);
+        }
+        P[i * AS_MAXT + j] = p;
+    }
+    __syncthreads();
+    // dv_j[e] = sum_i p_ij do_i[e]
+    for (int idx = tid; idx < T * C; idx += 256) {
+        const int j = idx / C, e = idx % C;
+        float a = 0.f;
+        for (int i = 0; i < T; ++i) a += P[i * AS_MAXT + j] * dout[(size_t)(r0 + i) * I + h * C + e];
+        dv[(size_t)(r0 + j) * I + h * C + e] = a;
+    }
+    __syncthreads();
+    // dS_ij = p_ij (do_i . v_j - delta_i) * scale   (in place)
+    for (int idx = tid; idx < T * T; idx += 256) {
+        const int i = idx / T, j = idx % T;
+        const float p = P[i * AS_MAXT + j];
+        float dp = 0.f;
+        if (p != 0.f) {
+            const float* di = dout + (size_t)(r0 + i) * I + h * C;
+            const float* vj = v + (size_t)(r0 + j) * I + h * C;
+            for (int e = 0; e < C; ++e) dp += di[e] * vj[e];
+        }
+        P[i * AS_MAXT + j] = p * (dp - delta[i]) * scale;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * C; idx += 256) {
+        const int i = idx / C, e = idx % C;
+        float a = 0.f, c = 0.f;
+        for (int j = 0; j < T; ++j) {
+            a += P[i * AS_MAXT + j] * k[(size_t)(r0 + j) * I + h * C + e];      // dq_i
+            c += P[j * AS_MAXT + i] * q[(size_t)(r0 + j) * I + h * C + e];      // dk_i (roles of i, j swapped)
+        }
+        dq[(size_t)(r0 + i) * I + h * C + e] = a;
+        dk[(size_t)(r0 + i) * I + h * C + e] = c;
+    }
+}
+
+// QuickGELU y = x sigmoid(1.702 x) and its backward from the pre-activation (clip/model.py:162-164)
+__global__ __launch_bounds__(256) void k_quickgelu(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i], s = 1.0f / (1.0f + expf(-1.702f * xv));
+    out[i] = dy == nullptr ? xv * s : dy[i] * s * (1.0f + 1.702f * xv * (1.0f - s));
+}
+
+extern "C" int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                const float* lse, const int32_t* q_off, int B, int Tmax, int H, int C, int causal,
+                                float* dq, float* dk, float* dv, void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !q_off || !dq || !dk || !dv) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    const float scale = 1.0f / sqrtf((float)C);
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_bwd<CC>), dim3(B, H), dim3(256), 0, (hipStream_t)stream, q, k, v, o, dout,
+                                     lse, q_off, H, causal, scale, dq, dk, dv));
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_quickgelu(const float* x, const float* dy, float* out, size_t n, void* stream) {
+    if (!x || !out) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_quickgelu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, out, n);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

@@ -300,14 +300,23 @@ class _LinearAct(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         res = _f32c(residual, "residual") if residual is not None else None
-        y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res)
+        pre = None
+        if act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3]):
+            # QuickGELU's derivative needs the pre-activation: keep it (learnable-prompt path only; the frozen
+            # forward uses the fused epilogue)
+            pre = gemm(x, 0, W, 0, M, N, K, bias=b, act=0)
+            y = torch.empty_like(pre)
+            rc = _lib.lib().mil_quickgelu(_p(pre), None, _p(y), pre.numel(), _stream())
+            _lib.check(rc, "mil_quickgelu")
+        else:
+            y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res)
         ctx.act = act
         ctx.has_b = b is not None
         ctx.has_res = residual is not None
         # with a residual the saved y is not the activation output; only act == none is used with residuals
         if ctx.has_res and act != 0:
             raise _lib.MilHipError("linear_act: residual is only supported with act='none'")
-        ctx.save_for_backward(x, W, y)
+        ctx.save_for_backward(x, W, y if pre is None else pre)
         return y
 
     @staticmethod
@@ -316,7 +325,12 @@ class _LinearAct(torch.autograd.Function):
         dy = _f32c(dy, "dy")
         M, K = x.shape
         N = W.shape[0]
-        dpre = act_bwd(dy, y, ctx.act)
+        if ctx.act == ACT["quickgelu"]:
+            dpre = torch.empty_like(dy)
+            rc = _lib.lib().mil_quickgelu(_p(y), _p(dy), _p(dpre), dy.numel(), _stream())     # y holds the pre-activation
+            _lib.check(rc, "mil_quickgelu")
+        else:
+            dpre = act_bwd(dy, y, ctx.act)
         dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
         dW = gemm(dpre, 1, x, 1, N, K, M, split_k=True) if ctx.needs_input_grad[1] else None
         db = colsum(dpre) if (ctx.has_b and ctx.needs_input_grad[2]) else None
@@ -361,10 +375,18 @@ class _AttnRows(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         segs, H, C = ctx.segs, ctx.H, ctx.C
-        if ctx.causal or segs.Tk_max > 16:
-            raise _lib.MilHipError("attention rows backward supports <= 16 keys per bag, non-causal (the CLIP tower is frozen)")
         I = H * C
         do = _f32c(do, "do")
+        if ctx.causal or segs.Tk_max > 16:
+            # whole-sequence self-attention (the CLIP text blocks under learnable prompts): q, k, v share the segments
+            if segs.q_lengths != segs.k_lengths or segs.Tk_max > 80:
+                raise _lib.MilHipError("attention backward: > 16 keys per bag is only supported for self-attention over "
+                                       "sequences of <= 80 tokens")
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            rc = _lib.lib().mil_attn_seq_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.q_off), segs.B,
+                                             segs.Tq_max, H, C, 1 if ctx.causal else 0, _p(dq), _p(dk), _p(dv), _stream())
+            _lib.check(rc, "mil_attn_seq_bwd")
+            return dq, dk, dv, None, None, None
         dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
         ws = torch.empty(max(1, segs.nblk) * 2 * 16 * I, device=q.device, dtype=torch.float32)
         rc = _lib.lib().mil_attn_rows_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.k_off), _p(segs.blk_map),

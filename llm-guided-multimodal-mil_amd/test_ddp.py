@@ -30,6 +30,8 @@ def test(args):
     model.eval()
     n_patch, feat, n_bags = [int(v) for v in args.synthetic]
     prompts = 10 if args.CI_prompt_version == "devided" else 1
+    if args.learnablePrompt:
+        prompts = len(args.clinical_features) + 1
     data = SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, args.seed + 1, args.ragged)
     preds, labels, times = [], [], []
     with torch.no_grad():

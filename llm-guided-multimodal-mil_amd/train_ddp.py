@@ -56,6 +56,8 @@ def main_worker(local_rank: int, nprocs: int, args):
     torch.manual_seed(args.seed)
     n_patch, feat, n_bags = [int(v) for v in args.synthetic]
     prompts = 10 if args.CI_prompt_version == "devided" else 1
+    if args.learnablePrompt:
+        prompts = len(args.clinical_features) + 1                                        # dim1/CLIP.py:19
     data = SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, args.seed, args.ragged)
     per_gpu = max(1, args.batch_size // world)                                           # train_ddp.py:75
     model = build_model(args).to(dev)
@@ -73,8 +75,12 @@ def main_worker(local_rank: int, nprocs: int, args):
         if world > 1:
             generator = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)
         criterion = torch.nn.BCELoss()
-        optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr0,
-                                     betas=(args.b1, args.b2), weight_decay=1e-7)        # train_ddp.py:115-118
+        trainable = [p for p in model.parameters() if p.requires_grad]
+        if args.learnablePrompt:                                                         # train_ddp.py:104-109
+            lr0 = args.lr = 1e-3
+            optimizer = torch.optim.SGD(trainable, lr=lr0, weight_decay=1e-7)
+        else:                                                                            # train_ddp.py:110-118
+            optimizer = torch.optim.Adam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7)
         if args.resume:
             ck = torch.load(args.resume, map_location=dev, weights_only=True)
             model.load_state_dict(ck["state_dict"])

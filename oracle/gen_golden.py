@@ -214,6 +214,32 @@ def gen_clip(cm, tag, seed, width, layers, vocab, heads, embed, P, store_params)
     npz(tag, **arrs)
 
 
+def gen_coop(cm, tag, seed, width, layers, vocab, heads, embed, P, n_ctx):
+    """Learnable-context branch, model/dim1/CLIP.py:32-60, run on the reference CLIP class (its tower, ln_final and
+    text_projection) with gradients to ctx."""
+    p = syn.clip_text_params(seed, width=width, layers=layers, vocab=vocab, embed=embed)
+    c = build_ref_clip(cm, p, width, layers, vocab, heads, embed)
+    for q in c.parameters():
+        q.requires_grad_(False)
+    x = syn.make_token_ids(seed + 1, 1, P, vocab=vocab)                  # [1, P, 77]
+    g = torch.Generator().manual_seed(seed + 2)
+    ctx = (torch.randn((P, n_ctx, width), generator=g) * 0.02).requires_grad_(True)
+    with torch.no_grad():
+        embedding = c.token_embedding(x[0, :, :]).type(c.dtype)         # CLIP.py:33
+    prefix = embedding[:, :1, :]
+    suffix = embedding[:, 1 + n_ctx:, :]
+    prompts = torch.cat([prefix, ctx, suffix], dim=1)                    # :45-52
+    x_ = prompts + c.positional_embedding.type(c.dtype)                  # :54
+    x_ = x_.permute(1, 0, 2)
+    x_ = c.transformer(x_)
+    x_ = x_.permute(1, 0, 2)
+    x_ = c.ln_final(x_).type(c.dtype)
+    x_ = x_[torch.arange(x_.shape[0]), x[0].argmax(dim=-1)] @ c.text_projection     # :60
+    go = torch.randn(x_.shape, generator=g)
+    (x_ * go).sum().backward()
+    npz(tag, seed=seed, cfg=np.array([width, layers, vocab, heads, embed, P, n_ctx]), out=x_, dctx=ctx.grad)
+
+
 # --------------------------------------------------------------------------- fused recipe (config 3)
 def gen_fused(ab, tw, cm, tag, seed, B, N, P, clip_layers, clip_width, clip_vocab, clip_heads):
     """model/aggregator.py:134-209, pathology + CI(text) branch, one bag per forward."""
@@ -283,6 +309,8 @@ def main():
     gen_clip(cm, "clip_text_small", 81, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, store_params=False)
     gen_clip(cm, "clip_text_vitb32", 82, width=512, layers=12, vocab=49408, heads=8, embed=512, P=2,
              store_params=False)
+    gen_coop(cm, "coop_small", 85, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, n_ctx=8)
+    gen_coop(cm, "coop_w512", 86, width=512, layers=2, vocab=49408, heads=8, embed=512, P=10, n_ctx=8)
     gen_fused(ab, tw, cm, "fused_small_clip", 91, B=2, N=96, P=1, clip_layers=2, clip_width=512,
               clip_vocab=49408, clip_heads=8)
     gen_fused(ab, tw, cm, "fused_P10", 92, B=2, N=64, P=10, clip_layers=2, clip_width=512,
@@ -292,4 +320,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "coop":        # regenerate only the learnable-context fixtures
+        torch.set_num_threads(8)
+        _ab, _tw, _cm = load_reference()
+        gen_coop(_cm, "coop_small", 85, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, n_ctx=8)
+        gen_coop(_cm, "coop_w512", 86, width=512, layers=2, vocab=49408, heads=8, embed=512, P=10, n_ctx=8)
+    else:
+        main()

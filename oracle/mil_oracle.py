@@ -183,15 +183,9 @@ def clip_causal_mask(ctx: int) -> Tensor:
     return torch.full((ctx, ctx), float("-inf")).triu_(1)
 
 
-def clip_encode_text(ids: Tensor, p: Params, heads: int, prefix: str = "clinic_extractor.model.") -> Tensor:
-    """clip/model.py:339-352 encode_text in fp32: ids int64 [P, ctx] -> [P, embed].
-
-    Blocks follow clip/model.py:167-199 (pre-LN, nn.MultiheadAttention with the additive
-    causal mask, QuickGELU x*sigmoid(1.702x) MLP); the feature is the ln_final row at
-    argmax(ids) (the EOT token has the largest id) times text_projection.
-    """
-    x = p[prefix + "token_embedding.weight"][ids]                         # [P, ctx, W]
-    x = x + p[prefix + "positional_embedding"]
+def _clip_tower(x: Tensor, eot: Tensor, p: Params, heads: int, prefix: str) -> Tensor:
+    """Blocks of clip/model.py:167-199 (pre-LN, nn.MultiheadAttention with the additive causal mask, QuickGELU MLP),
+    ln_final, the row at the EOT position, text_projection.  x [P, ctx, W] already holds token + positional embeddings."""
     P_, ctx, width = x.shape
     c = width // heads
     mask = clip_causal_mask(ctx)
@@ -213,8 +207,25 @@ def clip_encode_text(ids: Tensor, p: Params, heads: int, prefix: str = "clinic_e
         h = h * torch.sigmoid(1.702 * h)                                   # clip/model.py:162-164
         x = x + F.linear(h, p[b + "mlp.c_proj.weight"], p[b + "mlp.c_proj.bias"])
     x = F.layer_norm(x, (width,), p[prefix + "ln_final.weight"], p[prefix + "ln_final.bias"], 1e-5)
-    eot = ids.argmax(dim=-1)
     return x[torch.arange(P_), eot] @ p[prefix + "text_projection"]
+
+
+def clip_encode_text(ids: Tensor, p: Params, heads: int, prefix: str = "clinic_extractor.model.") -> Tensor:
+    """clip/model.py:339-352 encode_text in fp32: ids int64 [P, ctx] -> [P, embed].  The feature is the ln_final row
+    at argmax(ids) (the EOT token has the largest id) times text_projection."""
+    x = p[prefix + "token_embedding.weight"][ids] + p[prefix + "positional_embedding"]
+    return _clip_tower(x, ids.argmax(dim=-1), p, heads, prefix)
+
+
+def clip_learnable_prompts(ids: Tensor, ctx_vectors: Tensor, p: Params, heads: int,
+                           prefix: str = "clinic_extractor.model.") -> Tensor:
+    """Learnable-context (CoOp) branch, model/dim1/CLIP.py:32-60, for the prompts of ONE bag: ids [P, ctx],
+    ctx_vectors [P, n_ctx, W] replace token positions 1..n_ctx; the tower stays frozen, gradients reach ctx_vectors."""
+    n_ctx = ctx_vectors.shape[1]
+    emb = p[prefix + "token_embedding.weight"][ids].detach()               # :33
+    prompts = torch.cat([emb[:, :1, :], ctx_vectors, emb[:, 1 + n_ctx:, :]], dim=1)      # :45-52
+    x = prompts + p[prefix + "positional_embedding"]                       # :54
+    return _clip_tower(x, ids.argmax(dim=-1), p, heads, prefix)            # :55-60
 
 
 # --------------------------------------------------------------------------- full recipes

@@ -108,7 +108,7 @@ def test_out_of_scope_branches_raise():
     with pytest.raises(NotImplementedError):
         get_model(make_args(aggregator="TransMIL"))
     with pytest.raises(NotImplementedError):
-        get_model(make_args(learnablePrompt=1))
+        get_model(make_args(model_CI="simpleFCs_v1"))
 
 
 def test_image_only_module_vs_oracle():

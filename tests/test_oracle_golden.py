@@ -196,3 +196,19 @@ def test_adam_matches_torch():
         opt.step()
         cur, m, v = orc.adam_step(cur, gr, m, v, step)
         assert float((cur - ref.detach()).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("tag", ["coop_small", "coop_w512"])
+def test_learnable_prompts(tag):
+    g = load_golden(tag)
+    width, layers, vocab, heads, embed, P, n_ctx = [int(v) for v in g["cfg"]]
+    seed = int(g["seed"])
+    p = syn.clip_text_params(seed, width=width, layers=layers, vocab=vocab, embed=embed)
+    ids = syn.make_token_ids(seed + 1, 1, P, vocab=vocab)[0]
+    gen = torch.Generator().manual_seed(seed + 2)
+    ctx = (torch.randn((P, n_ctx, width), generator=gen) * 0.02).requires_grad_(True)
+    out = orc.clip_learnable_prompts(ids, ctx, p, heads)
+    go = torch.randn(out.shape, generator=gen)
+    (out * go).sum().backward()
+    assert rel_err(out.detach(), g["out"]) <= TOL
+    assert rel_err(ctx.grad, g["dctx"]) <= 1e-4
