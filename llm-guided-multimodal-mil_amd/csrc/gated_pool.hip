@@ -484,19 +484,28 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
         __syncthreads();
     }
 
-    // partial tile -> part[s][128m + 64wi + 32a + row][j0 + 64wj + 32b + r]
-    float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj + r;
+    // partial tile -> part[s][128m + 64wi + row][j0 + 64wj + col].  The accumulators hold a column per lane
+    // (16 rows each); going through LDS turns 64 four-byte stores per lane into 16 sixteen-byte ones
+    // (each wave transposes its own 64 x 64 tile in its own 16 KB of the staging area; stride 64 is conflict-free both ways).
+    {
+        __syncthreads();                                  // the staging buffers are dead from here on
+        float* tw = smem + wave * (64 * 64);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-#if defined(GB_VARIANT) && GB_VARIANT == 1
-                if (acc[a][b][i] == 12345.678f)
-#endif
-                pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
-            }
+                for (int i = 0; i < 16; ++i) tw[(32 * a + mfma32_row(i, h)) * 64 + 32 * b + r] = acc[a][b][i];
+        // same-wave write -> read: no barrier needed, the LDS ops of a wave complete in order (lgkmcnt)
+        float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj;
+        const int c4 = lane & 15, rr = lane >> 4;         // 16 float4 columns x 4 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = 4 * pass + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * 64 + 4 * c4);
+            *reinterpret_cast<f32x4*>(pt + (size_t)row * L + 4 * c4) = v;
+        }
+    }
 
     // bias / w partials (only the j-tile-0 workgroups publish them)
     if (jt == 0) {
