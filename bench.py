@@ -62,15 +62,15 @@ def kernel_breakdown(tr, x, lay, y, iters=20):
     w = fp.p("aggregator.attention_weights.weight").view(-1)
     out = {}
     out["gate_fwd"] = timed(lambda: tr._gate_fwd(x, True), iters)
-    out["pool_partial"] = timed(lambda: ops.attn_pool_partial(x, c["scores"], lay), iters)
-    partials = ops.attn_pool_partial(x, c["scores"], lay)
+    out["pool_partial"] = timed(lambda: ops.attn_pool_partial_h(x, c["scores"], lay, fp.p("fc.1.weight")), iters)
+    partials, hrow = ops.attn_pool_partial_h(x, c["scores"], lay, fp.p("fc.1.weight"))
     scale = 1.0 / c["prob"].numel()
     out["merge_head_loss"] = timed(lambda: ops.pool_merge_head(partials, lay, L, fp.p("fc.1.weight"), fp.p("fc.1.bias"),
                                                                y, scale), iters)
     out["head_bwd_params"] = timed(lambda: ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"),
                                                                c["loss_bag"], tr.loss_sum), iters)
-    ds, _ = ops.attn_pool_bwd(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay, False)
-    out["pool_bwd_ds"] = timed(lambda: ops.attn_pool_bwd(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay, False), iters)
+    ds = ops.attn_pool_bwd_from_h(c["scores"], c["lse"], hrow, c["dz"], c["cdot"], lay)
+    out["pool_bwd_ds_from_h"] = timed(lambda: ops.attn_pool_bwd_from_h(c["scores"], c["lse"], hrow, c["dz"], c["cdot"], lay), iters)
     g = {k: torch.empty_like(fp.p(k)) for k in fp.order}
     gargs = (g["aggregator.attention_V.0.weight"], g["aggregator.attention_V.0.bias"], g["aggregator.attention_U.0.weight"],
              g["aggregator.attention_U.0.bias"], g["aggregator.attention_weights.weight"].view(-1),
@@ -267,7 +267,7 @@ def main():
             line["kernels_tflops"] = {k: round(flops[k] / (kb[k] * 1e-3) / 1e12, 2) for k in flops}
             pool_bytes = R * L * 4 + 4 * R + 4 * L * B
             line["kernels_gbs"] = {"pool_partial": round(pool_bytes / (kb["pool_partial"] * 1e-3) / 1e9, 1),
-                                   "pool_bwd_ds": round(pool_bytes / (kb["pool_bwd_ds"] * 1e-3) / 1e9, 1)}
+                                   }
             line["roofline_pool"] = pool_roofline(dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(N, L)

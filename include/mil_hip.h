@@ -67,6 +67,15 @@ int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_m
 int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
                           float* partials, void* stream);
 
+/* Pool partial pass that also emits the head's projection of every patch, hrow[row][c] = x_row . Wf[c] (C <= 4):
+ * when ABMIL feeds the linear head directly (model/aggregator.py:199-200), dM = dz Wf, so the backward's
+ * x_i . dM equals sum_c dz[bag][c] hrow[i][c] and mil_attn_pool_bwd_from_h yields ds WITHOUT re-reading x
+ * (replaces mil_attn_pool_bwd: ds_i = A_i (sum_c dz[bag][c] hrow[i][c] - cdot[bag])). */
+int mil_attn_pool_partial_h(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
+                            float* partials, const float* Wf, int C, float* hrow, void* stream);
+int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float* hrow, const float* dz,
+                             const float* cdot, const int32_t* tile_map, int T, int C, float* ds, void* stream);
+
 /* Fused per-bag tail (one workgroup per bag): merge the partials -> M, lse; head z, p; and, when
  * labels y are given, the bag's BCE loss loss_bag[b] = scale * sum_c BCE(p_bc, y_bc) (log clamped at -100;
  * summed in fixed order by mil_head_bwd_params), dz, dM = dz Wf and cdot = M . dM, i.e. everything

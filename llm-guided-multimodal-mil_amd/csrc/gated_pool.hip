@@ -153,10 +153,14 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
 // lane l owns columns 4l + 256q (16-byte loads, 1 KiB per wave instruction).
 // Output partial: acc[t][L] weighted row sum with weights exp(s_i - m_tile) in partials[0 .. T*L),
 // then (m_tile, l_tile) pairs in partials[T*L + 2t ..].
+// Optional by-product (Wf != NULL, C <= 4): h[row][c] = x_row . Wf[c], the head's projection of every patch.  The
+// backward then needs no second pass over x: x_i . dM = sum_c dz[bag][c] h[i][c] because dM = dz Wf
+// (k_pool_ds_from_h replaces the 64 MiB read of k_pool_bwd_ds).
 template <int NQ>
 __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ x, const float* __restrict__ scores,
                                                       const int32_t* __restrict__ tile_map, float* __restrict__ partials,
-                                                      int L) {
+                                                      int L, const float* __restrict__ Wf, int C,
+                                                      float* __restrict__ hrow) {
     __shared__ float p_lds[MIL_POOL_TILE];
     __shared__ float ml_lds[2];
     __shared__ __attribute__((aligned(16))) float red[3 * NQ * 256];
@@ -192,6 +196,23 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
         const float p = p_lds[wave + 4 * i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] += p * v[i][q];
+    }
+    if (Wf != nullptr) {
+        for (int c = 0; c < C; ++c) {
+            f32x4 wf[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wf[q] = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 256 * q + 4 * lane);
+#pragma unroll
+            for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    d += v[i][q][0] * wf[q][0] + v[i][q][1] * wf[q][1] + v[i][q][2] * wf[q][2] + v[i][q][3] * wf[q][3];
+                d = wave_allsum(d);
+                const int rr = wave + 4 * i;
+                if (lane == 0 && rr < nrows) hrow[(size_t)(row0 + rr) * C + c] = d;
+            }
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -318,6 +339,23 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
             }
         }
     }
+}
+
+// ds_i = A_i (sum_c dz[bag][c] h[i][c] - cdot[bag]) from the forward's head projections: no pass over x.
+// 8 tiles per workgroup, 32 threads per tile.
+__global__ __launch_bounds__(256) void k_pool_ds_from_h(const float* __restrict__ scores, const float* __restrict__ lse,
+                                                        const float* __restrict__ hrow, const float* __restrict__ dz,
+                                                        const float* __restrict__ cdot,
+                                                        const int32_t* __restrict__ tile_map, int T, int C,
+                                                        float* __restrict__ ds) {
+    const int t = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (t >= T) return;
+    const int bag = tile_map[4 * t], row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
+    if (l >= nrows) return;
+    const size_t row = (size_t)(row0 + l);
+    float g = 0.f;
+    for (int c = 0; c < C; ++c) g += dz[bag * C + c] * hrow[row * C + c];
+    ds[row] = expf(scores[row] - lse[bag]) * (g - cdot[bag]);
 }
 
 // ================================================================================ K1 backward: gate dW (MFMA)
@@ -567,14 +605,31 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
 }
 
 static int launch_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
-                               float* partials, hipStream_t st) {
+                               float* partials, const float* Wf, int C, float* hrow, hipStream_t st) {
     if (T <= 0) return MIL_OK;
     switch (L / 256) {
-        case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-        case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-        case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
-        default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L); break;
+        case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
+        case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
+        case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
+        default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
     }
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_partial_h(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
+                                       float* partials, const float* Wf, int C, float* hrow, void* stream) {
+    if (!x || !scores || !tile_map || !partials || !Wf || !hrow) return MIL_EINVAL;
+    if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0 || C <= 0 || C > 4) return MIL_EINVAL;
+    return launch_pool_partial(x, scores, tile_map, T, L, partials, Wf, C, hrow, (hipStream_t)stream);
+}
+
+extern "C" int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float* hrow, const float* dz,
+                                        const float* cdot, const int32_t* tile_map, int T, int C, float* ds, void* stream) {
+    if (!scores || !lse || !hrow || !dz || !cdot || !tile_map || !ds || T < 0 || C <= 0 || C > 4) return MIL_EINVAL;
+    if (T == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_pool_ds_from_h, dim3((T + 7) / 8), dim3(256), 0, (hipStream_t)stream, scores, lse, hrow, dz, cdot,
+                       tile_map, T, C, ds);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -583,7 +638,7 @@ extern "C" int mil_attn_pool_partial(const float* x, const float* scores, const 
                                      float* partials, void* stream) {
     if (!x || !scores || !tile_map || !partials) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
-    return launch_pool_partial(x, scores, tile_map, T, L, partials, (hipStream_t)stream);
+    return launch_pool_partial(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_map,
@@ -592,7 +647,7 @@ extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int3
     if (!x || !scores || !tile_map || !bag_tile_off || !partials || !M || !lse) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || B < 0 || T < 0) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = launch_pool_partial(x, scores, tile_map, T, L, partials, st);
+    const int rc = launch_pool_partial(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, st);
     if (rc != MIL_OK) return rc;
     if (B > 0) {
         hipLaunchKernelGGL(k_pool_merge, dim3(B, L / 128), dim3(256), 0, st, partials, bag_tile_off, M, lse, L, T);

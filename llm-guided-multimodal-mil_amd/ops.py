@@ -77,6 +77,27 @@ def attn_pool_partial(x, scores, layout: BagLayout):
     return partials
 
 
+def attn_pool_partial_h(x, scores, layout: BagLayout, Wf):
+    """Tile partials plus hrow [R, C] = x Wf^T (head projection of every patch; lets the backward skip x)."""
+    x = _f32c(x, "x")
+    R, L = x.shape
+    C = Wf.shape[0]
+    partials = torch.empty(layout.T * (L + 2), device=x.device, dtype=torch.float32)
+    hrow = torch.empty((R, C), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_partial_h(_p(x), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials),
+                                            _p(_f32c(Wf, "Wf")), C, _p(hrow), _stream())
+    _lib.check(rc, "mil_attn_pool_partial_h")
+    return partials, hrow
+
+
+def attn_pool_bwd_from_h(scores, lse, hrow, dz, cdot, layout: BagLayout):
+    ds = torch.empty(scores.shape[0], device=scores.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_bwd_from_h(_p(scores), _p(lse), _p(hrow), _p(dz), _p(cdot), _p(layout.tile_map),
+                                             layout.T, hrow.shape[1], _p(ds), _stream())
+    _lib.check(rc, "mil_attn_pool_bwd_from_h")
+    return ds
+
+
 def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0):
     """Fused per-bag tail: returns dict(M, lse, logits, prob[, loss_bag, dz, dM, cdot]); with labels it also
     produces each bag's scaled BCE loss and the head's backward inputs for the pool."""

@@ -106,13 +106,21 @@ class ImageOnlyTrainer:
         """Inference when y is None; with labels the fused tail also produces loss, dz, dM, cdot."""
         fp = self.fp
         scores, gates = self._gate_fwd(x, save_gates=y is not None)
-        partials = (ops.attn_pool_partial_bf16 if x.dtype == torch.bfloat16 else ops.attn_pool_partial)(x, scores, layout)
+        hrow = None
+        if x.dtype == torch.bfloat16:
+            partials = ops.attn_pool_partial_bf16(x, scores, layout)
+        elif y is not None and fp.p("fc.1.weight").shape[0] <= 4:
+            # training: the pool pass also projects every patch on the head (x_i . Wf[c]); the backward then
+            # needs no second pass over x (ops.attn_pool_bwd_from_h)
+            partials, hrow = ops.attn_pool_partial_h(x, scores, layout, fp.p("fc.1.weight"))
+        else:
+            partials = ops.attn_pool_partial(x, scores, layout)
         scale = 1.0
         if y is not None:
             nb = global_bags if global_bags is not None else layout.B * self.world
             scale = 1.0 / (nb * fp.p("fc.1.weight").shape[0])
         t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale)
-        self.last = dict(x=x, layout=layout, scores=scores, gates=gates, **t)
+        self.last = dict(x=x, layout=layout, scores=scores, gates=gates, hrow=hrow, **t)
         return t["prob"], t["logits"]
 
     def backward(self):
@@ -122,6 +130,8 @@ class ImageOnlyTrainer:
         b16 = c["x"].dtype == torch.bfloat16
         if b16:
             ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
+        elif c.get("hrow") is not None:
+            ds = ops.attn_pool_bwd_from_h(c["scores"], c["lse"], c["hrow"], c["dz"], c["cdot"], c["layout"])
         else:
             ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
         dw_fn = ops.gate_bwd_params
