@@ -228,6 +228,29 @@ int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float
                      float* dk, float* dv, void* stream);
 /* QuickGELU x*sigmoid(1.702x) (clip/model.py:162-164): out = act(x) if dy == NULL, else out = dy * act'(x). */
 int mil_quickgelu(const float* x, const float* dy, float* out, size_t n, void* stream);
+/* ---- one-text-token form of the token->image attention (sam/transformer.py:291-295,113-118 with T = 1) -------
+ * The K and V projections are absorbed into H query vectors and H pooled key vectors (csrc/absorbed_attn.hip):
+ *   Qp[b][h] = Wk_h^T qp[b][h]              mil_absorb_query      (qp = q_proj output [B, H*C], Wk [H*C, E])
+ *   pooled[b][h] = sum_n softmax_n(Qp[b][h] . (keys_n + pe_n) / sqrt(C)) keys_n     mil_absorbed_pool_fwd
+ *   o[b][hC + c] = Wv[hC + c] . pooled[b][h] + bv[hC + c]                           mil_value_proj
+ * i.e. the [N, E] x [E, H*C] projections of k and v are replaced by one HBM-bound pass over the keys; k_proj.bias
+ * drops out of the softmax.  tile_map int32 [ntiles][3] = {bag, key0, nkeys <= 64}; H == 8, E == 512.
+ * forward workspace: ntiles * H * (E + 2) floats; backward workspace: ntiles * H * E floats.
+ * mil_absorb_query_bwd: dqp [B, H*C] and/or dWk [H*C, E] (either may be NULL) from dQp [B, H, E]; the same two
+ * entry points give the value projection's backward (dpooled = absorb_query(do, Wv); dWv = absorb_query_bwd(do, pooled)). */
+int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream);
+int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E, float* dqp,
+                         float* dWk, void* stream);
+int mil_absorbed_pool_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
+                          const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E,
+                          float* pooled, float* lse, float* workspace, void* stream);
+int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse, const float* dpooled,
+                          const float* cdot, const int32_t* k_off, const int32_t* tile_map,
+                          const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E, float* dkeys, float* dQp,
+                          float* workspace, void* stream);
+int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
+                   void* stream);
+
 /* nn.LayerNorm over the last dim E (multiple of 64, <= 512), eps inside the sqrt.  stats [rows, 2] =
  * (mean, rstd), saved for the backward.  backward workspace: mil_layernorm_bwd_blocks(rows) * 2 * E floats. */
 int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,

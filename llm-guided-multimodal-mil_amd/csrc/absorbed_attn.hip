@@ -1,0 +1,345 @@
+// K2, one-text-token form of the token->image attention (model/sam/transformer.py:291-295,113-118 with T = 1).
+//
+// With a single query per bag the N-sized K and V projections are not needed: per head h
+//   score_h[n] = q_h . (Wk_h kin_n + bk_h) / sqrt(c)  =  (Wk_h^T q_h) . kin_n / sqrt(c)  + const     (kin = keys + pe)
+//   out_h      = sum_n a_h[n] (Wv_h keys_n + bv_h)     =  Wv_h (sum_n a_h[n] keys_n) + bv_h          (sum_n a_h[n] = 1)
+// so the projections are ABSORBED into H query vectors Qp[h] = Wk_h^T q_h (E long) and H pooled key vectors
+// pooled[h] = sum_n a_h[n] keys_n; the constant q_h . bk_h drops out of the softmax (k_proj.bias gets exactly zero
+// gradient, as it mathematically must).  The image side becomes an H-head attention POOL streamed over the keys -
+// HBM-bound like the MIL pool - instead of two [N, 512] x [512, 256] GEMMs (2 x 8.6 GFLOP per 32 bags x 1024 patches)
+// forward and four more backward.  The reference computes the same numbers through q/k/v Linear + softmax + matmul.
+//
+// Kernels (E = 512 = 64 lanes x 8, H <= 8, head dim c, rows tiled 64 per workgroup, split-N partials + merge):
+//   k_absorb_query / _bwd     Qp[b][h][:] = sum_c qp[b][hc + c'] Wk[hc + c'][:]
+//   k_apool_partial / _merge  online-softmax pool of the keys under H absorbed queries
+//   k_apool_bwd               per row: recompute a_h[n]; dkeys, and per-tile partial of dQp
+//   k_value_proj / _bwd       o[b][hc + c'] = Wv[hc + c'] . pooled[b][h] + bv
+#include "mil_common.h"
+
+#define AP_H 8
+#define AP_TILE 64
+
+// ---------------------------------------------------------------------------------------------- absorbed query
+// grid (B, H), block E/4 threads (float4 per thread)
+__global__ void k_absorb_query(const float* __restrict__ qp, const float* __restrict__ Wk, int H, int C, int E,
+                               float* __restrict__ Qp) {
+    const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
+    const int I = H * C;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) {
+        const float q = qp[(size_t)b * I + h * C + c];
+        acc += q * *reinterpret_cast<const f32x4*>(Wk + (size_t)(h * C + c) * E + 4 * j4);
+    }
+    *reinterpret_cast<f32x4*>(Qp + ((size_t)b * H + h) * E + 4 * j4) = acc;
+}
+
+// dqp[b][hc + c'] = dQp[b][h] . Wk[hc + c'];   grid (B, H), 256 threads: 8 threads per c' (c <= 32) then shuffle
+__global__ __launch_bounds__(256) void k_absorb_query_bwd_q(const float* __restrict__ dQp, const float* __restrict__ Wk,
+                                                            int H, int C, int E, float* __restrict__ dqp) {
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int I = H * C;
+    const int per = 256 / C;                       // threads per output (8 for C = 32, 4 for C = 64)
+    const int c = tid / per, part = tid % per;
+    const float* g = dQp + ((size_t)b * H + h) * E;
+    const float* w = Wk + (size_t)(h * C + c) * E;
+    float v = 0.f;
+    for (int j = part; j < E; j += per) v += g[j] * w[j];
+    for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (part == 0) dqp[(size_t)b * I + h * C + c] = v;
+}
+
+// dWk[hc + c'][j] = sum_b qp[b][hc + c'] dQp[b][h][j];   grid H*C, block E/4
+__global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* __restrict__ dQp, int B, int H, int C,
+                                     int E, float* __restrict__ dWk) {
+    const int row = blockIdx.x, h = row / C, j4 = threadIdx.x, I = H * C;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int b = 0; b < B; ++b)
+        acc += qp[(size_t)b * I + row] * *reinterpret_cast<const f32x4*>(dQp + ((size_t)b * H + h) * E + 4 * j4);
+    *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- absorbed pool, forward
+// One workgroup (256 threads) per 64-key tile: tile_map[g] = {bag, key0, nkeys}.  Wave w walks rows w, w+4, ...
+// Lane l holds columns 4l + 256q (q < 2) of a row.  Per-wave running online-softmax state for the H heads; the four
+// waves are merged through LDS; partial per tile: acc [H][E], then (m, l) [H][2].
+__global__ __launch_bounds__(256) void k_apool_partial(const float* __restrict__ keys, const float* __restrict__ pe,
+                                                       const float* __restrict__ Qp, const int32_t* __restrict__ k_off,
+                                                       const int32_t* __restrict__ tile_map, float scale,
+                                                       float* __restrict__ pacc, float* __restrict__ pml) {
+    constexpr int E = 512, NQ = 2;
+    __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
+    __shared__ float mls[4][AP_H][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
+    const int pos0 = key0 - k_off[b];
+    f32x4 qv[AP_H][NQ], acc[AP_H][NQ];
+    float m[AP_H], l[AP_H];
+#pragma unroll
+    for (int h = 0; h < AP_H; ++h) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            qv[h][q] = scale * *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            acc[h][q] = f32x4{0, 0, 0, 0};
+        }
+        m[h] = -INFINITY;
+        l[h] = 0.f;
+    }
+    for (int rr = wave; rr < nkeys; rr += 4) {
+        f32x4 kv[NQ], kin[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            kv[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
+            kin[q] = kv[q] + *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
+        }
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            float d = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                d += kin[q][0] * qv[h][q][0] + kin[q][1] * qv[h][q][1] + kin[q][2] * qv[h][q][2] + kin[q][3] * qv[h][q][3];
+            const float s = wave_allsum(d);
+            const float mn = fmaxf(m[h], s);
+            const float alpha = __expf(m[h] - mn), p = __expf(s - mn);
+            l[h] = l[h] * alpha + p;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[h][q] = acc[h][q] * alpha + p * kv[q];
+            m[h] = mn;
+        }
+    }
+    // merge the four waves (a wave with no rows carries m = -inf, l = 0, acc = 0)
+    if (lane == 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) { mls[wave][h][0] = m[h]; mls[wave][h][1] = l[h]; }
+    }
+    __syncthreads();
+    float mt[AP_H], sc[AP_H];
+#pragma unroll
+    for (int h = 0; h < AP_H; ++h) {
+        mt[h] = fmaxf(fmaxf(mls[0][h][0], mls[1][h][0]), fmaxf(mls[2][h][0], mls[3][h][0]));
+        sc[h] = m[h] == -INFINITY ? 0.f : __expf(m[h] - mt[h]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                *reinterpret_cast<f32x4*>(red + ((wave - 1) * AP_H + h) * E + 256 * q + 4 * lane) = sc[h] * acc[h][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 v = sc[h] * acc[h][q];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * AP_H + h) * E + 256 * q + 4 * lane);
+                *reinterpret_cast<f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v;
+            }
+            if (lane == 0) {
+                float lt = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) lt += mls[w][h][0] == -INFINITY ? 0.f : mls[w][h][1] * __expf(mls[w][h][0] - mt[h]);
+                pml[((size_t)g * AP_H + h) * 2] = mt[h];
+                pml[((size_t)g * AP_H + h) * 2 + 1] = lt;
+            }
+        }
+    }
+}
+
+// merge over a bag's tiles: pooled[b][h][:], lse[b][h].   grid (B, H), block E/4 threads
+__global__ void k_apool_merge(const float* __restrict__ pacc, const float* __restrict__ pml,
+                              const int32_t* __restrict__ bag_tile_off, int E, float* __restrict__ pooled,
+                              float* __restrict__ lse) {
+    const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
+    const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
+    float m = -INFINITY;
+    for (int g = g0; g < g1; ++g) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
+    float l = 0.f;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int g = g0; g < g1; ++g) {
+        const float sc = __expf(pml[((size_t)g * AP_H + h) * 2] - m);
+        l += sc * pml[((size_t)g * AP_H + h) * 2 + 1];
+        acc += sc * *reinterpret_cast<const f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 4 * j4);
+    }
+    const float inv = g1 > g0 ? 1.0f / l : 0.f;
+    *reinterpret_cast<f32x4*>(pooled + ((size_t)b * AP_H + h) * E + 4 * j4) = acc * inv;
+    if (j4 == 0) lse[b * AP_H + h] = g1 > g0 ? m + logf(l) : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------- absorbed pool, backward
+// Per row n of a tile: a_h = exp(scale Qp_h . kin_n - lse_h);  da_h = dpooled_h . keys_n;  ds_h = a_h (da_h - cdot_h);
+//   dkeys_n = sum_h (a_h dpooled_h + scale ds_h Qp_h);   dQp_h += scale ds_h kin_n  (per-tile partial, merged per bag)
+__global__ __launch_bounds__(256) void k_apool_bwd(const float* __restrict__ keys, const float* __restrict__ pe,
+                                                   const float* __restrict__ Qp, const float* __restrict__ lse,
+                                                   const float* __restrict__ dpooled, const float* __restrict__ cdot,
+                                                   const int32_t* __restrict__ k_off, const int32_t* __restrict__ tile_map,
+                                                   float scale, float* __restrict__ dkeys, float* __restrict__ pdq) {
+    constexpr int E = 512, NQ = 2;
+    __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
+    const int pos0 = key0 - k_off[b];
+    f32x4 qv[AP_H][NQ], dp[AP_H][NQ], dq[AP_H][NQ];
+    float ls[AP_H], cd[AP_H];
+#pragma unroll
+    for (int h = 0; h < AP_H; ++h) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            qv[h][q] = *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            dq[h][q] = f32x4{0, 0, 0, 0};
+        }
+        ls[h] = lse[b * AP_H + h];
+        cd[h] = cdot[b * AP_H + h];
+    }
+    for (int rr = wave; rr < nkeys; rr += 4) {
+        f32x4 kv[NQ], kin[NQ], out[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            kv[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
+            kin[q] = kv[q] + *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
+            out[q] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                d1 += kin[q][0] * qv[h][q][0] + kin[q][1] * qv[h][q][1] + kin[q][2] * qv[h][q][2] + kin[q][3] * qv[h][q][3];
+                d2 += kv[q][0] * dp[h][q][0] + kv[q][1] * dp[h][q][1] + kv[q][2] * dp[h][q][2] + kv[q][3] * dp[h][q][3];
+            }
+            const float s = wave_allsum(d1) * scale, da = wave_allsum(d2);
+            const float a = __expf(s - ls[h]);
+            const float ds = a * (da - cd[h]) * scale;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                out[q] += a * dp[h][q] + ds * qv[h][q];
+                dq[h][q] += ds * kin[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dkeys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = out[q];
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                *reinterpret_cast<f32x4*>(red + ((wave - 1) * AP_H + h) * E + 256 * q + 4 * lane) = dq[h][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 v = dq[h][q];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * AP_H + h) * E + 256 * q + 4 * lane);
+                *reinterpret_cast<f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v;
+            }
+    }
+}
+
+// dQp[b][h][:] = sum over the bag's tiles.  grid (B, H), block E/4
+__global__ void k_apool_bwd_merge(const float* __restrict__ pdq, const int32_t* __restrict__ bag_tile_off, int E,
+                                  float* __restrict__ dQp) {
+    const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int g = bag_tile_off[b]; g < bag_tile_off[b + 1]; ++g)
+        acc += *reinterpret_cast<const f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 4 * j4);
+    *reinterpret_cast<f32x4*>(dQp + ((size_t)b * AP_H + h) * E + 4 * j4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- value projection
+// o[b][hc + c'] = Wv[hc + c'] . pooled[b][h] + bv[hc + c'];   grid (B, H), 256 threads
+__global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ pooled, const float* __restrict__ Wv,
+                                                    const float* __restrict__ bv, int H, int C, int E,
+                                                    float* __restrict__ o) {
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, I = H * C;
+    const int per = 256 / C, c = tid / per, part = tid % per;
+    const float* pv = pooled + ((size_t)b * H + h) * E;
+    const float* w = Wv + (size_t)(h * C + c) * E;
+    float v = 0.f;
+    for (int j = part; j < E; j += per) v += pv[j] * w[j];
+    for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (part == 0) o[(size_t)b * I + h * C + c] = v + bv[h * C + c];
+}
+
+// dpooled[b][h][:] = sum_c' do[b][hc + c'] Wv[hc + c'][:]     (same form as k_absorb_query)
+// dWv[hc + c'][:]   = sum_b do[b][hc + c'] pooled[b][h][:]    (same form as k_absorb_query_bwd_w)
+
+#define AP_CHECK(cond) do { if (!(cond)) return MIL_EINVAL; } while (0)
+
+extern "C" int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream) {
+    AP_CHECK(qp && Wk && Qp && B >= 0 && H > 0 && C > 0 && E > 0 && (E & 3) == 0 && E <= 4096);
+    if (B == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_absorb_query, dim3(B, H), dim3(E / 4), 0, (hipStream_t)stream, qp, Wk, H, C, E, Qp);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E,
+                                    float* dqp, float* dWk, void* stream) {
+    AP_CHECK(qp && Wk && dQp && B > 0 && H > 0 && (C == 32 || C == 64) && E > 0 && (E & 3) == 0 && E <= 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dqp != nullptr) {
+        hipLaunchKernelGGL(k_absorb_query_bwd_q, dim3(B, H), dim3(256), 0, st, dQp, Wk, H, C, E, dqp);
+        MIL_CHECK_LAUNCH();
+    }
+    if (dWk != nullptr) {
+        hipLaunchKernelGGL(k_absorb_query_bwd_w, dim3(H * C), dim3(E / 4), 0, st, qp, dQp, B, H, C, E, dWk);
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+extern "C" int mil_absorbed_pool_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
+                                     const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H,
+                                     int C, int E, float* pooled, float* lse, float* workspace, void* stream) {
+    AP_CHECK(keys && pe && Qp && k_off && tile_map && bag_tile_off && pooled && lse && workspace);
+    AP_CHECK(H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0);
+    if (B == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* pacc = workspace;
+    float* pml = workspace + (size_t)ntiles * AP_H * E;
+    const float scale = 1.0f / sqrtf((float)C);
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_apool_partial, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_apool_merge, dim3(B, AP_H), dim3(E / 4), 0, st, pacc, pml, bag_tile_off, E, pooled, lse);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse,
+                                     const float* dpooled, const float* cdot, const int32_t* k_off,
+                                     const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H,
+                                     int C, int E, float* dkeys, float* dQp, float* workspace, void* stream) {
+    AP_CHECK(keys && pe && Qp && lse && dpooled && cdot && k_off && tile_map && bag_tile_off && dkeys && dQp && workspace);
+    AP_CHECK(H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0);
+    if (B == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / sqrtf((float)C);
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_apool_bwd, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, cdot, k_off, tile_map,
+                           scale, dkeys, workspace);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(E / 4), 0, st, workspace, bag_tile_off, E, dQp);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
+                              void* stream) {
+    AP_CHECK(pooled && Wv && bv && o && B >= 0 && H > 0 && (C == 32 || C == 64) && E > 0);
+    if (B == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_value_proj, dim3(B, H), dim3(256), 0, (hipStream_t)stream, pooled, Wv, bv, H, C, E, o);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

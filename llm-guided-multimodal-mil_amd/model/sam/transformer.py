@@ -40,6 +40,14 @@ class Attention(nn.Module):
         o = core(qp, kp, vp, segs, self.num_heads)
         return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
 
+    def one_token(self, q, keys, pe_table, segs: AttnSegs, residual=None):
+        """Token->image attention when every bag has ONE text token: the K / V projections over the patches are
+        absorbed into H query vectors and H pooled key vectors (ops.one_token_attention) - an HBM-bound pass over
+        the keys instead of two [N, E] x [E, I] GEMMs.  keys come WITHOUT positional encoding (added on the fly)."""
+        o = ops.one_token_attention(q, keys, pe_table, segs, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight,
+                                    self.v_proj.weight, self.v_proj.bias, self.num_heads)
+        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
+
     def forward(self, q, k, v):
         """Reference signature: q [B, Tq, E], k, v [B, Tk, E] -> [B, Tq, E]."""
         B, Tq, E = q.shape
@@ -47,6 +55,12 @@ class Attention(nn.Module):
         segs = AttnSegs.make([Tq] * B, [Tk] * B, q.device)
         form = "pool" if (Tq <= 16 and Tk > 16) else "rows"
         return self.flat(q.reshape(B * Tq, E), k.reshape(B * Tk, E), v.reshape(B * Tk, E), segs, form).reshape(B, Tq, E)
+
+
+def one_token_ok(attn: "Attention", s_ti: AttnSegs, pe_table) -> bool:
+    """The absorbed one-token kernels are built for E = 512, 8 heads and exactly one query per bag."""
+    return (pe_table is not None and s_ti.Tq_max == 1 and min(s_ti.q_lengths, default=1) == 1
+            and attn.embedding_dim == 512 and attn.num_heads == 8 and attn.internal_dim // attn.num_heads in (32, 64))
 
 
 class _LN(nn.LayerNorm):
@@ -68,8 +82,10 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.skip_first_layer_pe = skip_first_layer_pe
 
-    def flat(self, queries, keys, query_pe, keys_pe_fn, s_tt: AttnSegs, s_ti: AttnSegs, s_it: AttnSegs):
-        """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe."""
+    def flat(self, queries, keys, query_pe, keys_pe_fn, s_tt: AttnSegs, s_ti: AttnSegs, s_it: AttnSegs, pe_table=None):
+        """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe.  With pe_table
+        given and exactly one text token per bag, both cross attentions take their one-token forms and keys + pe is
+        never materialised."""
         if self.skip_first_layer_pe:                                            # :282-283 (replaces, no residual)
             queries = self.self_attn.flat(queries, queries, queries, s_tt, "rows")
         else:                                                                   # :285-287
@@ -77,8 +93,13 @@ class TwoWayAttentionBlock(nn.Module):
             queries = self.self_attn.flat(q, q, queries, s_tt, "rows", residual=queries)
         queries = self.norm1(queries)
         q = queries + query_pe                                                  # :291-295
-        k = keys_pe_fn(keys)
-        queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
+        one_token = one_token_ok(self.cross_attn_token_to_image, s_ti, pe_table)
+        if one_token:
+            k = None
+            queries = self.norm2(self.cross_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries))
+        else:
+            k = keys_pe_fn(keys)
+            queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
         queries = self.norm3(self.mlp(queries, residual=queries))               # :298-300
         q = queries + query_pe                                                  # :303-307
         if s_it.Tk_max == 1 and min(s_it.k_lengths, default=1) == 1:
@@ -89,6 +110,8 @@ class TwoWayAttentionBlock(nn.Module):
             o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
             keys = self.norm4(ops.add_bag_row(keys, o, s_it))
         else:
+            if k is None:
+                k = keys_pe_fn(keys)
             keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys))
         return queries, keys
 
@@ -126,11 +149,13 @@ class TwoWayTransformer(nn.Module):
         keys_pe = lambda kk: ops.add_pe(kk, pe_table, s_ti.k_bag, s_ti.k_off)      # noqa: E731
         queries, keys = point, image
         for layer in self.layers:
-            queries, keys = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it)
+            queries, keys = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it, pe_table)
         q = queries + point                                                      # :114-118
-        k = keys_pe(keys)
-        queries = self.norm_final_attn(self.final_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
-        return queries, keys
+        if one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
+            out = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
+        else:
+            out = self.final_attn_token_to_image.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=queries)
+        return self.norm_final_attn(out), keys
 
     def forward(self, image_embedding, image_pe, point_embedding):
         """Reference signature (sam/transformer.py:58-63): image_embedding [B, N, E], image_pe [B or 1, N, E],

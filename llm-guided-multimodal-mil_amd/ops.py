@@ -673,3 +673,107 @@ class _ClipContrastive(torch.autograd.Function):
 def clip_contrastive_loss(out, feat):
     """CLIPloss_v1 (reference utils.py:261-284): out [b, E] bag embeddings vs frozen text features feat [b, F, E]."""
     return _ClipContrastive.apply(out, feat)
+
+
+# --------------------------------------------------------------------------- one-text-token token->image attention
+class _AbsorbQuery(torch.autograd.Function):
+    """Qp[b][h] = Wk_h^T qp[b][h]  (also the value projection's backward map)."""
+
+    @staticmethod
+    def forward(ctx, qp, Wk, H: int):
+        qp, Wk = _f32c(qp, "qp"), _f32c(Wk, "Wk")
+        B, I = qp.shape
+        E = Wk.shape[1]
+        Qp = torch.empty((B, H, E), device=qp.device, dtype=torch.float32)
+        rc = _lib.lib().mil_absorb_query(_p(qp), _p(Wk), B, H, I // H, E, _p(Qp), _stream())
+        _lib.check(rc, "mil_absorb_query")
+        ctx.H = H
+        ctx.save_for_backward(qp, Wk)
+        return Qp
+
+    @staticmethod
+    def backward(ctx, dQp):
+        qp, Wk = ctx.saved_tensors
+        B, I = qp.shape
+        E = Wk.shape[1]
+        dQp = _f32c(dQp, "dQp")
+        dqp = torch.empty_like(qp) if ctx.needs_input_grad[0] else None
+        dWk = torch.empty_like(Wk) if ctx.needs_input_grad[1] else None
+        rc = _lib.lib().mil_absorb_query_bwd(_p(qp), _p(Wk), _p(dQp), B, ctx.H, I // ctx.H, E, _p(dqp), _p(dWk), _stream())
+        _lib.check(rc, "mil_absorb_query_bwd")
+        return dqp, dWk, None
+
+
+class _AbsorbedPool(torch.autograd.Function):
+    """pooled[b][h] = sum_n softmax_n(Qp[b][h] . (keys_n + pe_n) / sqrt(C)) keys_n."""
+
+    @staticmethod
+    def forward(ctx, keys, pe, Qp, segs, C: int):
+        keys, pe, Qp = _f32c(keys, "keys"), _f32c(pe, "pe"), _f32c(Qp, "Qp")
+        B, H, E = Qp.shape
+        pooled = torch.empty_like(Qp)
+        lse = torch.empty((B, H), device=keys.device, dtype=torch.float32)
+        ws = torch.empty(max(1, segs.ntiles) * H * (E + 2), device=keys.device, dtype=torch.float32)
+        rc = _lib.lib().mil_absorbed_pool_fwd(_p(keys), _p(pe), _p(Qp), _p(segs.k_off), _p(segs.tile_map),
+                                              _p(segs.bag_tile_off), segs.ntiles, B, H, C, E, _p(pooled), _p(lse), _p(ws),
+                                              _stream())
+        _lib.check(rc, "mil_absorbed_pool_fwd")
+        ctx.segs, ctx.C = segs, C
+        ctx.save_for_backward(keys, pe, Qp, pooled, lse)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        keys, pe, Qp, pooled, lse = ctx.saved_tensors
+        segs, C = ctx.segs, ctx.C
+        B, H, E = Qp.shape
+        dpooled = _f32c(dpooled, "dpooled")
+        cdot = rowdot(dpooled.view(B * H, E), pooled.view(B * H, E))
+        dkeys = torch.empty_like(keys)
+        dQp = torch.empty_like(Qp)
+        ws = torch.empty(max(1, segs.ntiles) * H * E, device=keys.device, dtype=torch.float32)
+        rc = _lib.lib().mil_absorbed_pool_bwd(_p(keys), _p(pe), _p(Qp), _p(lse), _p(dpooled), _p(cdot), _p(segs.k_off),
+                                              _p(segs.tile_map), _p(segs.bag_tile_off), segs.ntiles, B, H, C, E, _p(dkeys),
+                                              _p(dQp), _p(ws), _stream())
+        _lib.check(rc, "mil_absorbed_pool_bwd")
+        return dkeys, None, dQp, None, None
+
+
+class _ValueProj(torch.autograd.Function):
+    """o[b][hC + c] = Wv[hC + c] . pooled[b][h] + bv[hC + c]."""
+
+    @staticmethod
+    def forward(ctx, pooled, Wv, bv):
+        pooled, Wv = _f32c(pooled, "pooled"), _f32c(Wv, "Wv")
+        B, H, E = pooled.shape
+        I = Wv.shape[0]
+        o = torch.empty((B, I), device=pooled.device, dtype=torch.float32)
+        rc = _lib.lib().mil_value_proj(_p(pooled), _p(Wv), _p(_f32c(bv, "bv")), B, H, I // H, E, _p(o), _stream())
+        _lib.check(rc, "mil_value_proj")
+        ctx.save_for_backward(pooled, Wv)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        pooled, Wv = ctx.saved_tensors
+        B, H, E = pooled.shape
+        I = Wv.shape[0]
+        do = _f32c(do, "do")
+        dpooled = torch.empty_like(pooled)
+        rc = _lib.lib().mil_absorb_query(_p(do), _p(Wv), B, H, I // H, E, _p(dpooled), _stream())
+        _lib.check(rc, "mil_absorb_query")
+        dWv = torch.empty_like(Wv)
+        rc = _lib.lib().mil_absorb_query_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, None, _p(dWv), _stream())
+        _lib.check(rc, "mil_absorb_query_bwd")
+        return dpooled, dWv, colsum(do)
+
+
+def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
+    """Token->image attention core for ONE text token per bag, projections absorbed (csrc/absorbed_attn.hip).
+    q_tok [B, E] (query + its pe), keys [R, E] WITHOUT positional encoding, pe [>= max N, E].  Returns the
+    pre-out_proj attention output [B, H*C].  k_proj.bias does not enter (softmax-invariant)."""
+    qp = linear_act(q_tok, Wq, bq)
+    C = Wq.shape[0] // H
+    Qp = _AbsorbQuery.apply(qp, Wk, H)
+    pooled = _AbsorbedPool.apply(keys, pe, Qp, segs, C)
+    return _ValueProj.apply(pooled, Wv, bv)
