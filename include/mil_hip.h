@@ -180,8 +180,9 @@ int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* 
  * MLPBlock sam/common.py:21-26, CLIP blocks clip/model.py:171-178];  dx = dy W (0,1);  dW = dy^T x (1,1).
  * act: 0 none, 1 tanh, 2 relu, 3 QuickGELU x*sigmoid(1.702x) (clip/model.py:162-164).  bias [N] / residual
  * [M, ldr] may be NULL.  k-contiguous operands need K % 32 == 0; all leading dimensions % 4 == 0.
- * The (1,1) form splits K across workgroups when a workspace of mil_gemm_workspace_floats() floats is
- * given (bias/act/residual must then be unset) and reduces the partials in a second launch. */
+ * With a workspace of mil_gemm_workspace_floats() floats (0 = not worth it) K is split across workgroups
+ * and a second launch sums the partials and applies the epilogue: always for the (1,1) weight-gradient form,
+ * for the others only when the output is a few tiles (token-side projections with a few dozen rows). */
 size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,

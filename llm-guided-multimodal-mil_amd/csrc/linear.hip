@@ -190,14 +190,20 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     }
 }
 
-// split-K reduce: C (+)= sum_s partial[s]  (+ bias etc. are not used on the split path: weight gradients only)
+// split-K reduce with the full epilogue: C (+)= act(sum_s partial[s] + bias) + residual
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int S, float* __restrict__ C,
-                                                       int ldc, int M, int N, int accumulate) {
+                                                       int ldc, int M, int N, const float* __restrict__ bias, int act,
+                                                       const float* __restrict__ residual, int ldr, int accumulate) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)M * N) return;
     const int row = (int)(idx / N), j = (int)(idx % N);
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += partial[((size_t)s * M + row) * N + j];
+    if (bias != nullptr) v += bias[j];
+    if (act == ACT_TANH) v = tanhf(v);
+    else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
+    if (residual != nullptr) v += residual[(size_t)row * ldr + j];
     float* o = C + (size_t)row * ldc + j;
     if (accumulate) v += *o;
     *o = v;
@@ -242,15 +248,33 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, c
     dpre[i] = act == ACT_TANH ? g * (1.0f - yy * yy) : act == ACT_RELU ? (yy > 0.f ? g : 0.f) : g;
 }
 
-extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
-    // split-K is only used for the transposed-A form (weight gradients: K = number of rows)
-    if (a_mode != 1) return 0;
+// Split-K policy.  Weight gradients (a_mode 1: K = number of rows) always split to fill the chip.  The other forms
+// split only when the output is a handful of tiles (token-side projections: M = bags x text tokens <= a few dozen
+// rows), where a single 128 x 128 workgroup per tile would walk all of K alone: 30-60 us of latency for <0.1 GFLOP.
+static int splitk_plan(int M, int N, int K, int a_mode, int* kchunk_out) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
+    int S;
+    if (a_mode == 1) {
+        S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
+    } else {
+        if (tiles > 32 || K < 256) { *kchunk_out = K; return 1; }
+        S = (2 * MIL_NUM_CU) / tiles;
+        if (S > K / 64) S = K / 64;                     // at least two 32-deep slices per split
+    }
     const int maxS = (K + LG_BK - 1) / LG_BK;
     if (S > maxS) S = maxS;
-    if (S < 2) return 0;
-    return (size_t)S * M * N;
+    if (S < 2) { *kchunk_out = K; return 1; }
+    const int kchunk = ((K + S - 1) / S + LG_BK - 1) / LG_BK * LG_BK;
+    S = (K + kchunk - 1) / kchunk;
+    *kchunk_out = S > 1 ? kchunk : K;
+    return S;
+}
+
+extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int kchunk;
+    const int S = splitk_plan(M, N, K, a_mode, &kchunk);
+    return S > 1 ? (size_t)S * M * N : 0;
 }
 
 extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
@@ -267,13 +291,10 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
     hipStream_t st = (hipStream_t)stream;
     int S = 1, kchunk = K;
     float* partial = nullptr;
-    const size_t need = mil_gemm_workspace_floats(M, N, K, a_mode);
-    if (need > 0 && workspace != nullptr && workspace_floats >= need && bias == nullptr && act == 0 && residual == nullptr) {
-        S = (int)(need / ((size_t)M * N));
-        kchunk = ((K + S - 1) / S + LG_BK - 1) / LG_BK * LG_BK;
-        S = (K + kchunk - 1) / kchunk;
-        partial = S > 1 ? workspace : nullptr;
-        if (S == 1) kchunk = K;
+    if (workspace != nullptr) {
+        int kc;
+        const int want = splitk_plan(M, N, K, a_mode, &kc);
+        if (want > 1 && workspace_floats >= (size_t)want * M * N) { S = want; kchunk = kc; partial = workspace; }
     }
     dim3 grid((N + 127) / 128, (M + 127) / 128, S);
     if (a_mode == 0 && b_mode == 0)
@@ -285,7 +306,8 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
     MIL_CHECK_LAUNCH();
     if (partial != nullptr) {
         const size_t n = (size_t)M * N;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, S, C, ldc, M, N, accumulate);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, S, C, ldc, M, N,
+                           bias, act, residual, ldr, accumulate);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;

@@ -272,7 +272,7 @@ ACT = {"none": 0, "tanh": 1, "relu": 2, "quickgelu": 3}
 
 
 def gemm(A, a_mode: int, B, b_mode: int, M: int, N: int, K: int, out=None, bias=None, act: int = 0, residual=None,
-         accumulate: bool = False, split_k: bool = False):
+         accumulate: bool = False, split_k: bool = True):
     """C[M,N] (+)= act(A_op . B_op + bias) + residual  (include/mil_hip.h: mil_gemm)."""
     A = _f32c(A, "A")
     B = _f32c(B, "B")
