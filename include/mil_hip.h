@@ -80,7 +80,7 @@ int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float*
  * labels y are given, the bag's BCE loss loss_bag[b] = scale * sum_c BCE(p_bc, y_bc) (log clamped at -100;
  * summed in fixed order by mil_head_bwd_params), dz, dM = dz Wf and cdot = M . dM, i.e. everything
  * between the pool's partial pass and the pool's backward.
- * ABMIL.py:57-59 + aggregator.py:128-131,200 + train_ddp.py:99,323-324.  L in {256, 512, 1024}. */
+ * ABMIL.py:57-59 + aggregator.py:128-131,200 + train_ddp.py:99,323-324.  L in {256, 512, 768, 1024}. */
 int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
                         const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                         float* lse, float* z, float* p, float* loss_bag, float* dz, float* dM, float* cdot,

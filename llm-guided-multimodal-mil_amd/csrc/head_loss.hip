@@ -167,14 +167,15 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     l = block_allsum_256(l, red);
     const float inv = nt > 0 ? 1.0f / l : 0.f;
 
-    const int L4 = L >> 2, NG = 256 / L4;          // L in {256, 512, 1024} -> NG in {4, 2, 1}
+    const int L4 = L >> 2, NG = 256 / L4;          // L in {256, 512, 768, 1024} -> NG in {4, 2, 1, 1}
     const int c4 = tid % L4, g = tid / L4;
+    const bool worker = g < NG;                    // L = 768 leaves 64 threads without a column group
     f32x4 acc = {0, 0, 0, 0};
     for (int tb = 0; tb < nt; tb += 1024) {
         __syncthreads();
         for (int k = tid; k < 1024; k += 256) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
         __syncthreads();
-        const int cnt = min(1024, nt - tb);
+        const int cnt = worker ? min(1024, nt - tb) : 0;
         int k = g;
         for (; k + 7 * NG < cnt; k += 8 * NG) {
             f32x4 v[8];
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
         for (; k < cnt; k += NG)
             acc += scale_lds[k] * *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + tb + k) * L + 4 * c4);
     }
-    *reinterpret_cast<f32x4*>(part_lds + g * L + 4 * c4) = acc;
+    if (worker) *reinterpret_cast<f32x4*>(part_lds + g * L + 4 * c4) = acc;
     __syncthreads();
     for (int j = tid; j < L; j += 256) {
         float v = 0.f;
@@ -238,7 +239,7 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
                                    void* stream) {
     if (!partials || !bag_tile_off || !Wf || !bf || !M || !lse || !z || !p) return MIL_EINVAL;
     if (y && (!loss_sum || !dz || !dM || !cdot)) return MIL_EINVAL;
-    if (!(L == 256 || L == 512 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
+    if (!(L == 256 || L == 512 || L == 768 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     hipLaunchKernelGGL(k_pool_merge_head, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
                        bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot);

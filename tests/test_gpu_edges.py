@@ -1,0 +1,83 @@
+"""GPU: edge cases of the K1 path the reference's data can produce: the largest bag of the cohort (15 592 patches,
+dataset.py:386-391), a bag without patches, the raw 768-d CTransPath width (aggregator_clip.py:36), more than two
+classes, a one-bag batch."""
+import pytest
+import torch
+
+from conftest import rel_err
+from mil_amd import synthetic as syn
+from mil_amd.bags import BagLayout
+from mil_amd.trainer import ImageOnlyTrainer
+from oracle import mil_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def _step(p, bags, y, L, **kw):
+    tr = ImageOnlyTrainer(p, DEV, lr=1e-3, **kw)
+    lengths = [b.shape[0] for b in bags]
+    x = torch.cat(bags, 0).to(DEV) if sum(lengths) else torch.zeros((0, L), device=DEV)
+    lay = BagLayout.make(lengths, DEV)
+    prob, z = tr.forward(x, lay, y.to(DEV))
+    tr.backward()
+    torch.cuda.synchronize()
+    return tr, prob, z
+
+
+def test_largest_bag_of_the_cohort():
+    L, N = 512, 15592
+    p = syn.image_only_params(101, L=L)
+    bags = [torch.randn((N, L), generator=torch.Generator().manual_seed(1)),
+            torch.randn((37, L), generator=torch.Generator().manual_seed(2))]
+    y = syn.make_labels(3, 2)
+    tr, prob, z = _step(p, bags, y, L)
+    loss, logits, rprob, grads = orc.batch_loss_and_grads(bags, y, p)
+    assert float((z.cpu() - logits).abs().max()) <= 2e-5
+    assert torch.equal(prob.cpu().argmax(-1), rprob.argmax(-1))
+    for k in grads:
+        if float(grads[k].norm()) > 1e-7:
+            assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= 2e-4, k
+
+
+def test_raw_768_wide_features_and_three_classes():
+    L = 768
+    p = syn.image_only_params(102, L=L, C=3)
+    bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(10 + i)) for i, n in enumerate([130, 64, 5])]
+    y = syn.make_labels(4, 3, C=3)
+    tr, prob, z = _step(p, bags, y, L)
+    loss, logits, rprob, grads = orc.batch_loss_and_grads(bags, y, p)
+    assert float((z.cpu() - logits).abs().max()) <= 2e-5
+    assert abs(float(tr.loss_sum.item()) - float(loss)) <= 1e-5
+    for k in grads:
+        if float(grads[k].norm()) > 1e-7:
+            assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= 2e-4, k
+
+
+def test_bag_without_patches_is_harmless():
+    """The reference would fail on an empty bag; here it pools to zero (logits = head bias), contributes a finite
+    loss and no gate gradient, and leaves its neighbours untouched."""
+    L = 512
+    p = syn.image_only_params(103, L=L)
+    full = [torch.randn((50, L), generator=torch.Generator().manual_seed(20)),
+            torch.randn((70, L), generator=torch.Generator().manual_seed(21))]
+    y3 = syn.make_labels(5, 3)
+    tr, prob, z = _step(p, [full[0], torch.zeros((0, L)), full[1]], y3, L)
+    assert torch.isfinite(z).all() and torch.isfinite(tr.fp.grad).all()
+    assert float((z[1].cpu() - p["fc.1.bias"]).abs().max()) <= 1e-7
+    for i, b in ((0, 0), (2, 1)):
+        o = orc.image_only_forward(full[b], p)
+        assert float((z[i].cpu() - o["logits"][0]).abs().max()) <= 2e-5
+
+
+def test_single_bag_single_patch():
+    L = 512
+    p = syn.image_only_params(104, L=L)
+    bags = [torch.randn((1, L), generator=torch.Generator().manual_seed(30))]
+    y = syn.make_labels(6, 1)
+    tr, prob, z = _step(p, bags, y, L)
+    loss, logits, rprob, grads = orc.batch_loss_and_grads(bags, y, p)
+    assert float((z.cpu() - logits).abs().max()) <= 2e-5
+    # one patch: the softmax weight is 1, so no gradient reaches the gate parameters
+    assert float(tr.fp.g("aggregator.attention_V.0.weight").abs().max()) <= 1e-7
+    assert rel_err(tr.fp.g("fc.1.weight").cpu(), grads["fc.1.weight"]) <= 1e-5
