@@ -170,8 +170,13 @@ def main():
     gpu = 0 if rehearsal else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
-    if world > 1:
+    force = os.environ.get("MIL_FORCE_COLLECTIVES") == "1"      # world size 1 through RCCL: checks init + collectives
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if force and world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
@@ -188,7 +193,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,7 +210,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -272,7 +277,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(N, L)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -49,5 +49,5 @@ def broadcast_flat(buf: torch.Tensor, src: int = 0):
 
 def allreduce_flat(buf: torch.Tensor):
     """The step's single data-path collective."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("MIL_FORCE_COLLECTIVES") == "1"):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -76,6 +78,8 @@ class ImageOnlyTrainer:
         self.fp = FlatParams(params, device, PARAM_ORDER)
         self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
         self.world = world_size
+        # MIL_FORCE_COLLECTIVES=1: issue the all-reduce even at world size 1 (exercises RCCL on a one-GPU box)
+        self.force_collectives = os.environ.get("MIL_FORCE_COLLECTIVES") == "1"
         # bf16 x only: weight gradient on the bf16 MFMA (dPre rounded to bf16) or on the fp32 MFMA (exact on the rounded x)
         self.bf16_grad_mfma = bf16_grad_mfma
         self.step_count = 0
@@ -148,7 +152,7 @@ class ImageOnlyTrainer:
     def reduce_and_step(self):
         """One all-reduce(sum) of the flat gradient over RCCL, then Adam.  The local loss was already
         normalised by the global bag count, so the sum IS DDP's mean-of-ranks gradient."""
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             allreduce_flat(self.fp.grad_ext)        # gradients + loss in one collective
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, self.step_count, self.lr,
