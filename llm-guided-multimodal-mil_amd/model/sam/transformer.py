@@ -86,7 +86,15 @@ class TwoWayAttentionBlock(nn.Module):
         """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe.  With pe_table
         given and exactly one text token per bag, both cross attentions take their one-token forms and keys + pe is
         never materialised."""
-        if self.skip_first_layer_pe:                                            # :282-283 (replaces, no residual)
+        if s_tt.Tk_max == 1 and min(s_tt.k_lengths, default=1) == 1:
+            # One text token per bag: self-attention over a single key returns that key's value whatever q and k
+            # are (softmax of one score = 1), so :282-287 reduce to out_proj(v_proj(queries)) and q_proj / k_proj
+            # get exactly zero gradient, as they do upstream.
+            a = self.self_attn
+            vp = ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias)
+            queries = ops.linear_act(vp, a.out_proj.weight, a.out_proj.bias, "none",
+                                     residual=None if self.skip_first_layer_pe else queries)
+        elif self.skip_first_layer_pe:                                          # :282-283 (replaces, no residual)
             queries = self.self_attn.flat(queries, queries, queries, s_tt, "rows")
         else:                                                                   # :285-287
             q = queries + query_pe

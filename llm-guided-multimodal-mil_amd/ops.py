@@ -310,6 +310,41 @@ def act_bwd(dy, y, act: int):
     return dpre
 
 
+SMALL_ROWS = 64        # include/mil_hip.h: MIL_SMALL_ROWS
+
+
+def _small_ok(M: int, N: int, K: int, *tensors) -> bool:
+    return (0 < M <= SMALL_ROWS and K % 8 == 0 and N % 8 == 0
+            and all(t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0) for t in tensors))
+
+
+def linear_small_fwd(x, W, b, act: int, residual=None):
+    """Token-side nn.Linear (M <= 64 rows) in one launch (include/mil_hip.h: mil_linear_small_fwd)."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_linear_small_fwd(_p(x), x.stride(0), _p(W), W.stride(0), _p(b), act, _p(residual),
+                                         residual.stride(0) if residual is not None else 0, _p(y), y.stride(0),
+                                         M, N, K, _stream())
+    _lib.check(rc, "mil_linear_small_fwd")
+    return y
+
+
+def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool):
+    """dx, dW, db of that layer in one launch (mil_linear_small_bwd)."""
+    M, K = x.shape
+    N = W.shape[0]
+    dx = torch.empty((M, K), device=x.device, dtype=torch.float32) if want_dx else None
+    dW = torch.empty((N, K), device=x.device, dtype=torch.float32) if want_dW else None
+    db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
+    yv = y_or_pre if act != 0 else None
+    rc = _lib.lib().mil_linear_small_bwd(_p(dy), dy.stride(0), _p(yv), yv.stride(0) if yv is not None else 0, act,
+                                         _p(x), x.stride(0), _p(W), W.stride(0), _p(dx), K, _p(dW), K, _p(db),
+                                         M, N, K, _stream())
+    _lib.check(rc, "mil_linear_small_bwd")
+    return dx, dW, db
+
+
 class _LinearAct(torch.autograd.Function):
     """y = act(x W^T + b) (+ residual): nn.Linear (+Tanh/ReLU) of aggregator.py:44-68, sam/transformer.py:413-416,
     sam/common.py:21-26.  x [M, K], W [N, K]."""
@@ -322,10 +357,15 @@ class _LinearAct(torch.autograd.Function):
         N = W.shape[0]
         res = _f32c(residual, "residual") if residual is not None else None
         pre = None
-        if act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3]):
+        ctx.small = _small_ok(M, N, K, x, W)
+        if residual is not None and act != 0:
+            raise _lib.MilHipError("linear_act: residual is only supported with act='none'")
+        if ctx.small and not (act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3])):
+            y = linear_small_fwd(x, W, b, act, res)
+        elif act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3]):
             # QuickGELU's derivative needs the pre-activation: keep it (learnable-prompt path only; the frozen
             # forward uses the fused epilogue)
-            pre = gemm(x, 0, W, 0, M, N, K, bias=b, act=0)
+            pre = linear_small_fwd(x, W, b, 0) if ctx.small else gemm(x, 0, W, 0, M, N, K, bias=b, act=0)
             y = torch.empty_like(pre)
             rc = _lib.lib().mil_quickgelu(_p(pre), None, _p(y), pre.numel(), _stream())
             _lib.check(rc, "mil_quickgelu")
@@ -335,8 +375,6 @@ class _LinearAct(torch.autograd.Function):
         ctx.has_b = b is not None
         ctx.has_res = residual is not None
         # with a residual the saved y is not the activation output; only act == none is used with residuals
-        if ctx.has_res and act != 0:
-            raise _lib.MilHipError("linear_act: residual is only supported with act='none'")
         ctx.save_for_backward(x, W, y if pre is None else pre)
         return y
 
@@ -346,6 +384,12 @@ class _LinearAct(torch.autograd.Function):
         dy = _f32c(dy, "dy")
         M, K = x.shape
         N = W.shape[0]
+        if ctx.small:
+            if dy.data_ptr() % 16:
+                dy = dy.clone()
+            dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                          ctx.has_b and ctx.needs_input_grad[2])
+            return dx, dW, db, None, (dy if ctx.has_res else None)
         if ctx.act == ACT["quickgelu"]:
             dpre = torch.empty_like(dy)
             rc = _lib.lib().mil_quickgelu(_p(y), _p(dy), _p(dpre), dy.numel(), _stream())     # y holds the pre-activation
