@@ -244,6 +244,127 @@ __global__ __launch_bounds__(256) void k_apool_bwd(const float* __restrict__ key
     }
 }
 
+// The two kernels below replace k_apool_bwd's per-row dot products (16 wave-wide reductions per row) by a skinny
+// MFMA product: for a 16-row group  acc[16 x 16] = keys[16 x 512] . [Qp | dpooled]^T + pe[16 x 512] . [Qp | 0]^T
+// (v_mfma_f32_16x16x4_f32, operands straight from global memory: lane (r, kq) loads 16 bytes of row r at
+// k = 16t + 4kq and feeds four MFMAs), so columns 0-7 hold Qp_h . kin_n and columns 8-15 dpooled_h . keys_n.
+//   ad[n][h] = a_h[n],   ad[n][8 + h] = scale * a_h[n] (da_h[n] - cdot_h)
+__global__ __launch_bounds__(256) void k_apool_dots(const float* __restrict__ keys, const float* __restrict__ pe,
+                                                    const float* __restrict__ Qp, const float* __restrict__ lse,
+                                                    const float* __restrict__ dpooled, const float* __restrict__ cdot,
+                                                    const int32_t* __restrict__ k_off, const int32_t* __restrict__ tile_map,
+                                                    float scale, float* __restrict__ ad) {
+    constexpr int E = 512;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
+    if (16 * wave >= nkeys) return;
+    const int pos0 = key0 - k_off[b];
+    const int r = lane & 15, kq = lane >> 4;
+    const int rowc = min(16 * wave + r, nkeys - 1);
+    const float* kvp = keys + (size_t)(key0 + rowc) * E + 4 * kq;
+    const float* pep = pe + (size_t)(pos0 + rowc) * E + 4 * kq;
+    const float* bp = (r < 8 ? Qp + ((size_t)b * AP_H + r) * E : dpooled + ((size_t)b * AP_H + (r - 8)) * E) + 4 * kq;
+    const float qmask = r < 8 ? 1.f : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < E / 16; t += 4) {
+        f32x4 a1[4], a2[4], bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a1[u] = *reinterpret_cast<const f32x4*>(kvp + 16 * (t + u));
+            a2[u] = *reinterpret_cast<const f32x4*>(pep + 16 * (t + u));
+            bb[u] = *reinterpret_cast<const f32x4*>(bp + 16 * (t + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][jj], bb[u][jj], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u][jj], bb[u][jj] * qmask, acc, 0, 0, 0);
+            }
+    }
+    // lane (c, g4) holds column c of rows 4 g4 + i: columns c < 8 pair with c + 8
+    const int h = r & 7;
+    const float ls = lse[b * AP_H + h], cd = cdot[b * AP_H + h];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float other = __shfl_xor(acc[i], 8);
+        const int row = 16 * wave + 4 * kq + i;
+        if (r < 8 && row < nkeys) {
+            const float a = __expf(acc[i] * scale - ls);
+            float* o = ad + (size_t)(key0 + row) * 16;
+            o[h] = a;
+            o[8 + h] = a * (other - cd) * scale;
+        }
+    }
+}
+
+// dkeys_n = sum_h (a_h dpooled_h + ds_h Qp_h);  per-tile partial of dQp_h = sum_n ds_h kin_n.  Column-parallel: lane l
+// owns columns 4l..4l+3 and 256+4l..+3, the four waves split the tile's rows; a_h / ds_h come from k_apool_dots.
+__global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict__ keys, const float* __restrict__ pe,
+                                                         const float* __restrict__ Qp, const float* __restrict__ dpooled,
+                                                         const float* __restrict__ ad, const int32_t* __restrict__ k_off,
+                                                         const int32_t* __restrict__ tile_map, float* __restrict__ dkeys,
+                                                         float* __restrict__ pdq) {
+    constexpr int E = 512, NQ = 2;
+    __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x;
+    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
+    const int pos0 = key0 - k_off[b];
+    f32x4 qv[AP_H][NQ], dp[AP_H][NQ], dq[AP_H][NQ];
+#pragma unroll
+    for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            qv[h][q] = *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            dq[h][q] = f32x4{0, 0, 0, 0};
+        }
+    for (int rr = wave; rr < nkeys; rr += 4) {
+        const float* adr = ad + (size_t)(key0 + rr) * 16;          // wave-uniform: scalar loads
+        float a[AP_H], ds[AP_H];
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) { a[h] = adr[h]; ds[h] = adr[8 + h]; }
+        f32x4 kin[NQ], out[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            kin[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) +
+                     *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
+            out[q] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                out[q] += a[h] * dp[h][q] + ds[h] * qv[h][q];
+                dq[h][q] += ds[h] * kin[q];
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dkeys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = out[q];
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                *reinterpret_cast<f32x4*>(red + ((wave - 1) * AP_H + h) * E + 256 * q + 4 * lane) = dq[h][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 v = dq[h][q];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * AP_H + h) * E + 256 * q + 4 * lane);
+                *reinterpret_cast<f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v;
+            }
+    }
+}
+
 // dQp[b][h][:] = sum over the bag's tiles.  grid (B, H), block E/4
 __global__ void k_apool_bwd_merge(const float* __restrict__ pdq, const int32_t* __restrict__ bag_tile_off, int E,
                                   float* __restrict__ dQp) {
@@ -318,19 +439,24 @@ extern "C" int mil_absorbed_pool_fwd(const float* keys, const float* pe, const f
 
 extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse,
                                      const float* dpooled, const float* cdot, const int32_t* k_off,
-                                     const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H,
-                                     int C, int E, float* dkeys, float* dQp, float* workspace, void* stream) {
+                                     const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int n_keys, int B,
+                                     int H, int C, int E, float* dkeys, float* dQp, float* workspace, void* stream) {
     AP_CHECK(keys && pe && Qp && lse && dpooled && cdot && k_off && tile_map && bag_tile_off && dkeys && dQp && workspace);
-    AP_CHECK(H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0);
+    AP_CHECK(H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0 && n_keys >= 0);
     if (B == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)C);
+    float* pdq = workspace;                                    // [ntiles][H][E]
+    float* ad = workspace + (size_t)ntiles * AP_H * E;         // [n_keys][16]
     if (ntiles > 0) {
-        hipLaunchKernelGGL(k_apool_bwd, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, cdot, k_off, tile_map,
-                           scale, dkeys, workspace);
+        hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, cdot, k_off, tile_map,
+                           scale, ad);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_apool_bwd_apply, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, dpooled, ad, k_off, tile_map,
+                           dkeys, pdq);
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(E / 4), 0, st, workspace, bag_tile_off, E, dQp);
+    hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(E / 4), 0, st, pdq, bag_tile_off, E, dQp);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -79,31 +79,25 @@ __global__ __launch_bounds__(64 * SL_WAVES) void k_small_fwd(const float* __rest
     for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
-    int t = t0;
-    for (; t + 4 <= t1; t += 4) {
-        f32x4 fb[4], fa[RT][4];
+    // 8 k-chunks per trip, every load issued before the first MFMA (the layer is one or two memory round trips
+    // deep: its time is latency, not bandwidth); chunks past the wave's range are clamped and zeroed
+    for (int t = t0; t < t1; t += 8) {
+        f32x4 fb[8], fa[RT][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            fb[u] = *reinterpret_cast<const f32x4*>(wrow + 8 * (t + u));
+        for (int u = 0; u < 8; ++u) {
+            const int tt = min(t + u, t1 - 1);
+            fb[u] = *reinterpret_cast<const f32x4*>(wrow + 8 * tt);
 #pragma unroll
-            for (int a = 0; a < RT; ++a) fa[a][u] = *reinterpret_cast<const f32x4*>(xrow[a] + 8 * (t + u));
+            for (int a = 0; a < RT; ++a) fa[a][u] = *reinterpret_cast<const f32x4*>(xrow[a] + 8 * tt);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u) {
+            if (t + u >= t1) fb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int a = 0; a < RT; ++a)
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][u][jj], fb[u][jj], acc[a], 0, 0, 0);
-    }
-    for (; t < t1; ++t) {
-        const f32x4 fb = *reinterpret_cast<const f32x4*>(wrow + 8 * t);
-#pragma unroll
-        for (int a = 0; a < RT; ++a) {
-            const f32x4 fa = *reinterpret_cast<const f32x4*>(xrow[a] + 8 * t);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[jj], fb[jj], acc[a], 0, 0, 0);
         }
     }
     sl_fold_store<RT>(red, acc, tid, M, N, n0, bias, act, residual, ldr, y, ldy);
@@ -122,6 +116,7 @@ __global__ __launch_bounds__(64 * SL_WAVES) void k_small_bwd(const float* __rest
     const int r = lane & 31, h = lane >> 5;
     if ((int)blockIdx.x < nW) {
         // ---- dW[n][k] = sum_m dpre[m][n] x[m][k]: 64 (n) x 128 (k) per workgroup, one 32 x 32 tile per wave
+        if (wave >= 8) return;
         const int kt = blockIdx.x % nKt, nt = blockIdx.x / nKt;
         const int wn = wave >> 2, wk = wave & 3;
         const int n = 64 * nt + 32 * wn + r, k = 128 * kt + 32 * wk + r;
@@ -131,10 +126,10 @@ __global__ __launch_bounds__(64 * SL_WAVES) void k_small_bwd(const float* __rest
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         float bsum = 0.f;
         const int steps = (M + 1) >> 1;
-        for (int s0 = 0; s0 < steps; s0 += 8) {
-            float fa[8], fb[8];
+        for (int s0 = 0; s0 < steps; s0 += 16) {
+            float fa[16], fb[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int m = 2 * (s0 + u) + h;
                 const int mm = min(m, M - 1);
                 float g = dy[(size_t)mm * lddy + nc];
@@ -143,7 +138,7 @@ __global__ __launch_bounds__(64 * SL_WAVES) void k_small_bwd(const float* __rest
                 fb[u] = m < M ? x[(size_t)mm * ldx + kc] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 bsum += fa[u];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
             }
@@ -175,12 +170,12 @@ __global__ __launch_bounds__(64 * SL_WAVES) void k_small_bwd(const float* __rest
     for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
-    for (int t = t0; t < t1; t += 2) {
-        f32x4 fa[RT][2];
-        float fb[2][4];
+    for (int t = t0; t < t1; t += 4) {
+        f32x4 fa[RT][4];
+        float fb[4][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int tt = min(t + u, t1 - 1);          // odd tail: reload the last chunk, masked below
+        for (int u = 0; u < 4; ++u) {
+            const int tt = min(t + u, t1 - 1);          // ragged tail: reload the last chunk, zeroed below
             const int nb = 8 * tt + 4 * h;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) fb[u][jj] = W[(size_t)(nb + jj) * ldw + kc];
@@ -197,7 +192,7 @@ __global__ __launch_bounds__(64 * SL_WAVES) void k_small_bwd(const float* __rest
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll

@@ -775,10 +775,11 @@ class _AbsorbedPool(torch.autograd.Function):
         cdot = rowdot(dpooled.view(B * H, E), pooled.view(B * H, E))
         dkeys = torch.empty_like(keys)
         dQp = torch.empty_like(Qp)
-        ws = torch.empty(max(1, segs.ntiles) * H * E, device=keys.device, dtype=torch.float32)
+        n_keys = keys.shape[0]
+        ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)
         rc = _lib.lib().mil_absorbed_pool_bwd(_p(keys), _p(pe), _p(Qp), _p(lse), _p(dpooled), _p(cdot), _p(segs.k_off),
-                                              _p(segs.tile_map), _p(segs.bag_tile_off), segs.ntiles, B, H, C, E, _p(dkeys),
-                                              _p(dQp), _p(ws), _stream())
+                                              _p(segs.tile_map), _p(segs.bag_tile_off), segs.ntiles, n_keys, B, H, C, E,
+                                              _p(dkeys), _p(dQp), _p(ws), _stream())
         _lib.check(rc, "mil_absorbed_pool_bwd")
         return dkeys, None, dQp, None, None
 
