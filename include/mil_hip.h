@@ -304,6 +304,13 @@ int mil_gather_eot(const int64_t* ids, const float* x, int nseq, int ctx, int W,
 int mil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                   int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, void* stream);
+/* The same step with the step number kept on the device: step_counter (int32, device) holds the number of steps
+ * already taken, the bias corrections use step_counter + 1 and the counter is incremented afterwards - so the
+ * launch sequence is identical every step and can be replayed from a hipGraph.  All four buffers 16-byte aligned
+ * (also required by mil_adam_step). */
+int mil_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                          int32_t* step_counter, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

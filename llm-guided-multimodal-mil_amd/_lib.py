@@ -75,6 +75,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_embed_tokens": (c_int, [_P] * 3 + [c_int] * 3 + [_P, _P]),
     "mil_gather_eot": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
+    "mil_adam_step_counted": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
 }
 
 _lib = None

@@ -62,4 +62,6 @@ def create_arg_parser(argv=None):
     p.add_argument("--ragged", action="store_true", help="draw a different patch count per bag")
     p.add_argument("--clip_layers", type=int, default=12)
     p.add_argument("--fused_step", action="store_true", help="image_only: fused trainer instead of autograd + DDP")
+    p.add_argument("--flat_adam", type=int, default=1, help="autograd path: parameters in one flat buffer, one gradient "
+                   "all-reduce and one Adam launch per step (optim.FlatAdam); 0 = torch DDP + torch.optim.Adam")
     return p.parse_args(argv)

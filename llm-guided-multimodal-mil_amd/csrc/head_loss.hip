@@ -114,22 +114,60 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
     }
 }
 
-// torch.optim.Adam, weight decay folded into the gradient (L2), bias-corrected.
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,
-                                              float* __restrict__ m, float* __restrict__ v, size_t n, float lr, float b1,
-                                              float b2, float eps, float wd, float gscale, float bc1, float bc2_sqrt) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float pi = param[i];
-    const float g = grad[i] * gscale + wd * pi;
-    const float mi = b1 * m[i] + (1.0f - b1) * g;
-    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
+// torch.optim.Adam, weight decay folded into the gradient (L2), bias-corrected.  Four elements per thread; the
+// bias corrections come from the host (step known there) or, for a step that is replayed from a hipGraph, from
+// a device-side counter (step_dev holds the number of steps ALREADY taken).
+__device__ __forceinline__ float adam_one(float& pi, float gi, float& mi, float& vi, float lr_bc1, float b1, float b2,
+                                          float eps, float wd, float gscale, float bc2_sqrt) {
+    const float g = gi * gscale + wd * pi;
+    mi = b1 * mi + (1.0f - b1) * g;
+    vi = b2 * vi + (1.0f - b2) * g * g;
     // torch: denom = sqrt(v)/sqrt(bc2) + eps; param -= (lr / bc1) * m / denom
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    param[i] = pi - (lr / bc1) * (mi / denom);
+    pi = pi - lr_bc1 * (mi / denom);
+    return pi;
 }
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,
+                                              float* __restrict__ m, float* __restrict__ v, size_t n, float lr, float b1,
+                                              float b2, float eps, float wd, float gscale, float bc1, float bc2_sqrt,
+                                              const int* __restrict__ step_dev) {
+    __shared__ float bc[2];
+    if (step_dev != nullptr) {
+        if (threadIdx.x == 0) {
+            const double st = (double)(*step_dev + 1);
+            bc[0] = (float)(1.0 - pow((double)b1, st));
+            bc[1] = (float)sqrt(1.0 - pow((double)b2, st));
+        }
+        __syncthreads();
+        bc1 = bc[0];
+        bc2_sqrt = bc[1];
+    }
+    const float lr_bc1 = lr / bc1;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4 p4 = *reinterpret_cast<const f32x4*>(param + i);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(grad + i);
+        f32x4 m4 = *reinterpret_cast<const f32x4*>(m + i);
+        f32x4 v4 = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = p4[e], me = m4[e], ve = v4[e];
+            adam_one(pe, g4[e], me, ve, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt);
+            p4[e] = pe; m4[e] = me; v4[e] = ve;
+        }
+        *reinterpret_cast<f32x4*>(param + i) = p4;
+        *reinterpret_cast<f32x4*>(m + i) = m4;
+        *reinterpret_cast<f32x4*>(v + i) = v4;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float pe = param[j], me = m[j], ve = v[j];
+            adam_one(pe, grad[j], me, ve, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt);
+            param[j] = pe; m[j] = me; v[j] = ve;
+        }
+    }
+}
+__global__ void k_step_inc(int* step_dev) { *step_dev += 1; }
 
 // ---------------------------------------------------------------------------------------------
 // Fused per-bag tail of the forward and head of the backward (one workgroup per bag):
@@ -294,10 +332,32 @@ extern "C" int mil_adam_step(float* param, const float* grad, float* exp_avg, fl
                              void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return MIL_EINVAL;
     if (n == 0) return MIL_OK;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return MIL_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2),
+                       (const int*)nullptr);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                     int32_t* step_counter, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n,
+                           lr, beta1, beta2, eps, weight_decay, grad_scale, 1.f, 1.f, (const int*)step_counter);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step_counter);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -209,6 +209,15 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float = 1e-5, bet
     _lib.check(rc, "mil_adam_step")
 
 
+def adam_step_counted(param, grad, exp_avg, exp_avg_sq, step_counter, lr: float = 1e-5, betas=(0.9, 0.999),
+                      eps: float = 1e-8, weight_decay: float = 1e-7, grad_scale: float = 1.0):
+    """Adam with the step number in a device int32 (incremented by the call): same launches every step."""
+    rc = _lib.lib().mil_adam_step_counted(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
+                                          _p(step_counter), lr, betas[0], betas[1], eps, weight_decay, grad_scale,
+                                          _stream())
+    _lib.check(rc, "mil_adam_step_counted")
+
+
 # --------------------------------------------------------------------------- autograd wrappers
 class _GatedAttentionPool(torch.autograd.Function):
     @staticmethod

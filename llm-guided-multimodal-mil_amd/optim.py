@@ -1,0 +1,92 @@
+"""Adam over ONE flat fp32 buffer for the autograd (fusion) path.
+
+The reference builds `torch.optim.Adam(params, lr, betas=(b1, b2), weight_decay=1e-7)` (train_ddp.py:115-118) and
+lets DDP all-reduce per-bucket gradients (train_ddp.py:79,347).  Here the trainable parameters are re-seated as
+views of one contiguous buffer, so that per step there is
+  * one gather of the gradients autograd produced into a flat gradient buffer (torch._foreach_copy_),
+  * one all-reduce of that buffer when world size > 1 (RCCL; the mean is folded into Adam's grad_scale),
+  * one Adam launch (mil_adam_step / mil_adam_step_counted) over everything.
+Same arithmetic as torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected, eps outside the
+sqrt); a parameter whose gradient is None (the q/k projections of a one-key attention) takes a zero gradient, i.e.
+only the weight-decay term, exactly like a dense zero gradient upstream."""
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-7, world_size: int = 1, counted: bool = False):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatAdam: parameters must be fp32 on one device")
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4                     # 16-byte aligned slots (vector loads, MFMA operand rows)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._pviews, self._gviews = [], []
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                                  # the module now computes on the flat buffer
+                self._pviews.append(view)
+                self._gviews.append(self.grad[off:off + p.numel()].view(p.shape))
+        self.defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}
+        self.param_groups = [dict(self.defaults, params=self.params)]    # lr schedulers write param_groups[0]["lr"]
+        self.world = world_size
+        self.step_count = 0
+        self.counted = counted
+        self.step_counter = torch.zeros(1, device=dev, dtype=torch.int32) if counted else None
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Gradients are dropped (autograd then hands over fresh tensors without an accumulate kernel)."""
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def gather(self):
+        have = [(g, p.grad) for g, p in zip(self._gviews, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.grad.zero_()
+        if have:
+            torch._foreach_copy_([h[0] for h in have], [h[1] for h in have])
+
+    @torch.no_grad()
+    def step(self):
+        self.gather()
+        scale = 1.0
+        if self.world > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)   # DDP averages: sum here, 1/world inside Adam
+            scale = 1.0 / self.world
+        g = self.param_groups[0]
+        if self.counted:
+            ops.adam_step_counted(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_counter, g["lr"],
+                                  g["betas"], g["eps"], g["weight_decay"], scale)
+        else:
+            self.step_count += 1
+            ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"], g["betas"],
+                          g["eps"], g["weight_decay"], scale)
+
+    def state_dict(self):
+        step = int(self.step_counter.item()) if self.counted else self.step_count
+        return {"step": step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        if self.counted:
+            self.step_counter.fill_(self.step_count)
+        self.param_groups[0].update(sd["param_groups"][0])

@@ -26,7 +26,7 @@ if __package__ in (None, ""):
 from .bags import BagLayout  # noqa: E402
 from .config import create_arg_parser  # noqa: E402
 from .dataset import SyntheticBags, collate_bags  # noqa: E402
-from .dist_utils import env_world, init_process_group, shard_indices  # noqa: E402
+from .dist_utils import broadcast_flat, env_world, init_process_group, shard_indices  # noqa: E402
 from .utils import AverageMeter, ProgressMeter, calculate_accuracy, save_checkpoint, scheduled_lr  # noqa: E402
 
 
@@ -72,14 +72,20 @@ def main_worker(local_rank: int, nprocs: int, args):
         tr = ImageOnlyTrainer(params, dev, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
     else:
         generator = model
-        if world > 1:
+        flat_adam = bool(getattr(args, "flat_adam", 1)) and not args.learnablePrompt
+        if world > 1 and not flat_adam:
             generator = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)
         criterion = torch.nn.BCELoss()
         trainable = [p for p in model.parameters() if p.requires_grad]
         if args.learnablePrompt:                                                         # train_ddp.py:104-109
             lr0 = args.lr = 1e-3
             optimizer = torch.optim.SGD(trainable, lr=lr0, weight_decay=1e-7)
-        else:                                                                            # train_ddp.py:110-118
+        elif flat_adam:                                                                  # train_ddp.py:110-118, flat
+            from .optim import FlatAdam
+            optimizer = FlatAdam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
+            if world > 1:
+                broadcast_flat(optimizer.flat, src=0)                                    # DDP's initial broadcast
+        else:
             optimizer = torch.optim.Adam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7)
         if args.resume:
             ck = torch.load(args.resume, map_location=dev, weights_only=True)

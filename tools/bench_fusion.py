@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--clip_layers", type=int, default=12)
 ap.add_argument("--cache_text", action="store_true")
+ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam instead of the flat one-launch Adam")
 ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -25,8 +26,12 @@ model = get_model(args).to(dev).eval()      # eval: parity mode (dropout off), g
 x = syn.make_bags(1, a.bags, a.patches, 768).to(dev)
 ids = syn.make_token_ids(2, a.bags, a.prompts).to(dev)
 y = syn.make_labels(3, a.bags).to(dev)
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7,
-                       capturable=a.graph)
+if a.torch_adam:
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7,
+                           capturable=a.graph)
+else:
+    from mil_amd.optim import FlatAdam
+    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7, counted=a.graph)
 crit = torch.nn.BCELoss()
 
 def step():
