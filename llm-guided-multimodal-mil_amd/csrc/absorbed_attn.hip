@@ -26,9 +26,16 @@ __global__ void k_absorb_query(const float* __restrict__ qp, const float* __rest
     const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
     const int I = H * C;
     f32x4 acc = {0, 0, 0, 0};
-    for (int c = 0; c < C; ++c) {
-        const float q = qp[(size_t)b * I + h * C + c];
-        acc += q * *reinterpret_cast<const f32x4*>(Wk + (size_t)(h * C + c) * E + 4 * j4);
+    for (int c0 = 0; c0 < C; c0 += 16) {            // C is 32 or 64: 16 rows of Wk in flight per trip
+        f32x4 wr[16];
+        float q[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            wr[u] = *reinterpret_cast<const f32x4*>(Wk + (size_t)(h * C + c0 + u) * E + 4 * j4);
+            q[u] = qp[(size_t)b * I + h * C + c0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += q[u] * wr[u];
     }
     *reinterpret_cast<f32x4*>(Qp + ((size_t)b * H + h) * E + 4 * j4) = acc;
 }
@@ -43,7 +50,18 @@ __global__ __launch_bounds__(256) void k_absorb_query_bwd_q(const float* __restr
     const float* g = dQp + ((size_t)b * H + h) * E;
     const float* w = Wk + (size_t)(h * C + c) * E;
     float v = 0.f;
-    for (int j = part; j < E; j += per) v += g[j] * w[j];
+    for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {      // 4 x 16-byte loads of each operand in flight
+        f32x4 gv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 4 * per * u, E - 4);
+            gv[u] = *reinterpret_cast<const f32x4*>(g + j);
+            wv[u] = *reinterpret_cast<const f32x4*>(w + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
+    }
     for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     if (part == 0) dqp[(size_t)b * I + h * C + c] = v;
 }
@@ -53,8 +71,18 @@ __global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* 
                                      int E, float* __restrict__ dWk) {
     const int row = blockIdx.x, h = row / C, j4 = threadIdx.x, I = H * C;
     f32x4 acc = {0, 0, 0, 0};
-    for (int b = 0; b < B; ++b)
-        acc += qp[(size_t)b * I + row] * *reinterpret_cast<const f32x4*>(dQp + ((size_t)b * H + h) * E + 4 * j4);
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        f32x4 gv[8];
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = min(b0 + u, B - 1);
+            gv[u] = *reinterpret_cast<const f32x4*>(dQp + ((size_t)b * H + h) * E + 4 * j4);
+            q[u] = b0 + u < B ? qp[(size_t)b * I + row] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += q[u] * gv[u];
+    }
     *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
 }
 
@@ -385,7 +413,18 @@ __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ po
     const float* pv = pooled + ((size_t)b * H + h) * E;
     const float* w = Wv + (size_t)(h * C + c) * E;
     float v = 0.f;
-    for (int j = part; j < E; j += per) v += pv[j] * w[j];
+    for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {
+        f32x4 gv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 4 * per * u, E - 4);
+            gv[u] = *reinterpret_cast<const f32x4*>(pv + j);
+            wv[u] = *reinterpret_cast<const f32x4*>(w + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
+    }
     for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     if (part == 0) o[(size_t)b * I + h * C + c] = v + bv[h * C + c];
 }
@@ -396,7 +435,7 @@ __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ po
 #define AP_CHECK(cond) do { if (!(cond)) return MIL_EINVAL; } while (0)
 
 extern "C" int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream) {
-    AP_CHECK(qp && Wk && Qp && B >= 0 && H > 0 && C > 0 && E > 0 && (E & 3) == 0 && E <= 4096);
+    AP_CHECK(qp && Wk && Qp && B >= 0 && H > 0 && C > 0 && (C % 16) == 0 && E > 0 && (E & 3) == 0 && E <= 4096);
     if (B == 0) return MIL_OK;
     hipLaunchKernelGGL(k_absorb_query, dim3(B, H), dim3(E / 4), 0, (hipStream_t)stream, qp, Wk, H, C, E, Qp);
     MIL_CHECK_LAUNCH();

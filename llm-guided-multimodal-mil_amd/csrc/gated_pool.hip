@@ -591,16 +591,49 @@ static inline int split_plan(int R, int L, int* KC_out) {
 
 extern "C" int mil_abi_version(void) { return 1; }
 
+// Tile quantisation: with one 128-row workgroup per CU, R = k * 256 * 128 + (a few rows) costs a whole extra round of
+// the grid for one workgroup (config 3: 32 bags x (1024 patches + 2 tokens) = 256.5 tiles -> 2x the kernel time).
+// When the rows beyond a whole number of rounds fit the few-rows linear (<= 64), they take that path instead:
+// V and U through mil_linear_small_fwd straight into the gates buffer, then one tiny scoring launch.
+__global__ __launch_bounds__(64) void k_gate_tail_scores(const float* __restrict__ gates, const float* __restrict__ wvec,
+                                                         const float* __restrict__ battn, float* __restrict__ scores) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float* gr = gates + (size_t)row * GF_NG;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v += wvec[64 * q + lane] * gr[64 * q + lane] * gr[192 + 64 * q + lane];
+    v = wave_allsum(v);
+    if (lane == 0) scores[row] = v + battn[0];
+}
+
+static inline int gate_tail_rows(int R, int tiles_per_round) {
+    const int tail = R % GF_TM, full = R / GF_TM;
+    return (tail >= 1 && tail <= MIL_SMALL_ROWS && full >= tiles_per_round && full % tiles_per_round == 0) ? tail : 0;
+}
+
 extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                    const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
                                    void* stream) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
-    const int grid = (R + GF_TM - 1) / GF_TM;
-    hipLaunchKernelGGL(k_gate_fwd, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores, gates,
-                       R, L);
+    hipStream_t st = (hipStream_t)stream;
+    const int tail = gates != nullptr ? gate_tail_rows(R, MIL_NUM_CU) : 0;       // the tail path keeps V, U in `gates`
+    const int Rm = R - tail;
+    const int grid = (Rm + GF_TM - 1) / GF_TM;
+    hipLaunchKernelGGL(k_gate_fwd, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L);
     MIL_CHECK_LAUNCH();
+    if (tail > 0) {
+        const float* xt = x + (size_t)Rm * L;
+        float* gt = gates + (size_t)Rm * GF_NG;
+        int rc = mil_linear_small_fwd(xt, L, Wv, L, bv, 1 /* tanh */, nullptr, 0, gt, GF_NG, tail, MIL_GATE_D, L, stream);
+        if (rc != MIL_OK) return rc;
+        rc = mil_linear_small_fwd(xt, L, Wu, L, bu, 4 /* sigmoid */, nullptr, 0, gt + MIL_GATE_D, GF_NG, tail, MIL_GATE_D, L,
+                                  stream);
+        if (rc != MIL_OK) return rc;
+        hipLaunchKernelGGL(k_gate_tail_scores, dim3(tail), dim3(64), 0, st, gt, w, b, scores + Rm);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
 }
 
@@ -849,13 +882,48 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
         }
 }
 
+// The same tile quantisation for dx (two 128 x 128 workgroups per CU): the rows beyond whole rounds, one workgroup
+// per row, thread = four columns, d looped (W is L2-resident).
+__global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restrict__ gates, const float* __restrict__ ds,
+                                                          const float* __restrict__ wvec, const float* __restrict__ Wv,
+                                                          const float* __restrict__ Wu, float* __restrict__ dx, int L) {
+    __shared__ float pv[MIL_GATE_D], pu[MIL_GATE_D];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float dsr = ds[row];
+    for (int d = tid; d < MIL_GATE_D; d += 128) {
+        const float v = gates[(size_t)row * GF_NG + d], u = gates[(size_t)row * GF_NG + 192 + d];
+        const float dsw = dsr * wvec[d];
+        pv[d] = dsw * u * (1.0f - v * v);
+        pu[d] = dsw * v * u * (1.0f - u);
+    }
+    __syncthreads();
+    for (int j = 4 * tid; j < L; j += 512) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int d = 0; d < MIL_GATE_D; ++d)
+            acc += pv[d] * *reinterpret_cast<const f32x4*>(Wv + (size_t)d * L + j) +
+                   pu[d] * *reinterpret_cast<const f32x4*>(Wu + (size_t)d * L + j);
+        f32x4* o = reinterpret_cast<f32x4*>(dx + (size_t)row * L + j);
+        *o += acc;
+    }
+}
+
 extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu,
                                   int R, int L, int D, float* dx, void* stream) {
     if (!gates || !ds || !w || !Wv || !Wu || !dx) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
-    const int grid = ((R + 127) / 128) * (L / 128);
-    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, (hipStream_t)stream, gates, ds, w, Wv, Wu, dx, R, L);
+    hipStream_t st = (hipStream_t)stream;
+    const int per_round = 2 * MIL_NUM_CU / (L / 128);          // row tiles per round of the grid
+    const int tail = per_round > 0 ? gate_tail_rows(R, per_round) : 0;
+    const int Rm = R - tail;
+    const int grid = ((Rm + 127) / 128) * (L / 128);
+    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, st, gates, ds, w, Wv, Wu, dx, Rm, L);
     MIL_CHECK_LAUNCH();
+    if (tail > 0) {
+        hipLaunchKernelGGL(k_gate_bwd_dx_tail, dim3(tail), dim3(128), 0, st, gates + (size_t)Rm * GF_NG, ds + Rm, w, Wv, Wu,
+                           dx + (size_t)Rm * L, L);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
 }

@@ -12,12 +12,13 @@
 #include "mil_common.h"
 
 #define SL_WAVES 8
-enum { SL_NONE = 0, SL_TANH = 1, SL_RELU = 2, SL_QUICKGELU = 3 };
+enum { SL_NONE = 0, SL_TANH = 1, SL_RELU = 2, SL_QUICKGELU = 3, SL_SIGMOID = 4 };
 
 __device__ __forceinline__ float sl_act(float v, int act) {
     if (act == SL_TANH) return tanhf(v);
     if (act == SL_RELU) return fmaxf(v, 0.f);
     if (act == SL_QUICKGELU) return v / (1.0f + expf(-1.702f * v));
+    if (act == SL_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
 }
 // dy * act'(.), from the activation OUTPUT for tanh / relu and from the PRE-activation for QuickGELU
@@ -28,6 +29,7 @@ __device__ __forceinline__ float sl_dact(float g, float yv, int act) {
         const float s = 1.0f / (1.0f + expf(-1.702f * yv));
         return g * s * (1.0f + 1.702f * yv * (1.0f - s));
     }
+    if (act == SL_SIGMOID) return g * yv * (1.0f - yv);
     return g;
 }
 
@@ -208,7 +210,7 @@ extern "C" int mil_linear_small_fwd(const float* x, int ldx, const float* W, int
                                     const float* residual, int ldr, float* y, int ldy, int M, int N, int K,
                                     void* stream) {
     if (!x || !W || !y || M <= 0 || M > MIL_SMALL_ROWS || N <= 0 || K <= 0) return MIL_EINVAL;
-    if ((K & 7) || (ldx & 3) || (ldw & 3) || act < 0 || act > 3) return MIL_EINVAL;
+    if ((K & 7) || (ldx & 3) || (ldw & 3) || act < 0 || act > 4) return MIL_EINVAL;
     if (!sl_aligned16(x) || !sl_aligned16(W)) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N + 31) / 32), block(64 * SL_WAVES);
@@ -223,7 +225,7 @@ extern "C" int mil_linear_small_fwd(const float* x, int ldx, const float* W, int
 extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* x,
                                     int ldx, const float* W, int ldw, float* dx, int lddx, float* dW, int lddw,
                                     float* db, int M, int N, int K, void* stream) {
-    if (!dy || M <= 0 || M > MIL_SMALL_ROWS || N <= 0 || K <= 0 || act < 0 || act > 3) return MIL_EINVAL;
+    if (!dy || M <= 0 || M > MIL_SMALL_ROWS || N <= 0 || K <= 0 || act < 0 || act > 4) return MIL_EINVAL;
     if (act != SL_NONE && !y_or_pre) return MIL_EINVAL;
     if ((dW || db) && !x) return MIL_EINVAL;
     if (dx && !W) return MIL_EINVAL;

@@ -81,3 +81,28 @@ def test_single_bag_single_patch():
     # one patch: the softmax weight is 1, so no gradient reaches the gate parameters
     assert float(tr.fp.g("aggregator.attention_V.0.weight").abs().max()) <= 1e-7
     assert rel_err(tr.fp.g("fc.1.weight").cpu(), grads["fc.1.weight"]) <= 1e-5
+
+
+def test_rows_beyond_a_whole_round_of_tiles_take_the_few_rows_path():
+    """R = 256 * 128 + 40: the 40 rows run through mil_linear_small_fwd / k_gate_bwd_dx_tail instead of costing a
+    second round of the grid.  Their scores, gates and dx must agree with the tiled kernels run on those rows alone."""
+    from mil_amd import ops
+    L, R, T = 512, 256 * 128 + 40, 40
+    p = {k: v.to(DEV) for k, v in syn.image_only_params(105, L=L).items()}
+    gp = [p["aggregator.attention_V.0.weight"], p["aggregator.attention_V.0.bias"], p["aggregator.attention_U.0.weight"],
+          p["aggregator.attention_U.0.bias"], p["aggregator.attention_weights.weight"].reshape(-1),
+          p["aggregator.attention_weights.bias"]]
+    x = torch.randn((R, L), generator=torch.Generator().manual_seed(9)).to(DEV)
+    scores, gates = ops.gate_scores_fwd(x, *gp, save_gates=True)
+    s_ref, g_ref = ops.gate_scores_fwd(x[R - T:].contiguous(), *gp, save_gates=True)
+    assert float((scores[R - T:] - s_ref).abs().max()) <= 2e-6
+    assert float((gates[R - T:] - g_ref).abs().max()) <= 2e-6
+    s_head, _ = ops.gate_scores_fwd(x[:128].contiguous(), *gp, save_gates=True)
+    assert float((scores[:128] - s_head).abs().max()) <= 1e-6
+    ds = torch.randn((R,), generator=torch.Generator().manual_seed(10)).to(DEV)
+    dx = torch.zeros((R, L), device=DEV)
+    ops.gate_bwd_input(gates, ds, gp[4], gp[0], gp[2], dx)
+    dx_ref = torch.zeros((T, L), device=DEV)
+    ops.gate_bwd_input(g_ref, ds[R - T:].contiguous(), gp[4], gp[0], gp[2], dx_ref)
+    assert rel_err(dx[R - T:].cpu(), dx_ref.cpu()) <= 2e-6
+    assert float(dx[:R - T].abs().sum()) > 0
