@@ -198,13 +198,13 @@ int mil_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act,
 
 /* nn.Linear on the text-token stream (M <= MIL_SMALL_ROWS rows: one token per bag; model/aggregator.py:44-68,
  * model/sam/transformer.py:413-416, sam/common.py:21-26).  Same arithmetic as mil_gemm's NT form, one launch:
- *   y[M, N] = act(x[M, K] . W[N, K]^T + bias) + residual          K % 8 == 0, ldx % 4 == 0, ldw % 4 == 0.
+ *   y[M, N] = act(x[M, K] . W[N, K]^T + bias) + residual          K % 16 == 0, ldx % 4 == 0, ldw % 4 == 0.
  * act: 0 none, 1 tanh, 2 relu, 3 QuickGELU, 4 sigmoid. */
 int mil_linear_small_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias, int act,
                          const float* residual, int ldr, float* y, int ldy, int M, int N, int K, void* stream);
 /* Whole backward of that layer in ONE launch (autograd of the Linear + activation above):
  *   dpre = dy * act'(.)   from y_or_pre = the activation OUTPUT (act 1, 2, 4) or the PRE-activation (act 3); NULL if act 0
- *   dW[N, K] = dpre^T x,  db[N] = column sums of dpre,  dx[M, K] = dpre W.      N % 8 == 0.
+ *   dW[N, K] = dpre^T x,  db[N] = column sums of dpre,  dx[M, K] = dpre W.      N % 16 == 0.
  * Any of dx / dW / db may be NULL (not wanted). */
 int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* x, int ldx,
                          const float* W, int ldw, float* dx, int lddx, float* dW, int lddw, float* db, int M, int N,

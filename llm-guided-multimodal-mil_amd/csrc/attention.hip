@@ -365,6 +365,61 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     }
 }
 
+// The token stream has a few dozen rows: one workgroup of 16 waves, wave w takes rows w, w + 16, w + 32, w + 48 with
+// all loads issued up front, and the parameter gradients are folded in LDS and written directly (no partials, no
+// column-sum launches).
+template <int NE>
+__global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ dy, const float* __restrict__ stats,
+                                                              int rows, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    __shared__ float red[16][2][64 * NE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, E = 64 * NE;
+    float dg[NE], db[NE], gm[NE], xv[4][NE], dv[4][NE], mean[4], rstd[4];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[lane + 64 * e]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = min(w + 16 * i, rows - 1);
+        mean[i] = stats[2 * row];
+        rstd[i] = stats[2 * row + 1];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            xv[i][e] = x[(size_t)row * E + lane + 64 * e];
+            dv[i][e] = dy[(size_t)row * E + lane + 64 * e];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w + 16 * i;
+        if (row >= rows) break;
+        float xh[NE], g[NE], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            xh[e] = (xv[i][e] - mean[i]) * rstd[i];
+            g[e] = dv[i][e] * gm[e];
+            s1 += g[e];
+            s2 += g[e] * xh[e];
+            dg[e] += dv[i][e] * xh[e];
+            db[e] += dv[i][e];
+        }
+        s1 = wave_allsum(s1) / E;
+        s2 = wave_allsum(s2) / E;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd[i] * (g[e] - s1 - xh[e] * s2);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { red[w][0][lane + 64 * e] = dg[e]; red[w][1][lane + 64 * e] = db[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * E; c += 1024) {
+        const int which = c / E, cc = c % E;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) v += red[ww][which][cc];
+        (which == 0 ? dgamma : dbeta)[cc] = v;
+    }
+}
+
 // ================================================================================ keys + pe (positional table row = index within the bag)
 // out[row] = x[row] + pe[row - row_off[bag]]   (model/sam/transformer.py:292,304: k = keys + key_pe with
 // key_pe = self.pe[:, :N] of model/aggregator.py:99-106,190).  One float4 per thread.
@@ -549,6 +604,18 @@ extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float
     if (!x || !gamma || !dy || !stats || !dx || !dgamma || !dbeta || !workspace) return MIL_EINVAL;
     if (rows <= 0 || (E % 64) != 0 || E > 512) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (rows <= 64) {
+        const dim3 g1(1), b1(1024);
+        switch (E / 64) {
+            case 1: hipLaunchKernelGGL(k_layernorm_bwd_small<1>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
+            case 2: hipLaunchKernelGGL(k_layernorm_bwd_small<2>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
+            case 4: hipLaunchKernelGGL(k_layernorm_bwd_small<4>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
+            case 8: hipLaunchKernelGGL(k_layernorm_bwd_small<8>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
+            default: return MIL_EINVAL;
+        }
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     const int nb = mil_layernorm_bwd_blocks(rows);
     const int rpb = (rows + nb - 1) / nb;
     const dim3 grid(nb), blk(256);

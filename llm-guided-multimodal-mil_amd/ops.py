@@ -323,7 +323,7 @@ SMALL_ROWS = 64        # include/mil_hip.h: MIL_SMALL_ROWS
 
 
 def _small_ok(M: int, N: int, K: int, *tensors) -> bool:
-    return (0 < M <= SMALL_ROWS and K % 8 == 0 and N % 8 == 0
+    return (0 < M <= SMALL_ROWS and K % 16 == 0 and N % 16 == 0
             and all(t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0) for t in tensors))
 
 
@@ -339,13 +339,20 @@ def linear_small_fwd(x, W, b, act: int, residual=None):
     return y
 
 
-def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool):
+def grad_slot(param):
+    """The flat-gradient view optim.FlatAdam reserved for this parameter (None without FlatAdam): a backward that
+    writes its result there and returns it hands autograd the final storage, so no gather copy is needed."""
+    slot = getattr(param, "_mil_grad", None)
+    return slot if (slot is not None and slot.shape == param.shape) else None
+
+
+def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool, dW_out=None, db_out=None):
     """dx, dW, db of that layer in one launch (mil_linear_small_bwd)."""
     M, K = x.shape
     N = W.shape[0]
     dx = torch.empty((M, K), device=x.device, dtype=torch.float32) if want_dx else None
-    dW = torch.empty((N, K), device=x.device, dtype=torch.float32) if want_dW else None
-    db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
+    dW = (dW_out if dW_out is not None else torch.empty((N, K), device=x.device, dtype=torch.float32)) if want_dW else None
+    db = (db_out if db_out is not None else torch.empty(N, device=x.device, dtype=torch.float32)) if want_db else None
     yv = y_or_pre if act != 0 else None
     rc = _lib.lib().mil_linear_small_bwd(_p(dy), dy.stride(0), _p(yv), yv.stride(0) if yv is not None else 0, act,
                                          _p(x), x.stride(0), _p(W), W.stride(0), _p(dx), K, _p(dW), K, _p(db),
@@ -382,6 +389,8 @@ class _LinearAct(torch.autograd.Function):
             y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res)
         ctx.act = act
         ctx.has_b = b is not None
+        ctx.b_slot = grad_slot(b) if b is not None else None
+        ctx.W_slot = grad_slot(W)
         ctx.has_res = residual is not None
         # with a residual the saved y is not the activation output; only act == none is used with residuals
         ctx.save_for_backward(x, W, y if pre is None else pre)
@@ -397,7 +406,7 @@ class _LinearAct(torch.autograd.Function):
             if dy.data_ptr() % 16:
                 dy = dy.clone()
             dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                          ctx.has_b and ctx.needs_input_grad[2])
+                                          ctx.has_b and ctx.needs_input_grad[2], ctx.W_slot, ctx.b_slot)
             return dx, dW, db, None, (dy if ctx.has_res else None)
         if ctx.act == ACT["quickgelu"]:
             dpre = torch.empty_like(dy)
@@ -406,8 +415,8 @@ class _LinearAct(torch.autograd.Function):
         else:
             dpre = act_bwd(dy, y, ctx.act)
         dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
-        dW = gemm(dpre, 1, x, 1, N, K, M, split_k=True) if ctx.needs_input_grad[1] else None
-        db = colsum(dpre) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dW = gemm(dpre, 1, x, 1, N, K, M, out=ctx.W_slot, split_k=True) if ctx.needs_input_grad[1] else None
+        db = colsum(dpre, out=ctx.b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res else None
         return dx, dW, db, None, dres
 

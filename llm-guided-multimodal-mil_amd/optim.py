@@ -6,7 +6,8 @@ views of one contiguous buffer, so that per step there is
   * one gather of the gradients autograd produced into a flat gradient buffer (torch._foreach_copy_),
   * one all-reduce of that buffer when world size > 1 (RCCL; the mean is folded into Adam's grad_scale),
   * one Adam launch (mil_adam_step / mil_adam_step_counted) over everything.
-Same arithmetic as torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected, eps outside the
+Backward kernels that know a parameter's slot (ops.grad_slot: the Linear layers) write the gradient there directly,
+so the gather only moves what the other ops produced.  Same arithmetic as torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected, eps outside the
 sqrt); a parameter whose gradient is None (the q/k projections of a one-key attention) takes a zero gradient, i.e.
 only the weight-decay term, exactly like a dense zero gradient upstream."""
 from typing import Iterable, List
@@ -42,6 +43,8 @@ class FlatAdam:
                 p.data = view                                  # the module now computes on the flat buffer
                 self._pviews.append(view)
                 self._gviews.append(self.grad[off:off + p.numel()].view(p.shape))
+                p._mil_grad = self._gviews[-1]                 # ops.grad_slot: backward kernels write here directly
+        self._is_zero = [True] * len(self.params)              # slot known to hold zeros (never-written / re-zeroed)
         self.defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}
         self.param_groups = [dict(self.defaults, params=self.params)]    # lr schedulers write param_groups[0]["lr"]
         self.world = world_size
@@ -56,11 +59,22 @@ class FlatAdam:
 
     @torch.no_grad()
     def gather(self):
-        have = [(g, p.grad) for g, p in zip(self._gviews, self.params) if p.grad is not None]
-        if len(have) != len(self.params):
-            self.grad.zero_()
-        if have:
-            torch._foreach_copy_([h[0] for h in have], [h[1] for h in have])
+        """Bring every gradient into the flat buffer: nothing to do for those a backward kernel already wrote in
+        place (p.grad IS the slot), one foreach copy for the rest, zeros for parameters without a gradient."""
+        dst, src = [], []
+        for i, (slot, p) in enumerate(zip(self._gviews, self.params)):
+            g = p.grad
+            if g is None:
+                if not self._is_zero[i]:
+                    slot.zero_()
+                    self._is_zero[i] = True
+                continue
+            self._is_zero[i] = False
+            if g.data_ptr() != slot.data_ptr():
+                dst.append(slot)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     @torch.no_grad()
     def step(self):
