@@ -343,7 +343,8 @@ def grad_slot(param):
     """The flat-gradient view optim.FlatAdam reserved for this parameter (None without FlatAdam): a backward that
     writes its result there and returns it hands autograd the final storage, so no gather copy is needed."""
     slot = getattr(param, "_mil_grad", None)
-    return slot if (slot is not None and slot.shape == param.shape) else None
+    # a fresh alias: autograd adopts a returned gradient without copying only if nothing else references that tensor
+    return slot.detach() if (slot is not None and slot.shape == param.shape) else None
 
 
 def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool, dW_out=None, db_out=None):
@@ -389,8 +390,7 @@ class _LinearAct(torch.autograd.Function):
             y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res)
         ctx.act = act
         ctx.has_b = b is not None
-        ctx.b_slot = grad_slot(b) if b is not None else None
-        ctx.W_slot = grad_slot(W)
+        ctx.b_param = b                     # only to look up its flat-gradient slot in backward
         ctx.has_res = residual is not None
         # with a residual the saved y is not the activation output; only act == none is used with residuals
         ctx.save_for_backward(x, W, y if pre is None else pre)
@@ -402,11 +402,13 @@ class _LinearAct(torch.autograd.Function):
         dy = _f32c(dy, "dy")
         M, K = x.shape
         N = W.shape[0]
+        W_slot = grad_slot(W)
+        b_slot = grad_slot(ctx.b_param) if ctx.b_param is not None else None
         if ctx.small:
             if dy.data_ptr() % 16:
                 dy = dy.clone()
             dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                          ctx.has_b and ctx.needs_input_grad[2], ctx.W_slot, ctx.b_slot)
+                                          ctx.has_b and ctx.needs_input_grad[2], W_slot, b_slot)
             return dx, dW, db, None, (dy if ctx.has_res else None)
         if ctx.act == ACT["quickgelu"]:
             dpre = torch.empty_like(dy)
@@ -415,8 +417,8 @@ class _LinearAct(torch.autograd.Function):
         else:
             dpre = act_bwd(dy, y, ctx.act)
         dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
-        dW = gemm(dpre, 1, x, 1, N, K, M, out=ctx.W_slot, split_k=True) if ctx.needs_input_grad[1] else None
-        db = colsum(dpre, out=ctx.b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dW = gemm(dpre, 1, x, 1, N, K, M, out=W_slot, split_k=True) if ctx.needs_input_grad[1] else None
+        db = colsum(dpre, out=b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res else None
         return dx, dW, db, None, dres
 

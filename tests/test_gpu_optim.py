@@ -39,3 +39,20 @@ def test_flat_adam_tracks_torch_adam(counted):
     assert all(p.data_ptr() >= o_our.flat.data_ptr() for p in ours.parameters())     # still views of the flat buffer
     sd = o_our.state_dict()
     assert sd["step"] == 6
+
+
+def test_linear_gradients_land_in_the_flat_slots_without_a_copy():
+    """ops.linear_act's backward writes dW / db into FlatAdam's slots and autograd adopts those tensors as .grad."""
+    from mil_amd import ops
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(512, 256).to(DEV)
+    big = torch.nn.Linear(512, 128).to(DEV)
+    opt = FlatAdam(list(lin.parameters()) + list(big.parameters()), lr=1e-3)
+    xs = torch.randn((32, 512), device=DEV)           # few-rows path
+    xb = torch.randn((300, 512), device=DEV)          # tiled path
+    opt.zero_grad()
+    (ops.linear_act(xs, lin.weight, lin.bias, "tanh").sum() + ops.linear_act(xb, big.weight, big.bias, "relu").sum()).backward()
+    for p in list(lin.parameters()) + list(big.parameters()):
+        assert p.grad is not None and p.grad.data_ptr() == p._mil_grad.data_ptr()
+    ref = torch.tanh(xs @ lin.weight.t() + lin.bias)
+    assert float((lin.bias.grad - (1 - ref * ref).sum(0)).abs().max()) <= 1e-4
