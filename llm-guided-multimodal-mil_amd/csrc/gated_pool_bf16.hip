@@ -163,6 +163,179 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- gate forward, deep pipeline
+// Large-R form (config 5: 131 072 rows x 1024): 256 rows x 384 gate columns per workgroup, K-slices of 32 bf16
+// (64-byte rows).  Two LDS rings filled by LDS-DMA: the x stream (HBM, long latency) runs FOUR slices ahead in a
+// five-slot ring, the gate weights (L2-resident) one slice ahead in a two-slot ring.  Per slice a wave issues its
+// three weight pieces first and its two x pieces last, so one counted s_waitcnt vmcnt(2) at the end of the slice
+// publishes "weights of s+1 and every x slice up to s+3" while the newest x pieces stay in flight across the barrier.
+// Against the 128-row kernel above the gate weights are re-streamed from L2 half as often.
+// Measured (round 1, ablations of this loop at R = 131 072, L = 1024): with the MFMAs removed the two streams alone
+// take 87 us (x only 60 us = 4.4 TB/s, weights only 54 us), i.e. ~0.27 us per 1 KiB LDS-DMA piece per wave: the
+// LDS-DMA issue path (~30 GB/s per CU), not HBM or the matrix pipe, bounds this kernel, and the two waves of a SIMD
+// run their DMA and MFMA phases in lockstep, so the full kernel is close to the SUM (140-150 us) rather than the max.
+// The next step is register-staged loads (global_load_dwordx4 + ds_write_b128) on a one-wave-per-SIMD layout.
+// Wave (wr, wc) = 64 rows x 3 d-chunks x {V, U}: 12 accumulator tiles (192 registers); B fragments rotate through
+// three register slots read two ahead of use (counted lgkmcnt waits).
+// LDS image: row = 4 chunks of 16 B, chunk c of row `row` stored at c ^ ((row >> 2) & 3): conflict-free for the
+// 16-lane groups of ds_read_b128, applied on the SOURCE address of the DMA (LDS side is lane-linear).
+//
+// LDS-DMA is issued through inline asm: the compiler models global_load_lds as a FLAT access that may return out of
+// order with DS reads, so with one in flight it turns EVERY LDS wait into lgkmcnt(0) and a read-ahead fragment
+// schedule collapses.  Issued here it is invisible to that bookkeeping; the vmcnt side is handled by hand anyway.
+__device__ __forceinline__ void dma16_raw(const void* gptr, unsigned lds_byte_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_addr_uniform)
+                 : "memory");
+}
+#define HC_TM 256
+#define HC_BK 32
+#define HC_XS (HC_TM * HC_BK)        // u16 per x slot  (16 KB)
+#define HC_WS (HB_NG * HC_BK)        // u16 per weight slot (24 KB)
+#define HC_NX 5
+
+__global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restrict__ x, const u16* __restrict__ Wv,
+                                                            const float* __restrict__ bv, const u16* __restrict__ Wu,
+                                                            const float* __restrict__ bu, const float* __restrict__ wvec,
+                                                            const float* __restrict__ battn, float* __restrict__ scores,
+                                                            float* __restrict__ gates, int R, int L) {
+    __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + 2 * HC_WS];      // 80 + 48 KB
+    u16* xring = smem;
+    u16* wring = smem + HC_NX * HC_XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * HC_TM;
+    // DMA pieces: 16 rows x 64 B each.  x: 16 pieces per slice, wave takes w and w + 8; weights: 24 pieces, wave takes
+    // w, w + 8, w + 16.
+    const int prow = lane >> 2, pch = lane & 3;
+    const u16* xsrc[2];
+    const u16* wsrc[3];
+    unsigned xdst[2], wdst[3];          // byte address inside slot 0 of the ring, wave-uniform
+    const unsigned lds0 = (unsigned)(uintptr_t)(hb_lds_void*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = wave + 8 * i, lr = 16 * p + prow;
+        const int gr = min(row0 + lr, R - 1);
+        xsrc[i] = x + (size_t)gr * L + 8 * (pch ^ ((lr >> 2) & 3));
+        xdst[i] = __builtin_amdgcn_readfirstlane(lds0 + 2u * (unsigned)(16 * p * HC_BK));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = wave + 8 * i, wrow = 16 * p + prow;
+        wsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 8 * (pch ^ ((wrow >> 2) & 3));
+        wdst[i] = __builtin_amdgcn_readfirstlane(lds0 + 2u * (unsigned)(HC_NX * HC_XS + 16 * p * HC_BK));
+    }
+    auto dma_x = [&](int i, int slot, int k0) { dma16_raw(xsrc[i] + k0, xdst[i] + 2u * (unsigned)(slot * HC_XS)); };
+    auto dma_w = [&](int i, int slot, int k0) { dma16_raw(wsrc[i] + k0, wdst[i] + 2u * (unsigned)(slot * HC_WS)); };
+
+    f32x16 acc[2][3][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][c][u][i] = 0.f;
+
+    const int nslice = L / HC_BK;
+#pragma unroll
+    for (int q = 0; q < HC_NX - 1; ++q) {
+        const int k0 = min(q, nslice - 1) * HC_BK;
+        dma_x(0, q, k0);
+        dma_x(1, q, k0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dma_w(i, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int fx = (r >> 2) & 3;       // rows 64 wr + 32 q + r and 32 (..) + r: (row >> 2) & 3 == (r >> 2) & 3
+    // Per slice: 12 B fragments j = 6 ks + 2 c + u, each feeding two MFMAs (row tiles q = 0, 1).  B fragments rotate
+    // through three register slots and are read two ahead of their use; the A pair of k-step 1 is read during
+    // k-step 0; the DMA pieces are spread over the fragment steps.  sched_barrier pins the order.
+    int xs = 0;                         // slot of slice s in the x ring; s & 1 in the weight ring
+    for (int s = 0; s < nslice; ++s) {
+        const int kw = min(s + 1, nslice - 1) * HC_BK, kx = min(s + HC_NX - 1, nslice - 1) * HC_BK;
+        const int xnew = xs == 0 ? HC_NX - 1 : xs - 1;          // slot of slice s + 4 = the one slice s - 1 used
+        const int wnew = (s + 1) & 1;
+        const u16* xa = xring + xs * HC_XS + (64 * wr + r) * HC_BK;
+        const u16* wb = wring + (s & 1) * HC_WS + (96 * wc + r) * HC_BK;
+        u16x8 a[2][2], bs[3];
+        auto read_a = [&](int ks) {
+            const int ch = 8 * ((2 * ks + h) ^ fx);
+            a[ks][0] = *reinterpret_cast<const u16x8*>(xa + ch);
+            a[ks][1] = *reinterpret_cast<const u16x8*>(xa + 32 * HC_BK + ch);
+        };
+        auto read_b = [&](int j) {
+            const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
+            const int ch = 8 * ((2 * ks + h) ^ fx);
+            bs[j % 3] = *reinterpret_cast<const u16x8*>(wb + (u * 192 + 32 * c) * HC_BK + ch);
+        };
+        read_a(0);
+        read_b(0);
+        read_b(1);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            if (j + 2 < 12) read_b(j + 2);
+            if (j == 2) read_a(1);
+            if (j == 1) dma_w(0, wnew, kw);
+            if (j == 3) dma_w(1, wnew, kw);
+            if (j == 5) dma_w(2, wnew, kw);
+            if (j == 7) dma_x(0, xnew, kx);
+            if (j == 9) dma_x(1, xnew, kx);
+            const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bs[j % 3]);
+            acc[0][c][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][0]), bf, acc[0][c][u], 0, 0, 0);
+            acc[1][c][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][1]), bf, acc[1][c][u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but this slice's two x pieces (slice s + 4) have landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        xs = xs == HC_NX - 1 ? 0 : xs + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail pieces must not land on the scratch below
+    __builtin_amdgcn_s_barrier();
+
+    float* sred = reinterpret_cast<float*>(smem);            // [2][256]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float part[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int d = 32 * (3 * wc + c) + r;
+            const float bvd = bv[d], bud = bu[d], wd = wvec[d];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = fast_tanh(acc[q][c][0][i] + bvd);
+                const float u = fast_sigmoid(acc[q][c][1][i] + bud);
+                part[i] += wd * v * u;
+                if (gates != nullptr) {
+                    const int gr = row0 + 64 * wr + 32 * q + mfma32_row(i, h);
+                    if (gr < R) {
+                        gates[(size_t)gr * HB_NG + d] = v;
+                        gates[(size_t)gr * HB_NG + 192 + d] = u;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = half_allsum(part[i]);
+            if (r == 0) sred[wc * HC_TM + 64 * wr + 32 * q + mfma32_row(i, h)] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < HC_TM) {
+        const int gr = row0 + tid;
+        if (gr < R) scores[gr] = sred[tid] + sred[HC_TM + tid] + battn[0];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- pool stages, bf16 x
 // Lane l owns the 8 columns 8l + 512q of a row (16-byte loads); NQ = L / 512.
 template <int NQ>
@@ -483,8 +656,13 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % HB_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
-    hipLaunchKernelGGL(k_gate_fwd_bf16, dim3((R + HB_TM - 1) / HB_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu,
-                       w, b, scores, gates, R, L);
+    // 256-row tiles with the three-stage pipeline once they fill the chip; the 128-row kernel for small R
+    if (R >= HC_TM * MIL_NUM_CU)
+        hipLaunchKernelGGL(k_gate_fwd_bf16_deep, dim3((R + HC_TM - 1) / HC_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv,
+                           Wu, bu, w, b, scores, gates, R, L);
+    else
+        hipLaunchKernelGGL(k_gate_fwd_bf16, dim3((R + HB_TM - 1) / HB_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu,
+                           bu, w, b, scores, gates, R, L);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

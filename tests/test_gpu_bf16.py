@@ -56,3 +56,20 @@ def test_cast_bf16_round_to_nearest_even():
     x = torch.tensor([1.0, 1.00390625, 1.005859375, -2.5, 3.0e38, 1e-40, float("inf")] + [0.1 * i for i in range(25)])
     got = ops.cast_bf16(x.to(DEV)).cpu()
     assert torch.equal(got, x.to(torch.bfloat16))
+
+
+def test_deep_pipeline_kernel_matches_the_128_row_kernel():
+    """R >= 65 536 switches mil_gate_scores_fwd_bf16 to the 256-row, two-ring LDS-DMA kernel: same k order, so its
+    scores and gates must equal the 128-row kernel's (run on slices) bit for bit, including a ragged last tile."""
+    from mil_amd import ops, synthetic as syn
+    L, R = 1024, 65536 + 72
+    p = {k: v.to(DEV) for k, v in syn.image_only_params(11, L=L).items()}
+    x16 = ops.cast_bf16(torch.randn((R, L), generator=torch.Generator().manual_seed(3)).to(DEV))
+    args = (ops.cast_bf16(p["aggregator.attention_V.0.weight"]), p["aggregator.attention_V.0.bias"],
+            ops.cast_bf16(p["aggregator.attention_U.0.weight"]), p["aggregator.attention_U.0.bias"],
+            p["aggregator.attention_weights.weight"].reshape(-1), p["aggregator.attention_weights.bias"])
+    s_all, g_all = ops.gate_scores_fwd_bf16(x16, *args, save_gates=True)
+    for lo, hi in ((0, 4096), (30000, 34000), (R - 1000, R)):
+        s_ref, g_ref = ops.gate_scores_fwd_bf16(x16[lo:hi].contiguous(), *args, save_gates=True)
+        assert torch.equal(s_all[lo:hi], s_ref)
+        assert torch.equal(g_all[lo:hi], g_ref)
