@@ -252,7 +252,7 @@ int mil_quickgelu(const float* x, const float* dy, float* out, size_t n, void* s
  * i.e. the [N, E] x [E, H*C] projections of k and v are replaced by one HBM-bound pass over the keys; k_proj.bias
  * drops out of the softmax.  tile_map int32 [ntiles][3] = {bag, key0, nkeys <= 64}; H == 8, E == 512.
  * forward workspace: ntiles * H * (E + 2) floats; backward workspace: ntiles * H * E + 16 * n_keys floats
- * (n_keys = total key rows).
+ * (n_keys = total key rows).  dkeys_acc (nullable): a gradient the keys already received elsewhere, added into dkeys.
  * mil_absorb_query_bwd: dqp [B, H*C] and/or dWk [H*C, E] (either may be NULL) from dQp [B, H, E]; the same two
  * entry points give the value projection's backward (dpooled = absorb_query(do, Wv); dWv = absorb_query_bwd(do, pooled)). */
 int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream);
@@ -263,8 +263,8 @@ int mil_absorbed_pool_fwd(const float* keys, const float* pe, const float* Qp, c
                           float* pooled, float* lse, float* workspace, void* stream);
 int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse, const float* dpooled,
                           const float* cdot, const int32_t* k_off, const int32_t* tile_map,
-                          const int32_t* bag_tile_off, int ntiles, int n_keys, int B, int H, int C, int E, float* dkeys,
-                          float* dQp, float* workspace, void* stream);
+                          const int32_t* bag_tile_off, int ntiles, int n_keys, int B, int H, int C, int E,
+                          const float* dkeys_acc, float* dkeys, float* dQp, float* workspace, void* stream);
 int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
                    void* stream);
 

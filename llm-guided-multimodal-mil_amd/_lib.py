@@ -63,7 +63,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_absorb_query": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_absorb_query_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "mil_absorbed_pool_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
-    "mil_absorbed_pool_bwd": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 3 + [_P]),
+    "mil_absorbed_pool_bwd": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 4 + [_P]),
     "mil_value_proj": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_layernorm_fwd": (c_int, [_P] * 3 + [c_int, c_int, c_float, _P, _P, _P]),
     "mil_layernorm_bwd_blocks": (c_int, [c_int]),

@@ -63,3 +63,34 @@ class BagLayout:
     @classmethod
     def uniform(cls, B: int, N: int, device) -> "BagLayout":
         return cls.make([N] * B, device)
+
+    @classmethod
+    def two_segment(cls, n_lengths: Sequence[int], t_lengths: Sequence[int], device) -> "BagLayout":
+        """Rows laid out as [all patch rows of all bags | all token rows of all bags]; bag b owns its patch range
+        and its token range.  The pool kernels only follow the tile map, so a bag need not be contiguous - this is
+        how the fused model pools over (text tokens + patches) without materialising the per-bag concatenation
+        of model/aggregator.py:192."""
+        key = ("2seg", tuple(int(v) for v in n_lengths), tuple(int(v) for v in t_lengths), str(device))
+        hit = cls._cache.get(key)
+        if hit is not None:
+            return hit
+        n = np.asarray(key[1], dtype=np.int64)
+        t = np.asarray(key[2], dtype=np.int64)
+        B = len(n)
+        tm_n, bto_n, bo_n = build_tile_map(n)
+        tm_t, bto_t, bo_t = build_tile_map(t)
+        tm_t = tm_t.copy()
+        tm_t[:, 1] += int(bo_n[-1])                      # token rows start after every patch row
+        tiles = []
+        for b in range(B):
+            tiles.append(tm_n[bto_n[b]:bto_n[b + 1]])
+            tiles.append(tm_t[bto_t[b]:bto_t[b + 1]])
+        tm = np.concatenate(tiles, 0) if tiles else np.zeros((0, 4), np.int32)
+        bto = (bto_n.astype(np.int64) + bto_t.astype(np.int64)).astype(np.int32)
+        lay = cls(lengths=[int(a + c) for a, c in zip(n, t)], R=int(bo_n[-1] + bo_t[-1]), B=B, T=int(tm.shape[0]),
+                  tile_map=torch.from_numpy(np.ascontiguousarray(tm)).to(device),
+                  bag_tile_off=torch.from_numpy(bto).to(device), bag_off=torch.from_numpy(bo_n).to(device))
+        if len(cls._cache) > 64:
+            cls._cache.clear()
+        cls._cache[key] = lay
+        return lay

@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void k_apool_dots(const float* __restrict__ ke
 __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict__ keys, const float* __restrict__ pe,
                                                          const float* __restrict__ Qp, const float* __restrict__ dpooled,
                                                          const float* __restrict__ ad, const int32_t* __restrict__ k_off,
-                                                         const int32_t* __restrict__ tile_map, float* __restrict__ dkeys,
+                                                         const int32_t* __restrict__ tile_map,
+                                                         const float* __restrict__ dkeys_acc, float* __restrict__ dkeys,
                                                          float* __restrict__ pdq) {
     constexpr int E = 512, NQ = 2;
     __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
@@ -360,7 +361,11 @@ __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict
         for (int q = 0; q < NQ; ++q) {
             kin[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) +
                      *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
-            out[q] = f32x4{0, 0, 0, 0};
+            // dkeys_acc: the gradient the keys receive from their other consumer, folded in here instead of in a
+            // separate [N, 512] add
+            out[q] = dkeys_acc != nullptr
+                         ? *reinterpret_cast<const f32x4*>(dkeys_acc + (size_t)(key0 + rr) * E + 256 * q + 4 * lane)
+                         : f32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int h = 0; h < AP_H; ++h)
@@ -479,7 +484,8 @@ extern "C" int mil_absorbed_pool_fwd(const float* keys, const float* pe, const f
 extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse,
                                      const float* dpooled, const float* cdot, const int32_t* k_off,
                                      const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int n_keys, int B,
-                                     int H, int C, int E, float* dkeys, float* dQp, float* workspace, void* stream) {
+                                     int H, int C, int E, const float* dkeys_acc, float* dkeys, float* dQp,
+                                     float* workspace, void* stream) {
     AP_CHECK(keys && pe && Qp && lse && dpooled && cdot && k_off && tile_map && bag_tile_off && dkeys && dQp && workspace);
     AP_CHECK(H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0 && n_keys >= 0);
     if (B == 0) return MIL_OK;
@@ -492,7 +498,7 @@ extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const f
                            scale, ad);
         MIL_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_apool_bwd_apply, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, dpooled, ad, k_off, tile_map,
-                           dkeys, pdq);
+                           dkeys_acc, dkeys, pdq);
         MIL_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(E / 4), 0, st, pdq, bag_tile_off, E, dQp);

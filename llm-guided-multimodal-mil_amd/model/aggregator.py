@@ -116,14 +116,14 @@ class aggregator(nn.Module):
                 flat = torch.cat([x[b, :n] for b, n in enumerate(n_len)], 0)
             xi = self._lin_tanh(self.fc_pathology, flat)                                  # :149
             point = self._lin_tanh(self.fc_CI2Pth, t.reshape(B * P, EMBED))               # :190
-            q, k = self.TwoWayTransformer_Pth.flat(xi, point, self.pe_rows(max(n_len), xi.device), n_len, [P] * B)
-            # multi-modal bag per patient: [text tokens | patch tokens]  (:192)
-            if lengths is None:
-                x0 = torch.cat([q.view(B, P, EMBED), k.view(B, N, EMBED)], dim=1).reshape(B * (P + N), EMBED)
-            else:
-                ks = k.split(n_len)
-                x0 = torch.cat([torch.cat([q[b * P:(b + 1) * P], ks[b]], 0) for b in range(B)], 0)
-            layout = BagLayout.make([P + n for n in n_len], x0.device)
+            q, k = self.TwoWayTransformer_Pth.flat(xi, point, self.pe_rows(max(n_len), xi.device), n_len, [P] * B,
+                                                   keys_tail_rows=B * P)
+            # multi-modal bag per patient = its text tokens + its patch tokens (:192).  Rows are kept as
+            # [all patches | all tokens] (the patch tokens stay where the last LayerNorm wrote them, only the few
+            # token rows are appended) and the tile map tells the pool kernels which rows belong to which bag;
+            # attention pooling does not depend on the order of a bag's rows.
+            x0 = ops.append_rows(k, q)
+            layout = BagLayout.two_segment(n_len, [P] * B, x0.device)
             M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0   # :198-199
             return self._head(M), q.view(B, P, EMBED)                                     # :200,207
         if "CI" in modality:

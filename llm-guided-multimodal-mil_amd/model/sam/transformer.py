@@ -43,10 +43,12 @@ class Attention(nn.Module):
     def one_token(self, q, keys, pe_table, segs: AttnSegs, residual=None):
         """Token->image attention when every bag has ONE text token: the K / V projections over the patches are
         absorbed into H query vectors and H pooled key vectors (ops.one_token_attention) - an HBM-bound pass over
-        the keys instead of two [N, E] x [E, I] GEMMs.  keys come WITHOUT positional encoding (added on the fly)."""
-        o = ops.one_token_attention(q, keys, pe_table, segs, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight,
-                                    self.v_proj.weight, self.v_proj.bias, self.num_heads)
-        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
+        the keys instead of two [N, E] x [E, I] GEMMs.  keys come WITHOUT positional encoding (added on the fly).
+        Returns (attention output, keys alias): later uses of the keys must go through the alias so that their
+        gradient is folded inside the pool's backward."""
+        o, keys_pass = ops.one_token_attention(q, keys, pe_table, segs, self.q_proj.weight, self.q_proj.bias,
+                                               self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads)
+        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual), keys_pass
 
     def forward(self, q, k, v):
         """Reference signature: q [B, Tq, E], k, v [B, Tk, E] -> [B, Tq, E]."""
@@ -64,8 +66,8 @@ def one_token_ok(attn: "Attention", s_ti: AttnSegs, pe_table) -> bool:
 
 
 class _LN(nn.LayerNorm):
-    def forward(self, x):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+    def forward(self, x, tail_rows: int = 0):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, tail_rows)
 
 
 class TwoWayAttentionBlock(nn.Module):
@@ -82,7 +84,8 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.skip_first_layer_pe = skip_first_layer_pe
 
-    def flat(self, queries, keys, query_pe, keys_pe_fn, s_tt: AttnSegs, s_ti: AttnSegs, s_it: AttnSegs, pe_table=None):
+    def flat(self, queries, keys, query_pe, keys_pe_fn, s_tt: AttnSegs, s_ti: AttnSegs, s_it: AttnSegs, pe_table=None,
+             keys_tail_rows: int = 0):
         """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe.  With pe_table
         given and exactly one text token per bag, both cross attentions take their one-token forms and keys + pe is
         never materialised."""
@@ -104,7 +107,8 @@ class TwoWayAttentionBlock(nn.Module):
         one_token = one_token_ok(self.cross_attn_token_to_image, s_ti, pe_table)
         if one_token:
             k = None
-            queries = self.norm2(self.cross_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries))
+            att, keys = self.cross_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
+            queries = self.norm2(att)
         else:
             k = keys_pe_fn(keys)
             queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
@@ -116,11 +120,11 @@ class TwoWayAttentionBlock(nn.Module):
             # [N, 512] projections and the attention core; bit-for-bit the general path's result up to rounding.
             a = self.cross_attn_image_to_token
             o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
-            keys = self.norm4(ops.add_bag_row(keys, o, s_it))
+            keys = self.norm4(ops.add_bag_row(keys, o, s_it), keys_tail_rows)
         else:
             if k is None:
                 k = keys_pe_fn(keys)
-            keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys))
+            keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys), keys_tail_rows)
         return queries, keys
 
     def forward(self, queries, keys, query_pe, key_pe):
@@ -147,20 +151,22 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = _LN(embedding_dim)
 
-    def flat(self, image, point, pe_table, n_lengths, t_lengths) -> Tuple[torch.Tensor, torch.Tensor]:
+    def flat(self, image, point, pe_table, n_lengths, t_lengths, keys_tail_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         """image [sum N_b, E] patch tokens, point [sum T_b, E] text tokens, pe_table [>= max N_b, E].
-        Returns (queries [sum T_b, E], keys [sum N_b, E])  (sam/transformer.py:100-120)."""
+        Returns (queries [sum T_b, E], keys [sum N_b, E])  (sam/transformer.py:100-120).  keys_tail_rows: the returned
+        keys are allocated with room for that many more rows behind them (ops.append_rows)."""
         dev = image.device
         s_tt = AttnSegs.make(t_lengths, t_lengths, dev)
         s_ti = AttnSegs.make(t_lengths, n_lengths, dev)
         s_it = AttnSegs.make(n_lengths, t_lengths, dev)
         keys_pe = lambda kk: ops.add_pe(kk, pe_table, s_ti.k_bag, s_ti.k_off)      # noqa: E731
         queries, keys = point, image
-        for layer in self.layers:
-            queries, keys = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it, pe_table)
+        for li, layer in enumerate(self.layers):
+            queries, keys = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it, pe_table,
+                                       keys_tail_rows if li == len(self.layers) - 1 else 0)
         q = queries + point                                                      # :114-118
         if one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
-            out = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
+            out, keys = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
         else:
             out = self.final_attn_token_to_image.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=queries)
         return self.norm_final_attn(out), keys

@@ -526,10 +526,11 @@ def attention_pool(q, k, v, segs, H: int):
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float):
+    def forward(ctx, x, gamma, beta, eps: float, tail_rows: int = 0):
         x = _f32c(x, "x")
         rows, E = x.shape
-        y = torch.empty_like(x)
+        # tail_rows > 0: allocate room for that many more rows behind the result (see append_rows)
+        y = torch.empty((rows + tail_rows, E), device=x.device, dtype=torch.float32)[:rows] if tail_rows else torch.empty_like(x)
         stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
         rc = _lib.lib().mil_layernorm_fwd(_p(x), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), rows, E, eps, _p(y),
                                           _p(stats), _stream())
@@ -550,12 +551,39 @@ class _LayerNorm(torch.autograd.Function):
         rc = _lib.lib().mil_layernorm_bwd(_p(x), _p(gamma), _p(dy), _p(stats), rows, E, _p(dx), _p(dg), _p(db), _p(ws),
                                           _stream())
         _lib.check(rc, "mil_layernorm_bwd")
-        return dx, dg, db, None
+        return dx, dg, db, None, None
 
 
-def layer_norm(x, gamma, beta, eps: float = 1e-5):
+def layer_norm(x, gamma, beta, eps: float = 1e-5, tail_rows: int = 0):
     lead = x.shape[:-1]
-    return _LayerNorm.apply(x.reshape(-1, x.shape[-1]), gamma, beta, eps).reshape(*lead, x.shape[-1])
+    return _LayerNorm.apply(x.reshape(-1, x.shape[-1]), gamma, beta, eps, tail_rows).reshape(*lead, x.shape[-1])
+
+
+class _AppendRows(torch.autograd.Function):
+    """torch.cat([base, extra], 0) that does not copy `base` when it was allocated with room behind it
+    (layer_norm(..., tail_rows=extra.shape[0])): only the few `extra` rows are written.  Used for the multi-modal
+    bag of model/aggregator.py:192 - the [N, 512] patch tokens stay where the last LayerNorm put them."""
+
+    @staticmethod
+    def forward(ctx, base, extra):
+        R, E = base.shape
+        T = extra.shape[0]
+        ctx.R = R
+        st = base.untyped_storage()
+        if (base.is_contiguous() and base.storage_offset() == 0 and base.dtype == torch.float32
+                and st.nbytes() >= (R + T) * E * 4):
+            big = torch.empty(0, device=base.device, dtype=torch.float32).set_(st, 0, (R + T, E), (E, 1))
+            big[R:].copy_(extra)
+            return big
+        return torch.cat([base, extra], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.R], g[ctx.R:]
+
+
+def append_rows(base, extra):
+    return _AppendRows.apply(base, extra)
 
 
 class _AddPE(torch.autograd.Function):
@@ -769,10 +797,14 @@ class _AbsorbQuery(torch.autograd.Function):
 
 
 class _AbsorbedPool(torch.autograd.Function):
-    """pooled[b][h] = sum_n softmax_n(Qp[b][h] . (keys_n + pe_n) / sqrt(C)) keys_n."""
+    """pooled[b][h] = sum_n softmax_n(Qp[b][h] . (keys_n + pe_n) / sqrt(C)) keys_n.
+    Also returns the keys unchanged (an alias): the caller hands THAT to the keys' other consumer, so both gradients
+    of the keys arrive at this node and the backward folds them in one pass instead of autograd adding two [N, 512]
+    tensors."""
 
     @staticmethod
     def forward(ctx, keys, pe, Qp, segs, C: int):
+        keys_in = keys
         keys, pe, Qp = _f32c(keys, "keys"), _f32c(pe, "pe"), _f32c(Qp, "Qp")
         B, H, E = Qp.shape
         pooled = torch.empty_like(Qp)
@@ -783,15 +815,19 @@ class _AbsorbedPool(torch.autograd.Function):
                                               _stream())
         _lib.check(rc, "mil_absorbed_pool_fwd")
         ctx.segs, ctx.C = segs, C
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(keys, pe, Qp, pooled, lse)
-        return pooled
+        return pooled, keys_in.view_as(keys_in)
 
     @staticmethod
-    def backward(ctx, dpooled):
+    def backward(ctx, dpooled, dkeys_pass):
         keys, pe, Qp, pooled, lse = ctx.saved_tensors
         segs, C = ctx.segs, ctx.C
         B, H, E = Qp.shape
+        if dpooled is None:
+            return dkeys_pass, None, None, None, None
         dpooled = _f32c(dpooled, "dpooled")
+        acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
         cdot = rowdot(dpooled.view(B * H, E), pooled.view(B * H, E))
         dkeys = torch.empty_like(keys)
         dQp = torch.empty_like(Qp)
@@ -799,7 +835,7 @@ class _AbsorbedPool(torch.autograd.Function):
         ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)
         rc = _lib.lib().mil_absorbed_pool_bwd(_p(keys), _p(pe), _p(Qp), _p(lse), _p(dpooled), _p(cdot), _p(segs.k_off),
                                               _p(segs.tile_map), _p(segs.bag_tile_off), segs.ntiles, n_keys, B, H, C, E,
-                                              _p(dkeys), _p(dQp), _p(ws), _stream())
+                                              _p(acc), _p(dkeys), _p(dQp), _p(ws), _stream())
         _lib.check(rc, "mil_absorbed_pool_bwd")
         return dkeys, None, dQp, None, None
 
@@ -836,9 +872,10 @@ class _ValueProj(torch.autograd.Function):
 def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
     """Token->image attention core for ONE text token per bag, projections absorbed (csrc/absorbed_attn.hip).
     q_tok [B, E] (query + its pe), keys [R, E] WITHOUT positional encoding, pe [>= max N, E].  Returns the
-    pre-out_proj attention output [B, H*C].  k_proj.bias does not enter (softmax-invariant)."""
+    pre-out_proj attention output [B, H*C] and an alias of `keys` to be used by the keys' other consumer (see
+    _AbsorbedPool).  k_proj.bias does not enter (softmax-invariant)."""
     qp = linear_act(q_tok, Wq, bq)
     C = Wq.shape[0] // H
     Qp = _AbsorbQuery.apply(qp, Wk, H)
-    pooled = _AbsorbedPool.apply(keys, pe, Qp, segs, C)
-    return _ValueProj.apply(pooled, Wv, bv)
+    pooled, keys_pass = _AbsorbedPool.apply(keys, pe, Qp, segs, C)
+    return _ValueProj.apply(pooled, Wv, bv), keys_pass

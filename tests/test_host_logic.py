@@ -86,3 +86,23 @@ def test_flags_and_meters():
     assert abs(m.avg - 2.0) < 1e-12
     out = torch.tensor([[0.4, 0.6], [0.7, 0.3]]); tgt = torch.tensor([[0.0, 1.0], [0.0, 1.0]])
     assert float(calculate_accuracy(out, tgt)) == 0.5
+
+
+def test_two_segment_layout_covers_patch_and_token_rows():
+    """[all patches | all tokens] row order: every row belongs to exactly one tile of the right bag."""
+    import torch
+    from mil_amd.bags import BagLayout
+    n, t = [70, 5, 33], [1, 1, 1]
+    lay = BagLayout.two_segment(n, t, torch.device("cpu"))
+    tm, bto = lay.tile_map.numpy(), lay.bag_tile_off.numpy()
+    assert lay.R == sum(n) + sum(t) and lay.B == 3 and lay.T == tm.shape[0] == bto[-1]
+    owner = -np.ones(lay.R, dtype=np.int64)
+    for b in range(3):
+        for bag, row0, nrows, _ in tm[bto[b]:bto[b + 1]]:
+            assert bag == b and 0 < nrows <= 32
+            assert (owner[row0:row0 + nrows] == -1).all()
+            owner[row0:row0 + nrows] = b
+    koff = np.concatenate([[0], np.cumsum(n)])
+    for b in range(3):
+        assert (owner[koff[b]:koff[b + 1]] == b).all()
+        assert owner[sum(n) + b] == b
