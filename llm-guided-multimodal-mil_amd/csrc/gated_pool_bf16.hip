@@ -174,7 +174,10 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
 // take 87 us (x only 60 us = 4.4 TB/s, weights only 54 us), i.e. ~0.27 us per 1 KiB LDS-DMA piece per wave: the
 // LDS-DMA issue path (~30 GB/s per CU), not HBM or the matrix pipe, bounds this kernel, and the two waves of a SIMD
 // run their DMA and MFMA phases in lockstep, so the full kernel is close to the SUM (140-150 us) rather than the max.
-// The next step is register-staged loads (global_load_dwordx4 + ds_write_b128) on a one-wave-per-SIMD layout.
+// Also tried (round 1): a one-wave-per-SIMD layout (256 threads, wave = 96 x 192 = 18 accumulator tiles, register-staged
+// global_load_dwordx4 + ds_write_b128 with asm loads and counted vmcnt): 240-250 us.  288 accumulator registers do
+// not fit the 256 AGPRs and hipcc then shuttles tiles between the two register files around every MFMA
+// (hundreds of v_accvgpr_read/write per slice); 16 tiles per wave is the limit, which N = 384 does not tile evenly.
 // Wave (wr, wc) = 64 rows x 3 d-chunks x {V, U}: 12 accumulator tiles (192 registers); B fragments rotate through
 // three register slots read two ahead of use (counted lgkmcnt waits).
 // LDS image: row = 4 chunks of 16 B, chunk c of row `row` stored at c ^ ((row >> 2) & 3): conflict-free for the
