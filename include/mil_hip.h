@@ -236,9 +236,13 @@ int mil_attn_pool_bwd_mh(const float* q, const float* k, const float* v, const f
                          const float* lse, const int32_t* q_off, const int32_t* tile_map,
                          const int32_t* bag_tile_off, int ntiles, int B, int Tmax, int H, int C, float* dq, float* dk,
                          float* dv, float* workspace, void* stream);
-/* Backward of the rows form for self-attention over whole sequences of <= 80 tokens (q, k, v share q_off), with
- * the causal mask of clip/model.py:324-330 if causal != 0: the text tower's backward for learnable prompts
- * (model/dim1/CLIP.py:29-62).  One workgroup per (sequence, head). */
+/* "seq" form: self-attention over whole sequences of <= 96 tokens (q, k, v share q_off), with the causal mask of
+ * clip/model.py:324-330 if causal != 0 - the CLIP text blocks (clip/model.py:171-184), forward and, for learnable
+ * prompts (model/dim1/CLIP.py:29-62), backward.  One workgroup per (sequence, head): the head's q / k / v rows are
+ * staged in LDS and every product runs on fp32 MFMA.  lse [Tq, H] is written by the forward (nullable) and read by
+ * the backward. */
+int mil_attn_seq_fwd(const float* q, const float* k, const float* v, const int32_t* q_off, int B, int Tmax, int H, int C,
+                     int causal, float* o, float* lse, void* stream);
 int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                      const float* lse, const int32_t* q_off, int B, int Tmax, int H, int C, int causal, float* dq,
                      float* dk, float* dv, void* stream);

@@ -744,7 +744,128 @@ extern "C" int mil_segment_colsum(const float* Y, const int32_t* row_off, int B,
 // per (bag, head): scores, probabilities and dS live in LDS ([T][T] floats), q/k/v/do rows are re-read from L2.
 //   p = softmax(q k^T scale (+ causal mask));  dv_j = sum_i p_ij do_i;  dS_ij = p_ij (do_i . v_j - delta_i);
 //   dq_i = scale sum_j dS_ij k_j;  dk_j = scale sum_i dS_ij q_i.
-#define AS_MAXT 80
+#define AS_MAXT 96          // padded sequence length: three 32-row MFMA tiles
+#define AS_PS 100           // row stride of the score / probability image (100 mod 32 = 4: conflict-free b128 rows)
+
+// One workgroup (4 waves) per (sequence, head); q / k / v (and do) rows of the head are staged once in LDS as
+// [96][C + 4] images (rows >= T zero), every product runs on v_mfma_f32_32x32x2_f32:
+//   NT  S = Q K^T, dP = dO V^T     both operands read with ds_read_b128 (lane (r, h): 16 bytes at k = 8t + 4h)
+//   NN  O = P V,  dQ = dS K        A with b128 from the probability image, B k-major with ds_read_b32
+//   TN  dV = P^T dO, dK = dS^T Q   both k-major
+// Tile (it, jt) of S is skipped when the causal mask empties it; k-ranges are trimmed the same way.
+template <int C>
+struct SeqTiles {
+    static constexpr int RS = C + 4;
+    // acc (32 x 32 tile) += A[32 it.., k] B[32 jt.., k]^T over k in [0, C)     (both images row-major, k contiguous)
+    static __device__ __forceinline__ void nt(const float* A, int it, const float* B, int jt, int r, int h, f32x16& acc) {
+#pragma unroll
+        for (int t = 0; t < C / 8; ++t) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(A + (32 * it + r) * RS + 8 * t + 4 * h);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(B + (32 * jt + r) * RS + 8 * t + 4 * h);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[jj], fb[jj], acc, 0, 0, 0);
+        }
+    }
+    // acc += P[32 it.., k] V[k, 32 ct..] over k in [8 t0, 8 t1)      (P image stride AS_PS, V image stride RS)
+    static __device__ __forceinline__ void nn(const float* P, int it, const float* V, int ct, int t0, int t1, int r, int h,
+                                              f32x16& acc) {
+        for (int t = t0; t < t1; ++t) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(P + (32 * it + r) * AS_PS + 8 * t + 4 * h);
+            float fb[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fb[jj] = V[(8 * t + 4 * h + jj) * RS + 32 * ct + r];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[jj], fb[jj], acc, 0, 0, 0);
+        }
+    }
+    // acc += P[k, 32 jt..]^T X[k, 32 ct..] over k in [8 t0, 8 t1)
+    static __device__ __forceinline__ void tn(const float* P, int jt, const float* X, int ct, int t0, int t1, int r, int h,
+                                              f32x16& acc) {
+        for (int t = t0; t < t1; ++t) {
+            float fa[4], fb[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                fa[jj] = P[(8 * t + 4 * h + jj) * AS_PS + 32 * jt + r];
+                fb[jj] = X[(8 * t + 4 * h + jj) * RS + 32 * ct + r];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[jj], fb[jj], acc, 0, 0, 0);
+        }
+    }
+    // stage rows [r0, r0 + T) of head h (C floats each, row stride I) as [96][RS], zero beyond T, times mul
+    static __device__ __forceinline__ void stage(const float* __restrict__ src, int r0, int T, int I, int hoff, float mul,
+                                                 float* dst, int tid) {
+        for (int idx = tid; idx < AS_MAXT * (C / 4); idx += 256) {
+            const int row = idx / (C / 4), c4 = idx % (C / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < T) v = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + row) * I + hoff + 4 * c4) * mul;
+            *reinterpret_cast<f32x4*>(dst + row * RS + 4 * c4) = v;
+        }
+    }
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void k_attn_seq_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const int32_t* __restrict__ q_off,
+                                                      int H, int causal, float scale, float* __restrict__ o,
+                                                      float* __restrict__ lse) {
+    using TL = SeqTiles<C>;
+    constexpr int RS = TL::RS;
+    __shared__ __attribute__((aligned(16))) float qs[AS_MAXT * RS], ks[AS_MAXT * RS], vs[AS_MAXT * RS];
+    __shared__ __attribute__((aligned(16))) float ps[AS_MAXT * AS_PS];
+    __shared__ float linv[AS_MAXT];
+    const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, I = H * C;
+    const int r = lane & 31, h = lane >> 5;
+    const int r0 = q_off[b], T = q_off[b + 1] - r0;
+    TL::stage(q, r0, T, I, hh * C, scale, qs, tid);
+    TL::stage(k, r0, T, I, hh * C, 1.f, ks, tid);
+    TL::stage(v, r0, T, I, hh * C, 1.f, vs, tid);
+    __syncthreads();
+    const int ntile = (T + 31) / 32;
+    for (int tile = wave; tile < 9; tile += 4) {
+        const int it = tile / 3, jt = tile % 3;
+        if (it >= ntile || jt >= ntile || (causal && jt > it)) continue;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        TL::nt(qs, it, ks, jt, r, h, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ps[(32 * it + mfma32_row(i, h)) * AS_PS + 32 * jt + r] = acc[i];
+    }
+    __syncthreads();
+    // softmax of row i over j <= lim: one wave per row, lanes over j (two chunks of 64 cover 96)
+    for (int i = wave; i < 32 * ntile; i += 4) {
+        const int lim = i < T ? (causal ? i : T - 1) : -1;
+        float* pr = ps + i * AS_PS;
+        const float s0 = lane <= lim ? pr[lane] : -INFINITY, s1 = (lane < 32 && 64 + lane <= lim) ? pr[64 + lane] : -INFINITY;
+        const float m = wave_allmax(fmaxf(s0, s1));
+        const float p0 = lane <= lim ? __expf(s0 - m) : 0.f, p1 = (lane < 32 && 64 + lane <= lim) ? __expf(s1 - m) : 0.f;
+        const float l = wave_allsum(p0 + p1);
+        pr[lane] = p0;
+        if (lane < 32) pr[64 + lane] = p1;
+        if (lane == 0) {
+            linv[i] = lim >= 0 ? 1.0f / l : 0.f;
+            if (i < T && lse != nullptr) lse[(size_t)(r0 + i) * H + hh] = m + logf(l);
+        }
+    }
+    __syncthreads();
+    for (int tile = wave; tile < 3 * (C / 32); tile += 4) {
+        const int it = tile / (C / 32), ct = tile % (C / 32);
+        if (it >= ntile) continue;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        TL::nn(ps, it, vs, ct, 0, causal ? 4 * (it + 1) : 4 * ntile, r, h, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * it + mfma32_row(i, h);
+            if (row < T) o[(size_t)(r0 + row) * I + hh * C + 32 * ct + r] = acc[i] * linv[row];
+        }
+    }
+}
+
+// Backward of the above (recomputes P from the saved lse).
+//   dV = P^T dO;  dP = dO V^T;  dS = P (dP - delta) scale;  dQ = dS K;  dK = dS^T Q,   delta_i = dO_i . O_i
 template <int C>
 __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const float* __restrict__ o,
@@ -752,58 +873,88 @@ __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ 
                                                       const int32_t* __restrict__ q_off, int H, int causal, float scale,
                                                       float* __restrict__ dq, float* __restrict__ dk,
                                                       float* __restrict__ dv) {
-    __shared__ float P[AS_MAXT * AS_MAXT];      // p, then dS
-    __shared__ float delta[AS_MAXT];
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, I = H * C;
+    using TL = SeqTiles<C>;
+    constexpr int RS = TL::RS;
+    __shared__ __attribute__((aligned(16))) float qs[AS_MAXT * RS], ks[AS_MAXT * RS], vs[AS_MAXT * RS], dos[AS_MAXT * RS];
+    __shared__ __attribute__((aligned(16))) float ps[AS_MAXT * AS_PS];
+    __shared__ float delta[AS_MAXT], lrow[AS_MAXT];
+    const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, I = H * C;
+    const int r = lane & 31, h = lane >> 5;
     const int r0 = q_off[b], T = q_off[b + 1] - r0;
-    for (int i = tid; i < T; i += 256) {
+    TL::stage(q, r0, T, I, hh * C, 1.f, qs, tid);
+    TL::stage(k, r0, T, I, hh * C, 1.f, ks, tid);
+    TL::stage(v, r0, T, I, hh * C, 1.f, vs, tid);
+    TL::stage(dout, r0, T, I, hh * C, 1.f, dos, tid);
+    for (int i = wave; i < AS_MAXT; i += 4) {
         float d = 0.f;
-        for (int e = 0; e < C; ++e) d += dout[(size_t)(r0 + i) * I + h * C + e] * o[(size_t)(r0 + i) * I + h * C + e];
-        delta[i] = d;
-    }
-    for (int idx = tid; idx < T * T; idx += 256) {
-        const int i = idx / T, j = idx % T;
-        float p = 0.f;
-        if (!causal || j <= i) {
-            const float* qi = q + (size_t)(r0 + i) * I + h * C;
-            const float* kj = k + (size_t)(r0 + j) * I + h * C;
-            float s = 0.f;
-            for (int e = 0; e < C; ++e) s += qi[e] * kj[e];
-            p = expf(s * scale - lse[(size_t)(r0 + i) * H + h]);
-        }
-        P[i * AS_MAXT + j] = p;
+        if (i < T && lane < C) d = dout[(size_t)(r0 + i) * I + hh * C + lane] * o[(size_t)(r0 + i) * I + hh * C + lane];
+        d = wave_allsum(d);
+        if (lane == 0) { delta[i] = d; lrow[i] = i < T ? lse[(size_t)(r0 + i) * H + hh] : 0.f; }
     }
     __syncthreads();
-    // dv_j[e] = sum_i p_ij do_i[e]
-    for (int idx = tid; idx < T * C; idx += 256) {
-        const int j = idx / C, e = idx % C;
-        float a = 0.f;
-        for (int i = 0; i < T; ++i) a += P[i * AS_MAXT + j] * dout[(size_t)(r0 + i) * I + h * C + e];
-        dv[(size_t)(r0 + j) * I + h * C + e] = a;
+    const int ntile = (T + 31) / 32;
+    // P = exp(scale S - lse), masked; empty tiles are written as zeros (dV / dK read whole k-ranges)
+    for (int tile = wave; tile < 9; tile += 4) {
+        const int it = tile / 3, jt = tile % 3;
+        if (it >= ntile || jt >= ntile) continue;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const bool live = !(causal && jt > it);
+        if (live) TL::nt(qs, it, ks, jt, r, h, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * it + mfma32_row(i, h), col = 32 * jt + r;
+            const bool keep = live && row < T && col < T && (!causal || col <= row);
+            ps[row * AS_PS + col] = keep ? __expf(acc[i] * scale - lrow[row]) : 0.f;
+        }
     }
     __syncthreads();
-    // dS_ij = p_ij (do_i . v_j - delta_i) * scale   (in place)
-    for (int idx = tid; idx < T * T; idx += 256) {
-        const int i = idx / T, j = idx % T;
-        const float p = P[i * AS_MAXT + j];
-        float dp = 0.f;
-        if (p != 0.f) {
-            const float* di = dout + (size_t)(r0 + i) * I + h * C;
-            const float* vj = v + (size_t)(r0 + j) * I + h * C;
-            for (int e = 0; e < C; ++e) dp += di[e] * vj[e];
+    for (int tile = wave; tile < 3 * (C / 32); tile += 4) {           // dV[j][c] = sum_i P[i][j] dO[i][c]
+        const int jt = tile / (C / 32), ct = tile % (C / 32);
+        if (jt >= ntile) continue;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        TL::tn(ps, jt, dos, ct, causal ? 4 * jt : 0, 4 * ntile, r, h, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * jt + mfma32_row(i, h);
+            if (row < T) dv[(size_t)(r0 + row) * I + hh * C + 32 * ct + r] = acc[i];
         }
-        P[i * AS_MAXT + j] = p * (dp - delta[i]) * scale;
     }
     __syncthreads();
-    for (int idx = tid; idx < T * C; idx += 256) {
-        const int i = idx / C, e = idx % C;
-        float a = 0.f, c = 0.f;
-        for (int j = 0; j < T; ++j) {
-            a += P[i * AS_MAXT + j] * k[(size_t)(r0 + j) * I + h * C + e];      // dq_i
-            c += P[j * AS_MAXT + i] * q[(size_t)(r0 + j) * I + h * C + e];      // dk_i (roles of i, j swapped)
+    for (int tile = wave; tile < 9; tile += 4) {                      // dS = P (dO V^T - delta) scale, in place
+        const int it = tile / 3, jt = tile % 3;
+        if (it >= ntile || jt >= ntile || (causal && jt > it)) continue;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        TL::nt(dos, it, vs, jt, r, h, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * it + mfma32_row(i, h);
+            float* pp = ps + row * AS_PS + 32 * jt + r;
+            *pp = *pp * (acc[i] - delta[row]) * scale;
         }
-        dq[(size_t)(r0 + i) * I + h * C + e] = a;
-        dk[(size_t)(r0 + i) * I + h * C + e] = c;
+    }
+    __syncthreads();
+    for (int tile = wave; tile < 6 * (C / 32); tile += 4) {           // dQ = dS K  and  dK = dS^T Q
+        const bool is_q = tile < 3 * (C / 32);
+        const int tt = is_q ? tile : tile - 3 * (C / 32);
+        const int rt = tt / (C / 32), ct = tt % (C / 32);
+        if (rt >= ntile) continue;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (is_q) TL::nn(ps, rt, ks, ct, 0, causal ? 4 * (rt + 1) : 4 * ntile, r, h, acc);
+        else TL::tn(ps, rt, qs, ct, causal ? 4 * rt : 0, 4 * ntile, r, h, acc);
+        float* dst = is_q ? dq : dk;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 32 * rt + mfma32_row(i, h);
+            if (row < T) dst[(size_t)(r0 + row) * I + hh * C + 32 * ct + r] = acc[i];
+        }
     }
 }
 
@@ -814,6 +965,18 @@ __global__ __launch_bounds__(256) void k_quickgelu(const float* __restrict__ x, 
     if (i >= n) return;
     const float xv = x[i], s = 1.0f / (1.0f + expf(-1.702f * xv));
     out[i] = dy == nullptr ? xv * s : dy[i] * s * (1.0f + 1.702f * xv * (1.0f - s));
+}
+
+extern "C" int mil_attn_seq_fwd(const float* q, const float* k, const float* v, const int32_t* q_off, int B, int Tmax, int H,
+                                int C, int causal, float* o, float* lse, void* stream) {
+    if (!q || !k || !v || !q_off || !o) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    const float scale = 1.0f / sqrtf((float)C);
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_fwd<CC>), dim3(B, H), dim3(256), 0, (hipStream_t)stream, q, k, v, q_off, H,
+                                     causal, scale, o, lse));
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
 }
 
 extern "C" int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,

@@ -438,6 +438,9 @@ def _head_dim(I: int, H: int) -> int:
     return c
 
 
+SEQ_MAX_TOKENS = 96      # csrc/attention.hip: AS_MAXT
+
+
 class _AttnRows(torch.autograd.Function):
     """softmax(q k^T / sqrt(c)) v, one thread per (query row, head): sam/transformer.py:441-446 for
     image->token / token self attention, clip/model.py:183 with causal=True."""
@@ -449,9 +452,15 @@ class _AttnRows(torch.autograd.Function):
         C = _head_dim(I, H)
         o = torch.empty_like(q)
         lse = torch.empty((Tq, H), device=q.device, dtype=torch.float32)
-        rc = _lib.lib().mil_attn_rows_fwd(_p(q), _p(k), _p(v), _p(segs.q_off), _p(segs.k_off), _p(segs.q_bag), Tq, H, C,
-                                          1 if causal else 0, _p(o), _p(lse), _stream())
-        _lib.check(rc, "mil_attn_rows_fwd")
+        if 16 < segs.Tk_max <= SEQ_MAX_TOKENS and segs.q_lengths == segs.k_lengths:
+            # whole-sequence self-attention (CLIP text blocks): LDS-staged heads on MFMA, one workgroup per (sequence, head)
+            rc = _lib.lib().mil_attn_seq_fwd(_p(q), _p(k), _p(v), _p(segs.q_off), segs.B, segs.Tq_max, H, C,
+                                             1 if causal else 0, _p(o), _p(lse), _stream())
+            _lib.check(rc, "mil_attn_seq_fwd")
+        else:
+            rc = _lib.lib().mil_attn_rows_fwd(_p(q), _p(k), _p(v), _p(segs.q_off), _p(segs.k_off), _p(segs.q_bag), Tq, H, C,
+                                              1 if causal else 0, _p(o), _p(lse), _stream())
+            _lib.check(rc, "mil_attn_rows_fwd")
         ctx.segs, ctx.H, ctx.C, ctx.causal = segs, H, C, causal
         ctx.save_for_backward(q, k, v, o, lse)
         return o
@@ -464,9 +473,9 @@ class _AttnRows(torch.autograd.Function):
         do = _f32c(do, "do")
         if ctx.causal or segs.Tk_max > 16:
             # whole-sequence self-attention (the CLIP text blocks under learnable prompts): q, k, v share the segments
-            if segs.q_lengths != segs.k_lengths or segs.Tk_max > 80:
+            if segs.q_lengths != segs.k_lengths or segs.Tk_max > SEQ_MAX_TOKENS:
                 raise _lib.MilHipError("attention backward: > 16 keys per bag is only supported for self-attention over "
-                                       "sequences of <= 80 tokens")
+                                       f"sequences of <= {SEQ_MAX_TOKENS} tokens")
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
             rc = _lib.lib().mil_attn_seq_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.q_off), segs.B,
                                              segs.Tq_max, H, C, 1 if ctx.causal else 0, _p(dq), _p(dk), _p(dv), _stream())

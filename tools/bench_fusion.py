@@ -15,18 +15,24 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--clip_layers", type=int, default=12)
 ap.add_argument("--cache_text", action="store_true")
+ap.add_argument("--coop", action="store_true", help="learnable prompts (upstream default --learnablePrompt 1): 10 prompts "
+                "per bag, ctx trained through the frozen text tower every step; SGD lr 1e-3 as train_ddp.py:104-109")
 ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam instead of the flat one-launch Adam")
 ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
 dev = torch.device("cuda")
+if a.coop:
+    a.prompts = 10
 args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
-                       learnablePrompt=0, alignment_base="CI", model_CT="resnetMC3_18", clip_layers=a.clip_layers, cache_text=int(a.cache_text))
+                       learnablePrompt=int(a.coop), n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI", model_CT="resnetMC3_18", clip_layers=a.clip_layers, cache_text=int(a.cache_text))
 torch.manual_seed(1234)
 model = get_model(args).to(dev).eval()      # eval: parity mode (dropout off), gradients still flow
 x = syn.make_bags(1, a.bags, a.patches, 768).to(dev)
 ids = syn.make_token_ids(2, a.bags, a.prompts).to(dev)
 y = syn.make_labels(3, a.bags).to(dev)
-if a.torch_adam:
+if a.coop:
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-7)
+elif a.torch_adam:
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7,
                            capturable=a.graph)
 else:
@@ -43,8 +49,10 @@ def step():
     return loss
 
 if a.graph:
-    with torch.no_grad():
-        tfeat = model.clinic_extractor(ids)          # frozen tower: outside the graph (cached per note in training)
+    tfeat = None
+    if not a.coop:
+        with torch.no_grad():
+            tfeat = model.clinic_extractor(ids)      # frozen tower: outside the graph (cached per note in training)
     def gstep():
         prob, _ = model([x], ids, text_features=tfeat)
         loss = crit(prob, y)
