@@ -745,9 +745,11 @@ extern "C" int mil_segment_colsum(const float* Y, const int32_t* row_off, int B,
 //   p = softmax(q k^T scale (+ causal mask));  dv_j = sum_i p_ij do_i;  dS_ij = p_ij (do_i . v_j - delta_i);
 //   dq_i = scale sum_j dS_ij k_j;  dk_j = scale sum_i dS_ij q_i.
 #define AS_MAXT 96          // padded sequence length: three 32-row MFMA tiles
+#define AS_THREADS 512      // 8 waves per (sequence, head) workgroup
+#define AS_NW (AS_THREADS / 64)
 #define AS_PS 100           // row stride of the score / probability image (100 mod 32 = 4: conflict-free b128 rows)
 
-// One workgroup (4 waves) per (sequence, head); q / k / v (and do) rows of the head are staged once in LDS as
+// One workgroup (8 waves) per (sequence, head); q / k / v (and do) rows of the head are staged once in LDS as
 // [96][C + 4] images (rows >= T zero), every product runs on v_mfma_f32_32x32x2_f32:
 //   NT  S = Q K^T, dP = dO V^T     both operands read with ds_read_b128 (lane (r, h): 16 bytes at k = 8t + 4h)
 //   NN  O = P V,  dQ = dS K        A with b128 from the probability image, B k-major with ds_read_b32
@@ -795,7 +797,8 @@ struct SeqTiles {
     // stage rows [r0, r0 + T) of head h (C floats each, row stride I) as [96][RS], zero beyond T, times mul
     static __device__ __forceinline__ void stage(const float* __restrict__ src, int r0, int T, int I, int hoff, float mul,
                                                  float* dst, int tid) {
-        for (int idx = tid; idx < AS_MAXT * (C / 4); idx += 256) {
+#pragma unroll
+        for (int idx = tid; idx < AS_MAXT * (C / 4); idx += AS_THREADS) {
             const int row = idx / (C / 4), c4 = idx % (C / 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < T) v = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + row) * I + hoff + 4 * c4) * mul;
@@ -805,14 +808,21 @@ struct SeqTiles {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void k_attn_seq_fwd(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(AS_THREADS) void k_attn_seq_fwd(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const int32_t* __restrict__ q_off,
                                                       int H, int causal, float scale, float* __restrict__ o,
                                                       float* __restrict__ lse) {
     using TL = SeqTiles<C>;
     constexpr int RS = TL::RS;
-    __shared__ __attribute__((aligned(16))) float qs[AS_MAXT * RS], ks[AS_MAXT * RS], vs[AS_MAXT * RS];
-    __shared__ __attribute__((aligned(16))) float ps[AS_MAXT * AS_PS];
+    // the score image overlays q and k once every wave holds its S tiles in registers (2 x 26 KB >= 38 KB): 78 KB per
+    // workgroup for C = 64, i.e. two workgroups per CU
+    __shared__ __attribute__((aligned(16))) float smem[3 * AS_MAXT * RS];
+    static_assert(2 * AS_MAXT * RS >= AS_MAXT * AS_PS || C == 32, "score image must fit over q and k");
+    __shared__ __attribute__((aligned(16))) float ps32[C == 32 ? AS_MAXT * AS_PS : 4];
+    float* qs = smem;
+    float* ks = smem + AS_MAXT * RS;
+    float* vs = smem + 2 * AS_MAXT * RS;
+    float* ps = C == 32 ? ps32 : smem;
     __shared__ float linv[AS_MAXT];
     const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, I = H * C;
     const int r = lane & 31, h = lane >> 5;
@@ -822,19 +832,26 @@ __global__ __launch_bounds__(256) void k_attn_seq_fwd(const float* __restrict__ 
     TL::stage(v, r0, T, I, hh * C, 1.f, vs, tid);
     __syncthreads();
     const int ntile = (T + 31) / 32;
-    for (int tile = wave; tile < 9; tile += 4) {
-        const int it = tile / 3, jt = tile % 3;
-        if (it >= ntile || jt >= ntile || (causal && jt > it)) continue;
-        f32x16 acc;
+    f32x16 sacc[2];                          // tiles wave and wave + 8 of the 3 x 3 score grid
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        TL::nt(qs, it, ks, jt, r, h, acc);
+    for (int u = 0; u < 2; ++u) {
+        const int tile = wave + AS_NW * u, it = tile / 3, jt = tile % 3;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ps[(32 * it + mfma32_row(i, h)) * AS_PS + 32 * jt + r] = acc[i];
+        for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
+        if (tile < 9 && it < ntile && jt < ntile && !(causal && jt > it)) TL::nt(qs, it, ks, jt, r, h, sacc[u]);
+    }
+    __syncthreads();                         // q, k are dead: their space becomes the score image
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int tile = wave + AS_NW * u, it = tile / 3, jt = tile % 3;
+        if (tile < 9 && it < ntile && jt < ntile && !(causal && jt > it)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ps[(32 * it + mfma32_row(i, h)) * AS_PS + 32 * jt + r] = sacc[u][i];
+        }
     }
     __syncthreads();
     // softmax of row i over j <= lim: one wave per row, lanes over j (two chunks of 64 cover 96)
-    for (int i = wave; i < 32 * ntile; i += 4) {
+    for (int i = wave; i < 32 * ntile; i += AS_NW) {
         const int lim = i < T ? (causal ? i : T - 1) : -1;
         float* pr = ps + i * AS_PS;
         const float s0 = lane <= lim ? pr[lane] : -INFINITY, s1 = (lane < 32 && 64 + lane <= lim) ? pr[64 + lane] : -INFINITY;
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_fwd(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int tile = wave; tile < 3 * (C / 32); tile += 4) {
+    for (int tile = wave; tile < 3 * (C / 32); tile += AS_NW) {
         const int it = tile / (C / 32), ct = tile % (C / 32);
         if (it >= ntile) continue;
         f32x16 acc;
@@ -867,7 +884,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_fwd(const float* __restrict__ 
 // Backward of the above (recomputes P from the saved lse).
 //   dV = P^T dO;  dP = dO V^T;  dS = P (dP - delta) scale;  dQ = dS K;  dK = dS^T Q,   delta_i = dO_i . O_i
 template <int C>
-__global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(AS_THREADS) void k_attn_seq_bwd(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const float* __restrict__ o,
                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                       const int32_t* __restrict__ q_off, int H, int causal, float scale,
@@ -885,7 +902,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ 
     TL::stage(k, r0, T, I, hh * C, 1.f, ks, tid);
     TL::stage(v, r0, T, I, hh * C, 1.f, vs, tid);
     TL::stage(dout, r0, T, I, hh * C, 1.f, dos, tid);
-    for (int i = wave; i < AS_MAXT; i += 4) {
+    for (int i = wave; i < AS_MAXT; i += AS_NW) {
         float d = 0.f;
         if (i < T && lane < C) d = dout[(size_t)(r0 + i) * I + hh * C + lane] * o[(size_t)(r0 + i) * I + hh * C + lane];
         d = wave_allsum(d);
@@ -894,7 +911,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ 
     __syncthreads();
     const int ntile = (T + 31) / 32;
     // P = exp(scale S - lse), masked; empty tiles are written as zeros (dV / dK read whole k-ranges)
-    for (int tile = wave; tile < 9; tile += 4) {
+    for (int tile = wave; tile < 9; tile += AS_NW) {
         const int it = tile / 3, jt = tile % 3;
         if (it >= ntile || jt >= ntile) continue;
         f32x16 acc;
@@ -910,7 +927,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int tile = wave; tile < 3 * (C / 32); tile += 4) {           // dV[j][c] = sum_i P[i][j] dO[i][c]
+    for (int tile = wave; tile < 3 * (C / 32); tile += AS_NW) {           // dV[j][c] = sum_i P[i][j] dO[i][c]
         const int jt = tile / (C / 32), ct = tile % (C / 32);
         if (jt >= ntile) continue;
         f32x16 acc;
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int tile = wave; tile < 9; tile += 4) {                      // dS = P (dO V^T - delta) scale, in place
+    for (int tile = wave; tile < 9; tile += AS_NW) {                      // dS = P (dO V^T - delta) scale, in place
         const int it = tile / 3, jt = tile % 3;
         if (it >= ntile || jt >= ntile || (causal && jt > it)) continue;
         f32x16 acc;
@@ -939,7 +956,7 @@ __global__ __launch_bounds__(256) void k_attn_seq_bwd(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int tile = wave; tile < 6 * (C / 32); tile += 4) {           // dQ = dS K  and  dK = dS^T Q
+    for (int tile = wave; tile < 6 * (C / 32); tile += AS_NW) {           // dQ = dS K  and  dK = dS^T Q
         const bool is_q = tile < 3 * (C / 32);
         const int tt = is_q ? tile : tile - 3 * (C / 32);
         const int rt = tt / (C / 32), ct = tt % (C / 32);
@@ -973,7 +990,7 @@ extern "C" int mil_attn_seq_fwd(const float* q, const float* k, const float* v, 
     if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     const float scale = 1.0f / sqrtf((float)C);
-    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_fwd<CC>), dim3(B, H), dim3(256), 0, (hipStream_t)stream, q, k, v, q_off, H,
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_fwd<CC>), dim3(B, H), dim3(AS_THREADS), 0, (hipStream_t)stream, q, k, v, q_off, H,
                                      causal, scale, o, lse));
     MIL_CHECK_LAUNCH();
     return MIL_OK;
@@ -986,7 +1003,7 @@ extern "C" int mil_attn_seq_bwd(const float* q, const float* k, const float* v, 
     if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     const float scale = 1.0f / sqrtf((float)C);
-    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_bwd<CC>), dim3(B, H), dim3(256), 0, (hipStream_t)stream, q, k, v, o, dout,
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_bwd<CC>), dim3(B, H), dim3(AS_THREADS), 0, (hipStream_t)stream, q, k, v, o, dout,
                                      lse, q_off, H, causal, scale, dq, dk, dv));
     MIL_CHECK_LAUNCH();
     return MIL_OK;
