@@ -240,12 +240,13 @@ int mil_attn_pool_bwd_mh(const float* q, const float* k, const float* v, const f
  * clip/model.py:324-330 if causal != 0 - the CLIP text blocks (clip/model.py:171-184), forward and, for learnable
  * prompts (model/dim1/CLIP.py:29-62), backward.  One workgroup per (sequence, head): the head's q / k / v rows are
  * staged in LDS and every product runs on fp32 MFMA.  lse [Tq, H] is written by the forward (nullable) and read by
- * the backward. */
-int mil_attn_seq_fwd(const float* q, const float* k, const float* v, const int32_t* q_off, int B, int Tmax, int H, int C,
-                     int causal, float* o, float* lse, void* stream);
-int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+ * the backward.  q, k, v rows are ld floats apart (ld = 3 H C when they are the column blocks of one packed
+ * in_proj output, clip/model.py:171-178), dq, dk, dv rows ldd floats; o, dout, lse are dense. */
+int mil_attn_seq_fwd(const float* q, const float* k, const float* v, int ld, const int32_t* q_off, int B, int Tmax, int H,
+                     int C, int causal, float* o, float* lse, void* stream);
+int mil_attn_seq_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout,
                      const float* lse, const int32_t* q_off, int B, int Tmax, int H, int C, int causal, float* dq,
-                     float* dk, float* dv, void* stream);
+                     float* dk, float* dv, int ldd, void* stream);
 /* QuickGELU x*sigmoid(1.702x) (clip/model.py:162-164): out = act(x) if dy == NULL, else out = dy * act'(x). */
 int mil_quickgelu(const float* x, const float* dy, float* out, size_t n, void* stream);
 /* ---- one-text-token form of the token->image attention (sam/transformer.py:291-295,113-118 with T = 1) -------

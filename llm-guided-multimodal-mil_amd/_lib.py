@@ -58,8 +58,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_attn_rows_bwd": (c_int, [_P] * 9 + [c_int] * 4 + [_P] * 4 + [_P]),
     "mil_attn_pool_fwd_mh": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
     "mil_attn_pool_bwd_mh": (c_int, [_P] * 9 + [c_int] * 5 + [_P] * 4 + [_P]),
-    "mil_attn_seq_fwd": (c_int, [_P] * 4 + [c_int] * 5 + [_P, _P, _P]),
-    "mil_attn_seq_bwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P] * 3 + [_P]),
+    "mil_attn_seq_fwd": (c_int, [_P] * 3 + [c_int, _P] + [c_int] * 5 + [_P, _P, _P]),
+    "mil_attn_seq_bwd": (c_int, [_P] * 3 + [c_int] + [_P] * 4 + [c_int] * 5 + [_P] * 3 + [c_int, _P]),
     "mil_quickgelu": (c_int, [_P, _P, _P, c_size_t, _P]),
     "mil_absorb_query": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_absorb_query_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

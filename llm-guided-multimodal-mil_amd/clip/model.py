@@ -36,10 +36,14 @@ class ResidualAttentionBlock(nn.Module):
         W = x.shape[1]
         h = ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        q = ops.linear_act(h, w[:W], b[:W])
-        k = ops.linear_act(h, w[W:2 * W], b[W:2 * W])
-        v = ops.linear_act(h, w[2 * W:], b[2 * W:])
-        o = ops.attention_rows(q, k, v, segs, self.n_head, causal=True)
+        if ops.seq_attention_ok(segs):
+            # one in_proj GEMM of width 3 W; the attention kernels read its column blocks in place
+            o = ops.attention_seq_packed(ops.linear_act(h, w, b), segs, self.n_head, causal=True)
+        else:
+            q = ops.linear_act(h, w[:W], b[:W])
+            k = ops.linear_act(h, w[W:2 * W], b[W:2 * W])
+            v = ops.linear_act(h, w[2 * W:], b[2 * W:])
+            o = ops.attention_rows(q, k, v, segs, self.n_head, causal=True)
         x = ops.linear_act(o, self.attn.out_proj.weight, self.attn.out_proj.bias, "none", residual=x)
         h = ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
         h = ops.linear_act(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "quickgelu")

@@ -794,14 +794,14 @@ struct SeqTiles {
             for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[jj], fb[jj], acc, 0, 0, 0);
         }
     }
-    // stage rows [r0, r0 + T) of head h (C floats each, row stride I) as [96][RS], zero beyond T, times mul
-    static __device__ __forceinline__ void stage(const float* __restrict__ src, int r0, int T, int I, int hoff, float mul,
+    // stage rows [r0, r0 + T) of head h (C floats each, row stride ld) as [96][RS], zero beyond T, times mul
+    static __device__ __forceinline__ void stage(const float* __restrict__ src, int r0, int T, int ld, int hoff, float mul,
                                                  float* dst, int tid) {
 #pragma unroll
         for (int idx = tid; idx < AS_MAXT * (C / 4); idx += AS_THREADS) {
             const int row = idx / (C / 4), c4 = idx % (C / 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < T) v = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + row) * I + hoff + 4 * c4) * mul;
+            if (row < T) v = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + row) * ld + hoff + 4 * c4) * mul;
             *reinterpret_cast<f32x4*>(dst + row * RS + 4 * c4) = v;
         }
     }
@@ -809,9 +809,9 @@ struct SeqTiles {
 
 template <int C>
 __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_fwd(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, const int32_t* __restrict__ q_off,
-                                                      int H, int causal, float scale, float* __restrict__ o,
-                                                      float* __restrict__ lse) {
+                                                      const float* __restrict__ v, int ld,
+                                                      const int32_t* __restrict__ q_off, int H, int causal, float scale,
+                                                      float* __restrict__ o, float* __restrict__ lse) {
     using TL = SeqTiles<C>;
     constexpr int RS = TL::RS;
     // the score image overlays q and k once every wave holds its S tiles in registers (2 x 26 KB >= 38 KB): 78 KB per
@@ -827,9 +827,9 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_fwd(const float* __rest
     const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, I = H * C;
     const int r = lane & 31, h = lane >> 5;
     const int r0 = q_off[b], T = q_off[b + 1] - r0;
-    TL::stage(q, r0, T, I, hh * C, scale, qs, tid);
-    TL::stage(k, r0, T, I, hh * C, 1.f, ks, tid);
-    TL::stage(v, r0, T, I, hh * C, 1.f, vs, tid);
+    TL::stage(q, r0, T, ld, hh * C, scale, qs, tid);
+    TL::stage(k, r0, T, ld, hh * C, 1.f, ks, tid);
+    TL::stage(v, r0, T, ld, hh * C, 1.f, vs, tid);
     __syncthreads();
     const int ntile = (T + 31) / 32;
     f32x16 sacc[2];                          // tiles wave and wave + 8 of the 3 x 3 score grid
@@ -885,11 +885,11 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_fwd(const float* __rest
 //   dV = P^T dO;  dP = dO V^T;  dS = P (dP - delta) scale;  dQ = dS K;  dK = dS^T Q,   delta_i = dO_i . O_i
 template <int C>
 __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_bwd(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, const float* __restrict__ o,
+                                                      const float* __restrict__ v, int ld, const float* __restrict__ o,
                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                       const int32_t* __restrict__ q_off, int H, int causal, float scale,
                                                       float* __restrict__ dq, float* __restrict__ dk,
-                                                      float* __restrict__ dv) {
+                                                      float* __restrict__ dv, int ldd) {
     using TL = SeqTiles<C>;
     constexpr int RS = TL::RS;
     __shared__ __attribute__((aligned(16))) float qs[AS_MAXT * RS], ks[AS_MAXT * RS], vs[AS_MAXT * RS], dos[AS_MAXT * RS];
@@ -898,9 +898,9 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_bwd(const float* __rest
     const int b = blockIdx.x, hh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, I = H * C;
     const int r = lane & 31, h = lane >> 5;
     const int r0 = q_off[b], T = q_off[b + 1] - r0;
-    TL::stage(q, r0, T, I, hh * C, 1.f, qs, tid);
-    TL::stage(k, r0, T, I, hh * C, 1.f, ks, tid);
-    TL::stage(v, r0, T, I, hh * C, 1.f, vs, tid);
+    TL::stage(q, r0, T, ld, hh * C, 1.f, qs, tid);
+    TL::stage(k, r0, T, ld, hh * C, 1.f, ks, tid);
+    TL::stage(v, r0, T, ld, hh * C, 1.f, vs, tid);
     TL::stage(dout, r0, T, I, hh * C, 1.f, dos, tid);
     for (int i = wave; i < AS_MAXT; i += AS_NW) {
         float d = 0.f;
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_bwd(const float* __rest
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = 32 * jt + mfma32_row(i, h);
-            if (row < T) dv[(size_t)(r0 + row) * I + hh * C + 32 * ct + r] = acc[i];
+            if (row < T) dv[(size_t)(r0 + row) * ldd + hh * C + 32 * ct + r] = acc[i];
         }
     }
     __syncthreads();
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_seq_bwd(const float* __rest
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = 32 * rt + mfma32_row(i, h);
-            if (row < T) dst[(size_t)(r0 + row) * I + hh * C + 32 * ct + r] = acc[i];
+            if (row < T) dst[(size_t)(r0 + row) * ldd + hh * C + 32 * ct + r] = acc[i];
         }
     }
 }
@@ -984,27 +984,28 @@ __global__ __launch_bounds__(256) void k_quickgelu(const float* __restrict__ x, 
     out[i] = dy == nullptr ? xv * s : dy[i] * s * (1.0f + 1.702f * xv * (1.0f - s));
 }
 
-extern "C" int mil_attn_seq_fwd(const float* q, const float* k, const float* v, const int32_t* q_off, int B, int Tmax, int H,
-                                int C, int causal, float* o, float* lse, void* stream) {
+extern "C" int mil_attn_seq_fwd(const float* q, const float* k, const float* v, int ld, const int32_t* q_off, int B, int Tmax,
+                                int H, int C, int causal, float* o, float* lse, void* stream) {
     if (!q || !k || !v || !q_off || !o) return MIL_EINVAL;
-    if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT || ld < H * C || (ld & 3)) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     const float scale = 1.0f / sqrtf((float)C);
-    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_fwd<CC>), dim3(B, H), dim3(AS_THREADS), 0, (hipStream_t)stream, q, k, v, q_off, H,
-                                     causal, scale, o, lse));
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_fwd<CC>), dim3(B, H), dim3(AS_THREADS), 0, (hipStream_t)stream, q, k, v, ld, q_off,
+                                     H, causal, scale, o, lse));
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
-extern "C" int mil_attn_seq_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+extern "C" int mil_attn_seq_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout,
                                 const float* lse, const int32_t* q_off, int B, int Tmax, int H, int C, int causal,
-                                float* dq, float* dk, float* dv, void* stream) {
+                                float* dq, float* dk, float* dv, int ldd, void* stream) {
     if (!q || !k || !v || !o || !dout || !lse || !q_off || !dq || !dk || !dv) return MIL_EINVAL;
     if ((C != 32 && C != 64) || H <= 0 || B < 0 || Tmax <= 0 || Tmax > AS_MAXT) return MIL_EINVAL;
+    if (ld < H * C || (ld & 3) || ldd < H * C) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     const float scale = 1.0f / sqrtf((float)C);
-    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_bwd<CC>), dim3(B, H), dim3(AS_THREADS), 0, (hipStream_t)stream, q, k, v, o, dout,
-                                     lse, q_off, H, causal, scale, dq, dk, dv));
+    DISPATCH_C(C, hipLaunchKernelGGL((k_attn_seq_bwd<CC>), dim3(B, H), dim3(AS_THREADS), 0, (hipStream_t)stream, q, k, v, ld, o,
+                                     dout, lse, q_off, H, causal, scale, dq, dk, dv, ldd));
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

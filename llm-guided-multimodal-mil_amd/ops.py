@@ -454,7 +454,7 @@ class _AttnRows(torch.autograd.Function):
         lse = torch.empty((Tq, H), device=q.device, dtype=torch.float32)
         if 16 < segs.Tk_max <= SEQ_MAX_TOKENS and segs.q_lengths == segs.k_lengths:
             # whole-sequence self-attention (CLIP text blocks): LDS-staged heads on MFMA, one workgroup per (sequence, head)
-            rc = _lib.lib().mil_attn_seq_fwd(_p(q), _p(k), _p(v), _p(segs.q_off), segs.B, segs.Tq_max, H, C,
+            rc = _lib.lib().mil_attn_seq_fwd(_p(q), _p(k), _p(v), I, _p(segs.q_off), segs.B, segs.Tq_max, H, C,
                                              1 if causal else 0, _p(o), _p(lse), _stream())
             _lib.check(rc, "mil_attn_seq_fwd")
         else:
@@ -477,8 +477,9 @@ class _AttnRows(torch.autograd.Function):
                 raise _lib.MilHipError("attention backward: > 16 keys per bag is only supported for self-attention over "
                                        f"sequences of <= {SEQ_MAX_TOKENS} tokens")
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            rc = _lib.lib().mil_attn_seq_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.q_off), segs.B,
-                                             segs.Tq_max, H, C, 1 if ctx.causal else 0, _p(dq), _p(dk), _p(dv), _stream())
+            rc = _lib.lib().mil_attn_seq_bwd(_p(q), _p(k), _p(v), I, _p(o), _p(do), _p(lse), _p(segs.q_off), segs.B,
+                                             segs.Tq_max, H, C, 1 if ctx.causal else 0, _p(dq), _p(dk), _p(dv), I,
+                                             _stream())
             _lib.check(rc, "mil_attn_seq_bwd")
             return dq, dk, dv, None, None, None
         dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
@@ -492,6 +493,51 @@ class _AttnRows(torch.autograd.Function):
 
 def attention_rows(q, k, v, segs, H: int, causal: bool = False):
     return _AttnRows.apply(q, k, v, segs, H, causal)
+
+
+class _AttnSeqPacked(torch.autograd.Function):
+    """Whole-sequence self-attention on the PACKED in_proj output qkv [rows, 3 W] (clip/model.py:171-178: one
+    nn.MultiheadAttention in_proj of width 3 W): the kernels read q / k / v as column blocks (row stride 3 W) and the
+    backward writes dq | dk | dv into one [rows, 3 W] tensor, so the projection and its backward are ONE GEMM each."""
+
+    @staticmethod
+    def forward(ctx, qkv, segs, H: int, causal: bool):
+        qkv = _f32c(qkv, "qkv")
+        rows, W3 = qkv.shape
+        W = W3 // 3
+        C = _head_dim(W, H)
+        o = torch.empty((rows, W), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((rows, H), device=qkv.device, dtype=torch.float32)
+        base = qkv.data_ptr()
+        rc = _lib.lib().mil_attn_seq_fwd(base, base + 4 * W, base + 8 * W, W3, _p(segs.q_off), segs.B, segs.Tq_max, H, C,
+                                         1 if causal else 0, _p(o), _p(lse), _stream())
+        _lib.check(rc, "mil_attn_seq_fwd")
+        ctx.segs, ctx.H, ctx.C, ctx.causal = segs, H, C, causal
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        segs, H, C = ctx.segs, ctx.H, ctx.C
+        W3 = qkv.shape[1]
+        W = W3 // 3
+        do = _f32c(do, "do")
+        dqkv = torch.empty_like(qkv)
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        rc = _lib.lib().mil_attn_seq_bwd(base, base + 4 * W, base + 8 * W, W3, _p(o), _p(do), _p(lse), _p(segs.q_off),
+                                         segs.B, segs.Tq_max, H, C, 1 if ctx.causal else 0, dbase, dbase + 4 * W,
+                                         dbase + 8 * W, W3, _stream())
+        _lib.check(rc, "mil_attn_seq_bwd")
+        return dqkv, None, None, None
+
+
+def seq_attention_ok(segs) -> bool:
+    return 16 < segs.Tk_max <= SEQ_MAX_TOKENS and segs.q_lengths == segs.k_lengths
+
+
+def attention_seq_packed(qkv, segs, H: int, causal: bool = False):
+    return _AttnSeqPacked.apply(qkv, segs, H, causal)
 
 
 class _AttnPool(torch.autograd.Function):
