@@ -270,9 +270,42 @@ static int splitk_plan(int M, int N, int K, int a_mode, int* kchunk_out) {
     return S;
 }
 
+// Tile quantisation of a tall product (a_mode 0): with two 128 x 128 workgroups per CU a launch runs in rounds of 512
+// tiles, and a last round that is mostly empty still costs a whole round (M = 24 640 text-tower rows x N = 512:
+// 772 tiles = 1.5 rounds -> 2).  The rows of that last partial round are issued as a second launch with split-K
+// chosen to fill the round (772 -> 512 + 260 x 2), its partials folded by k_splitk_reduce with the epilogue.
+static bool tail_plan(int M, int N, int K, int a_mode, int* rows_main, int* S_out, int* kchunk_out) {
+    if (a_mode != 0) return false;
+    const int slots = 2 * MIL_NUM_CU;
+    const int ct = (N + 127) / 128, rt = (M + 127) / 128;
+    if (ct > slots || (long)rt * ct <= slots) return false;
+    const int per_round = slots / ct;
+    const int rem_rt = rt % per_round;
+    if (rem_rt == 0) return false;
+    const int tiles_rem = rem_rt * ct;
+    if (10 * tiles_rem > 7 * slots) return false;          // the last round is already mostly full
+    // split factor: the tail then takes ceil(tiles_rem S / slots) / S of a round, plus the partial-sum traffic
+    // (charged 0.04 of a round per split: 17 MB written and read per split at M_tail = 8 K rows, N = 512)
+    int S = 1;
+    float best = 1.0f;
+    for (int c = 2; c <= 8 && c <= K / 64; ++c) {
+        const float cost = (float)((tiles_rem * c + slots - 1) / slots) / (float)c + 0.04f * (float)c;
+        if (cost < best - 0.05f) { best = cost; S = c; }
+    }
+    if (S < 2) return false;
+    const int kchunk = ((K + S - 1) / S + LG_BK - 1) / LG_BK * LG_BK;
+    S = (K + kchunk - 1) / kchunk;
+    if (S < 2) return false;
+    *rows_main = (rt - rem_rt) * 128;
+    *S_out = S;
+    *kchunk_out = kchunk;
+    return true;
+}
+
 extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    int kchunk;
+    int kchunk, rows_main, S_tail;
+    if (tail_plan(M, N, K, a_mode, &rows_main, &S_tail, &kchunk)) return (size_t)S_tail * (M - rows_main) * N;
     const int S = splitk_plan(M, N, K, a_mode, &kchunk);
     return S > 1 ? (size_t)S * M * N : 0;
 }
@@ -289,6 +322,31 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
     if (b_mode == 1 && (N < 4 || (N & 3))) return MIL_EINVAL;
     if (a_mode == 1 && b_mode == 0) return MIL_EINVAL;             // TT form is never needed
     hipStream_t st = (hipStream_t)stream;
+    {
+        int rows_main, S_tail, kc_tail;
+        if (workspace != nullptr && tail_plan(M, N, K, a_mode, &rows_main, &S_tail, &kc_tail) &&
+            workspace_floats >= (size_t)S_tail * (M - rows_main) * N) {
+            // whole rounds without split-K, then the rows of the last partial round with split-K
+            int rc = mil_gemm(A, lda, a_mode, B, ldb, b_mode, C, ldc, rows_main, N, K, bias, act, residual, ldr, accumulate,
+                              nullptr, 0, stream);
+            if (rc != MIL_OK) return rc;
+            const int Mt = M - rows_main;
+            const float* At = A + (size_t)rows_main * lda;
+            float* Ct = C + (size_t)rows_main * ldc;
+            const float* Rt = residual ? residual + (size_t)rows_main * ldr : nullptr;
+            const dim3 gridt((N + 127) / 128, (Mt + 127) / 128, S_tail);
+            if (b_mode == 0)
+                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace);
+            else
+                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace);
+            MIL_CHECK_LAUNCH();
+            const size_t n = (size_t)Mt * N;
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, S_tail, Ct, ldc,
+                               Mt, N, bias, act, Rt, ldr, accumulate);
+            MIL_CHECK_LAUNCH();
+            return MIL_OK;
+        }
+    }
     int S = 1, kchunk = K;
     float* partial = nullptr;
     if (workspace != nullptr) {

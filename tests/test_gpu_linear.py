@@ -47,3 +47,22 @@ def test_linear_residual_and_accumulate():
     out = torch.ones(50, 512, device=dev)
     ops.gemm(xd.detach(), 0, Wd.detach(), 0, 50, 512, 256, out=out, accumulate=True)
     assert rel_err(out.cpu(), x @ W.t() + 1) <= 2e-6
+
+
+@pytest.mark.parametrize("b_mode", [0, 1])
+def test_tall_gemm_with_a_split_last_round(b_mode):
+    """M x N tiles = 592 = one round of 512 + 80: the last 20 row tiles run as a second launch with split-K and the
+    epilogue in the reduce kernel; the result must not depend on that plan."""
+    from mil_amd import ops, _lib
+    M, N, K = 128 * 148 - 37, 512, 256
+    assert _lib.lib().mil_gemm_workspace_floats(M, N, K, 0) > 0
+    g = torch.Generator().manual_seed(b_mode)
+    A = torch.randn((M, K), generator=g)
+    B = torch.randn((N, K) if b_mode == 0 else (K, N), generator=g) / K ** 0.5
+    bias = torch.randn((N,), generator=g)
+    res = torch.randn((M, N), generator=g)
+    ref = A @ (B.t() if b_mode == 0 else B) + bias + res
+    out = ops.gemm(A.cuda(), 0, B.cuda(), b_mode, M, N, K, bias=bias.cuda(), act=0, residual=res.cuda())
+    assert rel_err(out.cpu(), ref) <= 2e-6
+    plain = ops.gemm(A.cuda(), 0, B.cuda(), b_mode, M, N, K, bias=bias.cuda(), act=0, residual=res.cuda(), split_k=False)
+    assert rel_err(out.cpu(), plain.cpu()) <= 2e-6
