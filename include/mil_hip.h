@@ -188,6 +188,13 @@ size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
              int accumulate, float* workspace, size_t workspace_floats, void* stream);
+/* mil_gemm (a_mode 0) with one auxiliary [M, N] tensor touched in the epilogue:
+ *   aux_mode 1: aux = the pre-activation (product + bias, before act) is stored too - QuickGELU's backward needs it;
+ *   aux_mode 2: the result is multiplied by QuickGELU'(aux) - the activation backward of clip/model.py:162-164 fused
+ *               into the product that forms the gradient w.r.t. the activation output. */
+int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M, int N,
+                 int K, const float* bias, int act, const float* residual, int ldr, int accumulate, float* workspace,
+                 size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream);
 /* out[j] (+)= sum_i Y[i][j]  (bias gradients).  With a workspace of mil_colsum_workspace_floats(M, N) floats
  * a tall matrix is summed in 256-row chunks by many workgroups and folded in a second launch (fixed order). */
 size_t mil_colsum_workspace_floats(int M, int N);

@@ -48,6 +48,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
+    "mil_gemm_aux": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
+                         _P, c_size_t, _P, c_int, c_int, _P]),
     "mil_colsum_workspace_floats": (c_size_t, [c_int, c_int]),
     "mil_colsum": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "mil_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),

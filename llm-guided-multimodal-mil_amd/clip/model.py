@@ -46,8 +46,8 @@ class ResidualAttentionBlock(nn.Module):
             o = ops.attention_rows(q, k, v, segs, self.n_head, causal=True)
         x = ops.linear_act(o, self.attn.out_proj.weight, self.attn.out_proj.bias, "none", residual=x)
         h = ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
-        h = ops.linear_act(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "quickgelu")
-        return ops.linear_act(h, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "none", residual=x)
+        return ops.mlp_quickgelu(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias,
+                                 residual=x)
 
 
 class Transformer(nn.Module):

@@ -23,6 +23,21 @@
 
 enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_QUICKGELU = 3 };
 
+// aux_mode 1: also store the pre-activation (bias added, before act) to aux - the backward of QuickGELU needs it;
+// aux_mode 2: multiply by QuickGELU'(aux[row][j]) - the activation backward fused into the epilogue of the product
+// that forms the gradient (clip/model.py:162-164 inside the MLP of :176-178).
+enum { AUX_NONE = 0, AUX_STORE_PRE = 1, AUX_MUL_DGELU = 2 };
+__device__ __forceinline__ float epilogue_aux(float v, float* __restrict__ aux, int ldaux, int aux_mode, int row, int j) {
+    if (aux_mode == AUX_STORE_PRE) {
+        aux[(size_t)row * ldaux + j] = v;
+    } else if (aux_mode == AUX_MUL_DGELU) {
+        const float p = aux[(size_t)row * ldaux + j];
+        const float sg = 1.0f / (1.0f + expf(-1.702f * p));
+        v *= sg * (1.0f + 1.702f * p * (1.0f - sg));
+    }
+    return v;
+}
+
 template <int MODE>
 struct OperandTile {
     // MODE 0: [128 rows][32 k] from row-major src (k contiguous);  MODE 1: [32 k][128 cols] from k-major src.
@@ -71,7 +86,8 @@ template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K, int kchunk,
                                               const float* __restrict__ bias, int act, const float* __restrict__ residual,
-                                              int ldr, int accumulate, float* __restrict__ partial) {
+                                              int ldr, int accumulate, float* __restrict__ partial,
+                                              float* __restrict__ aux, int ldaux, int aux_mode) {
     constexpr int ASZ = AMODE == 0 ? 128 * LG_KS : LG_BK * 128;
     constexpr int BSZ = BMODE == 0 ? 128 * LG_KS : LG_BK * 128;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
@@ -160,7 +176,9 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
         __syncthreads();
     }
 
-    // epilogue: lane holds column j, 16 rows per tile
+    // epilogue: lane holds column j, 16 rows per tile.  The residual / auxiliary / accumulate operands of a tile are
+    // loaded as one batch of 16 (clamped rows, no branches) before any arithmetic, so their latency is paid once per
+    // tile instead of once per element.
     const bool split = partial != nullptr;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -168,38 +186,56 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
         if (j >= N) continue;
         const float bj = (!split && bias != nullptr) ? bias[j] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            const int rbase = i0 + 64 * wi + 32 * a;
+            if (split) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = rbase + mfma32_row(i, h);
+                    if (row < M) partial[((size_t)blockIdx.z * M + row) * N + j] = acc[a][b][i];
+                }
+                continue;
+            }
+            float rv[16], pv[16], cv[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = i0 + 64 * wi + 32 * a + mfma32_row(i, h);
+                const int rc = min(rbase + mfma32_row(i, h), M - 1);
+                rv[i] = residual != nullptr ? residual[(size_t)rc * ldr + j] : 0.f;
+                pv[i] = aux_mode == AUX_MUL_DGELU ? aux[(size_t)rc * ldaux + j] : 0.f;
+                cv[i] = accumulate ? C[(size_t)rc * ldc + j] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = rbase + mfma32_row(i, h);
                 if (row >= M) continue;
-                float v = acc[a][b][i];
-                if (split) {
-                    partial[((size_t)blockIdx.z * M + row) * N + j] = v;
-                    continue;
+                float v = acc[a][b][i] + bj;
+                if (aux_mode == AUX_STORE_PRE) {
+                    aux[(size_t)row * ldaux + j] = v;
+                } else if (aux_mode == AUX_MUL_DGELU) {
+                    const float sg = 1.0f / (1.0f + __expf(-1.702f * pv[i]));
+                    v *= sg * (1.0f + 1.702f * pv[i] * (1.0f - sg));
                 }
-                v += bj;
                 if (act == ACT_TANH) v = tanhf(v);
                 else if (act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (act == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
-                if (residual != nullptr) v += residual[(size_t)row * ldr + j];
-                float* o = C + (size_t)row * ldc + j;
-                if (accumulate) v += *o;
-                *o = v;
+                C[(size_t)row * ldc + j] = v + rv[i] + cv[i];
             }
+        }
     }
 }
 
 // split-K reduce with the full epilogue: C (+)= act(sum_s partial[s] + bias) + residual
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int S, float* __restrict__ C,
                                                        int ldc, int M, int N, const float* __restrict__ bias, int act,
-                                                       const float* __restrict__ residual, int ldr, int accumulate) {
+                                                       const float* __restrict__ residual, int ldr, int accumulate,
+                                                       float* __restrict__ aux, int ldaux, int aux_mode) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)M * N) return;
     const int row = (int)(idx / N), j = (int)(idx % N);
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += partial[((size_t)s * M + row) * N + j];
     if (bias != nullptr) v += bias[j];
+    v = epilogue_aux(v, aux, ldaux, aux_mode, row, j);
     if (act == ACT_TANH) v = tanhf(v);
     else if (act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
@@ -310,9 +346,9 @@ extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
     return S > 1 ? (size_t)S * M * N : 0;
 }
 
-extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
-                        int M, int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
-                        float* workspace, size_t workspace_floats, void* stream) {
+static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M,
+                     int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
+                     float* workspace, size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return MIL_EINVAL;
     if (M == 0 || N == 0) return MIL_OK;
     if ((lda & 3) || (ldb & 3) || act < 0 || act > 3) return MIL_EINVAL;
@@ -327,22 +363,23 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
         if (workspace != nullptr && tail_plan(M, N, K, a_mode, &rows_main, &S_tail, &kc_tail) &&
             workspace_floats >= (size_t)S_tail * (M - rows_main) * N) {
             // whole rounds without split-K, then the rows of the last partial round with split-K
-            int rc = mil_gemm(A, lda, a_mode, B, ldb, b_mode, C, ldc, rows_main, N, K, bias, act, residual, ldr, accumulate,
-                              nullptr, 0, stream);
+            int rc = gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, rows_main, N, K, bias, act, residual, ldr, accumulate,
+                               nullptr, 0, aux, ldaux, aux_mode, stream);
             if (rc != MIL_OK) return rc;
             const int Mt = M - rows_main;
             const float* At = A + (size_t)rows_main * lda;
             float* Ct = C + (size_t)rows_main * ldc;
             const float* Rt = residual ? residual + (size_t)rows_main * ldr : nullptr;
+            float* Xt = aux ? aux + (size_t)rows_main * ldaux : nullptr;
             const dim3 gridt((N + 127) / 128, (Mt + 127) / 128, S_tail);
             if (b_mode == 0)
-                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace);
+                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode);
             else
-                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace);
+                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode);
             MIL_CHECK_LAUNCH();
             const size_t n = (size_t)Mt * N;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, S_tail, Ct, ldc,
-                               Mt, N, bias, act, Rt, ldr, accumulate);
+                               Mt, N, bias, act, Rt, ldr, accumulate, Xt, ldaux, aux_mode);
             MIL_CHECK_LAUNCH();
             return MIL_OK;
         }
@@ -356,19 +393,36 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
     }
     dim3 grid((N + 127) / 128, (M + 127) / 128, S);
     if (a_mode == 0 && b_mode == 0)
-        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial);
+        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode);
     else if (a_mode == 0 && b_mode == 1)
-        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial);
+        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode);
     else
-        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial);
+        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode);
     MIL_CHECK_LAUNCH();
     if (partial != nullptr) {
         const size_t n = (size_t)M * N;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, S, C, ldc, M, N,
-                           bias, act, residual, ldr, accumulate);
+                           bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
+}
+
+extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                        int M, int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
+                        float* workspace, size_t workspace_floats, void* stream) {
+    return gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
+                     workspace_floats, nullptr, 0, AUX_NONE, stream);
+}
+
+extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                            int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
+                            int accumulate, float* workspace, size_t workspace_floats, float* aux, int ldaux, int aux_mode,
+                            void* stream) {
+    if (aux_mode < 0 || aux_mode > 2 || (aux_mode != AUX_NONE && (!aux || ldaux < N)) || (aux_mode != AUX_NONE && a_mode != 0))
+        return MIL_EINVAL;
+    return gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
+                     workspace_floats, aux, ldaux, aux_mode, stream);
 }
 
 extern "C" size_t mil_colsum_workspace_floats(int M, int N) {

@@ -299,6 +299,20 @@ def gemm(A, a_mode: int, B, b_mode: int, M: int, N: int, K: int, out=None, bias=
     return out
 
 
+def gemm_aux(A, B, b_mode: int, M: int, N: int, K: int, aux, aux_mode: int, bias=None, act: int = 0, residual=None):
+    """C = act(A . B_op + bias) + residual with one auxiliary [M, N] tensor handled in the epilogue
+    (include/mil_hip.h: mil_gemm_aux; aux_mode 1 = store the pre-activation, 2 = multiply by QuickGELU'(aux))."""
+    A, B = _f32c(A, "A"), _f32c(B, "B")
+    out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    nws = _lib.lib().mil_gemm_workspace_floats(M, N, K, 0)
+    ws = torch.empty(nws, device=A.device, dtype=torch.float32) if nws else None
+    rc = _lib.lib().mil_gemm_aux(_p(A), A.stride(0), 0, _p(B), B.stride(0), b_mode, _p(out), out.stride(0), M, N, K,
+                                 _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0, 0,
+                                 _p(ws), nws, _p(aux), aux.stride(0), aux_mode, _stream())
+    _lib.check(rc, "mil_gemm_aux")
+    return out
+
+
 def colsum(Y, out=None, accumulate: bool = False):
     M, N = Y.shape
     if out is None:
@@ -421,6 +435,53 @@ class _LinearAct(torch.autograd.Function):
         db = colsum(dpre, out=b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res else None
         return dx, dW, db, None, dres
+
+
+class _MlpQuickGelu(torch.autograd.Function):
+    """x + c_proj(QuickGELU(c_fc(x_ln)))  (clip/model.py:176-178,196-198) as one autograd node: the c_fc product stores
+    its pre-activation from the epilogue, and in the backward the product dout . W2 is multiplied by QuickGELU' in its
+    epilogue - no stand-alone activation forward / backward passes over the [rows, 4 W] tensors."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, residual):
+        x, W1, W2 = _f32c(x, "x"), _f32c(W1, "W1"), _f32c(W2, "W2")
+        M, K = x.shape
+        N1 = W1.shape[0]
+        need = any(ctx.needs_input_grad[:5])
+        if need:
+            pre = torch.empty((M, N1), device=x.device, dtype=torch.float32)
+            h = gemm_aux(x, W1, 0, M, N1, K, pre, 1, bias=b1, act=ACT["quickgelu"])
+        else:
+            pre = None
+            h = gemm(x, 0, W1, 0, M, N1, K, bias=b1, act=ACT["quickgelu"])
+        out = gemm(h, 0, W2, 0, M, W2.shape[0], N1, bias=b2, residual=_f32c(residual, "residual") if residual is not None else None)
+        ctx.has_res = residual is not None
+        keep_h = ctx.needs_input_grad[3]
+        ctx.save_for_backward(x, W1, W2, pre, h if keep_h else None)
+        ctx.params = (b1, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W1, W2, pre, h = ctx.saved_tensors
+        b1, b2 = ctx.params
+        dout = _f32c(dout, "dout")
+        M, K = x.shape
+        N1, N2 = W1.shape[0], W2.shape[0]
+        dpre = gemm_aux(dout, W2, 1, M, N1, N2, pre, 2)                      # (dout . W2) * QuickGELU'(pre)
+        dx = gemm(dpre, 0, W1, 1, M, K, N1) if ctx.needs_input_grad[0] else None
+        dW1 = gemm(dpre, 1, x, 1, N1, K, M, out=grad_slot(W1)) if ctx.needs_input_grad[1] else None
+        db1 = colsum(dpre, out=grad_slot(b1)) if (b1 is not None and ctx.needs_input_grad[2]) else None
+        dW2 = gemm(dout, 1, h, 1, N2, N1, M, out=grad_slot(W2)) if ctx.needs_input_grad[3] else None
+        db2 = colsum(dout, out=grad_slot(b2)) if (b2 is not None and ctx.needs_input_grad[4]) else None
+        return dx, dW1, db1, dW2, db2, (dout if ctx.has_res else None)
+
+
+def mlp_quickgelu(x, W1, b1, W2, b2, residual=None):
+    """c_proj(QuickGELU(c_fc(x))) + residual; tall inputs take the fused node, a few rows the one-launch kernels."""
+    if x.shape[0] <= SMALL_ROWS:
+        return linear_act(linear_act(x, W1, b1, "quickgelu"), W2, b2, "none", residual=residual)
+    return _MlpQuickGelu.apply(x, W1, b1, W2, b2, residual)
 
 
 def linear_act(x, W, b=None, act: str = "none", residual=None):

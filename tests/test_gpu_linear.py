@@ -66,3 +66,28 @@ def test_tall_gemm_with_a_split_last_round(b_mode):
     assert rel_err(out.cpu(), ref) <= 2e-6
     plain = ops.gemm(A.cuda(), 0, B.cuda(), b_mode, M, N, K, bias=bias.cuda(), act=0, residual=res.cuda(), split_k=False)
     assert rel_err(out.cpu(), plain.cpu()) <= 2e-6
+
+
+def test_fused_quickgelu_mlp_matches_torch():
+    """ops.mlp_quickgelu (tall path): pre-activation stored from the c_fc epilogue, QuickGELU' folded into the epilogue of
+    dout . W2 - forward and every gradient against torch on the host."""
+    from mil_amd import ops
+    M, W = 300, 128
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((M, W), generator=g)
+    W1 = torch.randn((4 * W, W), generator=g) / W ** 0.5
+    b1 = torch.randn((4 * W,), generator=g) * 0.1
+    W2 = torch.randn((W, 4 * W), generator=g) / (4 * W) ** 0.5
+    b2 = torch.randn((W,), generator=g) * 0.1
+    res = torch.randn((M, W), generator=g)
+    go = torch.randn((M, W), generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, W1, b1, W2, b2, res)]
+    pre = ref_in[0] @ ref_in[1].t() + ref_in[2]
+    ref = (pre * torch.sigmoid(1.702 * pre)) @ ref_in[3].t() + ref_in[4] + ref_in[5]
+    ref.backward(go)
+    dev_in = [t.cuda().requires_grad_(True) for t in (x, W1, b1, W2, b2, res)]
+    out = ops.mlp_quickgelu(*dev_in[:5], residual=dev_in[5])
+    out.backward(go.cuda())
+    assert rel_err(out.detach().cpu(), ref.detach()) <= 3e-6
+    for a, b, name in zip(dev_in, ref_in, ("x", "W1", "b1", "W2", "b2", "residual")):
+        assert rel_err(a.grad.cpu(), b.grad) <= 1e-5, name
