@@ -288,6 +288,183 @@ __global__ __launch_bounds__(512) void k_attn_pool_bwd(const float* __restrict__
         if (t < T) pdq[((size_t)blockIdx.x * AT_MAXT + t) * I + j] = dq[t];
 }
 
+// ---- pool form without wave reductions in the key loop (used for all T <= 16; the kernels above remain as the
+// reference implementation of the tiling).  The per-key, per-query dot products over the head's c channels are
+// the expensive part of the shuffle version (80-160 cross-lane steps per key); here they are plain per-thread
+// loops: phase A thread = (key n of the tile, head h) holds that key's c channels in registers and reads the
+// queries from LDS (a wave has one h: broadcast reads), phase B does the softmax statistics of the tile with one
+// wave per (t, h), phase C thread = channel j accumulates over the keys with the probabilities read from LDS as
+// b128 over four keys.  Partials keep the layout of k_attn_pool_fwd / _bwd, so merge and reduce are shared.
+template <int C>
+__global__ __launch_bounds__(512) void k_attn_pool_fwd_lds(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const int32_t* __restrict__ q_off,
+                                                           const int32_t* __restrict__ tile_map, int H, float scale,
+                                                           float* __restrict__ pacc, float* __restrict__ pml) {
+    __shared__ __attribute__((aligned(16))) float lds[AT_MAXT * 512 + 8 * AT_MAXT * 64];     // qs [16][I], sbuf [H][16][64]; I <= 512, H <= 8
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, I = H * C, nw = I >> 6;
+    const int b = tile_map[3 * blockIdx.x], key0 = tile_map[3 * blockIdx.x + 1], nkeys = tile_map[3 * blockIdx.x + 2];
+    const int qb = q_off[b], T = q_off[b + 1] - qb;
+    float* qs = lds;
+    float* sbuf = lds + AT_MAXT * I;
+    for (int idx = tid; idx < T * I; idx += I) qs[idx] = q[(size_t)qb * I + idx] * scale;
+    __syncthreads();
+    // phase A: scores
+    for (int pr = tid; pr < 64 * H; pr += I) {
+        const int n = pr & 63, h = pr >> 6;
+        f32x4 kr[C / 4];
+        const float* krow = k + (size_t)(key0 + min(n, nkeys - 1)) * I + h * C;
+#pragma unroll
+        for (int c = 0; c < C / 4; ++c) kr[c] = *reinterpret_cast<const f32x4*>(krow + 4 * c);
+        for (int t = 0; t < T; ++t) {
+            const float* qt = qs + t * I + h * C;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < C / 4; ++c) {
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qt + 4 * c);
+                s += kr[c][0] * qq[0] + kr[c][1] * qq[1] + kr[c][2] * qq[2] + kr[c][3] * qq[3];
+            }
+            sbuf[(h * AT_MAXT + t) * 64 + n] = n < nkeys ? s : -INFINITY;
+        }
+    }
+    __syncthreads();
+    // phase B: per (t, h) max / sum over the tile's keys, scores -> probabilities
+    for (int it = wave; it < T * H; it += nw) {
+        const int t = it / H, h = it % H;
+        float* sp = sbuf + (h * AT_MAXT + t) * 64;
+        const float sv = sp[lane];
+        const float m = wave_allmax(sv);
+        const float pv = lane < nkeys ? expf(sv - m) : 0.f;
+        const float l = wave_allsum(pv);
+        sp[lane] = pv;
+        if (lane == 0) {
+            pml[(((size_t)blockIdx.x * AT_MAXT + t) * H + h) * 2] = m;
+            pml[(((size_t)blockIdx.x * AT_MAXT + t) * H + h) * 2 + 1] = l;
+        }
+    }
+    __syncthreads();
+    // phase C: acc[t][j] = sum_n p[t][h][n] v[n][j]
+    const int j = tid, h = j / C;
+    float acc[AT_MAXT];
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) acc[t] = 0.f;
+    for (int n0 = 0; n0 < nkeys; n0 += 4) {
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] = v[(size_t)(key0 + min(n0 + u, nkeys - 1)) * I + j];     // p = 0 beyond nkeys
+#pragma unroll
+        for (int t = 0; t < AT_MAXT; ++t) {
+            if (t < T) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(sbuf + (h * AT_MAXT + t) * 64 + n0);
+                acc[t] += p4[0] * vv[0] + p4[1] * vv[1] + p4[2] * vv[2] + p4[3] * vv[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t)
+        if (t < T) pacc[((size_t)blockIdx.x * AT_MAXT + t) * I + j] = acc[t];
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_attn_pool_bwd_lds(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ o,
+                                                           const float* __restrict__ dout, const float* __restrict__ lse,
+                                                           const int32_t* __restrict__ q_off,
+                                                           const int32_t* __restrict__ tile_map, int H, float scale,
+                                                           float* __restrict__ dk, float* __restrict__ dv,
+                                                           float* __restrict__ pdq) {
+    // qs, dos [16][I]; pbuf, dsbuf [H][16][64]; lsd [16][H][2]   (I <= 512, H <= 8: 129 KB)
+    __shared__ __attribute__((aligned(16))) float lds[2 * AT_MAXT * 512 + 2 * 8 * AT_MAXT * 64 + AT_MAXT * 8 * 2];
+    const int tid = threadIdx.x, I = H * C;
+    const int b = tile_map[3 * blockIdx.x], key0 = tile_map[3 * blockIdx.x + 1], nkeys = tile_map[3 * blockIdx.x + 2];
+    const int qb = q_off[b], T = q_off[b + 1] - qb;
+    float* qs = lds;
+    float* dos = qs + AT_MAXT * I;
+    float* pbuf = dos + AT_MAXT * I;
+    float* dsbuf = pbuf + H * AT_MAXT * 64;
+    float* lsd = dsbuf + H * AT_MAXT * 64;
+    for (int idx = tid; idx < T * I; idx += I) {
+        qs[idx] = q[(size_t)qb * I + idx];
+        dos[idx] = dout[(size_t)qb * I + idx];
+    }
+    {   // delta[t][h] = do_t^h . o_t^h ; thread j contributes one channel, head_allsum folds the head's c lanes
+        const int j = tid, h = j / C;
+        for (int t = 0; t < T; ++t) {
+            const float d = head_allsum<C>(dout[(size_t)(qb + t) * I + j] * o[(size_t)(qb + t) * I + j]);
+            if ((j % C) == 0) {
+                lsd[(t * H + h) * 2] = lse[(size_t)(qb + t) * H + h];
+                lsd[(t * H + h) * 2 + 1] = d;
+            }
+        }
+    }
+    __syncthreads();
+    for (int pr = tid; pr < 64 * H; pr += I) {
+        const int n = pr & 63, h = pr >> 6;
+        f32x4 kr[C / 4], vr[C / 4];
+        const size_t rowoff = (size_t)(key0 + min(n, nkeys - 1)) * I + h * C;
+#pragma unroll
+        for (int c = 0; c < C / 4; ++c) {
+            kr[c] = *reinterpret_cast<const f32x4*>(k + rowoff + 4 * c);
+            vr[c] = *reinterpret_cast<const f32x4*>(v + rowoff + 4 * c);
+        }
+        for (int t = 0; t < T; ++t) {
+            const float* qt = qs + t * I + h * C;
+            const float* dt = dos + t * I + h * C;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < C / 4; ++c) {
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qt + 4 * c);
+                const f32x4 dd = *reinterpret_cast<const f32x4*>(dt + 4 * c);
+                s += kr[c][0] * qq[0] + kr[c][1] * qq[1] + kr[c][2] * qq[2] + kr[c][3] * qq[3];
+                dp += vr[c][0] * dd[0] + vr[c][1] * dd[1] + vr[c][2] * dd[2] + vr[c][3] * dd[3];
+            }
+            const float pv = n < nkeys ? expf(s * scale - lsd[(t * H + h) * 2]) : 0.f;
+            pbuf[(h * AT_MAXT + t) * 64 + n] = pv;
+            dsbuf[(h * AT_MAXT + t) * 64 + n] = pv * (dp - lsd[(t * H + h) * 2 + 1]) * scale;
+        }
+    }
+    __syncthreads();
+    const int j = tid, h = j / C;
+    float qv[AT_MAXT], dov[AT_MAXT], dq[AT_MAXT];
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+        qv[t] = t < T ? qs[t * I + j] : 0.f;
+        dov[t] = t < T ? dos[t * I + j] : 0.f;
+        dq[t] = 0.f;
+    }
+    for (int n0 = 0; n0 < nkeys; n0 += 4) {
+        float kq[4], dkk[4], dvv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kq[u] = k[(size_t)(key0 + min(n0 + u, nkeys - 1)) * I + j];
+            dkk[u] = 0.f;
+            dvv[u] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < AT_MAXT; ++t) {
+            if (t < T) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(pbuf + (h * AT_MAXT + t) * 64 + n0);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsbuf + (h * AT_MAXT + t) * 64 + n0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    dkk[u] += d4[u] * qv[t];
+                    dvv[u] += p4[u] * dov[t];
+                }
+                dq[t] += d4[0] * kq[0] + d4[1] * kq[1] + d4[2] * kq[2] + d4[3] * kq[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (n0 + u < nkeys) {
+                dk[(size_t)(key0 + n0 + u) * I + j] = dkk[u];
+                dv[(size_t)(key0 + n0 + u) * I + j] = dvv[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t)
+        if (t < T) pdq[((size_t)blockIdx.x * AT_MAXT + t) * I + j] = dq[t];
+}
+
 // dq[qb + t][j] = sum over the bag's tiles.  grid = (B, T_max), block = I
 __global__ void k_attn_pool_bwd_reduce(const float* __restrict__ pdq, const int32_t* __restrict__ q_off,
                                        const int32_t* __restrict__ bag_tile_off, int I, float* __restrict__ dq) {
@@ -537,7 +714,7 @@ extern "C" int mil_attn_pool_fwd_mh(const float* q, const float* k, const float*
                                     const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int Tmax,
                                     int H, int C, float* o, float* lse, float* workspace, void* stream) {
     if (!q || !k || !v || !q_off || !tile_map || !bag_tile_off || !o || !lse || !workspace) return MIL_EINVAL;
-    if ((C != 32 && C != 64) || H <= 0 || H * C > 512 || Tmax <= 0 || Tmax > AT_MAXT) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || H > 8 || H * C > 512 || Tmax <= 0 || Tmax > AT_MAXT) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     const float scale = 1.0f / sqrtf((float)C);
     const int I = H * C;
@@ -545,8 +722,8 @@ extern "C" int mil_attn_pool_fwd_mh(const float* q, const float* k, const float*
     float* pml = workspace + (size_t)ntiles * AT_MAXT * I;
     hipStream_t st = (hipStream_t)stream;
     if (ntiles > 0) {
-        DISPATCH_CT(C, Tmax, hipLaunchKernelGGL((k_attn_pool_fwd<CC, TT>), dim3(ntiles), dim3(I), 0, st, q, k, v, q_off,
-                                                tile_map, H, scale, pacc, pml));
+        DISPATCH_C(C, hipLaunchKernelGGL((k_attn_pool_fwd_lds<CC>), dim3(ntiles), dim3(I), 0, st, q, k, v, q_off, tile_map,
+                                         H, scale, pacc, pml));
         MIL_CHECK_LAUNCH();
     }
     DISPATCH_C(C, hipLaunchKernelGGL((k_attn_pool_merge<CC>), dim3(B, Tmax), dim3(I), 0, st, pacc, pml, q_off, bag_tile_off,
@@ -561,14 +738,14 @@ extern "C" int mil_attn_pool_bwd_mh(const float* q, const float* k, const float*
                                     float* dk, float* dv, float* workspace, void* stream) {
     if (!q || !k || !v || !o || !dout || !lse || !q_off || !tile_map || !bag_tile_off || !dq || !dk || !dv || !workspace)
         return MIL_EINVAL;
-    if ((C != 32 && C != 64) || H <= 0 || H * C > 512 || Tmax <= 0 || Tmax > AT_MAXT) return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || H > 8 || H * C > 512 || Tmax <= 0 || Tmax > AT_MAXT) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     const float scale = 1.0f / sqrtf((float)C);
     const int I = H * C;
     hipStream_t st = (hipStream_t)stream;
     if (ntiles > 0) {
-        DISPATCH_CT(C, Tmax, hipLaunchKernelGGL((k_attn_pool_bwd<CC, TT>), dim3(ntiles), dim3(I), 0, st, q, k, v, o, dout,
-                                                lse, q_off, tile_map, H, scale, dk, dv, workspace));
+        DISPATCH_C(C, hipLaunchKernelGGL((k_attn_pool_bwd_lds<CC>), dim3(ntiles), dim3(I), 0, st, q, k, v, o, dout, lse,
+                                         q_off, tile_map, H, scale, dk, dv, workspace));
         MIL_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_attn_pool_bwd_reduce, dim3(B, Tmax), dim3(I), 0, st, workspace, q_off, bag_tile_off, I, dq);
