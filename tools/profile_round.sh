@@ -14,9 +14,12 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown > $OUT/write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/mfma -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown > $OUT/mfma.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fusion -- python3 $ROOT/tools/bench_fusion.py --cache_text --steps 20 --warmup 5 > $OUT/fusion.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/coop -- python3 $ROOT/tools/bench_fusion.py --coop --steps 6 --warmup 2 > $OUT/coop.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bf16 -- $B --dtype bf16 --patches 4096 --dim 1024 --steps 30 --warmup 5 --no-cpu-baseline --no-breakdown > $OUT/bf16.log 2>&1
 tail -1 $OUT/stats.log > $OUT/bench_line_under_profiler.json
 python3 $ROOT/bench.py --steps 200 --warmup 20 > $OUT/bench_line.json 2> $OUT/bench_line.err
 python3 $ROOT/tools/bench_fusion.py --graph --steps 50 --warmup 5 > $OUT/fusion_line.json 2>/dev/null
 python3 $ROOT/bench.py --dtype bf16 --patches 4096 --dim 1024 --no-cpu-baseline --no-breakdown > $OUT/bf16_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --coop --steps 10 --warmup 3 > $OUT/coop_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --graph --prompts 10 --steps 20 --warmup 3 > $OUT/p10_line.json 2>/dev/null
 echo done

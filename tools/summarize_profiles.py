@@ -38,6 +38,9 @@ stats("stats", f"{TAG}_bench_kernel_stats.csv",
 stats("fusion", f"{TAG}_fusion_kernel_stats.csv",
       "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_fusion.py --cache_text --steps 20 --warmup 5\n"
       "# BASELINE config 3 (32 bags x 1024 x 768 + CLIP ViT-B/32 text): 25 eager steps; the first step also runs the frozen text tower\n", top=60)
+stats("coop", f"{TAG}_coop_kernel_stats.csv",
+      "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_fusion.py --coop --steps 6 --warmup 2\n"
+      "# upstream's default mode: learnable prompts (10 per bag) trained THROUGH the frozen ViT-B/32 text tower, 32 bags x 1024 x 768\n", top=30)
 stats("bf16", f"{TAG}_bf16_kernel_stats.csv",
       "# rocprofv3 --kernel-trace --stats -- python3 bench.py --dtype bf16 --patches 4096 --dim 1024 --steps 30 --warmup 5\n"
       "# BASELINE config 5 (32 bags x 4096 x 1024, bf16 storage)\n", top=20)
@@ -69,7 +72,8 @@ with open(os.path.join(DST, f"{TAG}_bench_mfma_busy_pmc.csv"), "w") as o:
         o.write(f"{k},{len(v['SQ_VALU_MFMA_BUSY_CYCLES'])},{mean['SQ_VALU_MFMA_BUSY_CYCLES']:.0f},{gui:.0f},{frac:.3f},"
                 f"{mean.get('SQ_LDS_BANK_CONFLICT', 0):.0f},{mean.get('SQ_WAVE_CYCLES', 0):.0f},{mean.get('SQ_WAIT_ANY', 0):.0f},{mean.get('SQ_WAIT_INST_ANY', 0):.0f}\n")
 lines = {}
-for key, fn in (("bench", "bench_line.json"), ("fusion", "fusion_line.json"), ("bf16", "bf16_line.json")):
+for key, fn in (("bench", "bench_line.json"), ("fusion", "fusion_line.json"), ("bf16", "bf16_line.json"),
+                ("fusion_coop", "coop_line.json"), ("fusion_10_prompts", "p10_line.json")):
     try:
         txt = [l for l in open(os.path.join(SRC, fn)).read().splitlines() if l.startswith("{")][-1]
         lines[key] = json.loads(txt)
