@@ -591,6 +591,102 @@ static inline int split_plan(int R, int L, int* KC_out) {
 
 extern "C" int mil_abi_version(void) { return 1; }
 
+// Small batches (the authors train with ONE bag per GPU: R = 1 000 - 15 000 rows): 128-row tiles would leave most CUs
+// idle (8 workgroups for 1024 patches, each walking all of K: the kernel takes its full ~100 us for 1/32 of the
+// work).  This form uses 32-row tiles: 6 waves, wave c owns d-chunk c of V and of U (two accumulator tiles), so the
+// scores still complete inside the workgroup.  Register-staged double buffering (the weight slice is 48 KB per step:
+// the stream from L2, not the matrix pipe, is what a workgroup waits for).
+#define GS_TM 32
+#define GS_LS 36
+__global__ __launch_bounds__(384) void k_gate_fwd_r32(const float* __restrict__ x, const float* __restrict__ Wv,
+                                                      const float* __restrict__ bv, const float* __restrict__ Wu,
+                                                      const float* __restrict__ bu, const float* __restrict__ wvec,
+                                                      const float* __restrict__ battn, float* __restrict__ scores,
+                                                      float* __restrict__ gates, int R, int L) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GS_TM + GF_NG) * GS_LS];
+    float* xs = smem;                            // [2][32][36]
+    float* ws = smem + 2 * GS_TM * GS_LS;        // [2][384][36]
+    const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * GS_TM;
+    const float* wsrc[8];
+    int wdst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + 384 * i, wrow = id >> 3, ch = id & 7;
+        wsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 4 * ch;
+        wdst[i] = wrow * GS_LS + 4 * ch;
+    }
+    const int xrow = (tid & 255) >> 3, xch = tid & 7;
+    const float* xsrc = x + (size_t)min(row0 + xrow, R - 1) * L + 4 * xch;
+    const int xdst = xrow * GS_LS + 4 * xch;
+    f32x4 wreg[8], xreg;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wreg[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
+        xreg = *reinterpret_cast<const f32x4*>(xsrc + k0);
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(ws + buf * GF_NG * GS_LS + wdst[i]) = wreg[i];
+        if (tid < 256) *reinterpret_cast<f32x4*>(xs + buf * GS_TM * GS_LS + xdst) = xreg;
+    };
+    f32x16 accv, accu;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accv[i] = 0.f; accu[i] = 0.f; }
+    const int nslice = L / GF_BK;
+    gload(0);
+    swrite(0);
+    gload(min(1, nslice - 1) * GF_BK);
+    __syncthreads();
+    for (int s = 0; s < nslice; ++s) {
+        const int buf = s & 1;
+        const float* xa = xs + buf * GS_TM * GS_LS + r * GS_LS + 4 * h;
+        const float* wv = ws + buf * GF_NG * GS_LS + (32 * c + r) * GS_LS + 4 * h;
+        const float* wu = wv + 192 * GS_LS;
+        f32x4 fa[4], fv[4], fu[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t] = *reinterpret_cast<const f32x4*>(xa + 8 * t);
+            fv[t] = *reinterpret_cast<const f32x4*>(wv + 8 * t);
+            fu[t] = *reinterpret_cast<const f32x4*>(wu + 8 * t);
+        }
+        swrite(buf ^ 1);                                         // slice s+1: registers -> the other buffer
+        gload(min(s + 2, nslice - 1) * GF_BK);                   // slice s+2 into the registers
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fv[t][jj], accv, 0, 0, 0);
+                accu = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fu[t][jj], accu, 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    const int d = 32 * c + r;
+    const float bvd = bv[d], bud = bu[d], wd = wvec[d];
+    float* sred = smem;                          // [6][32]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = fast_tanh(accv[i] + bvd);
+        const float u = fast_sigmoid(accu[i] + bud);
+        const int lr = mfma32_row(i, h), gr = row0 + lr;
+        if (gates != nullptr && gr < R) {
+            gates[(size_t)gr * GF_NG + d] = v;
+            gates[(size_t)gr * GF_NG + 192 + d] = u;
+        }
+        const float part = half_allsum(wd * v * u);
+        if (r == 0) sred[c * GS_TM + lr] = part;
+    }
+    __syncthreads();
+    if (tid < GS_TM && row0 + tid < R) {
+        float sc = battn[0];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) sc += sred[cc * GS_TM + tid];
+        scores[row0 + tid] = sc;
+    }
+}
+
 // Tile quantisation: with one 128-row workgroup per CU, R = k * 256 * 128 + (a few rows) costs a whole extra round of
 // the grid for one workgroup (config 3: 32 bags x (1024 patches + 2 tokens) = 256.5 tiles -> 2x the kernel time).
 // When the rows beyond a whole number of rounds fit the few-rows linear (<= 64), they take that path instead:
@@ -618,6 +714,13 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
+    if ((R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4) {
+        // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
+        hipLaunchKernelGGL(k_gate_fwd_r32, dim3((R + GS_TM - 1) / GS_TM), dim3(384), 0, st, x, Wv, bv, Wu, bu, w, b, scores,
+                           gates, R, L);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     const int tail = gates != nullptr ? gate_tail_rows(R, MIL_NUM_CU) : 0;       // the tail path keeps V, U in `gates`
     const int Rm = R - tail;
     const int grid = (Rm + GF_TM - 1) / GF_TM;
