@@ -593,90 +593,112 @@ extern "C" int mil_abi_version(void) { return 1; }
 
 // Small batches (the authors train with ONE bag per GPU: R = 1 000 - 15 000 rows): 128-row tiles would leave most CUs
 // idle (8 workgroups for 1024 patches, each walking all of K: the kernel takes its full ~100 us for 1/32 of the
-// work).  This form uses 32-row tiles: 6 waves, wave c owns d-chunk c of V and of U (two accumulator tiles), so the
-// scores still complete inside the workgroup.  Register-staged double buffering (the weight slice is 48 KB per step:
-// the stream from L2, not the matrix pipe, is what a workgroup waits for).
+// work).  This form uses 32-row tiles and 12 waves: wave (c, u) owns ONE accumulator tile - d-chunk c of V (u = 0) or
+// of U (u = 1) - so the four SIMDs carry three waves each (six waves with two tiles would put two on some SIMDs
+// and one on others); the U waves hand sigmoid(U) to their V partners through LDS for the gate product, and the
+// scores still complete inside the workgroup.  Register-staged, two register sets: every load has two iterations to
+// land (one L2 round trip is longer than one slice of MFMAs here).
 #define GS_TM 32
 #define GS_LS 36
-__global__ __launch_bounds__(384) void k_gate_fwd_r32(const float* __restrict__ x, const float* __restrict__ Wv,
-                                                      const float* __restrict__ bv, const float* __restrict__ Wu,
-                                                      const float* __restrict__ bu, const float* __restrict__ wvec,
-                                                      const float* __restrict__ battn, float* __restrict__ scores,
-                                                      float* __restrict__ gates, int R, int L) {
+#define GS_THREADS 768
+__global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __restrict__ x, const float* __restrict__ Wv,
+                                                             const float* __restrict__ bv, const float* __restrict__ Wu,
+                                                             const float* __restrict__ bu, const float* __restrict__ wvec,
+                                                             const float* __restrict__ battn, float* __restrict__ scores,
+                                                             float* __restrict__ gates, int R, int L) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (GS_TM + GF_NG) * GS_LS];
     float* xs = smem;                            // [2][32][36]
     float* ws = smem + 2 * GS_TM * GS_LS;        // [2][384][36]
-    const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = wave >> 1, isu = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * GS_TM;
-    const float* wsrc[8];
-    int wdst[8];
+    const float* wsrc[4];
+    int wdst[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int id = tid + 384 * i, wrow = id >> 3, ch = id & 7;
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + GS_THREADS * i, wrow = id >> 3, ch = id & 7;
         wsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 4 * ch;
         wdst[i] = wrow * GS_LS + 4 * ch;
     }
     const int xrow = (tid & 255) >> 3, xch = tid & 7;
     const float* xsrc = x + (size_t)min(row0 + xrow, R - 1) * L + 4 * xch;
     const int xdst = xrow * GS_LS + 4 * xch;
-    f32x4 wreg[8], xreg;
-    auto gload = [&](int k0) {
+    f32x4 wreg[2][4], xreg[2];
+    auto gload = [&](int set, int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wreg[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
-        xreg = *reinterpret_cast<const f32x4*>(xsrc + k0);
+        for (int i = 0; i < 4; ++i) wreg[set][i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
+        xreg[set] = *reinterpret_cast<const f32x4*>(xsrc + k0);
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int set, int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(ws + buf * GF_NG * GS_LS + wdst[i]) = wreg[i];
-        if (tid < 256) *reinterpret_cast<f32x4*>(xs + buf * GS_TM * GS_LS + xdst) = xreg;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ws + buf * GF_NG * GS_LS + wdst[i]) = wreg[set][i];
+        if (tid < 256) *reinterpret_cast<f32x4*>(xs + buf * GS_TM * GS_LS + xdst) = xreg[set];
     };
-    f32x16 accv, accu;
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { accv[i] = 0.f; accu[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int nslice = L / GF_BK;
-    gload(0);
-    swrite(0);
-    gload(min(1, nslice - 1) * GF_BK);
+    gload(0, 0);
+    swrite(0, 0);
+    gload(1, min(1, nslice - 1) * GF_BK);
+    gload(0, min(2, nslice - 1) * GF_BK);
     __syncthreads();
-    for (int s = 0; s < nslice; ++s) {
+    auto iteration = [&](int s, int set) {                       // set = (s + 1) & 1
         const int buf = s & 1;
         const float* xa = xs + buf * GS_TM * GS_LS + r * GS_LS + 4 * h;
-        const float* wv = ws + buf * GF_NG * GS_LS + (32 * c + r) * GS_LS + 4 * h;
-        const float* wu = wv + 192 * GS_LS;
-        f32x4 fa[4], fv[4], fu[4];
+        const float* wb = ws + buf * GF_NG * GS_LS + (192 * isu + 32 * c + r) * GS_LS + 4 * h;
+        f32x4 fa[4], fb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             fa[t] = *reinterpret_cast<const f32x4*>(xa + 8 * t);
-            fv[t] = *reinterpret_cast<const f32x4*>(wv + 8 * t);
-            fu[t] = *reinterpret_cast<const f32x4*>(wu + 8 * t);
+            fb[t] = *reinterpret_cast<const f32x4*>(wb + 8 * t);
         }
-        swrite(buf ^ 1);                                         // slice s+1: registers -> the other buffer
-        gload(min(s + 2, nslice - 1) * GF_BK);                   // slice s+2 into the registers
+        swrite(set, buf ^ 1);                                    // slice s+1: registers -> the other buffer
+        gload(set, min(s + 3, nslice - 1) * GF_BK);              // the same registers take slice s+3
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fv[t][jj], accv, 0, 0, 0);
-                accu = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fu[t][jj], accu, 0, 0, 0);
-            }
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fb[t][jj], acc, 0, 0, 0);
         __syncthreads();
+    };
+    for (int s = 0; s < nslice; s += 2) {
+        iteration(s, 1);
+        if (s + 1 < nslice) iteration(s + 1, 0);
     }
     const int d = 32 * c + r;
-    const float bvd = bv[d], bud = bu[d], wd = wvec[d];
-    float* sred = smem;                          // [6][32]
-    __syncthreads();
+    float* uex = smem;                           // [6][32][33]: sigmoid(U) tiles for the V partners
+    float* sred = smem + 6 * 32 * 33;            // [6][32]
+    float gv[16];
+    if (isu) {
+        const float bud = bu[d];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float v = fast_tanh(accv[i] + bvd);
-        const float u = fast_sigmoid(accu[i] + bud);
-        const int lr = mfma32_row(i, h), gr = row0 + lr;
-        if (gates != nullptr && gr < R) {
-            gates[(size_t)gr * GF_NG + d] = v;
-            gates[(size_t)gr * GF_NG + 192 + d] = u;
+        for (int i = 0; i < 16; ++i) {
+            gv[i] = fast_sigmoid(acc[i] + bud);
+            uex[(c * 32 + mfma32_row(i, h)) * 33 + r] = gv[i];
         }
-        const float part = half_allsum(wd * v * u);
-        if (r == 0) sred[c * GS_TM + lr] = part;
+    } else {
+        const float bvd = bv[d];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = fast_tanh(acc[i] + bvd);
+    }
+    if (gates != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gr = row0 + mfma32_row(i, h);
+            if (gr < R) gates[(size_t)gr * GF_NG + 192 * isu + d] = gv[i];
+        }
+    }
+    __syncthreads();
+    if (!isu) {
+        const float wd = wvec[d];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = mfma32_row(i, h);
+            const float part = half_allsum(wd * gv[i] * uex[(c * 32 + lr) * 33 + r]);
+            if (r == 0) sred[c * GS_TM + lr] = part;
+        }
     }
     __syncthreads();
     if (tid < GS_TM && row0 + tid < R) {
@@ -716,7 +738,7 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
     hipStream_t st = (hipStream_t)stream;
     if ((R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4) {
         // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
-        hipLaunchKernelGGL(k_gate_fwd_r32, dim3((R + GS_TM - 1) / GS_TM), dim3(384), 0, st, x, Wv, bv, Wu, bu, w, b, scores,
+        hipLaunchKernelGGL(k_gate_fwd_r32, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b, scores,
                            gates, R, L);
         MIL_CHECK_LAUNCH();
         return MIL_OK;
