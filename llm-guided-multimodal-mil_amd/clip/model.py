@@ -7,6 +7,7 @@ attn.out_proj.*, ln_1.*, mlp.c_fc.*, mlp.c_proj.*, ln_2.*}, ln_final.*, text_pro
 never run on this path and is not instantiated (its keys are ignored when loading a full CLIP state_dict)."""
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -98,30 +99,43 @@ class CLIPText(nn.Module):
             self._proj_t = self.text_projection.detach().t().contiguous()     # frozen: [embed, W] = nn.Linear layout
         return self._proj_t
 
+    @staticmethod
+    def _live_rows(text: torch.Tensor):
+        """The blocks are causal and only the EOT row is read out (clip/model.py:324-330,350-352), so rows behind a
+        sequence's EOT cannot influence the result: run the tower on each sequence's prefix [0, eot] only.
+        Returns (lengths, flat indices of the live rows in [P * ctx], index of every sequence's EOT row among them)."""
+        P, ctx = text.shape
+        eot = text.argmax(dim=-1).cpu().numpy().astype(np.int64)          # one small device->host copy per call
+        lengths = (eot + 1).tolist()
+        starts = np.arange(P, dtype=np.int64) * ctx
+        live = np.concatenate([np.arange(s0, s0 + n, dtype=np.int64) for s0, n in zip(starts, lengths)])
+        last = np.cumsum(eot + 1) - 1
+        dev = text.device
+        return lengths, torch.from_numpy(live).to(dev), torch.from_numpy(last).to(dev)
+
+    def _tower(self, x_full: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
+        """x_full [P * ctx, W] (embeddings + positions) -> EOT features [P, embed_dim]."""
+        lengths, live, last = self._live_rows(text)
+        x = x_full if live.numel() == x_full.shape[0] else x_full.index_select(0, live)
+        segs = AttnSegs.make(lengths, lengths, x.device)
+        for blk in self.transformer.resblocks:
+            x = blk.flat(x, segs)
+        # ln_final is row-wise: normalise the EOT rows only
+        eot = ops.layer_norm(x.index_select(0, last), self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
+        return ops.linear_act(eot, self._proj(eot.device))
+
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:
         """text int64 [P, ctx] -> [P, embed_dim]."""
-        P, ctx = text.shape
         x = ops.embed_tokens(text, self.token_embedding.weight, self.positional_embedding)     # [P*ctx, W]
-        segs = AttnSegs.make([ctx] * P, [ctx] * P, text.device)
-        for blk in self.transformer.resblocks:
-            x = blk.flat(x, segs)
-        x = ops.layer_norm(x, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
-        eot = ops.gather_eot(text, x)                                                          # [P, W]
-        return ops.linear_act(eot, self._proj(eot.device))
+        return self._tower(x, text)
 
     def encode_embedded(self, prompts: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
         """Differentiable tower for already-embedded prompts (learnable context, model/dim1/CLIP.py:54-60):
         prompts [P, ctx, W] = token embeddings with the context rows replaced (positional embedding NOT yet
         added), text int64 [P, ctx] only locates the EOT row.  Gradients flow to `prompts`; the weights stay frozen."""
         P, ctx, W = prompts.shape
-        x = (prompts + self.positional_embedding).reshape(P * ctx, W)
-        segs = AttnSegs.make([ctx] * P, [ctx] * P, prompts.device)
-        for blk in self.transformer.resblocks:
-            x = blk.flat(x, segs)
-        x = ops.layer_norm(x, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
-        eot = x.view(P, ctx, W)[torch.arange(P, device=x.device), text.argmax(dim=-1)]
-        return ops.linear_act(eot, self._proj(eot.device))
+        return self._tower((prompts + self.positional_embedding).reshape(P * ctx, W), text)
 
 
 def build_text_model(state_dict: dict) -> CLIPText:
