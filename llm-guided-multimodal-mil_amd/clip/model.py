@@ -51,6 +51,25 @@ class ResidualAttentionBlock(nn.Module):
                                  residual=x)
 
 
+def _flat_last_rows(self, x, last, segs):
+    """This block's output at the rows `last` (one per sequence, the final row of its prefix) - clip/model.py:183-199
+    restricted to the rows that are read out."""
+    W = x.shape[1]
+    h = ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+    w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+    k = ops.linear_act(h, w[W:2 * W], b[W:2 * W])
+    v = ops.linear_act(h, w[2 * W:], b[2 * W:])
+    q = ops.linear_act(h.index_select(0, last), w[:W], b[:W])
+    o = ops.attention_pool(q, k, v, segs, self.n_head)
+    x_e = ops.linear_act(o, self.attn.out_proj.weight, self.attn.out_proj.bias, "none", residual=x.index_select(0, last))
+    h_e = ops.layer_norm(x_e, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+    return ops.mlp_quickgelu(h_e, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias,
+                             residual=x_e)
+
+
+ResidualAttentionBlock.flat_last_rows = _flat_last_rows
+
+
 class Transformer(nn.Module):
     def __init__(self, width: int, layers: int, heads: int):
         super().__init__()
@@ -118,10 +137,14 @@ class CLIPText(nn.Module):
         lengths, live, last = self._live_rows(text)
         x = x_full if live.numel() == x_full.shape[0] else x_full.index_select(0, live)
         segs = AttnSegs.make(lengths, lengths, x.device)
-        for blk in self.transformer.resblocks:
+        blocks = list(self.transformer.resblocks)
+        for blk in blocks[:-1]:
             x = blk.flat(x, segs)
+        # Last block: only its EOT rows are read out, so q, out_proj and the MLP run on those rows alone; k and v are
+        # still needed from every row of the prefix (the EOT query attends to all of them: no mask left to apply).
+        x_e = blocks[-1].flat_last_rows(x, last, AttnSegs.make([1] * len(lengths), lengths, x.device))
         # ln_final is row-wise: normalise the EOT rows only
-        eot = ops.layer_norm(x.index_select(0, last), self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
+        eot = ops.layer_norm(x_e, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
         return ops.linear_act(eot, self._proj(eot.device))
 
     @torch.no_grad()
