@@ -122,7 +122,7 @@ class aggregator(nn.Module):
             # [all patches | all tokens] (the patch tokens stay where the last LayerNorm wrote them, only the few
             # token rows are appended) and the tile map tells the pool kernels which rows belong to which bag;
             # attention pooling does not depend on the order of a bag's rows.
-            x0 = ops.append_rows(k, q)
+            x0 = ops.append_rows(k, q, tail_reserved=True)     # k comes from the last block's norm4 with keys_tail_rows
             layout = BagLayout.two_segment(n_len, [P] * B, x0.device)
             M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0   # :198-199
             return self._head(M), q.view(B, P, EMBED)                                     # :200,207

@@ -681,13 +681,15 @@ class _AppendRows(torch.autograd.Function):
     bag of model/aggregator.py:192 - the [N, 512] patch tokens stay where the last LayerNorm put them."""
 
     @staticmethod
-    def forward(ctx, base, extra):
+    def forward(ctx, base, extra, tail_reserved: bool):
         R, E = base.shape
         T = extra.shape[0]
         ctx.R = R
         st = base.untyped_storage()
-        if (base.is_contiguous() and base.storage_offset() == 0 and base.dtype == torch.float32
-                and st.nbytes() >= (R + T) * E * 4):
+        # tail_reserved is the CALLER's statement that the rows behind `base` were reserved for this purpose
+        # (layer_norm(..., tail_rows=T)); without it a prefix view of somebody else's buffer would qualify too.
+        if (tail_reserved and base.is_contiguous() and base.storage_offset() == 0 and base.dtype == torch.float32
+                and st.nbytes() == (R + T) * E * 4):
             big = torch.empty(0, device=base.device, dtype=torch.float32).set_(st, 0, (R + T, E), (E, 1))
             big[R:].copy_(extra)
             return big
@@ -695,11 +697,13 @@ class _AppendRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g[:ctx.R], g[ctx.R:]
+        return g[:ctx.R], g[ctx.R:], None
 
 
-def append_rows(base, extra):
-    return _AppendRows.apply(base, extra)
+def append_rows(base, extra, tail_reserved: bool = False):
+    """torch.cat([base, extra], 0); with tail_reserved=True and `base` allocated by layer_norm(..., tail_rows=len(extra))
+    the base rows are not copied."""
+    return _AppendRows.apply(base, extra, tail_reserved)
 
 
 class _AddPE(torch.autograd.Function):
