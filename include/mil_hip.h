@@ -195,6 +195,15 @@ int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b
 int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M, int N,
                  int K, const float* bias, int act, const float* residual, int ldr, int accumulate, float* workspace,
                  size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream);
+/* Grouped form (one group = one bag, rows [grp_off[g], grp_off[g+1])), used by the absorbed multi-token attention
+ * where every bag multiplies its rows with its own small matrix (T x H absorbed query / key / value vectors):
+ *   a_mode 0: C[rows_g, :N] = A[rows_g, :K] . B_g + bias_g + residual[rows_g]   B_g = B + g * strideB
+ *             (b_mode 0: B_g [N, K], b_mode 1: B_g [K, N]);  bias_g = bias + g * strideBias (nullable);  K % 32 == 0
+ *   a_mode 1: C_g[M, N] = A[rows_g, :M]^T . B[rows_g, :N],  C_g = C + g * strideC    (M % 4 == 0, N % 4 == 0)
+ * max_group_rows bounds the launch grid.  No split-K: results are deterministic. */
+int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                     const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB, long strideC,
+                     const float* bias, long strideBias, const float* residual, int ldr, void* stream);
 /* out[j] (+)= sum_i Y[i][j]  (bias gradients).  With a workspace of mil_colsum_workspace_floats(M, N) floats
  * a tall matrix is summed in 256-row chunks by many workgroups and folded in a second launch (fixed order). */
 size_t mil_colsum_workspace_floats(int M, int N);
@@ -279,6 +288,16 @@ int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, c
                           const float* dkeys_acc, float* dkeys, float* dQp, float* workspace, void* stream);
 int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
                    void* stream);
+/* Softmax stages of the multi-token absorbed attention (T text tokens per bag: T x H absorbed vectors, score matrix
+ * [rows, ld] with column c = t H + h, columns >= T H are padding and come out as zeros):
+ *   mil_grp_col_softmax      in place, over the ROWS of each group (bag) per column     (token -> image)
+ *   mil_row_softmax_t        in place, over the T tokens of each (row, head)           (image -> token)
+ * and their backwards dS = A (dA - sum A dA) over the same axis. */
+int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int TH, void* stream);
+int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int TH, float* dS,
+                            void* stream);
+int mil_row_softmax_t(float* S, int ld, int R, int T, int H, void* stream);
+int mil_row_softmax_t_bwd(const float* A, const float* dA, int ld, int R, int T, int H, float* dS, void* stream);
 
 /* nn.LayerNorm over the last dim E (multiple of 64, <= 512), eps inside the sqrt.  stats [rows, 2] =
  * (mean, rstd), saved for the backward.  backward workspace: mil_layernorm_bwd_blocks(rows) * 2 * E floats. */

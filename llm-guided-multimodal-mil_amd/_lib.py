@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
-from ctypes import c_float, c_int, c_size_t, c_void_p
+from ctypes import c_long, c_float, c_int, c_size_t, c_void_p
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -48,6 +48,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
+    "mil_gemm_grouped": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
+                                 c_long, c_long, _P, c_long, _P, c_int, _P]),
     "mil_gemm_aux": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P, c_int, c_int, _P]),
     "mil_colsum_workspace_floats": (c_size_t, [c_int, c_int]),
@@ -67,6 +69,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_absorb_query_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "mil_absorbed_pool_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
     "mil_absorbed_pool_bwd": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 4 + [_P]),
+    "mil_grp_col_softmax": (c_int, [_P, c_int, _P, c_int, c_int, _P]),
+    "mil_grp_col_softmax_bwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, _P, _P]),
+    "mil_row_softmax_t": (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
+    "mil_row_softmax_t_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_value_proj": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_layernorm_fwd": (c_int, [_P] * 3 + [c_int, c_int, c_float, _P, _P, _P]),
     "mil_layernorm_bwd_blocks": (c_int, [c_int]),

@@ -437,6 +437,152 @@ __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ po
 // dpooled[b][h][:] = sum_c' do[b][hc + c'] Wv[hc + c'][:]     (same form as k_absorb_query)
 // dWv[hc + c'][:]   = sum_b do[b][hc + c'] pooled[b][h][:]    (same form as k_absorb_query_bwd_w)
 
+// ---------------------------------------------------------------------------------------------- multi-token absorbed attention
+// With T text tokens per bag the same absorption yields T x H query (or key / value) vectors per bag and the image side
+// becomes skinny grouped products (mil_gemm_grouped) around a softmax on a [rows, T*H] score matrix (column c = t H + h,
+// padded to a multiple of 32 with zeros):
+//   token -> image: softmax over the ROWS (patches) of a bag, per column         k_grp_col_softmax / _bwd
+//   image -> token: softmax over the T tokens of a row, per head                k_row_softmax_t / _bwd
+// Column softmax: grid (G, ceil(ld / 32)), 1024 threads = 32 row lanes x 32 columns; a thread keeps its <= 64 values of
+// the column in registers (groups of up to 2048 rows: one read of the slab), longer groups fall back to re-reading.
+#define CS_RL 32
+#define CS_KEEP 64
+__global__ __launch_bounds__(1024) void k_grp_col_softmax(float* __restrict__ S, int ld, const int32_t* __restrict__ grp_off,
+                                                          int TH) {
+    __shared__ float red[CS_RL][33];
+    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, rl = threadIdx.x >> 5;
+    const int r0 = grp_off[g], r1 = grp_off[g + 1], n = r1 - r0;
+    const bool live = c < TH && c < ld;
+    const bool fits = n <= CS_RL * CS_KEEP;
+    float v[CS_KEEP];
+    float m = -INFINITY;
+    if (live) {
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < CS_KEEP; ++i) {
+                const int row = r0 + rl + CS_RL * i;
+                v[i] = row < r1 ? S[(size_t)row * ld + c] : -INFINITY;
+                m = fmaxf(m, v[i]);
+            }
+        } else {
+            for (int row = r0 + rl; row < r1; row += CS_RL) m = fmaxf(m, S[(size_t)row * ld + c]);
+        }
+    }
+    red[rl][cl] = m;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CS_RL; ++i) m = fmaxf(m, red[i][cl]);
+    __syncthreads();
+    float l = 0.f;
+    if (live) {
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < CS_KEEP; ++i) { v[i] = expf(v[i] - m); l += v[i]; }      // exp(-inf) = 0 for the padding slots
+        } else {
+            for (int row = r0 + rl; row < r1; row += CS_RL) l += expf(S[(size_t)row * ld + c] - m);
+        }
+    }
+    red[rl][cl] = l;
+    __syncthreads();
+    l = 0.f;
+#pragma unroll
+    for (int i = 0; i < CS_RL; ++i) l += red[i][cl];
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (c >= ld) return;
+    if (live && fits) {
+#pragma unroll
+        for (int i = 0; i < CS_KEEP; ++i) {
+            const int row = r0 + rl + CS_RL * i;
+            if (row < r1) S[(size_t)row * ld + c] = v[i] * inv;
+        }
+    } else {
+        for (int row = r0 + rl; row < r1; row += CS_RL) {
+            float* p = S + (size_t)row * ld + c;
+            *p = live ? expf(*p - m) * inv : 0.f;
+        }
+    }
+}
+
+// dS = A (dA - sum_rows A dA)  per (group, column); columns >= TH get 0
+__global__ __launch_bounds__(1024) void k_grp_col_softmax_bwd(const float* __restrict__ A, const float* __restrict__ dA, int ld,
+                                                              const int32_t* __restrict__ grp_off, int TH,
+                                                              float* __restrict__ dS) {
+    __shared__ float red[CS_RL][33];
+    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, rl = threadIdx.x >> 5;
+    const int r0 = grp_off[g], r1 = grp_off[g + 1], n = r1 - r0;
+    const bool live = c < TH && c < ld;
+    const bool fits = n <= CS_RL * (CS_KEEP / 2);
+    float a[CS_KEEP / 2], d[CS_KEEP / 2];
+    float cd = 0.f;
+    if (live) {
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < CS_KEEP / 2; ++i) {
+                const int row = r0 + rl + CS_RL * i;
+                a[i] = row < r1 ? A[(size_t)row * ld + c] : 0.f;
+                d[i] = row < r1 ? dA[(size_t)row * ld + c] : 0.f;
+                cd += a[i] * d[i];
+            }
+        } else {
+            for (int row = r0 + rl; row < r1; row += CS_RL) cd += A[(size_t)row * ld + c] * dA[(size_t)row * ld + c];
+        }
+    }
+    red[rl][cl] = cd;
+    __syncthreads();
+    cd = 0.f;
+#pragma unroll
+    for (int i = 0; i < CS_RL; ++i) cd += red[i][cl];
+    if (c >= ld) return;
+    if (live && fits) {
+#pragma unroll
+        for (int i = 0; i < CS_KEEP / 2; ++i) {
+            const int row = r0 + rl + CS_RL * i;
+            if (row < r1) dS[(size_t)row * ld + c] = a[i] * (d[i] - cd);
+        }
+    } else {
+        for (int row = r0 + rl; row < r1; row += CS_RL) {
+            const size_t o = (size_t)row * ld + c;
+            dS[o] = live ? A[o] * (dA[o] - cd) : 0.f;
+        }
+    }
+}
+
+// Row softmax over the T tokens of each (row, head): column t H + h.  Thread = (row, h); T <= 16.  In place.
+__global__ __launch_bounds__(256) void k_row_softmax_t(float* __restrict__ S, int ld, int R, int T, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R * H) return;
+    const int row = idx / H, h = idx % H;
+    float* p = S + (size_t)row * ld + h;
+    float v[16], m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { v[t] = t < T ? p[t * H] : -INFINITY; m = fmaxf(m, v[t]); }
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { v[t] = t < T ? expf(v[t] - m) : 0.f; l += v[t]; }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) if (t < T) p[t * H] = v[t] * inv;
+    for (int c = T * H + h; c < ld; c += H) S[(size_t)row * ld + c] = 0.f;        // padding columns
+}
+
+__global__ __launch_bounds__(256) void k_row_softmax_t_bwd(const float* __restrict__ A, const float* __restrict__ dA, int ld,
+                                                           int R, int T, int H, float* __restrict__ dS) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R * H) return;
+    const int row = idx / H, h = idx % H;
+    const size_t base = (size_t)row * ld + h;
+    float a[16], d[16], cd = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        a[t] = t < T ? A[base + t * H] : 0.f;
+        d[t] = t < T ? dA[base + t * H] : 0.f;
+        cd += a[t] * d[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) if (t < T) dS[base + t * H] = a[t] * (d[t] - cd);
+    for (int c = T * H + h; c < ld; c += H) dS[(size_t)row * ld + c] = 0.f;
+}
+
 #define AP_CHECK(cond) do { if (!(cond)) return MIL_EINVAL; } while (0)
 
 extern "C" int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream) {
@@ -511,6 +657,42 @@ extern "C" int mil_value_proj(const float* pooled, const float* Wv, const float*
     AP_CHECK(pooled && Wv && bv && o && B >= 0 && H > 0 && (C == 32 || C == 64) && E > 0);
     if (B == 0) return MIL_OK;
     hipLaunchKernelGGL(k_value_proj, dim3(B, H), dim3(256), 0, (hipStream_t)stream, pooled, Wv, bv, H, C, E, o);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int TH, void* stream) {
+    AP_CHECK(S && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld);
+    if (G == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_grp_col_softmax, dim3(G, (ld + 31) / 32), dim3(1024), 0, (hipStream_t)stream, S, ld, grp_off, TH);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int TH,
+                                       float* dS, void* stream) {
+    AP_CHECK(A && dA && dS && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld);
+    if (G == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_grp_col_softmax_bwd, dim3(G, (ld + 31) / 32), dim3(1024), 0, (hipStream_t)stream, A, dA, ld, grp_off,
+                       TH, dS);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_row_softmax_t(float* S, int ld, int R, int T, int H, void* stream) {
+    AP_CHECK(S && R >= 0 && T > 0 && T <= 16 && H > 0 && T * H <= ld);
+    if (R == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_row_softmax_t, dim3((unsigned)(((size_t)R * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, ld,
+                       R, T, H);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_row_softmax_t_bwd(const float* A, const float* dA, int ld, int R, int T, int H, float* dS, void* stream) {
+    AP_CHECK(A && dA && dS && R >= 0 && T > 0 && T <= 16 && H > 0 && T * H <= ld);
+    if (R == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_row_softmax_t_bwd, dim3((unsigned)(((size_t)R * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       A, dA, ld, R, T, H, dS);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -23,6 +23,15 @@
 
 enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_QUICKGELU = 3 };
 
+// Grouped launches (one group per bag): the skinny products of the absorbed multi-token attention, where every bag
+// multiplies its own rows with its own small matrix.
+enum { GRP_NONE = 0, GRP_ROWS = 1, GRP_CONTRACT = 2 };
+struct GemmGroups {
+    const int32_t* off;      // [G + 1] row offsets
+    long strideB, strideC, strideBias;
+    int mode;
+};
+
 // aux_mode 1: also store the pre-activation (bias added, before act) to aux - the backward of QuickGELU needs it;
 // aux_mode 2: multiply by QuickGELU'(aux[row][j]) - the activation backward fused into the epilogue of the product
 // that forms the gradient (clip/model.py:162-164 inside the MLP of :176-178).
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                                               float* __restrict__ C, int ldc, int M, int N, int K, int kchunk,
                                               const float* __restrict__ bias, int act, const float* __restrict__ residual,
                                               int ldr, int accumulate, float* __restrict__ partial,
-                                              float* __restrict__ aux, int ldaux, int aux_mode) {
+                                              float* __restrict__ aux, int ldaux, int aux_mode, GemmGroups gg) {
     constexpr int ASZ = AMODE == 0 ? 128 * LG_KS : LG_BK * 128;
     constexpr int BSZ = BMODE == 0 ? 128 * LG_KS : LG_BK * 128;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
@@ -97,7 +106,27 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    if (gg.mode != GRP_NONE) {
+        // grouped launch: blockIdx.z is the group (bag); no split-K
+        const int g = blockIdx.z, goff = gg.off[g], gn = gg.off[g + 1] - goff;
+        if (gg.mode == GRP_ROWS) {                 // rows of A / C belong to groups, B (and bias) are per group
+            M = gn;
+            if (i0 >= M) return;
+            A += (size_t)goff * lda;
+            C += (size_t)goff * ldc;
+            if (residual != nullptr) residual += (size_t)goff * ldr;
+            B += (size_t)g * gg.strideB;
+            if (bias != nullptr) bias += (size_t)g * gg.strideBias;
+        } else {                                   // GRP_CONTRACT: the contraction runs over the group's rows, C is per group
+            K = gn;
+            A += (size_t)goff * lda;
+            B += (size_t)goff * ldb;
+            C += (size_t)g * gg.strideC;
+        }
+        kbeg = 0;
+        kend = K;
+    }
     const int nslice = (kend - kbeg + LG_BK - 1) / LG_BK;
 
     OperandTile<AMODE> ta;
@@ -373,9 +402,9 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
             float* Xt = aux ? aux + (size_t)rows_main * ldaux : nullptr;
             const dim3 gridt((N + 127) / 128, (Mt + 127) / 128, S_tail);
             if (b_mode == 0)
-                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode);
+                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
             else
-                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode);
+                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
             MIL_CHECK_LAUNCH();
             const size_t n = (size_t)Mt * N;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, S_tail, Ct, ldc,
@@ -393,11 +422,11 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
     }
     dim3 grid((N + 127) / 128, (M + 127) / 128, S);
     if (a_mode == 0 && b_mode == 0)
-        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode);
+        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
     else if (a_mode == 0 && b_mode == 1)
-        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode);
+        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
     else
-        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode);
+        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
     MIL_CHECK_LAUNCH();
     if (partial != nullptr) {
         const size_t n = (size_t)M * N;
@@ -423,6 +452,33 @@ extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B,
         return MIL_EINVAL;
     return gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
                      workspace_floats, aux, ldaux, aux_mode, stream);
+}
+
+extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                                const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB,
+                                long strideC, const float* bias, long strideBias, const float* residual, int ldr,
+                                void* stream) {
+    if (!A || !B || !C || !grp_off || G < 0 || max_group_rows < 0 || N <= 0) return MIL_EINVAL;
+    if (G == 0 || max_group_rows == 0) return MIL_OK;
+    if ((lda & 3) || (ldb & 3)) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GemmGroups gg{grp_off, strideB, strideC, strideBias, a_mode == 0 ? GRP_ROWS : GRP_CONTRACT};
+    if (a_mode == 0) {
+        // C[rows_g, :N] = A[rows_g, :K] . B_g   (b_mode 0: B_g [N, K];  b_mode 1: B_g [K, N]);  K % 32 == 0
+        if (K <= 0 || (K % LG_BK) != 0 || (b_mode == 1 && (N & 3))) return MIL_EINVAL;
+        const dim3 grid((N + 127) / 128, (max_group_rows + 127) / 128, G);
+        if (b_mode == 0)
+            hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, 0, N, K, K, bias, 0, residual, ldr, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
+        else
+            hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, 0, N, K, K, bias, 0, residual, ldr, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
+    } else {
+        // C_g[M, N] = A[rows_g, :M]^T . B[rows_g, :N]   (contraction over the group's rows)
+        if (b_mode != 1 || M < 4 || (M & 3) || (N & 3) || bias || residual) return MIL_EINVAL;
+        const dim3 grid((N + 127) / 128, (M + 127) / 128, G);
+        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, 0, 0, (const float*)nullptr, 0, (const float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
+    }
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
 }
 
 extern "C" size_t mil_colsum_workspace_floats(int M, int N) {

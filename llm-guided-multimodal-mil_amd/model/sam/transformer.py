@@ -50,6 +50,19 @@ class Attention(nn.Module):
                                                self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads)
         return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual), keys_pass
 
+    def multi_token_pool(self, q, keys, kin, segs: AttnSegs, residual=None):
+        """Token->image attention with T > 1 text tokens per bag, K / V projections absorbed (ops.multi_token_pool_attention):
+        q [B*T, E] queries (+pe), keys [R, E] (values), kin [R, E] = keys + pe (scores)."""
+        o = ops.multi_token_pool_attention(q, keys, kin, segs, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight,
+                                           self.v_proj.weight, self.v_proj.bias, self.num_heads)
+        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
+
+    def multi_token_rows(self, kin, k_tok, v_tok, segs: AttnSegs, residual=None):
+        """Image->token attention with T > 1 tokens per bag, q / out projections absorbed: returns out_proj(attn) + residual."""
+        return ops.multi_token_rows_attention(kin, k_tok, v_tok, segs, self.q_proj.weight, self.q_proj.bias,
+                                              self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias,
+                                              self.out_proj.weight, self.out_proj.bias, self.num_heads, residual=residual)
+
     def forward(self, q, k, v):
         """Reference signature: q [B, Tq, E], k, v [B, Tk, E] -> [B, Tq, E]."""
         B, Tq, E = q.shape
@@ -105,10 +118,16 @@ class TwoWayAttentionBlock(nn.Module):
         queries = self.norm1(queries)
         q = queries + query_pe                                                  # :291-295
         one_token = one_token_ok(self.cross_attn_token_to_image, s_ti, pe_table)
+        a0 = self.cross_attn_token_to_image
+        multi = (not one_token) and ops.multi_token_ok(a0.embedding_dim, a0.num_heads, s_ti.q_lengths) \
+            and a0.internal_dim // a0.num_heads in (32, 64)
         if one_token:
             k = None
             att, keys = self.cross_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
             queries = self.norm2(att)
+        elif multi:
+            k = keys_pe_fn(keys)
+            queries = self.norm2(self.cross_attn_token_to_image.multi_token_pool(q, keys, k, s_ti, residual=queries))
         else:
             k = keys_pe_fn(keys)
             queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
@@ -121,6 +140,8 @@ class TwoWayAttentionBlock(nn.Module):
             a = self.cross_attn_image_to_token
             o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
             keys = self.norm4(ops.add_bag_row(keys, o, s_it), keys_tail_rows)
+        elif multi:
+            keys = self.norm4(self.cross_attn_image_to_token.multi_token_rows(k, q, queries, s_it, residual=keys), keys_tail_rows)
         else:
             if k is None:
                 k = keys_pe_fn(keys)
@@ -167,6 +188,8 @@ class TwoWayTransformer(nn.Module):
         q = queries + point                                                      # :114-118
         if one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
             out, keys = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
+        elif ops.multi_token_ok(self.embedding_dim, self.num_heads, s_ti.q_lengths):
+            out = self.final_attn_token_to_image.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=queries)
         else:
             out = self.final_attn_token_to_image.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=queries)
         return self.norm_final_attn(out), keys

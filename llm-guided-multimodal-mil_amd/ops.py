@@ -999,3 +999,196 @@ def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
     Qp = _AbsorbQuery.apply(qp, Wk, H)
     pooled, keys_pass = _AbsorbedPool.apply(keys, pe, Qp, segs, C)
     return _ValueProj.apply(pooled, Wv, bv), keys_pass
+
+
+# --------------------------------------------------------------------------- multi-token absorbed attention (1 < T <= 12)
+def _gg(A, a_mode, B, b_mode, grp_off, G, max_rows, M, N, K, strideB, strideC, out, bias=None, stride_bias=0, residual=None):
+    rc = _lib.lib().mil_gemm_grouped(_p(A), A.stride(0), a_mode, _p(B), B.stride(-2), b_mode, _p(out), out.stride(-2),
+                                     _p(grp_off), G, max_rows, M, N, K, strideB, strideC, _p(bias), stride_bias,
+                                     _p(residual), residual.stride(0) if residual is not None else 0, _stream())
+    _lib.check(rc, "mil_gemm_grouped")
+    return out
+
+
+def _gg_nt(A, B, bias, grp_off, max_rows):
+    """C[rows_g] = A[rows_g] . B[g]^T + bias[g];  A [R, K], B [G, N, K], bias [G, N] or None -> [R, N]."""
+    G, N, K = B.shape
+    out = torch.empty((A.shape[0], N), device=A.device, dtype=torch.float32)
+    return _gg(A, 0, B, 0, grp_off, G, max_rows, 0, N, K, N * K, 0, out, bias, N if bias is not None else 0)
+
+
+def _gg_nn(A, B, bias, residual, grp_off, max_rows):
+    """C[rows_g] = A[rows_g] . B[g] + bias + residual;  A [R, K], B [G, K, N], bias [N] shared or None."""
+    G, K, N = B.shape
+    out = torch.empty((A.shape[0], N), device=A.device, dtype=torch.float32)
+    return _gg(A, 0, B, 1, grp_off, G, max_rows, 0, N, K, K * N, 0, out, bias, 0, residual)
+
+
+def _gg_tn(A, X, grp_off, G, max_rows):
+    """C[g] = A[rows_g]^T . X[rows_g];  A [R, M], X [R, N] -> [G, M, N]."""
+    M, N = A.shape[1], X.shape[1]
+    out = torch.empty((G, M, N), device=A.device, dtype=torch.float32)
+    return _gg(A, 1, X, 1, grp_off, G, max_rows, M, N, 0, 0, M * N, out)
+
+
+def _seg_colsum(Y, grp_off, G, max_rows):
+    N = Y.shape[1]
+    out = torch.empty((G, N), device=Y.device, dtype=torch.float32)
+    nch = (max_rows + 255) // 256
+    ws = torch.empty(nch * G * N, device=Y.device, dtype=torch.float32) if nch > 1 else None
+    rc = _lib.lib().mil_segment_colsum(_p(Y), _p(grp_off), G, max_rows, N, _p(out), _p(ws), _stream())
+    _lib.check(rc, "mil_segment_colsum")
+    return out
+
+
+class _GroupedNT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, bias, grp_off, max_rows: int):
+        A, B = _f32c(A, "A"), _f32c(B, "B")
+        ctx.save_for_backward(A, B, grp_off)
+        ctx.max_rows, ctx.has_bias = max_rows, bias is not None
+        return _gg_nt(A, B, _f32c(bias, "bias") if bias is not None else None, grp_off, max_rows)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B, grp_off = ctx.saved_tensors
+        dC = _f32c(dC, "dC")
+        G = B.shape[0]
+        dA = _gg_nn(dC, B, None, None, grp_off, ctx.max_rows) if ctx.needs_input_grad[0] else None
+        dB = _gg_tn(dC, A, grp_off, G, ctx.max_rows) if ctx.needs_input_grad[1] else None
+        db = _seg_colsum(dC, grp_off, G, ctx.max_rows) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dA, dB, db, None, None
+
+
+class _GroupedNN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, bias, residual, grp_off, max_rows: int):
+        A, B = _f32c(A, "A"), _f32c(B, "B")
+        ctx.save_for_backward(A, B, grp_off)
+        ctx.max_rows, ctx.has_bias, ctx.has_res = max_rows, bias is not None, residual is not None
+        return _gg_nn(A, B, _f32c(bias, "bias") if bias is not None else None,
+                      _f32c(residual, "residual") if residual is not None else None, grp_off, max_rows)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B, grp_off = ctx.saved_tensors
+        dC = _f32c(dC, "dC")
+        G = B.shape[0]
+        dA = _gg_nt(dC, B, None, grp_off, ctx.max_rows) if ctx.needs_input_grad[0] else None       # B[g] is [K, N] = [out, in]
+        dB = _gg_tn(A, dC, grp_off, G, ctx.max_rows) if ctx.needs_input_grad[1] else None
+        db = colsum(dC) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dA, dB, db, (dC if ctx.has_res else None), None, None
+
+
+class _GroupedTN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, X, grp_off, G: int, max_rows: int):
+        A, X = _f32c(A, "A"), _f32c(X, "X")
+        ctx.save_for_backward(A, X, grp_off)
+        ctx.max_rows = max_rows
+        return _gg_tn(A, X, grp_off, G, max_rows)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, X, grp_off = ctx.saved_tensors
+        dC = _f32c(dC, "dC")
+        dA = _gg_nt(X, dC, None, grp_off, ctx.max_rows) if ctx.needs_input_grad[0] else None        # dC[g] is [M, N] = [out, in]
+        dX = _gg_nn(A, dC, None, None, grp_off, ctx.max_rows) if ctx.needs_input_grad[1] else None
+        return dA, dX, None, None, None
+
+
+class _GrpColSoftmax(torch.autograd.Function):
+    """Softmax over the rows of each group, per column (columns >= TH are padding: zeros)."""
+
+    @staticmethod
+    def forward(ctx, S, grp_off, G: int, TH: int):
+        A = S if (S.is_contiguous() and S.dtype == torch.float32) else _f32c(S, "S").clone()
+        if A is S:
+            ctx.mark_dirty(S)              # in place: the scores are the fresh output of the product that formed them
+        rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(grp_off), G, TH, _stream())
+        _lib.check(rc, "mil_grp_col_softmax")
+        ctx.save_for_backward(A, grp_off)
+        ctx.G, ctx.TH = G, TH
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        A, grp_off = ctx.saved_tensors
+        dA = _f32c(dA, "dA")
+        dS = torch.empty_like(A)
+        rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(grp_off), ctx.G, ctx.TH, _p(dS), _stream())
+        _lib.check(rc, "mil_grp_col_softmax_bwd")
+        return dS, None, None, None
+
+
+class _RowSoftmaxT(torch.autograd.Function):
+    """Softmax over the T tokens of every (row, head); column t H + h."""
+
+    @staticmethod
+    def forward(ctx, S, T: int, H: int):
+        A = S if (S.is_contiguous() and S.dtype == torch.float32) else _f32c(S, "S").clone()
+        if A is S:
+            ctx.mark_dirty(S)
+        rc = _lib.lib().mil_row_softmax_t(_p(A), A.stride(0), A.shape[0], T, H, _stream())
+        _lib.check(rc, "mil_row_softmax_t")
+        ctx.save_for_backward(A)
+        ctx.T, ctx.H = T, H
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        (A,) = ctx.saved_tensors
+        dA = _f32c(dA, "dA")
+        dS = torch.empty_like(A)
+        rc = _lib.lib().mil_row_softmax_t_bwd(_p(A), _p(dA), A.stride(0), A.shape[0], ctx.T, ctx.H, _p(dS), _stream())
+        _lib.check(rc, "mil_row_softmax_t_bwd")
+        return dS, None, None
+
+
+def _pad_vectors(V, B: int, TH: int):
+    """[B * T, H, E] absorbed vectors -> [B, TH padded to a multiple of 32, E] (zero rows behind)."""
+    E = V.shape[-1]
+    V = V.reshape(B, TH, E)
+    pad = (-TH) % 32
+    return torch.nn.functional.pad(V, (0, 0, 0, pad)) if pad else V
+
+
+def multi_token_ok(E: int, H: int, t_lengths) -> bool:
+    T = t_lengths[0] if len(t_lengths) else 0
+    return E == 512 and H == 8 and 1 < T <= 12 and all(t == T for t in t_lengths)
+
+
+def multi_token_pool_attention(q_tok, keys, kin, segs, Wq, bq, Wk, Wv, bv, H: int):
+    """Token -> image attention for T text tokens per bag with the K / V projections absorbed
+    (model/sam/transformer.py:291-295,113-118): the image side is three skinny grouped products around a column
+    softmax instead of two [N, 512] x [512, 256] projections and an attention core.  segs: queries = tokens, keys = patches.
+    Returns the pre-out_proj output [B * T, H * C]."""
+    B, T = segs.B, segs.Tq_max
+    TH = T * H
+    C = Wq.shape[0] // H
+    qp = linear_act(q_tok, Wq, bq) * (1.0 / C ** 0.5)
+    Qp = _pad_vectors(_AbsorbQuery.apply(qp, Wk, H), B, TH)                      # k_proj.bias is softmax-invariant
+    S = _GroupedNT.apply(kin, Qp, None, segs.k_off, segs.Tk_max)
+    A = _GrpColSoftmax.apply(S, segs.k_off, B, TH)
+    pooled = _GroupedTN.apply(A, keys, segs.k_off, B, segs.Tk_max)               # [B, THp, E]
+    return _ValueProj.apply(pooled[:, :TH].reshape(B * T, H, keys.shape[1]), Wv, bv)
+
+
+def multi_token_rows_attention(kin, k_tok, v_tok, segs, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H: int, residual=None):
+    """Image -> token attention (every patch over the T text tokens of its bag, sam/transformer.py:303-307) with the
+    q and out projections absorbed into T x H key vectors Wq_h^T k_th (+ the scalar bq_h . k_th) and value vectors
+    Wo_h v_th.  segs: queries = patches, keys = tokens.  Returns out_proj(attention) + residual, [R, E]."""
+    B, T = segs.B, segs.Tk_max
+    TH = T * H
+    C = Wq.shape[0] // H
+    scale = 1.0 / C ** 0.5
+    kp = linear_act(k_tok, Wk, bk)                                                # [B * T, H * C]
+    vp = linear_act(v_tok, Wv, bv)
+    Kp = _pad_vectors(_AbsorbQuery.apply(kp * scale, Wq, H), B, TH)
+    cb = ((kp.view(B * T, H, C) * bq.view(1, H, C)).sum(-1) * scale).reshape(B, TH)
+    pad = (-TH) % 32
+    cb = torch.nn.functional.pad(cb, (0, pad)) if pad else cb
+    S = _GroupedNT.apply(kin, Kp, cb.contiguous(), segs.q_off, segs.Tq_max)
+    A = _RowSoftmaxT.apply(S, T, H)
+    Vp = _pad_vectors(_AbsorbQuery.apply(vp, Wo.t().contiguous(), H), B, TH)      # Vp[t, h] = Wo[:, hC:(h+1)C] v_th
+    return _GroupedNN.apply(A, Vp, bo, residual, segs.q_off, segs.Tq_max)

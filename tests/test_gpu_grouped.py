@@ -1,0 +1,102 @@
+"""GPU: grouped skinny products and the two softmax stages of the multi-token absorbed attention against torch,
+ragged groups, forward and autograd backward (ops._GroupedNT/_GroupedNN/_GroupedTN are closed under differentiation)."""
+import pytest
+import torch
+
+from conftest import rel_err
+from mil_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+LENS = [300, 64, 1, 517]
+
+
+def _off():
+    off = torch.zeros(len(LENS) + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.tensor(LENS), 0)
+    return off
+
+
+def _grads(fn, ins, go):
+    ins = [t.clone().requires_grad_(True) for t in ins]
+    out = fn(*ins)
+    out.backward(go)
+    return out.detach(), [t.grad for t in ins]
+
+
+def test_grouped_products_and_their_backwards():
+    g = torch.Generator().manual_seed(0)
+    R, G, N, K = sum(LENS), len(LENS), 96, 512
+    off = _off()
+    A = torch.randn((R, K), generator=g)
+    B = torch.randn((G, N, K), generator=g) / K ** 0.5
+    bias = torch.randn((G, N), generator=g)
+    go = torch.randn((R, N), generator=g)
+    seg = [(int(off[i]), int(off[i + 1])) for i in range(G)]
+
+    def ref_nt(A, B, bias):
+        return torch.cat([A[a:b] @ B[i].t() + bias[i] for i, (a, b) in enumerate(seg)], 0)
+
+    o_ref, g_ref = _grads(ref_nt, [A, B, bias], go)
+    o, gr = _grads(lambda a, b, c: ops._GroupedNT.apply(a, b, c, off.to(DEV), max(LENS)), [A.to(DEV), B.to(DEV), bias.to(DEV)],
+                   go.to(DEV))
+    assert rel_err(o.cpu(), o_ref) <= 2e-6
+    for x, y in zip(gr, g_ref):
+        assert rel_err(x.cpu(), y) <= 1e-5
+
+    P = torch.randn((R, N), generator=g)
+    V = torch.randn((G, N, K), generator=g) / N ** 0.5
+    res = torch.randn((R, K), generator=g)
+    bo = torch.randn((K,), generator=g)
+    go2 = torch.randn((R, K), generator=g)
+
+    def ref_nn(P, V, bo, res):
+        return torch.cat([P[a:b] @ V[i] for i, (a, b) in enumerate(seg)], 0) + bo + res
+
+    o_ref, g_ref = _grads(ref_nn, [P, V, bo, res], go2)
+    o, gr = _grads(lambda p, v, b, r: ops._GroupedNN.apply(p, v, b, r, off.to(DEV), max(LENS)),
+                   [P.to(DEV), V.to(DEV), bo.to(DEV), res.to(DEV)], go2.to(DEV))
+    assert rel_err(o.cpu(), o_ref) <= 2e-6
+    for x, y in zip(gr, g_ref):
+        assert rel_err(x.cpu(), y) <= 1e-5
+
+    go3 = torch.randn((G, N, K), generator=g)
+
+    def ref_tn(P, X):
+        return torch.stack([P[a:b].t() @ X[a:b] for a, b in seg], 0)
+
+    o_ref, g_ref = _grads(ref_tn, [P, A], go3)
+    o, gr = _grads(lambda p, x: ops._GroupedTN.apply(p, x, off.to(DEV), G, max(LENS)), [P.to(DEV), A.to(DEV)], go3.to(DEV))
+    assert rel_err(o.cpu(), o_ref) <= 2e-6
+    for x, y in zip(gr, g_ref):
+        assert rel_err(x.cpu(), y) <= 1e-5
+
+
+def test_column_and_row_softmax_stages():
+    g = torch.Generator().manual_seed(1)
+    R, G, T, H, ld = sum(LENS), len(LENS), 10, 8, 96
+    TH = T * H
+    off = _off()
+    S = torch.randn((R, ld), generator=g) * 3
+    go = torch.randn((R, ld), generator=g)
+    seg = [(int(off[i]), int(off[i + 1])) for i in range(G)]
+
+    def ref_col(S):
+        out = torch.zeros_like(S)
+        out[:, :TH] = torch.cat([torch.softmax(S[a:b, :TH], 0) for a, b in seg], 0)
+        return out
+
+    o_ref, (g_ref,) = _grads(ref_col, [S], go)
+    o, (gr,) = _grads(lambda s: ops._GrpColSoftmax.apply(s * 1.0, off.to(DEV), G, TH), [S.to(DEV)], go.to(DEV))
+    assert float((o.cpu() - o_ref).abs().max()) <= 1e-6 and float(o[:, TH:].abs().max()) == 0.0
+    assert rel_err(gr.cpu(), g_ref) <= 1e-5
+
+    def ref_row(S):
+        out = torch.zeros_like(S)
+        out[:, :TH] = torch.softmax(S[:, :TH].reshape(R, T, H), 1).reshape(R, TH)
+        return out
+
+    o_ref, (g_ref,) = _grads(ref_row, [S], go)
+    o, (gr,) = _grads(lambda s: ops._RowSoftmaxT.apply(s * 1.0, T, H), [S.to(DEV)], go.to(DEV))
+    assert float((o.cpu() - o_ref).abs().max()) <= 1e-6 and float(o[:, TH:].abs().max()) == 0.0
+    assert rel_err(gr.cpu(), g_ref) <= 1e-5
