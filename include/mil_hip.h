@@ -200,10 +200,14 @@ int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, i
  *   a_mode 0: C[rows_g, :N] = A[rows_g, :K] . B_g + bias_g + residual[rows_g]   B_g = B + g * strideB
  *             (b_mode 0: B_g [N, K], b_mode 1: B_g [K, N]);  bias_g = bias + g * strideBias (nullable);  K % 32 == 0
  *   a_mode 1: C_g[M, N] = A[rows_g, :M]^T . B[rows_g, :N],  C_g = C + g * strideC    (M % 4 == 0, N % 4 == 0)
- * max_group_rows bounds the launch grid.  No split-K: results are deterministic. */
+ * max_group_rows bounds the launch grid.  With a workspace of mil_gemm_grouped_workspace_floats(...) floats the a_mode 1
+ * form (few output tiles per group) splits each group's rows over several workgroups and folds the partial tiles in
+ * a fixed order; results are deterministic either way. */
+size_t mil_gemm_grouped_workspace_floats(int a_mode, int G, int max_group_rows, int M, int N);
 int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
                      const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB, long strideC,
-                     const float* bias, long strideBias, const float* residual, int ldr, void* stream);
+                     const float* bias, long strideBias, const float* residual, int ldr, float* workspace,
+                     size_t workspace_floats, void* stream);
 /* out[j] (+)= sum_i Y[i][j]  (bias gradients).  With a workspace of mil_colsum_workspace_floats(M, N) floats
  * a tall matrix is summed in 256-row chunks by many workgroups and folded in a second launch (fixed order). */
 size_t mil_colsum_workspace_floats(int M, int N);

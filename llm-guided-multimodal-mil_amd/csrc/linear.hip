@@ -29,7 +29,7 @@ enum { GRP_NONE = 0, GRP_ROWS = 1, GRP_CONTRACT = 2 };
 struct GemmGroups {
     const int32_t* off;      // [G + 1] row offsets
     long strideB, strideC, strideBias;
-    int mode;
+    int mode, splits;
 };
 
 // aux_mode 1: also store the pre-activation (bias added, before act) to aux - the backward of QuickGELU needs it;
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    int i0 = blockIdx.y * 128;
+    const int j0 = blockIdx.x * 128;
     int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
     if (gg.mode != GRP_NONE) {
         // grouped launch: blockIdx.z is the group (bag); no split-K
@@ -118,14 +119,27 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
             if (residual != nullptr) residual += (size_t)goff * ldr;
             B += (size_t)g * gg.strideB;
             if (bias != nullptr) bias += (size_t)g * gg.strideBias;
+            kbeg = 0;
+            kend = K;
         } else {                                   // GRP_CONTRACT: the contraction runs over the group's rows, C is per group
             K = gn;
             A += (size_t)goff * lda;
             B += (size_t)goff * ldb;
-            C += (size_t)g * gg.strideC;
+            kbeg = 0;
+            kend = K;
+            if (gg.splits > 1) {
+                // M <= 128: blockIdx.y is a chunk of the group's rows instead of a row tile; partial C tiles go to
+                // C[(g * splits + chunk)] (a workspace) and are summed by k_grouped_fold
+                const int sidx = blockIdx.y;
+                const int chunk = ((gn + gg.splits - 1) / gg.splits + LG_BK - 1) / LG_BK * LG_BK;
+                kbeg = min(gn, sidx * chunk);
+                kend = min(gn, kbeg + chunk);
+                i0 = 0;
+                C += ((size_t)g * gg.splits + sidx) * gg.strideC;
+            } else {
+                C += (size_t)g * gg.strideC;
+            }
         }
-        kbeg = 0;
-        kend = K;
     }
     const int nslice = (kend - kbeg + LG_BK - 1) / LG_BK;
 
@@ -402,9 +416,9 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
             float* Xt = aux ? aux + (size_t)rows_main * ldaux : nullptr;
             const dim3 gridt((N + 127) / 128, (Mt + 127) / 128, S_tail);
             if (b_mode == 0)
-                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
+                hipLaunchKernelGGL((k_gemm<0, 0>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE, 1});
             else
-                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
+                hipLaunchKernelGGL((k_gemm<0, 1>), gridt, dim3(256), 0, st, At, lda, B, ldb, Ct, ldc, Mt, N, K, kc_tail, bias, act, Rt, ldr, accumulate, workspace, Xt, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE, 1});
             MIL_CHECK_LAUNCH();
             const size_t n = (size_t)Mt * N;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, S_tail, Ct, ldc,
@@ -422,11 +436,11 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
     }
     dim3 grid((N + 127) / 128, (M + 127) / 128, S);
     if (a_mode == 0 && b_mode == 0)
-        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
+        hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE, 1});
     else if (a_mode == 0 && b_mode == 1)
-        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
+        hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE, 1});
     else
-        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE});
+        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, bias, act, residual, ldr, accumulate, partial, aux, ldaux, aux_mode, GemmGroups{nullptr, 0, 0, 0, GRP_NONE, 1});
     MIL_CHECK_LAUNCH();
     if (partial != nullptr) {
         const size_t n = (size_t)M * N;
@@ -454,15 +468,35 @@ extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B,
                      workspace_floats, aux, ldaux, aux_mode, stream);
 }
 
+// C_g = sum over the row chunks of a split grouped contraction (fixed order)
+__global__ __launch_bounds__(256) void k_grouped_fold(const float* __restrict__ part, int splits, size_t per, float* __restrict__ C,
+                                                      size_t total) {
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= total) return;
+    const size_t g = i4 / per, o = i4 % per;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < splits; ++sidx) v += *reinterpret_cast<const f32x4*>(part + (g * splits + sidx) * per + o);
+    *reinterpret_cast<f32x4*>(C + i4) = v;
+}
+
+extern "C" size_t mil_gemm_grouped_workspace_floats(int a_mode, int G, int max_group_rows, int M, int N) {
+    if (a_mode != 1 || M > 128 || G <= 0) return 0;
+    const int tiles = G * ((N + 127) / 128);
+    int S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
+    if (S > max_group_rows / 128) S = max_group_rows / 128;         // at least four 32-row slices per chunk
+    if (S > 8) S = 8;
+    return S >= 2 ? (size_t)G * S * M * N : 0;
+}
+
 extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
                                 const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB,
                                 long strideC, const float* bias, long strideBias, const float* residual, int ldr,
-                                void* stream) {
+                                float* workspace, size_t workspace_floats, void* stream) {
     if (!A || !B || !C || !grp_off || G < 0 || max_group_rows < 0 || N <= 0) return MIL_EINVAL;
     if (G == 0 || max_group_rows == 0) return MIL_OK;
     if ((lda & 3) || (ldb & 3)) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    GemmGroups gg{grp_off, strideB, strideC, strideBias, a_mode == 0 ? GRP_ROWS : GRP_CONTRACT};
+    GemmGroups gg{grp_off, strideB, strideC, strideBias, a_mode == 0 ? GRP_ROWS : GRP_CONTRACT, 1};
     if (a_mode == 0) {
         // C[rows_g, :N] = A[rows_g, :K] . B_g   (b_mode 0: B_g [N, K];  b_mode 1: B_g [K, N]);  K % 32 == 0
         if (K <= 0 || (K % LG_BK) != 0 || (b_mode == 1 && (N & 3))) return MIL_EINVAL;
@@ -474,8 +508,20 @@ extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float
     } else {
         // C_g[M, N] = A[rows_g, :M]^T . B[rows_g, :N]   (contraction over the group's rows)
         if (b_mode != 1 || M < 4 || (M & 3) || (N & 3) || bias || residual) return MIL_EINVAL;
-        const dim3 grid((N + 127) / 128, (M + 127) / 128, G);
-        hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, 0, 0, (const float*)nullptr, 0, (const float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
+        const size_t want = mil_gemm_grouped_workspace_floats(a_mode, G, max_group_rows, M, N);
+        if (workspace != nullptr && want > 0 && workspace_floats >= want && strideC == (long)M * N && ldc == N) {
+            // few output tiles per group: split each group's rows over S workgroups, fold the partial tiles afterwards
+            gg.splits = (int)(want / ((size_t)G * M * N));
+            const dim3 grid((N + 127) / 128, gg.splits, G);
+            hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, workspace, ldc, M, N, 0, 0, (const float*)nullptr, 0, (const float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
+            MIL_CHECK_LAUNCH();
+            const size_t total = (size_t)G * M * N;
+            hipLaunchKernelGGL(k_grouped_fold, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, workspace, gg.splits,
+                               (size_t)M * N, C, total);
+        } else {
+            const dim3 grid((N + 127) / 128, (M + 127) / 128, G);
+            hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, 0, 0, (const float*)nullptr, 0, (const float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
+        }
     }
     MIL_CHECK_LAUNCH();
     return MIL_OK;

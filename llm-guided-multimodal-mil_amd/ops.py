@@ -1003,9 +1003,12 @@ def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
 
 # --------------------------------------------------------------------------- multi-token absorbed attention (1 < T <= 12)
 def _gg(A, a_mode, B, b_mode, grp_off, G, max_rows, M, N, K, strideB, strideC, out, bias=None, stride_bias=0, residual=None):
+    nws = _lib.lib().mil_gemm_grouped_workspace_floats(a_mode, G, max_rows, M, N) if a_mode == 1 else 0
+    ws = torch.empty(nws, device=A.device, dtype=torch.float32) if nws else None
     rc = _lib.lib().mil_gemm_grouped(_p(A), A.stride(0), a_mode, _p(B), B.stride(-2), b_mode, _p(out), out.stride(-2),
                                      _p(grp_off), G, max_rows, M, N, K, strideB, strideC, _p(bias), stride_bias,
-                                     _p(residual), residual.stride(0) if residual is not None else 0, _stream())
+                                     _p(residual), residual.stride(0) if residual is not None else 0, _p(ws), nws,
+                                     _stream())
     _lib.check(rc, "mil_gemm_grouped")
     return out
 
