@@ -121,7 +121,7 @@ def main_worker(local_rank: int, nprocs: int, args):
                 loss.backward()
                 optimizer.step()
             if it % 10 == 0 or it == steps - 1:
-                losses.update(float(loss), x.shape[0])                                   # host sync only when logging
+                losses.update(float(loss.detach()), x.shape[0])                                   # host sync only when logging
                 accs.update(float(calculate_accuracy(prob.detach(), y)), x.shape[0])
                 bt.update(time.time() - end)
                 progress.display(it)

@@ -79,4 +79,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): loss = step()
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 print(json.dumps({"workload": f"fusion {a.bags} bags x {a.patches} x 768, {a.prompts} prompt(s), CLIP {a.clip_layers} layers",
-                  "ms_per_step": round(el / a.steps * 1e3, 3), "bags_per_s": round(a.bags * a.steps / el, 1), "loss": float(loss)}))
+                  "ms_per_step": round(el / a.steps * 1e3, 3), "bags_per_s": round(a.bags * a.steps / el, 1), "loss": float(loss.detach())}))
