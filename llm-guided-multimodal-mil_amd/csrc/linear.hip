@@ -336,9 +336,26 @@ static int splitk_plan(int M, int N, int K, int a_mode, int* kchunk_out) {
     if (a_mode == 1) {
         S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
     } else {
-        if (tiles > 32 || K < 256) { *kchunk_out = K; return 1; }
-        S = (2 * MIL_NUM_CU) / tiles;
-        if (S > K / 64) S = K / 64;                     // at least two 32-deep slices per split
+        if (K < 256) { *kchunk_out = K; return 1; }
+        const int slots = 2 * MIL_NUM_CU;
+        if (tiles > 32) {
+            // One partial round of the 512 resident workgroups (e.g. 10 K text-tower rows x N = 512 = 324 tiles): a round costs
+            // its full K walk however empty it is, so splitting K into S makes it ceil(tiles S / slots) / S of that - if
+            // the partial-sum traffic (M N floats written and read per split) is cheaper than the gain.  Times in us:
+            // ~6 us per 32-deep slice pair of a full round, ~4 TB/s for the partials.
+            if (tiles >= slots) { *kchunk_out = K; return 1; }
+            const float t_round = 6.0f * (float)K / 32.0f;
+            const float t_part = 8.0f * (float)M * (float)N / 4.0e6f;
+            float best = t_round;
+            S = 1;
+            for (int c = 2; c <= 6 && c <= K / 128; ++c) {
+                const float cost = (float)((tiles * c + slots - 1) / slots) / (float)c * t_round + (float)c * t_part;
+                if (cost < 0.9f * best) { best = cost; S = c; }
+            }
+        } else {
+            S = slots / tiles;
+            if (S > K / 64) S = K / 64;                 // at least two 32-deep slices per split
+        }
     }
     const int maxS = (K + LG_BK - 1) / LG_BK;
     if (S > maxS) S = maxS;
