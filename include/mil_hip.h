@@ -195,6 +195,16 @@ int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b
 int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M, int N,
                  int K, const float* bias, int act, const float* residual, int ldr, int accumulate, float* workspace,
                  size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream);
+/* Split-bf16 NT product for FROZEN weights (opt-in: the CLIP text tower under learnable prompts):
+ *   C[M, N] = act(A[M, K] . B[N, K]^T + bias) + residual, with the aux modes of mil_gemm_aux.
+ * A is fp32 and split into `pieces` bf16 summands while it is staged; B_pieces uint16 [pieces][N][ldb] holds the
+ * weights' summands (mil_split_bf16, formed once).  pieces = 2 keeps 3 cross terms (relative error ~2^-16), pieces = 3
+ * keeps 6 (~2^-23, the rounding of an fp32 product); accumulation is fp32 (v_mfma_f32_32x32x16_bf16).
+ * K % 32 == 0, lda % 4 == 0, ldb % 8 == 0, 16-byte aligned operands. */
+int mil_split_bf16(const float* src, uint16_t* dst, size_t n, int pieces, void* stream);
+int mil_gemm_split(const float* A, int lda, const uint16_t* B_pieces, int pieces, int ldb, float* C, int ldc, int M, int N,
+                   int K, const float* bias, int act, const float* residual, int ldr, float* aux, int ldaux, int aux_mode,
+                   void* stream);
 /* Grouped form (one group = one bag, rows [grp_off[g], grp_off[g+1])), used by the absorbed multi-token attention
  * where every bag multiplies its rows with its own small matrix (T x H absorbed query / key / value vectors):
  *   a_mode 0: C[rows_g, :N] = A[rows_g, :K] . B_g + bias_g + residual[rows_g]   B_g = B + g * strideB

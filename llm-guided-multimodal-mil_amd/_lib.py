@@ -48,6 +48,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
+    "mil_split_bf16": (c_int, [_P, _P, c_size_t, c_int, _P]),
+    "mil_gemm_split": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int,
+                               c_int, _P]),
     "mil_gemm_grouped": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
                                  c_long, c_long, _P, c_long, _P, c_int, _P, c_size_t, _P]),
     "mil_gemm_grouped_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -32,11 +32,32 @@ class ResidualAttentionBlock(nn.Module):
                                               ("c_proj", nn.Linear(d_model * 4, d_model))]))
         self.ln_2 = nn.LayerNorm(d_model)
         self.n_head = n_head
+        self.gemm_pieces = 0            # 0: fp32 MFMA GEMM (default); 2 / 3: split-bf16 products for the FROZEN weights
+        self._split = {}
+
+    def _fs(self, name: str, W):
+        """bf16 pieces of a frozen weight, formed once (re-formed if the tensor is replaced or modified)."""
+        hit = self._split.get(name)
+        if hit is None or hit.pieces != self.gemm_pieces or hit.key != (W.data_ptr(), W._version):
+            hit = self._split[name] = ops.FrozenSplit(W, self.gemm_pieces)
+        return hit
+
+    def _split_ok(self, x) -> bool:
+        frozen = not (self.attn.in_proj_weight.requires_grad or self.mlp.c_fc.weight.requires_grad)
+        return self.gemm_pieces in (2, 3) and frozen and x.shape[0] > ops.SMALL_ROWS
 
     def flat(self, x, segs):
         W = x.shape[1]
         h = ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        if self._split_ok(x) and ops.seq_attention_ok(segs):
+            # opt-in: the four frozen-weight products (and their dx halves) on the split-bf16 GEMM (csrc/linear_x.hip)
+            qkv = ops.linear_frozen_split(h, self._fs("in_proj", w), b)
+            o = ops.attention_seq_packed(qkv, segs, self.n_head, causal=True)
+            x = ops.linear_frozen_split(o, self._fs("out_proj", self.attn.out_proj.weight), self.attn.out_proj.bias, residual=x)
+            h = ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+            return ops.mlp_quickgelu_frozen_split(h, self._fs("c_fc", self.mlp.c_fc.weight), self.mlp.c_fc.bias,
+                                                  self._fs("c_proj", self.mlp.c_proj.weight), self.mlp.c_proj.bias, residual=x)
         if ops.seq_attention_ok(segs):
             # one in_proj GEMM of width 3 W; the attention kernels read its column blocks in place
             o = ops.attention_seq_packed(ops.linear_act(h, w, b), segs, self.n_head, causal=True)
@@ -117,6 +138,13 @@ class CLIPText(nn.Module):
         if self._proj_t is None or self._proj_t.device != device:
             self._proj_t = self.text_projection.detach().t().contiguous()     # frozen: [embed, W] = nn.Linear layout
         return self._proj_t
+
+    def set_gemm_pieces(self, pieces: int):
+        """0 = fp32 MFMA GEMMs (default, the parity path); 2 or 3 = split-bf16 products for the frozen block weights
+        (2: 3 cross terms, ~3e-6 relative error, 2.3x the fp32 GEMM rate; 3: 6 terms, fp32-level error, 1.45x)."""
+        for blk in self.transformer.resblocks:
+            blk.gemm_pieces = int(pieces)
+        return self
 
     @staticmethod
     def _live_rows(text: torch.Tensor):

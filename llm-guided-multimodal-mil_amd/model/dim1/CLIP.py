@@ -23,6 +23,8 @@ class CLIP(nn.Module):
                               int(getattr(args, "clip_heads", 8)), int(getattr(args, "clip_layers", 12)))
         for p in self.model.parameters():
             p.requires_grad_(False)
+        # opt-in: split-bf16 products for the frozen tower's GEMMs (clip/model.py: set_gemm_pieces); default fp32
+        self.model.set_gemm_pieces(int(getattr(args, "clip_gemm_pieces", 0)))
         self._cache = {}
         if getattr(args, "learnablePrompt", 0):
             self.ctx_dim = self.model.ln_final.weight.shape[0]

@@ -1195,3 +1195,82 @@ def multi_token_rows_attention(kin, k_tok, v_tok, segs, Wq, bq, Wk, bk, Wv, bv, 
     A = _RowSoftmaxT.apply(S, T, H)
     Vp = _pad_vectors(_AbsorbQuery.apply(vp, Wo.t().contiguous(), H), B, TH)      # Vp[t, h] = Wo[:, hC:(h+1)C] v_th
     return _GroupedNN.apply(A, Vp, bo, residual, segs.q_off, segs.Tq_max)
+
+
+# --------------------------------------------------------------------------- split-bf16 products for frozen weights (opt-in)
+def split_bf16(W, pieces: int):
+    """uint16 [pieces, *W.shape]: bf16 summands of a frozen fp32 weight (include/mil_hip.h: mil_split_bf16)."""
+    W = _f32c(W.detach(), "W")
+    out = torch.empty((pieces,) + tuple(W.shape), device=W.device, dtype=torch.uint16)
+    rc = _lib.lib().mil_split_bf16(_p(W), _p(out), W.numel(), pieces, _stream())
+    _lib.check(rc, "mil_split_bf16")
+    return out
+
+
+def gemm_split(A, Wp, bias=None, act: int = 0, residual=None, aux=None, aux_mode: int = 0):
+    """act(A . W^T + bias) + residual with W given as its bf16 pieces Wp [pieces, N, K] (mil_gemm_split)."""
+    A = _f32c(A, "A")
+    pieces, N, K = Wp.shape
+    M = A.shape[0]
+    out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    rc = _lib.lib().mil_gemm_split(_p(A), A.stride(0), _p(Wp), pieces, K, _p(out), N, M, N, K, _p(bias), act, _p(residual),
+                                   residual.stride(0) if residual is not None else 0, _p(aux),
+                                   aux.stride(0) if aux is not None else 0, aux_mode, _stream())
+    _lib.check(rc, "mil_gemm_split")
+    return out
+
+
+class FrozenSplit:
+    """bf16 pieces of a frozen nn.Linear weight W [N, K] and of its transpose (for the dx half of the backward)."""
+
+    def __init__(self, W, pieces: int):
+        self.pieces = pieces
+        self.fwd = split_bf16(W, pieces)                             # [pieces, N, K]
+        self.bwd = split_bf16(W.detach().t().contiguous(), pieces)   # [pieces, K, N]
+        self.key = (W.data_ptr(), W._version)
+
+
+class _LinearFrozenSplit(torch.autograd.Function):
+    """act(x W^T + b) + residual for a FROZEN W given as bf16 pieces: forward and dx on the split-bf16 product."""
+
+    @staticmethod
+    def forward(ctx, x, fs: FrozenSplit, b, residual):
+        ctx.fs, ctx.has_res = fs, residual is not None
+        return gemm_split(x, fs.fwd, bias=b, residual=_f32c(residual, "residual") if residual is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy, "dy")
+        dx = gemm_split(dy, ctx.fs.bwd) if ctx.needs_input_grad[0] else None
+        return dx, None, None, (dy if ctx.has_res else None)
+
+
+class _MlpQuickGeluFrozenSplit(torch.autograd.Function):
+    """The fused MLP node (_MlpQuickGelu) on split-bf16 products; both weights frozen."""
+
+    @staticmethod
+    def forward(ctx, x, fs1: FrozenSplit, b1, fs2: FrozenSplit, b2, residual):
+        x = _f32c(x, "x")
+        need = ctx.needs_input_grad[0]
+        pre = torch.empty((x.shape[0], fs1.fwd.shape[1]), device=x.device, dtype=torch.float32) if need else None
+        h = gemm_split(x, fs1.fwd, bias=b1, act=ACT["quickgelu"], aux=pre, aux_mode=1 if need else 0)
+        out = gemm_split(h, fs2.fwd, bias=b2, residual=_f32c(residual, "residual") if residual is not None else None)
+        ctx.fs1, ctx.fs2, ctx.has_res = fs1, fs2, residual is not None
+        ctx.save_for_backward(pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pre,) = ctx.saved_tensors
+        dout = _f32c(dout, "dout")
+        dpre = gemm_split(dout, ctx.fs2.bwd, aux=pre, aux_mode=2)
+        dx = gemm_split(dpre, ctx.fs1.bwd)
+        return dx, None, None, None, None, (dout if ctx.has_res else None)
+
+
+def linear_frozen_split(x, fs: FrozenSplit, b=None, residual=None):
+    return _LinearFrozenSplit.apply(x, fs, b, residual)
+
+
+def mlp_quickgelu_frozen_split(x, fs1: FrozenSplit, b1, fs2: FrozenSplit, b2, residual=None):
+    return _MlpQuickGeluFrozenSplit.apply(x, fs1, b1, fs2, b2, residual)

@@ -17,6 +17,7 @@ ap.add_argument("--clip_layers", type=int, default=12)
 ap.add_argument("--cache_text", action="store_true")
 ap.add_argument("--coop", action="store_true", help="learnable prompts (upstream default --learnablePrompt 1): 10 prompts "
                 "per bag, ctx trained through the frozen text tower every step; SGD lr 1e-3 as train_ddp.py:104-109")
+ap.add_argument("--clip_gemm_pieces", type=int, default=0, help="2 / 3: split-bf16 products for the frozen text tower's GEMMs")
 ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam instead of the flat one-launch Adam")
 ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
@@ -24,7 +25,7 @@ dev = torch.device("cuda")
 if a.coop:
     a.prompts = 10
 args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
-                       learnablePrompt=int(a.coop), n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI", model_CT="resnetMC3_18", clip_layers=a.clip_layers, cache_text=int(a.cache_text))
+                       learnablePrompt=int(a.coop), n_ctx=8, clinical_features=["f"] * 9, clip_gemm_pieces=a.clip_gemm_pieces, alignment_base="CI", model_CT="resnetMC3_18", clip_layers=a.clip_layers, cache_text=int(a.cache_text))
 torch.manual_seed(1234)
 model = get_model(args).to(dev).eval()      # eval: parity mode (dropout off), gradients still flow
 x = syn.make_bags(1, a.bags, a.patches, 768).to(dev)
