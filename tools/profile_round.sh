@@ -22,4 +22,7 @@ python3 $ROOT/tools/bench_fusion.py --graph --steps 50 --warmup 5 > $OUT/fusion_
 python3 $ROOT/bench.py --dtype bf16 --patches 4096 --dim 1024 --no-cpu-baseline --no-breakdown > $OUT/bf16_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --coop --steps 10 --warmup 3 > $OUT/coop_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --prompts 10 --steps 20 --warmup 3 > $OUT/p10_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --coop --clip_gemm_pieces 3 --steps 10 --warmup 3 > $OUT/coop3_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --coop --clip_gemm_pieces 2 --steps 10 --warmup 3 > $OUT/coop2_line.json 2>/dev/null
+python3 $ROOT/tools/kbench_split.py > $OUT/kbench_split.txt 2>/dev/null
 echo done

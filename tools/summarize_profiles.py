@@ -73,11 +73,18 @@ with open(os.path.join(DST, f"{TAG}_bench_mfma_busy_pmc.csv"), "w") as o:
                 f"{mean.get('SQ_LDS_BANK_CONFLICT', 0):.0f},{mean.get('SQ_WAVE_CYCLES', 0):.0f},{mean.get('SQ_WAIT_ANY', 0):.0f},{mean.get('SQ_WAIT_INST_ANY', 0):.0f}\n")
 lines = {}
 for key, fn in (("bench", "bench_line.json"), ("fusion", "fusion_line.json"), ("bf16", "bf16_line.json"),
-                ("fusion_coop", "coop_line.json"), ("fusion_10_prompts", "p10_line.json")):
+                ("fusion_coop", "coop_line.json"), ("fusion_10_prompts", "p10_line.json"),
+                ("fusion_coop_split3", "coop3_line.json"), ("fusion_coop_split2", "coop2_line.json")):
     try:
         txt = [l for l in open(os.path.join(SRC, fn)).read().splitlines() if l.startswith("{")][-1]
         lines[key] = json.loads(txt)
     except Exception as e:          # noqa: BLE001
         lines[key] = {"error": str(e)}
 json.dump(lines, open(os.path.join(DST, f"{TAG}_bench_line.json"), "w"), indent=1)
+try:
+    txt = open(os.path.join(SRC, "kbench_split.txt")).read()
+    open(os.path.join(DST, f"{TAG}_split_gemm_kbench.txt"), "w").write(
+        "# python3 tools/kbench_split.py: fp32 MFMA GEMM vs split-bf16 products (2 / 3 pieces), error against float64 on 512 rows\n" + txt)
+except OSError:
+    pass
 print("wrote", sorted(os.listdir(DST)))
