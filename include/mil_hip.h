@@ -160,6 +160,10 @@ int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, const float*
                              int R, int L, int D, void* stream);
 int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
                                float* partials, void* stream);
+/* mil_attn_pool_partial_bf16 with the head-projection by-product of mil_attn_pool_partial_h (hrow [R, C] = x Wf^T on the
+ * stored bf16 values, C <= 4): the backward then takes mil_attn_pool_bwd_from_h and never re-reads x. */
+int mil_attn_pool_partial_h_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
+                                 float* partials, const float* Wf, int C, float* hrow, void* stream);
 int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, const float* lse, const float* dM,
                            const float* cdot, const int32_t* tile_map, int T, int L, float* ds, void* stream);
 /* Gate parameter gradients on the bf16 MFMA: x and dPre rounded to bf16, fp32 accumulation, fp32 partials and

@@ -41,6 +41,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
     "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P]),
+    "mil_attn_pool_partial_h_bf16": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),
     "mil_attn_pool_bwd_bf16": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
     "mil_gate_bwd_workspace_floats_bf16": (c_size_t, [c_int, c_int]),
     "mil_gate_bwd_params_bf16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),

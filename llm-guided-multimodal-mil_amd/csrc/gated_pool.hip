@@ -197,7 +197,27 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] += p * v[i][q];
     }
-    if (Wf != nullptr) {
+    if (Wf != nullptr && C == 2) {
+        // two classes (the usual head): the tile's 8 x 2 dot products of this wave go through ONE 16-value reduction
+        float d16[16];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 wf[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) wf[q] = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 256 * q + 4 * lane);
+#pragma unroll
+            for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    d += v[i][q][0] * wf[q][0] + v[i][q][1] * wf[q][1] + v[i][q][2] * wf[q][2] + v[i][q][3] * wf[q][3];
+                d16[2 * i + c] = d;
+            }
+        }
+        const float tot = wave_reduce16(d16, lane);
+        const int k = wave_reduce16_index(lane), rr = wave + 4 * (k >> 1);
+        if ((lane & 3) == 0 && rr < nrows) hrow[(size_t)(row0 + rr) * 2 + (k & 1)] = tot;
+    } else if (Wf != nullptr) {
         for (int c = 0; c < C; ++c) {
             f32x4 wf[NQ];
 #pragma unroll

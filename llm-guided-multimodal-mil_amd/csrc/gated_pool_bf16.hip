@@ -344,7 +344,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 template <int NQ>
 __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict__ x, const float* __restrict__ scores,
                                                            const int32_t* __restrict__ tile_map,
-                                                           float* __restrict__ partials, int L) {
+                                                           float* __restrict__ partials, int L,
+                                                           const float* __restrict__ Wf, int C, float* __restrict__ hrow) {
     __shared__ float p_lds[MIL_POOL_TILE];
     __shared__ float ml_lds[2];
     __shared__ __attribute__((aligned(16))) float red[3 * NQ * 512];
@@ -380,6 +381,56 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[q][e] += p * bf16_to_f32(v[i][q][e]);
+    }
+    if (Wf != nullptr && C == 2) {
+        float d16[16];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float wf[NQ][8];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wf[q][e] = w0[e]; wf[q][4 + e] = w1[e]; }
+            }
+#pragma unroll
+            for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += bf16_to_f32(v[i][q][e]) * wf[q][e];
+                d16[2 * i + c] = d;
+            }
+        }
+        const float tot = wave_reduce16(d16, lane);
+        const int k = wave_reduce16_index(lane), rr = wave + 4 * (k >> 1);
+        if ((lane & 3) == 0 && rr < nrows) hrow[(size_t)(row0 + rr) * 2 + (k & 1)] = tot;
+    } else if (Wf != nullptr) {
+        // by-product (as in k_pool_partial): h[row][c] = x_row . Wf[c], so the backward needs no second pass over x
+        const int nrows_ = nrows;
+        for (int c = 0; c < C; ++c) {
+            float wf[NQ][8];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wf[q][e] = w0[e]; wf[q][4 + e] = w1[e]; }
+            }
+#pragma unroll
+            for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += bf16_to_f32(v[i][q][e]) * wf[q][e];
+                d = wave_allsum(d);
+                const int rr = wave + 4 * i;
+                if (lane == 0 && rr < nrows_) hrow[(size_t)(row0 + rr) * C + c] = d;
+            }
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -676,8 +727,20 @@ extern "C" int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores
     if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L);
-    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L);
+    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr);
+    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_attn_pool_partial_h_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
+                                            float* partials, const float* Wf, int C, float* hrow, void* stream) {
+    if (!x || !scores || !tile_map || !partials || !Wf || !hrow) return MIL_EINVAL;
+    if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0 || C <= 0 || C > 4) return MIL_EINVAL;
+    if (T == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow);
+    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

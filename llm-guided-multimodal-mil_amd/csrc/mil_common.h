@@ -36,6 +36,27 @@ __device__ __forceinline__ float half_allsum(float v) {
     return v;
 }
 
+// Sum 16 per-lane values over the 64 lanes of a wave with 17 cross-lane steps instead of 16 x 6: each step halves the
+// number of values a lane carries while it doubles the lanes summed.  Afterwards lane l holds the wave total of value
+// index k(l) = 8 b5 + 4 b4 + 2 b3 + b2 (b_i = bit i of l); wave_reduce16_owner(k) is one lane holding index k.
+__device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
+    float w8[8], w4[4], w2[2];
+    const bool s5 = lane & 32, s4 = lane & 16, s3 = lane & 8, s2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w8[j] = (s5 ? v[j + 8] : v[j]) + __shfl_xor(s5 ? v[j] : v[j + 8], 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (s4 ? w8[j + 4] : w8[j]) + __shfl_xor(s4 ? w8[j] : w8[j + 4], 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w2[j] = (s3 ? w4[j + 2] : w4[j]) + __shfl_xor(s3 ? w4[j] : w4[j + 2], 8);
+    float r = (s2 ? w2[1] : w2[0]) + __shfl_xor(s2 ? w2[0] : w2[1], 4);
+    r += __shfl_xor(r, 2);
+    r += __shfl_xor(r, 1);
+    return r;
+}
+__device__ __forceinline__ int wave_reduce16_index(int lane) {
+    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // exp2-based forms: v_exp_f32 + v_rcp_f32, abs error ~1e-7 on outputs in [-1, 1].

@@ -793,6 +793,19 @@ def attn_pool_partial_bf16(x16, scores, layout: BagLayout):
     return partials
 
 
+def attn_pool_partial_h_bf16(x16, scores, layout: BagLayout, Wf):
+    """bf16 tile partials plus hrow [R, C] = x Wf^T (mil_attn_pool_partial_h_bf16)."""
+    x16 = _bf16c(x16, "x")
+    R, L = x16.shape
+    C = Wf.shape[0]
+    partials = torch.empty(layout.T * (L + 2), device=x16.device, dtype=torch.float32)
+    hrow = torch.empty((R, C), device=x16.device, dtype=torch.float32)
+    rc = _lib.lib().mil_attn_pool_partial_h_bf16(_p(x16), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials),
+                                                 _p(_f32c(Wf, "Wf")), C, _p(hrow), _stream())
+    _lib.check(rc, "mil_attn_pool_partial_h_bf16")
+    return partials, hrow
+
+
 def attn_pool_bwd_bf16(x16, scores, lse, dM, cdot, layout: BagLayout):
     x16 = _bf16c(x16, "x")
     R, L = x16.shape

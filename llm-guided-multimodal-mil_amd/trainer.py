@@ -111,7 +111,9 @@ class ImageOnlyTrainer:
         fp = self.fp
         scores, gates = self._gate_fwd(x, save_gates=y is not None)
         hrow = None
-        if x.dtype == torch.bfloat16:
+        if x.dtype == torch.bfloat16 and y is not None and fp.p("fc.1.weight").shape[0] <= 4:
+            partials, hrow = ops.attn_pool_partial_h_bf16(x, scores, layout, fp.p("fc.1.weight"))
+        elif x.dtype == torch.bfloat16:
             partials = ops.attn_pool_partial_bf16(x, scores, layout)
         elif y is not None and fp.p("fc.1.weight").shape[0] <= 4:
             # training: the pool pass also projects every patch on the head (x_i . Wf[c]); the backward then
@@ -132,10 +134,10 @@ class ImageOnlyTrainer:
         c, fp = self.last, self.fp
         ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum)
         b16 = c["x"].dtype == torch.bfloat16
-        if b16:
-            ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
-        elif c.get("hrow") is not None:
+        if c.get("hrow") is not None:
             ds = ops.attn_pool_bwd_from_h(c["scores"], c["lse"], c["hrow"], c["dz"], c["cdot"], c["layout"])
+        elif b16:
+            ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
         else:
             ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
         dw_fn = ops.gate_bwd_params
