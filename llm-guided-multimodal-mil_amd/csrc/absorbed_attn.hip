@@ -120,13 +120,19 @@ __global__ __launch_bounds__(256) void k_apool_partial(const float* __restrict__
             kv[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
             kin[q] = kv[q] + *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
         }
+        float d8[AP_H];
 #pragma unroll
         for (int h = 0; h < AP_H; ++h) {
             float d = 0.f;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 d += kin[q][0] * qv[h][q][0] + kin[q][1] * qv[h][q][1] + kin[q][2] * qv[h][q][2] + kin[q][3] * qv[h][q][3];
-            const float s = wave_allsum(d);
+            d8[h] = d;
+        }
+        const float tot = wave_reduce8(d8, lane);              // the eight head scores of this key in 10 cross-lane steps
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            const float s = wave_reduce8_get(tot, h);
             const float mn = fmaxf(m[h], s);
             const float alpha = __expf(m[h] - mn), p = __expf(s - mn);
             l[h] = l[h] * alpha + p;

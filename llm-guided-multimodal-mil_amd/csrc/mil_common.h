@@ -53,6 +53,24 @@ __device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
     r += __shfl_xor(r, 1);
     return r;
 }
+// Eight values: 10 cross-lane steps instead of 8 x 6; lane l ends with the total of index 4 b5 + 2 b4 + b3.
+__device__ __forceinline__ float wave_reduce8(const float (&v)[8], int lane) {
+    float w4[4], w2[2];
+    const bool s5 = lane & 32, s4 = lane & 16, s3 = lane & 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (s5 ? v[j + 4] : v[j]) + __shfl_xor(s5 ? v[j] : v[j + 4], 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w2[j] = (s4 ? w4[j + 2] : w4[j]) + __shfl_xor(s4 ? w4[j] : w4[j + 2], 16);
+    float r = (s3 ? w2[1] : w2[0]) + __shfl_xor(s3 ? w2[0] : w2[1], 8);
+    r += __shfl_xor(r, 4);
+    r += __shfl_xor(r, 2);
+    r += __shfl_xor(r, 1);
+    return r;
+}
+// the total of index k (0..7) of wave_reduce8, made wave-uniform (k is a compile-time constant after unrolling)
+__device__ __forceinline__ float wave_reduce8_get(float r, int k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), ((k >> 2) & 1) * 32 + ((k >> 1) & 1) * 16 + (k & 1) * 8));
+}
 __device__ __forceinline__ int wave_reduce16_index(int lane) {
     return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
 }
