@@ -123,3 +123,40 @@ def test_image_only_module_vs_oracle():
         o = orc.image_only_forward(x[b], p)
         assert float((m.last_logits[b].cpu() - o["logits"][0]).abs().max()) <= 2e-5
         assert float((emb[b].detach().cpu() - o["M"][0]).abs().max()) <= 1e-5
+
+
+def test_ten_prompts_ragged_batch_absorbed_path_matches_the_general_path(monkeypatch):
+    """10 prompts per bag, ragged bags: the multi-token absorbed attention (grouped skinny products, two-segment bag layout)
+    against the general projection + attention-core path of the same module - outputs and every parameter gradient -
+    and against the same bags run one at a time."""
+    from mil_amd import ops
+    torch.manual_seed(11)
+    model = get_model(make_args(clip_layers=1)).to(DEV).eval()
+    ns = [40, 100, 77]
+    x = torch.zeros(3, 100, 768)
+    gen = torch.Generator().manual_seed(5)
+    for b, n in enumerate(ns):
+        x[b, :n] = torch.randn(n, 768, generator=gen)
+    ids = syn.make_token_ids(12, 3, 10).to(DEV)
+    y = syn.make_labels(13, 3).to(DEV)
+
+    def run():
+        model.zero_grad()
+        prob, _ = model([x.to(DEV)], ids, lengths=ns)
+        torch.nn.BCELoss()(prob, y).backward()
+        return prob.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    p_abs, g_abs = run()
+    monkeypatch.setattr(ops, "multi_token_ok", lambda *a, **k: False)
+    p_gen, g_gen = run()
+    assert float((p_abs - p_gen).abs().max()) <= 2e-6
+    # token->image k_proj.bias is softmax-invariant: exactly no gradient on the absorbed path, rounding noise on the general one
+    assert {k for k in g_gen if not k.endswith("k_proj.bias")} <= set(g_abs)
+    for k in g_gen:
+        if float(g_gen[k].norm()) > 1e-7 and not k.endswith("k_proj.bias"):
+            assert rel_err(g_abs[k].cpu(), g_gen[k].cpu()) <= 2e-4, k
+    monkeypatch.undo()
+    with torch.no_grad():
+        for b, n in enumerate(ns):
+            p1, _ = model([x[b:b + 1, :n].to(DEV)], ids[b:b + 1])
+            assert float((p_abs[b] - p1[0]).abs().max()) <= 2e-6
