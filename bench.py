@@ -65,12 +65,12 @@ def kernel_breakdown(tr, x, lay, y, iters=20):
     out["pool_partial"] = timed(lambda: ops.attn_pool_partial_h(x, c["scores"], lay, fp.p("fc.1.weight")), iters)
     partials, hrow = ops.attn_pool_partial_h(x, c["scores"], lay, fp.p("fc.1.weight"))
     scale = 1.0 / c["prob"].numel()
-    out["merge_head_loss"] = timed(lambda: ops.pool_merge_head(partials, lay, L, fp.p("fc.1.weight"), fp.p("fc.1.bias"),
-                                                               y, scale), iters)
+    # with hrow the fused tail also writes the score gradient ds (the former k_pool_ds_from_h launch)
+    out["merge_head_loss_ds"] = timed(lambda: ops.pool_merge_head(partials, lay, L, fp.p("fc.1.weight"), fp.p("fc.1.bias"),
+                                                                  y, scale, scores=c["scores"], hrow=hrow), iters)
     out["head_bwd_params"] = timed(lambda: ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"),
                                                                c["loss_bag"], tr.loss_sum), iters)
-    ds = ops.attn_pool_bwd_from_h(c["scores"], c["lse"], hrow, c["dz"], c["cdot"], lay)
-    out["pool_bwd_ds_from_h"] = timed(lambda: ops.attn_pool_bwd_from_h(c["scores"], c["lse"], hrow, c["dz"], c["cdot"], lay), iters)
+    ds = c["ds"]
     g = {k: torch.empty_like(fp.p(k)) for k in fp.order}
     gargs = (g["aggregator.attention_V.0.weight"], g["aggregator.attention_V.0.bias"], g["aggregator.attention_U.0.weight"],
              g["aggregator.attention_U.0.bias"], g["aggregator.attention_weights.weight"].view(-1),

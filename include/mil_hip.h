@@ -80,12 +80,14 @@ int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float*
 /* Fused per-bag tail (one workgroup per bag): merge the partials -> M, lse; head z, p; and, when
  * labels y are given, the bag's BCE loss loss_bag[b] = scale * sum_c BCE(p_bc, y_bc) (log clamped at -100;
  * summed in fixed order by mil_head_bwd_params), dz, dM = dz Wf and cdot = M . dM, i.e. everything
- * between the pool's partial pass and the pool's backward.
+ * between the pool's partial pass and the pool's backward.  With ds (and tile_map, scores, hrow = the head
+ * projections of mil_attn_pool_partial_h) it also writes the score gradient of every row of the bag
+ * (= mil_attn_pool_bwd_from_h, folded into this launch); ds requires y.
  * ABMIL.py:57-59 + aggregator.py:128-131,200 + train_ddp.py:99,323-324.  L in {256, 512, 768, 1024}. */
 int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
                         const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                         float* lse, float* z, float* p, float* loss_bag, float* dz, float* dM, float* cdot,
-                        void* stream);
+                        const int32_t* tile_map, const float* scores, const float* hrow, float* ds, void* stream);
 
 /* ---- K3b: per-bag head ------------------------------------------------------------------
  * z = M Wf^T + bf (logits), p = sigmoid(z).  model/aggregator.py:128-131,200 (eval: the

@@ -25,7 +25,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_attn_pool_partial": (c_int, [_P] * 3 + [c_int, c_int, _P, _P]),
     "mil_attn_pool_partial_h": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_int, _P, _P]),
     "mil_attn_pool_bwd_from_h": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
-    "mil_pool_merge_head": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 8 + [_P]),
+    "mil_pool_merge_head": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12 + [_P]),
     "mil_head_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P]),
     "mil_bce_fwd_bwd": (c_int, [_P] * 4 + [c_int, c_int, c_float, _P]),
     "mil_head_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),

@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
                                                          float* __restrict__ M, float* __restrict__ lse,
                                                          float* __restrict__ z, float* __restrict__ p,
                                                          float* __restrict__ loss_sum, float* __restrict__ dz,
-                                                         float* __restrict__ dM, float* __restrict__ cdot) {
+                                                         float* __restrict__ dM, float* __restrict__ cdot,
+                                                         const int32_t* __restrict__ tile_map,
+                                                         const float* __restrict__ scores, const float* __restrict__ hrow,
+                                                         float* __restrict__ ds) {
     __shared__ float red[4];
     __shared__ float scale_lds[1024];
     __shared__ __attribute__((aligned(16))) float m_lds[1024];
@@ -269,18 +272,34 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     }
     dot = block_allsum_256(dot, red);
     if (tid == 0) cdot[b] = dot;
+    if (ds != nullptr) {
+        // the score gradient of this bag's rows from the forward's head projections (k_pool_ds_from_h, fused here: every
+        // quantity it needs - lse, dz, M . dM - was just formed by this workgroup):  ds_i = A_i (sum_c dz_c h_i[c] - M . dM)
+        const float lse_b = m + logf(l);
+        for (int g8 = t0 + (tid >> 5); g8 < t1; g8 += 8) {
+            const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+            if (lr < nrows) {
+                const size_t row = (size_t)(row0 + lr);
+                float gd = 0.f;
+                for (int c = 0; c < C; ++c) gd += dzs[c] * hrow[row * C + c];
+                ds[row] = expf(scores[row] - lse_b) * (gd - dot);
+            }
+        }
+    }
 }
 
 extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
                                    const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                                    float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
+                                   const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
                                    void* stream) {
     if (!partials || !bag_tile_off || !Wf || !bf || !M || !lse || !z || !p) return MIL_EINVAL;
     if (y && (!loss_sum || !dz || !dM || !cdot)) return MIL_EINVAL;
+    if (ds && (!y || !tile_map || !scores || !hrow)) return MIL_EINVAL;
     if (!(L == 256 || L == 512 || L == 768 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     hipLaunchKernelGGL(k_pool_merge_head, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
-                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot);
+                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -98,19 +98,24 @@ def attn_pool_bwd_from_h(scores, lse, hrow, dz, cdot, layout: BagLayout):
     return ds
 
 
-def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0):
-    """Fused per-bag tail: returns dict(M, lse, logits, prob[, loss_bag, dz, dM, cdot]); with labels it also
-    produces each bag's scaled BCE loss and the head's backward inputs for the pool."""
+def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0, scores=None, hrow=None):
+    """Fused per-bag tail: returns dict(M, lse, logits, prob[, loss_bag, dz, dM, cdot[, ds]]); with labels it also
+    produces each bag's scaled BCE loss and the head's backward inputs for the pool, and with the forward's head
+    projections `hrow` (attn_pool_partial_h) the score gradient ds of every row as well."""
     B, C, dev = layout.B, Wf.shape[0], partials.device
     out = dict(M=torch.empty((B, L), device=dev), lse=torch.empty(B, device=dev),
                logits=torch.empty((B, C), device=dev), prob=torch.empty((B, C), device=dev))
     if y is not None:
         out.update(dz=torch.empty((B, C), device=dev), dM=torch.empty((B, L), device=dev),
                    cdot=torch.empty(B, device=dev), loss_bag=torch.empty(B, device=dev))
+        if hrow is not None and scores is not None:
+            out["ds"] = torch.empty(scores.shape[0], device=dev)
     rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
                                         _p(_f32c(bf, "bf")), C, _p(y), float(scale), _p(out["M"]), _p(out["lse"]),
                                         _p(out["logits"]), _p(out["prob"]), _p(out.get("loss_bag")), _p(out.get("dz")),
-                                        _p(out.get("dM")), _p(out.get("cdot")), _stream())
+                                        _p(out.get("dM")), _p(out.get("cdot")),
+                                        _p(layout.tile_map) if "ds" in out else None, _p(scores) if "ds" in out else None,
+                                        _p(hrow) if "ds" in out else None, _p(out.get("ds")), _stream())
     _lib.check(rc, "mil_pool_merge_head")
     return out
 

@@ -125,7 +125,8 @@ class ImageOnlyTrainer:
         if y is not None:
             nb = global_bags if global_bags is not None else layout.B * self.world
             scale = 1.0 / (nb * fp.p("fc.1.weight").shape[0])
-        t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale)
+        t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale,
+                                scores=scores, hrow=hrow)                 # with hrow: ds comes out of this launch too
         self.last = dict(x=x, layout=layout, scores=scores, gates=gates, hrow=hrow, **t)
         return t["prob"], t["logits"]
 
@@ -134,7 +135,9 @@ class ImageOnlyTrainer:
         c, fp = self.last, self.fp
         ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum)
         b16 = c["x"].dtype == torch.bfloat16
-        if c.get("hrow") is not None:
+        if c.get("ds") is not None:
+            ds = c["ds"]
+        elif c.get("hrow") is not None:
             ds = ops.attn_pool_bwd_from_h(c["scores"], c["lse"], c["hrow"], c["dz"], c["cdot"], c["layout"])
         elif b16:
             ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
