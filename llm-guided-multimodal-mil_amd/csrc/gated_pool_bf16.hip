@@ -178,6 +178,9 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
 // global_load_dwordx4 + ds_write_b128 with asm loads and counted vmcnt): 240-250 us.  288 accumulator registers do
 // not fit the 256 AGPRs and hipcc then shuttles tiles between the two register files around every MFMA
 // (hundreds of v_accvgpr_read/write per slice); 16 tiles per wave is the limit, which N = 384 does not tile evenly.
+// And the 128-row kernel with register staging (asm global_load_dwordx4 two slices ahead + ds_write_b128) instead of
+// LDS-DMA: 170 us, bit-identical results - the same as with DMA (171), so at 128 rows the staging method is not the
+// limiter either (7 LDS fragment reads per 6 MFMAs: 224 KB of reads + 64 KB of writes per slice against 1536 MFMA cycles).
 // Wave (wr, wc) = 64 rows x 3 d-chunks x {V, U}: 12 accumulator tiles (192 registers); B fragments rotate through
 // three register slots read two ahead of use (counted lgkmcnt waits).
 // LDS image: row = 4 chunks of 16 B, chunk c of row `row` stored at c ^ ((row >> 2) & 3): conflict-free for the

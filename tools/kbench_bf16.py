@@ -32,8 +32,10 @@ for q in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)
     keep = _lib._lib
     _lib._lib = load(q)
     t = timed(lambda: ops.gate_scores_fwd_bf16(*args, save_gates=False))
-    print(f"variant {os.path.basename(q):28s} fwd (no gates) {t:7.1f} us")
+    sv, gv = ops.gate_scores_fwd_bf16(*args, save_gates=True)
     _lib._lib = keep
+    sm, gm = ops.gate_scores_fwd_bf16(*args, save_gates=True)
+    print(f"variant {os.path.basename(q):28s} fwd (no gates) {t:7.1f} us   max|dscore| vs main {float((sv - sm).abs().max()):.1e} max|dgates| {float((gv - gm).abs().max()):.1e}")
 for save in (True, False):
     t = timed(lambda: ops.gate_scores_fwd_bf16(*args, save_gates=save))
     print(f"gate_fwd_bf16 R={R} L={L} save_gates={save}: {t:7.1f} us  {flops / t / 1e6:7.1f} TF  x-stream {R * L * 2 / t / 1e6:5.2f} TB/s")
