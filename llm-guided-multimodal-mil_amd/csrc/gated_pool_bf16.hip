@@ -509,6 +509,14 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds_bf16(const u16* __restrict_
 // Workgroup 256 threads, output tile 128 (gi) x 256 (j): wave (wi, wj) = 64 x 128 = 2 x 4 MFMA tiles, so one staged
 // (and VALU-built) dPre slice feeds twice the MFMAs of a 128-wide tile.  Row stride 160 bf16 = 320 B: the four rows of
 // a transpose read start 80 words apart -> banks 0/16/32/48, conflict-free.
+// waves_per_eu(2, 2): left alone hipcc takes 134 VGPRs + 128 AGPRs = one wave per SIMD, i.e. ONE workgroup per CU and
+// two rounds for the 504-workgroup grid; capped at 256 registers it allocates without spills and both rounds are resident.
+// Measured at config 5 (R = 131 072, L = 1024; tools/kbench_dw16.py): 230 us with the reduce.  Ablations: MFMAs removed
+// 192 us, loads removed 125 us, both register-staged operands prefetched two slices ahead (needs the bias sums dropped to
+// avoid spills) 225 us / 159 us without MFMAs.  PMC: 535 MB of HBM reads (minimum 470), 13.2 M L2 requests = 1.7 GB.  So
+// neither HBM nor prefetch depth: per slice the CU moves 96 KB of transpose reads + 48 KB of staging writes through LDS
+// (~1400 clk at the LDS rates) against 1024 MFMA clk, with the fragment reads of each k-step exposed (no register room
+// to double-buffer 6 fragments next to 128 accumulators at two waves per SIMD).
 #define WB_BKR 32
 #define WB_S 160
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -533,7 +541,7 @@ __device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const float* __restrict__ gates,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const float* __restrict__ gates,
                                                           const float* __restrict__ ds, const float* __restrict__ wvec,
                                                           float* __restrict__ part, float* __restrict__ pbias, int R, int L,
                                                           int KC, int NJ) {
