@@ -12,7 +12,7 @@
 // Kernels (E = 512 = 64 lanes x 8, H <= 8, head dim c, rows tiled 64 per workgroup, split-N partials + merge):
 //   k_absorb_query / _bwd     Qp[b][h][:] = sum_c qp[b][hc + c'] Wk[hc + c'][:]
 //   k_apool_partial / _merge  online-softmax pool of the keys under H absorbed queries
-//   k_apool_bwd               per row: recompute a_h[n]; dkeys, and per-tile partial of dQp
+//   k_apool_dots / _bwd_apply per row: recompute a_h[n] (MFMA dots); dkeys, and per-tile partial of dQp
 //   k_value_proj / _bwd       o[b][hc + c'] = Wv[hc + c'] . pooled[b][h] + bv
 #include "mil_common.h"
 
@@ -205,80 +205,7 @@ __global__ void k_apool_merge(const float* __restrict__ pacc, const float* __res
 // ---------------------------------------------------------------------------------------------- absorbed pool, backward
 // Per row n of a tile: a_h = exp(scale Qp_h . kin_n - lse_h);  da_h = dpooled_h . keys_n;  ds_h = a_h (da_h - cdot_h);
 //   dkeys_n = sum_h (a_h dpooled_h + scale ds_h Qp_h);   dQp_h += scale ds_h kin_n  (per-tile partial, merged per bag)
-__global__ __launch_bounds__(256) void k_apool_bwd(const float* __restrict__ keys, const float* __restrict__ pe,
-                                                   const float* __restrict__ Qp, const float* __restrict__ lse,
-                                                   const float* __restrict__ dpooled, const float* __restrict__ cdot,
-                                                   const int32_t* __restrict__ k_off, const int32_t* __restrict__ tile_map,
-                                                   float scale, float* __restrict__ dkeys, float* __restrict__ pdq) {
-    constexpr int E = 512, NQ = 2;
-    __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
-    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
-    const int pos0 = key0 - k_off[b];
-    f32x4 qv[AP_H][NQ], dp[AP_H][NQ], dq[AP_H][NQ];
-    float ls[AP_H], cd[AP_H];
-#pragma unroll
-    for (int h = 0; h < AP_H; ++h) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            qv[h][q] = *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
-            dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
-            dq[h][q] = f32x4{0, 0, 0, 0};
-        }
-        ls[h] = lse[b * AP_H + h];
-        cd[h] = cdot[b * AP_H + h];
-    }
-    for (int rr = wave; rr < nkeys; rr += 4) {
-        f32x4 kv[NQ], kin[NQ], out[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            kv[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
-            kin[q] = kv[q] + *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
-            out[q] = f32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int h = 0; h < AP_H; ++h) {
-            float d1 = 0.f, d2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                d1 += kin[q][0] * qv[h][q][0] + kin[q][1] * qv[h][q][1] + kin[q][2] * qv[h][q][2] + kin[q][3] * qv[h][q][3];
-                d2 += kv[q][0] * dp[h][q][0] + kv[q][1] * dp[h][q][1] + kv[q][2] * dp[h][q][2] + kv[q][3] * dp[h][q][3];
-            }
-            const float s = wave_allsum(d1) * scale, da = wave_allsum(d2);
-            const float a = __expf(s - ls[h]);
-            const float ds = a * (da - cd[h]) * scale;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                out[q] += a * dp[h][q] + ds * qv[h][q];
-                dq[h][q] += ds * kin[q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dkeys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = out[q];
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int h = 0; h < AP_H; ++h)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                *reinterpret_cast<f32x4*>(red + ((wave - 1) * AP_H + h) * E + 256 * q + 4 * lane) = dq[h][q];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int h = 0; h < AP_H; ++h)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                f32x4 v = dq[h][q];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * AP_H + h) * E + 256 * q + 4 * lane);
-                *reinterpret_cast<f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v;
-            }
-    }
-}
-
-// The two kernels below replace k_apool_bwd's per-row dot products (16 wave-wide reductions per row) by a skinny
+// Two kernels: the per-row dot products (16 per row; as wave-wide reductions they cost 16 shuffle trees per row) are a skinny
 // MFMA product: for a 16-row group  acc[16 x 16] = keys[16 x 512] . [Qp | dpooled]^T + pe[16 x 512] . [Qp | 0]^T
 // (v_mfma_f32_16x16x4_f32, operands straight from global memory: lane (r, kq) loads 16 bytes of row r at
 // k = 16t + 4kq and feeds four MFMAs), so columns 0-7 hold Qp_h . kin_n and columns 8-15 dpooled_h . keys_n.
