@@ -363,6 +363,11 @@ int mil_adam_step_counted(float* param, const float* grad, float* exp_avg, float
                           int32_t* step_counter, float lr, float beta1, float beta2, float eps, float weight_decay,
                           float grad_scale, void* stream);
 
+/* torch.optim.SGD step without momentum (train_ddp.py:103-108: the optimizer of the learnable-prompt runs) over a
+ * flat fp32 buffer: g = grad_scale * grad + weight_decay * param;  param -= lr * g.  Both buffers 16-byte aligned. */
+int mil_sgd_step(float* param, const float* grad, size_t n, float lr, float weight_decay, float grad_scale,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gather_eot": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
     "mil_adam_step_counted": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
+    "mil_sgd_step": (c_int, [_P, _P, c_size_t] + [c_float] * 3 + [_P]),
 }
 
 _lib = None

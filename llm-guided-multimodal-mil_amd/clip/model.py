@@ -111,6 +111,7 @@ class CLIPText(nn.Module):
         self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * 2.6592600369327779)      # ln(1/0.07), clip/model.py:291
         self._proj_t = None
+        self.static_rows = False        # True: fixed-shape tower (graph-capturable), see _tower_static
         self.initialize_parameters()
 
     def initialize_parameters(self):
@@ -160,8 +161,25 @@ class CLIPText(nn.Module):
         dev = text.device
         return lengths, torch.from_numpy(live).to(dev), torch.from_numpy(last).to(dev)
 
+    def _tower_static(self, x_full: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
+        """Fixed-shape form of `_tower` (static_rows): every block runs on all P * ctx rows under the causal mask and the
+        EOT rows are gathered on the device - the reference's own formulation (clip/model.py:343-350).  Nothing depends
+        on the token ids on the host (no device->host copy, launch sequence independent of the notes), so a training step
+        through the tower can be captured in a hipGraph; the price is the rows behind each EOT (about 2x the rows at
+        20-40-token notes), which is why the live-prefix form stays the default."""
+        P, ctx = text.shape
+        segs = AttnSegs.make([ctx] * P, [ctx] * P, x_full.device)
+        x = x_full
+        for blk in self.transformer.resblocks:
+            x = blk.flat(x, segs)
+        last = torch.arange(P, device=text.device) * ctx + text.argmax(dim=-1)
+        eot = ops.layer_norm(x.index_select(0, last), self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
+        return ops.linear_act(eot, self._proj(eot.device))
+
     def _tower(self, x_full: torch.Tensor, text: torch.Tensor) -> torch.Tensor:
         """x_full [P * ctx, W] (embeddings + positions) -> EOT features [P, embed_dim]."""
+        if self.static_rows:
+            return self._tower_static(x_full, text)
         lengths, live, last = self._live_rows(text)
         x = x_full if live.numel() == x_full.shape[0] else x_full.index_select(0, live)
         segs = AttnSegs.make(lengths, lengths, x.device)

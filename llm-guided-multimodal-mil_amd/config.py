@@ -65,6 +65,8 @@ def create_arg_parser(argv=None):
     p.add_argument("--clip_gemm_pieces", type=int, default=0, choices=[0, 2, 3],
                    help="frozen CLIP text tower: 0 = fp32 MFMA GEMMs (parity path); 2 / 3 = split-bf16 products "
                         "(3 / 6 cross terms: ~3e-6 / fp32-level relative error, 2.3x / 1.45x the fp32 GEMM rate)")
+    p.add_argument("--hip_graph", type=int, default=0, help="autograd path: capture forward + backward of a repeating "
+                   "batch shape in a hipGraph and replay it (graph_step.py); meant for the one-bag-per-GPU regime")
     p.add_argument("--flat_adam", type=int, default=1, help="autograd path: parameters in one flat buffer, one gradient "
                    "all-reduce and one Adam launch per step (optim.FlatAdam); 0 = torch DDP + torch.optim.Adam")
     return p.parse_args(argv)

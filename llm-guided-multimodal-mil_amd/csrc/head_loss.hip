@@ -381,6 +381,33 @@ extern "C" int mil_adam_step_counted(float* param, const float* grad, float* exp
     return MIL_OK;
 }
 
+// torch.optim.SGD without momentum (train_ddp.py:103-108, the learnable-prompt runs): g = grad_scale * grad + wd * p;
+// p -= lr * g.  One float4 per thread.
+__global__ __launch_bounds__(256) void k_sgd(float* __restrict__ param, const float* __restrict__ grad, size_t n, float lr,
+                                             float wd, float gscale) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4 p4 = *reinterpret_cast<const f32x4*>(param + i);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(grad + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p4[e] = p4[e] - lr * (g4[e] * gscale + wd * p4[e]);
+        *reinterpret_cast<f32x4*>(param + i) = p4;
+    } else {
+        for (size_t j = i; j < n; ++j) param[j] = param[j] - lr * (grad[j] * gscale + wd * param[j]);
+    }
+}
+
+extern "C" int mil_sgd_step(float* param, const float* grad, size_t n, float lr, float weight_decay, float grad_scale,
+                            void* stream) {
+    if (!param || !grad) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad)) & 15) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_sgd, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, n, lr,
+                       weight_decay, grad_scale);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 // out[b] = a[b] . c[b]   (row-wise dot of two [B, L] matrices; cdot for the pool backward).
 __global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ a, const float* __restrict__ c,
                                                 float* __restrict__ out, int L) {

@@ -223,6 +223,12 @@ def adam_step_counted(param, grad, exp_avg, exp_avg_sq, step_counter, lr: float 
     _lib.check(rc, "mil_adam_step_counted")
 
 
+def sgd_step(param, grad, lr: float = 1e-3, weight_decay: float = 1e-7, grad_scale: float = 1.0):
+    """torch.optim.SGD (no momentum, L2 weight decay) over a flat buffer, in place."""
+    rc = _lib.lib().mil_sgd_step(_p(param), _p(grad), param.numel(), lr, weight_decay, grad_scale, _stream())
+    _lib.check(rc, "mil_sgd_step")
+
+
 # --------------------------------------------------------------------------- autograd wrappers
 class _GatedAttentionPool(torch.autograd.Function):
     @staticmethod

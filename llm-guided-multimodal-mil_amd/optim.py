@@ -19,6 +19,8 @@ from . import ops
 
 
 class FlatAdam:
+    needs_moments = True
+
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-7, world_size: int = 1, counted: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -33,8 +35,8 @@ class FlatAdam:
             n += (p.numel() + 3) // 4 * 4                     # 16-byte aligned slots (vector loads, MFMA operand rows)
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n if self.needs_moments else 0, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n if self.needs_moments else 0, device=dev, dtype=torch.float32)
         self._pviews, self._gviews = [], []
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
@@ -77,12 +79,17 @@ class FlatAdam:
             torch._foreach_copy_(dst, src)
 
     @torch.no_grad()
-    def step(self):
+    def reduce(self) -> float:
+        """Gather + the step's single gradient exchange; returns the scale that turns the sum into DDP's mean."""
         self.gather()
-        scale = 1.0
         if self.world > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)   # DDP averages: sum here, 1/world inside Adam
-            scale = 1.0 / self.world
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)   # DDP averages: sum here, 1/world inside the update
+            return 1.0 / self.world
+        return 1.0
+
+    @torch.no_grad()
+    def step(self):
+        scale = self.reduce()
         g = self.param_groups[0]
         if self.counted:
             ops.adam_step_counted(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_counter, g["lr"],
@@ -103,4 +110,27 @@ class FlatAdam:
         self.step_count = int(sd["step"])
         if self.counted:
             self.step_counter.fill_(self.step_count)
+        self.param_groups[0].update(sd["param_groups"][0])
+
+
+class FlatSGD(FlatAdam):
+    """torch.optim.SGD(params, lr, weight_decay=1e-7) - the optimizer of the learnable-prompt runs (train_ddp.py:103-108) -
+    over the same flat parameter / gradient buffers: one gather, one all-reduce, one mil_sgd_step launch."""
+    needs_moments = False
+
+    def __init__(self, params, lr: float = 1e-3, weight_decay: float = 1e-7, world_size: int = 1):
+        super().__init__(params, lr=lr, weight_decay=weight_decay, world_size=world_size)
+        self.defaults = {"lr": lr, "weight_decay": weight_decay}
+        self.param_groups = [dict(self.defaults, params=self.params)]
+
+    @torch.no_grad()
+    def step(self):
+        scale = self.reduce()
+        g = self.param_groups[0]
+        ops.sgd_step(self.flat, self.grad, g["lr"], g["weight_decay"], scale)
+
+    def state_dict(self):
+        return {"param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
         self.param_groups[0].update(sd["param_groups"][0])

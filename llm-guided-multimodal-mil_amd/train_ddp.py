@@ -72,21 +72,35 @@ def main_worker(local_rank: int, nprocs: int, args):
         tr = ImageOnlyTrainer(params, dev, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
     else:
         generator = model
-        flat_adam = bool(getattr(args, "flat_adam", 1)) and not args.learnablePrompt
-        if world > 1 and not flat_adam:
+        flat_opt = bool(getattr(args, "flat_adam", 1))
+        if world > 1 and not flat_opt:
             generator = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)
         criterion = torch.nn.BCELoss()
         trainable = [p for p in model.parameters() if p.requires_grad]
         if args.learnablePrompt:                                                         # train_ddp.py:104-109
             lr0 = args.lr = 1e-3
-            optimizer = torch.optim.SGD(trainable, lr=lr0, weight_decay=1e-7)
-        elif flat_adam:                                                                  # train_ddp.py:110-118, flat
+            if flat_opt:
+                from .optim import FlatSGD
+                optimizer = FlatSGD(trainable, lr=lr0, weight_decay=1e-7, world_size=world)
+            else:
+                optimizer = torch.optim.SGD(trainable, lr=lr0, weight_decay=1e-7)
+        elif flat_opt:                                                                   # train_ddp.py:110-118, flat
             from .optim import FlatAdam
             optimizer = FlatAdam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
-            if world > 1:
-                broadcast_flat(optimizer.flat, src=0)                                    # DDP's initial broadcast
         else:
             optimizer = torch.optim.Adam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7)
+        if flat_opt and world > 1:
+            broadcast_flat(optimizer.flat, src=0)                                        # DDP's initial broadcast
+        graphed = None
+        if getattr(args, "hip_graph", 0):
+            # replay the step body from a hipGraph once a batch shape repeats (graph_step.py); optimizer and the
+            # gradient all-reduce stay outside, so this needs the flat optimizers when world > 1 (no DDP hooks)
+            if world > 1 and not flat_opt:
+                raise ValueError("--hip_graph with several GPUs needs --flat_adam 1")
+            from .graph_step import GraphedStep
+            graphed = GraphedStep(trainable)
+            if args.variant != "image_only" and args.learnablePrompt:
+                model.clinic_extractor.model.static_rows = True     # the tower is inside the graph: fixed-shape form
         if args.resume:
             ck = torch.load(args.resume, map_location=dev, weights_only=True)
             model.load_state_dict(ck["state_dict"])
@@ -112,14 +126,35 @@ def main_worker(local_rank: int, nprocs: int, args):
             else:
                 for g in optimizer.param_groups:
                     g["lr"] = lr
-                if args.variant == "image_only":
-                    _, prob = generator([x], batch["lengths"])
+                lengths = batch["lengths"]
+                if graphed is not None:
+                    key = (tuple(int(v) for v in lengths), args.variant)
+                    if args.variant == "image_only":
+                        def body(x_, y_):
+                            prob_ = generator([x_], lengths)[1]
+                            return criterion(prob_, y_), prob_
+                        loss, prob = graphed.run(key, (x, y), body)
+                    elif args.learnablePrompt:
+                        def body(x_, ids_, y_):
+                            prob_ = generator([x_], ids_, lengths)[0]
+                            return criterion(prob_, y_), prob_
+                        loss, prob = graphed.run(key, (x, batch["CI"].to(dev), y), body)
+                    else:
+                        tfeat = model.clinic_extractor(batch["CI"].to(dev))      # frozen tower (no_grad): outside the graph
+                        def body(x_, t_, y_):
+                            prob_ = generator([x_], None, lengths, text_features=t_)[0]
+                            return criterion(prob_, y_), prob_
+                        loss, prob = graphed.run(key, (x, tfeat, y), body)
+                    optimizer.step()
                 else:
-                    prob, _ = generator([x], batch["CI"].to(dev), batch["lengths"])
-                loss = criterion(prob, y)                                                # loss_point 'Last'
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
+                    if args.variant == "image_only":
+                        _, prob = generator([x], lengths)
+                    else:
+                        prob, _ = generator([x], batch["CI"].to(dev), lengths)
+                    loss = criterion(prob, y)                                            # loss_point 'Last'
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
             if it % 10 == 0 or it == steps - 1:
                 losses.update(float(loss.detach()), x.shape[0])                                   # host sync only when logging
                 accs.update(float(calculate_accuracy(prob.detach(), y)), x.shape[0])

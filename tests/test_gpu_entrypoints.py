@@ -40,3 +40,14 @@ def test_image_only_variant_fused_and_autograd_agree(tmp_path):
     for k, v in f.items():
         ka = k.replace("aggregator.", "extractor_pathology.")
         assert ka in a and a[ka].shape == v.shape, k
+
+
+def test_hip_graph_training_with_learnable_prompts(tmp_path):
+    """One bag per step, fixed shapes, learnable prompts: the step body is replayed from a hipGraph (graph_step.py) and
+    the flat SGD runs outside it."""
+    out = run("train_ddp.py", "--synthetic", "[96, 768, 8]", "--clip_layers", "2", "--batch_size", "1", "--learnablePrompt", "1",
+              "--clinical_features", "['a', 'b']", "--n_ctx", "4", "--hip_graph", "1", "--n_epochs", "1",
+              "--iter_per_epoch", "5", "--save_dir", str(tmp_path))
+    assert "Epoch: [0]" in out and "Loss" in out
+    ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
+    assert "clinic_extractor.ctx" in ck["state_dict"]

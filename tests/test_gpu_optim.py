@@ -56,3 +56,25 @@ def test_linear_gradients_land_in_the_flat_slots_without_a_copy():
         assert p.grad is not None and p.grad.data_ptr() == p._mil_grad.data_ptr()
     ref = torch.tanh(xs @ lin.weight.t() + lin.bias)
     assert float((lin.bias.grad - (1 - ref * ref).sum(0)).abs().max()) <= 1e-4
+
+
+def test_flat_sgd_tracks_torch_sgd():
+    """optim.FlatSGD (mil_sgd_step) against torch.optim.SGD(lr=1e-3, weight_decay=1e-7), the learnable-prompt optimizer
+    (train_ddp.py:103-108)."""
+    from mil_amd.optim import FlatSGD
+    ref = _model()
+    ours = copy.deepcopy(ref)
+    o_ref = torch.optim.SGD(ref.parameters(), lr=1e-2, weight_decay=1e-3)
+    o_our = FlatSGD(ours.parameters(), lr=1e-2, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(0)
+    for step in range(5):
+        x = torch.randn((11, 37), generator=g).to(DEV)
+        for m, o in ((ref, o_ref), (ours, o_our)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            if m is ref and m.extra.grad is None:
+                m.extra.grad = torch.zeros_like(m.extra)
+            o.step()
+    for (k, a), b in zip(ref.named_parameters(), ours.parameters()):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), k
+    assert o_our.exp_avg.numel() == 0

@@ -18,7 +18,7 @@ ap.add_argument("--cache_text", action="store_true")
 ap.add_argument("--coop", action="store_true", help="learnable prompts (upstream default --learnablePrompt 1): 10 prompts "
                 "per bag, ctx trained through the frozen text tower every step; SGD lr 1e-3 as train_ddp.py:104-109")
 ap.add_argument("--clip_gemm_pieces", type=int, default=0, help="2 / 3: split-bf16 products for the frozen text tower's GEMMs")
-ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam instead of the flat one-launch Adam")
+ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam / SGD instead of the flat one-launch optimizers")
 ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -31,8 +31,13 @@ model = get_model(args).to(dev).eval()      # eval: parity mode (dropout off), g
 x = syn.make_bags(1, a.bags, a.patches, 768).to(dev)
 ids = syn.make_token_ids(2, a.bags, a.prompts).to(dev)
 y = syn.make_labels(3, a.bags).to(dev)
-if a.coop:
+if a.coop and a.graph:
+    model.clinic_extractor.model.static_rows = True      # tower inside the graph: fixed-shape form (no host sync)
+if a.coop and a.torch_adam:
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-7)
+elif a.coop:
+    from mil_amd.optim import FlatSGD
+    opt = FlatSGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-7)
 elif a.torch_adam:
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7,
                            capturable=a.graph)
