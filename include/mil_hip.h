@@ -326,6 +326,11 @@ int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int
 int mil_layernorm_bwd_blocks(int rows);
 int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* stats, int rows, int E,
                       float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+/* The same backward with (a) dres [rows, E] or NULL: the gradient that reached x along the residual branch around the
+ * norm (x + f(LN(x)), clip/model.py:183-199, sam/transformer.py:283-309), added into dx here; (b) dgamma = dbeta = NULL
+ * for frozen parameters (the CLIP tower under learnable prompts): no parameter sums, workspace may be NULL. */
+int mil_layernorm_bwd_res(const float* x, const float* gamma, const float* dy, const float* stats, const float* dres,
+                          int rows, int E, float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
 /* out[row] = x[row] + pe[row - row_off[row_bag[row]]]: keys + key_pe (sam/transformer.py:292,304) with the
  * table rows indexed by the position inside the bag (aggregator.py:190 passes pe[:, :N]). */
 int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,

@@ -82,6 +82,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_layernorm_fwd": (c_int, [_P] * 3 + [c_int, c_int, c_float, _P, _P, _P]),
     "mil_layernorm_bwd_blocks": (c_int, [c_int]),
     "mil_layernorm_bwd": (c_int, [_P] * 4 + [c_int, c_int] + [_P] * 4 + [_P]),
+    "mil_layernorm_bwd_res": (c_int, [_P] * 5 + [c_int, c_int] + [_P] * 4 + [_P]),
     "mil_add_pe": (c_int, [_P] * 4 + [c_int, c_int, _P, _P]),
     "mil_add_bag_row": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "mil_segment_colsum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),

@@ -48,16 +48,18 @@ class ResidualAttentionBlock(nn.Module):
 
     def flat(self, x, segs):
         W = x.shape[1]
-        h = ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+        # layer_norm_res hands x back as `xr`: the residual adds read xr, so the gradient of the skip branch is added
+        # inside the LayerNorm backward kernel
+        h, xr = ops.layer_norm_res(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if self._split_ok(x) and ops.seq_attention_ok(segs):
             # opt-in: the four frozen-weight products (and their dx halves) on the split-bf16 GEMM (csrc/linear_x.hip)
             qkv = ops.linear_frozen_split(h, self._fs("in_proj", w), b)
             o = ops.attention_seq_packed(qkv, segs, self.n_head, causal=True)
-            x = ops.linear_frozen_split(o, self._fs("out_proj", self.attn.out_proj.weight), self.attn.out_proj.bias, residual=x)
-            h = ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+            x = ops.linear_frozen_split(o, self._fs("out_proj", self.attn.out_proj.weight), self.attn.out_proj.bias, residual=xr)
+            h, xr = ops.layer_norm_res(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
             return ops.mlp_quickgelu_frozen_split(h, self._fs("c_fc", self.mlp.c_fc.weight), self.mlp.c_fc.bias,
-                                                  self._fs("c_proj", self.mlp.c_proj.weight), self.mlp.c_proj.bias, residual=x)
+                                                  self._fs("c_proj", self.mlp.c_proj.weight), self.mlp.c_proj.bias, residual=xr)
         if ops.seq_attention_ok(segs):
             # one in_proj GEMM of width 3 W; the attention kernels read its column blocks in place
             o = ops.attention_seq_packed(ops.linear_act(h, w, b), segs, self.n_head, causal=True)
@@ -66,10 +68,10 @@ class ResidualAttentionBlock(nn.Module):
             k = ops.linear_act(h, w[W:2 * W], b[W:2 * W])
             v = ops.linear_act(h, w[2 * W:], b[2 * W:])
             o = ops.attention_rows(q, k, v, segs, self.n_head, causal=True)
-        x = ops.linear_act(o, self.attn.out_proj.weight, self.attn.out_proj.bias, "none", residual=x)
-        h = ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+        x = ops.linear_act(o, self.attn.out_proj.weight, self.attn.out_proj.bias, "none", residual=xr)
+        h, xr = ops.layer_norm_res(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
         return ops.mlp_quickgelu(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias,
-                                 residual=x)
+                                 residual=xr)
 
 
 def _flat_last_rows(self, x, last, segs):

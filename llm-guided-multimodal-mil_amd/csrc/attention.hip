@@ -501,44 +501,69 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
     if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
-// dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  per-workgroup partial dgamma/dbeta [nblk][2][E]
-template <int NE>
+// dx = rstd (g - mean(g) - xhat mean(g xhat)) (+ dres), g = dy gamma;  per-workgroup partial dgamma/dbeta [nblk][2][E].
+// PARAMS = false: frozen gamma / beta (the CLIP tower): no parameter sums, no partials.  dres (optional): gradient that
+// reached x along the residual branch around the norm - added here instead of by a separate elementwise launch.
+// Each wave takes its rows two at a time so that four row loads are in flight before the first reduction.
+template <int NE, bool PARAMS>
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ dy, const float* __restrict__ stats,
-                                                       int rows, int rows_per_blk, float* __restrict__ dx,
-                                                       float* __restrict__ part) {
-    __shared__ float red[4][2][64 * NE];
+                                                       const float* __restrict__ dres, int rows, int rows_per_blk,
+                                                       float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[PARAMS ? 4 : 1][2][64 * NE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, E = 64 * NE;
     float dg[NE], db[NE], gm[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[lane + 64 * e]; }
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-    for (int row = r0 + w; row < r1; row += 4) {
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-        float xh[NE], g[NE];
-        float s1 = 0.f, s2 = 0.f;
+    for (int row = r0 + w; row < r1; row += 8) {
+        const int rowb = row + 4;
+        const bool two = rowb < r1;
+        const int rb = two ? rowb : row;
+        float xa[NE], da[NE], xb[NE], dbv[NE], ra[NE], rbv[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int c = lane + 64 * e;
-            const float d = dy[(size_t)row * E + c];
-            xh[e] = (x[(size_t)row * E + c] - mean) * rstd;
-            g[e] = d * gm[e];
-            s1 += g[e];
-            s2 += g[e] * xh[e];
-            dg[e] += d * xh[e];
-            db[e] += d;
+            da[e] = dy[(size_t)row * E + c];
+            xa[e] = x[(size_t)row * E + c];
+            dbv[e] = dy[(size_t)rb * E + c];
+            xb[e] = x[(size_t)rb * E + c];
+            ra[e] = dres != nullptr ? dres[(size_t)row * E + c] : 0.f;
+            rbv[e] = dres != nullptr ? dres[(size_t)rb * E + c] : 0.f;
         }
-        s1 = wave_allsum(s1) / E;
-        s2 = wave_allsum(s2) / E;
+        const float mean_a = stats[2 * row], rstd_a = stats[2 * row + 1];
+        const float mean_b = stats[2 * rb], rstd_b = stats[2 * rb + 1];
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd * (g[e] - s1 - xh[e] * s2);
+        for (int e = 0; e < NE; ++e) {
+            xa[e] = (xa[e] - mean_a) * rstd_a;
+            xb[e] = (xb[e] - mean_b) * rstd_b;
+            if (PARAMS) {
+                dg[e] += da[e] * xa[e];
+                db[e] += da[e];
+                if (two) { dg[e] += dbv[e] * xb[e]; db[e] += dbv[e]; }
+            }
+            da[e] *= gm[e];
+            dbv[e] *= gm[e];
+            s1a += da[e]; s2a += da[e] * xa[e];
+            s1b += dbv[e]; s2b += dbv[e] * xb[e];
+        }
+        s1a = wave_allsum(s1a) / E; s2a = wave_allsum(s2a) / E;
+        s1b = wave_allsum(s1b) / E; s2b = wave_allsum(s2b) / E;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            dx[(size_t)row * E + lane + 64 * e] = rstd_a * (da[e] - s1a - xa[e] * s2a) + ra[e];
+            if (two) dx[(size_t)rowb * E + lane + 64 * e] = rstd_b * (dbv[e] - s1b - xb[e] * s2b) + rbv[e];
+        }
     }
+    if (PARAMS) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { red[w][0][lane + 64 * e] = dg[e]; red[w][1][lane + 64 * e] = db[e]; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * E; c += 256) {
-        const int which = c / E, cc = c % E;
-        part[((size_t)blockIdx.x * 2 + which) * E + cc] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+        for (int e = 0; e < NE; ++e) { red[w][0][lane + 64 * e] = dg[e]; red[w][1][lane + 64 * e] = db[e]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * E; c += 256) {
+            const int which = c / E, cc = c % E;
+            part[((size_t)blockIdx.x * 2 + which) * E + cc] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+        }
     }
 }
 
@@ -548,11 +573,12 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 template <int NE>
 __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ dy, const float* __restrict__ stats,
-                                                              int rows, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                              const float* __restrict__ dres, int rows,
+                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
     __shared__ float red[16][2][64 * NE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, E = 64 * NE;
-    float dg[NE], db[NE], gm[NE], xv[4][NE], dv[4][NE], mean[4], rstd[4];
+    float dg[NE], db[NE], gm[NE], xv[4][NE], dv[4][NE], rv[4][NE], mean[4], rstd[4];
 #pragma unroll
     for (int e = 0; e < NE; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[lane + 64 * e]; }
 #pragma unroll
@@ -564,6 +590,7 @@ __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __res
         for (int e = 0; e < NE; ++e) {
             xv[i][e] = x[(size_t)row * E + lane + 64 * e];
             dv[i][e] = dy[(size_t)row * E + lane + 64 * e];
+            rv[i][e] = dres != nullptr ? dres[(size_t)row * E + lane + 64 * e] : 0.f;
         }
     }
 #pragma unroll
@@ -583,8 +610,9 @@ __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __res
         s1 = wave_allsum(s1) / E;
         s2 = wave_allsum(s2) / E;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd[i] * (g[e] - s1 - xh[e] * s2);
+        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd[i] * (g[e] - s1 - xh[e] * s2) + rv[i][e];
     }
+    if (dgamma == nullptr) return;          // frozen parameters (uniform over the workgroup)
 #pragma unroll
     for (int e = 0; e < NE; ++e) { red[w][0][lane + 64 * e] = dg[e]; red[w][1][lane + 64 * e] = db[e]; }
     __syncthreads();
@@ -771,23 +799,31 @@ extern "C" int mil_layernorm_fwd(const float* x, const float* gamma, const float
 }
 
 extern "C" int mil_layernorm_bwd_blocks(int rows) {
-    int nb = (rows + 63) / 64;
+    int nb = (rows + 15) / 16;          // 16 rows per workgroup = two passes of its four waves, two rows each
     if (nb > 1024) nb = 1024;
     return nb < 1 ? 1 : nb;
 }
 
-extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* stats, int rows, int E,
-                                 float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
-    if (!x || !gamma || !dy || !stats || !dx || !dgamma || !dbeta || !workspace) return MIL_EINVAL;
+#define LNB_LAUNCH(NEV)                                                                                                  \
+    if (params) hipLaunchKernelGGL((k_layernorm_bwd<NEV, true>), grid, blk, 0, st, x, gamma, dy, stats, dres, rows, rpb, dx, workspace); \
+    else hipLaunchKernelGGL((k_layernorm_bwd<NEV, false>), grid, blk, 0, st, x, gamma, dy, stats, dres, rows, rpb, dx, workspace);
+
+extern "C" int mil_layernorm_bwd_res(const float* x, const float* gamma, const float* dy, const float* stats,
+                                     const float* dres, int rows, int E, float* dx, float* dgamma, float* dbeta,
+                                     float* workspace, void* stream) {
+    if (!x || !gamma || !dy || !stats || !dx) return MIL_EINVAL;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return MIL_EINVAL;
+    const bool params = dgamma != nullptr;
+    if (params && !workspace) return MIL_EINVAL;
     if (rows <= 0 || (E % 64) != 0 || E > 512) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (rows <= 64) {
         const dim3 g1(1), b1(1024);
         switch (E / 64) {
-            case 1: hipLaunchKernelGGL(k_layernorm_bwd_small<1>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
-            case 2: hipLaunchKernelGGL(k_layernorm_bwd_small<2>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
-            case 4: hipLaunchKernelGGL(k_layernorm_bwd_small<4>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
-            case 8: hipLaunchKernelGGL(k_layernorm_bwd_small<8>, g1, b1, 0, st, x, gamma, dy, stats, rows, dx, dgamma, dbeta); break;
+            case 1: hipLaunchKernelGGL(k_layernorm_bwd_small<1>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
+            case 2: hipLaunchKernelGGL(k_layernorm_bwd_small<2>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
+            case 4: hipLaunchKernelGGL(k_layernorm_bwd_small<4>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
+            case 8: hipLaunchKernelGGL(k_layernorm_bwd_small<8>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
             default: return MIL_EINVAL;
         }
         MIL_CHECK_LAUNCH();
@@ -797,17 +833,24 @@ extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float
     const int rpb = (rows + nb - 1) / nb;
     const dim3 grid(nb), blk(256);
     switch (E / 64) {
-        case 1: hipLaunchKernelGGL(k_layernorm_bwd<1>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
-        case 2: hipLaunchKernelGGL(k_layernorm_bwd<2>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
-        case 4: hipLaunchKernelGGL(k_layernorm_bwd<4>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
-        case 8: hipLaunchKernelGGL(k_layernorm_bwd<8>, grid, blk, 0, st, x, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 1: LNB_LAUNCH(1); break;
+        case 2: LNB_LAUNCH(2); break;
+        case 4: LNB_LAUNCH(4); break;
+        case 8: LNB_LAUNCH(8); break;
         default: return MIL_EINVAL;
     }
     MIL_CHECK_LAUNCH();
+    if (!params) return MIL_OK;
     // partials are [nb][2][E]: two strided column sums
     int rc = mil_colsum(workspace, 2 * E, nb, E, dgamma, 0, nullptr, stream);
     if (rc) return rc;
     return mil_colsum(workspace + E, 2 * E, nb, E, dbeta, 0, nullptr, stream);
+}
+
+extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* stats, int rows, int E,
+                                 float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
+    if (!dgamma || !dbeta || !workspace) return MIL_EINVAL;
+    return mil_layernorm_bwd_res(x, gamma, dy, stats, nullptr, rows, E, dx, dgamma, dbeta, workspace, stream);
 }
 
 extern "C" int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,

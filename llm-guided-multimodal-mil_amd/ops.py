@@ -668,17 +668,58 @@ class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, stats = ctx.saved_tensors
-        rows, E = x.shape
-        dy = _f32c(dy, "dy")
-        dx = torch.empty_like(x)
+        dx, dg, db = _layer_norm_bwd(x, gamma, stats, dy, None, ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dg, db, None, None
+
+
+def _layer_norm_bwd(x, gamma, stats, dy, dres, want_params: bool):
+    """dx (+ dres), dgamma, dbeta of a LayerNorm; frozen parameters skip their sums (and the two column-sum launches)."""
+    rows, E = x.shape
+    dy = _f32c(dy, "dy")
+    dx = torch.empty_like(x)
+    dg = db = ws = None
+    if want_params:
         dg = torch.empty(E, device=x.device, dtype=torch.float32)
         db = torch.empty_like(dg)
-        nb = _lib.lib().mil_layernorm_bwd_blocks(rows)
-        ws = torch.empty(nb * 2 * E, device=x.device, dtype=torch.float32)
-        rc = _lib.lib().mil_layernorm_bwd(_p(x), _p(gamma), _p(dy), _p(stats), rows, E, _p(dx), _p(dg), _p(db), _p(ws),
-                                          _stream())
-        _lib.check(rc, "mil_layernorm_bwd")
-        return dx, dg, db, None, None
+        ws = torch.empty(_lib.lib().mil_layernorm_bwd_blocks(rows) * 2 * E, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_layernorm_bwd_res(_p(x), _p(gamma), _p(dy), _p(stats), _p(dres), rows, E, _p(dx), _p(dg), _p(db),
+                                          _p(ws), _stream())
+    _lib.check(rc, "mil_layernorm_bwd_res")
+    return dx, dg, db
+
+
+class _LayerNormRes(torch.autograd.Function):
+    """LayerNorm that also hands back its input (an alias): a pre-norm residual block x + f(LN(x)) (clip/model.py:183-199)
+    passes THAT to the residual add, so the gradient of the residual branch arrives at this node and is added inside the
+    backward kernel instead of by an elementwise launch of autograd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        x_in = x
+        x = _f32c(x, "x")
+        rows, E = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_layernorm_fwd(_p(x), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), rows, E, eps, _p(y),
+                                          _p(stats), _stream())
+        _lib.check(rc, "mil_layernorm_fwd")
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, gamma, stats)
+        return y, x_in.view_as(x_in)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        if dy is None:
+            return dres, None, None, None
+        x, gamma, stats = ctx.saved_tensors
+        dres = _f32c(dres, "dres") if dres is not None else None
+        dx, dg, db = _layer_norm_bwd(x, gamma, stats, dy, dres, ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dg, db, None
+
+
+def layer_norm_res(x, gamma, beta, eps: float = 1e-5):
+    """(LayerNorm(x), x) for a 2-D x - use the returned x for the residual add that skips the norm."""
+    return _LayerNormRes.apply(x, gamma, beta, eps)
 
 
 def layer_norm(x, gamma, beta, eps: float = 1e-5, tail_rows: int = 0):

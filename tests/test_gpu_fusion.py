@@ -60,6 +60,31 @@ def test_layernorm_fwd_bwd():
         assert rel_err(wd.grad.cpu(), wr.grad) <= 1e-4 and rel_err(bd.grad.cpu(), br.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("frozen", [False, True])
+def test_layernorm_with_residual_alias_and_frozen_parameters(frozen):
+    """ops.layer_norm_res: pre-norm residual x + W LN(x); the skip gradient is added inside the LayerNorm backward kernel,
+    frozen gamma / beta skip the parameter sums.  Row counts hit the one-workgroup kernel, odd pairs and the tiled one."""
+    gen = torch.Generator().manual_seed(5)
+    for rows, E in ((3, 512), (64, 512), (65, 512), (770, 512), (1001, 256)):
+        x = torch.randn(rows, E, generator=gen)
+        w, b = torch.randn(E, generator=gen), torch.randn(E, generator=gen)
+        go = torch.randn(rows, E, generator=gen)
+        xd = x.to(DEV).requires_grad_(True)
+        wd, bd = (t.to(DEV).requires_grad_(not frozen) for t in (w, b))
+        y, xr_ = ops.layer_norm_res(xd, wd, bd)
+        ((torch.tanh(y) + xr_) * go.to(DEV)).sum().backward()
+        xr = x.clone().requires_grad_(True)
+        wr, br = (t.clone().requires_grad_(True) for t in (w, b))
+        yr = torch.nn.functional.layer_norm(xr, (E,), wr, br, 1e-5)
+        ((torch.tanh(yr) + xr) * go).sum().backward()
+        assert rel_err(y.detach().cpu(), yr.detach()) <= 1e-5
+        assert rel_err(xd.grad.cpu(), xr.grad) <= 1e-4, rows
+        if frozen:
+            assert wd.grad is None and bd.grad is None
+        else:
+            assert rel_err(wd.grad.cpu(), wr.grad) <= 1e-4 and rel_err(bd.grad.cpu(), br.grad) <= 1e-4
+
+
 def test_device_pe_table_matches_reference_formula():
     pe = ops.sinusoid_pe(2000, 512, torch.device(DEV)).cpu()
     ref = orc.sinusoidal_pe(2000, 512)
