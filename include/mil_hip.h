@@ -312,10 +312,12 @@ int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B,
  * [rows, ld] with column c = t H + h, columns >= T H are padding and come out as zeros):
  *   mil_grp_col_softmax      in place, over the ROWS of each group (bag) per column     (token -> image)
  *   mil_row_softmax_t        in place, over the T tokens of each (row, head)           (image -> token)
- * and their backwards dS = A (dA - sum A dA) over the same axis. */
-int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int TH, void* stream);
-int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int TH, float* dS,
-                            void* stream);
+ * and their backwards dS = A (dA - sum A dA) over the same axis.  max_group_rows = rows of the longest group (0 = not
+ * known): selects the workgroup shape that holds a whole group in registers (up to 32 768 rows forward, 16 384 backward;
+ * longer groups re-read their columns). */
+int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH, void* stream);
+int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int max_group_rows,
+                            int TH, float* dS, void* stream);
 int mil_row_softmax_t(float* S, int ld, int R, int T, int H, void* stream);
 int mil_row_softmax_t_bwd(const float* A, const float* dA, int ld, int R, int T, int H, float* dS, void* stream);
 

@@ -378,58 +378,75 @@ __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ po
 //   image -> token: softmax over the T tokens of a row, per head                k_row_softmax_t / _bwd
 // Column softmax: grid (G, ceil(ld / 32)), 1024 threads = 32 row lanes x 32 columns; a thread keeps its <= 64 values of
 // the column in registers (groups of up to 2048 rows: one read of the slab), longer groups fall back to re-reading.
-#define CS_RL 32
+// Workgroup = 1024 threads = CW columns x (1024 / CW) row lanes; a thread keeps its rows of the column in registers
+// (CS_KEEP of them), so a group of up to (1024 / CW) * CS_KEEP rows is read once.  CW = 32 covers 2048 rows (bench bags),
+// CW = 8 8192 and CW = 2 32768 (the authors' bags reach ~15 000 patches); longer groups take the re-reading loop.
 #define CS_KEEP 64
+
+// reduce over the row lanes of a column: lanes of a wave that share (lane % CW), then the 16 waves through LDS
+template <int CW, bool MAX>
+__device__ __forceinline__ float cs_reduce(float v, float (*red)[33], int cl) {
+    if (CW < 64) {
+#pragma unroll
+        for (int o = CW; o < 64; o <<= 1) {
+            const float t = __shfl_xor(v, o);
+            v = MAX ? fmaxf(v, t) : v + t;
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                    // the previous use of red is over
+    if ((threadIdx.x & 63) < CW) red[wave][cl] = v;
+    __syncthreads();
+    float r = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r = MAX ? fmaxf(r, red[i][cl]) : r + red[i][cl];
+    return r;
+}
+
+template <int CW>
 __global__ __launch_bounds__(1024) void k_grp_col_softmax(float* __restrict__ S, int ld, const int32_t* __restrict__ grp_off,
                                                           int TH) {
-    __shared__ float red[CS_RL][33];
-    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, rl = threadIdx.x >> 5;
+    constexpr int RL = 1024 / CW;
+    __shared__ float red[16][33];
+    const int g = blockIdx.x, cl = threadIdx.x % CW, c = blockIdx.y * CW + cl, rl = threadIdx.x / CW;
     const int r0 = grp_off[g], r1 = grp_off[g + 1], n = r1 - r0;
     const bool live = c < TH && c < ld;
-    const bool fits = n <= CS_RL * CS_KEEP;
+    const bool fits = n <= RL * CS_KEEP;
     float v[CS_KEEP];
     float m = -INFINITY;
     if (live) {
         if (fits) {
 #pragma unroll
             for (int i = 0; i < CS_KEEP; ++i) {
-                const int row = r0 + rl + CS_RL * i;
+                const int row = r0 + rl + RL * i;
                 v[i] = row < r1 ? S[(size_t)row * ld + c] : -INFINITY;
                 m = fmaxf(m, v[i]);
             }
         } else {
-            for (int row = r0 + rl; row < r1; row += CS_RL) m = fmaxf(m, S[(size_t)row * ld + c]);
+            for (int row = r0 + rl; row < r1; row += RL) m = fmaxf(m, S[(size_t)row * ld + c]);
         }
     }
-    red[rl][cl] = m;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < CS_RL; ++i) m = fmaxf(m, red[i][cl]);
-    __syncthreads();
+    m = cs_reduce<CW, true>(m, red, cl);
     float l = 0.f;
     if (live) {
         if (fits) {
 #pragma unroll
             for (int i = 0; i < CS_KEEP; ++i) { v[i] = expf(v[i] - m); l += v[i]; }      // exp(-inf) = 0 for the padding slots
         } else {
-            for (int row = r0 + rl; row < r1; row += CS_RL) l += expf(S[(size_t)row * ld + c] - m);
+            for (int row = r0 + rl; row < r1; row += RL) l += expf(S[(size_t)row * ld + c] - m);
         }
     }
-    red[rl][cl] = l;
-    __syncthreads();
-    l = 0.f;
-#pragma unroll
-    for (int i = 0; i < CS_RL; ++i) l += red[i][cl];
+    l = cs_reduce<CW, false>(l, red, cl);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     if (c >= ld) return;
     if (live && fits) {
 #pragma unroll
         for (int i = 0; i < CS_KEEP; ++i) {
-            const int row = r0 + rl + CS_RL * i;
+            const int row = r0 + rl + RL * i;
             if (row < r1) S[(size_t)row * ld + c] = v[i] * inv;
         }
     } else {
-        for (int row = r0 + rl; row < r1; row += CS_RL) {
+        for (int row = r0 + rl; row < r1; row += RL) {
             float* p = S + (size_t)row * ld + c;
             *p = live ? expf(*p - m) * inv : 0.f;
         }
@@ -437,43 +454,41 @@ __global__ __launch_bounds__(1024) void k_grp_col_softmax(float* __restrict__ S,
 }
 
 // dS = A (dA - sum_rows A dA)  per (group, column); columns >= TH get 0
+template <int CW>
 __global__ __launch_bounds__(1024) void k_grp_col_softmax_bwd(const float* __restrict__ A, const float* __restrict__ dA, int ld,
                                                               const int32_t* __restrict__ grp_off, int TH,
                                                               float* __restrict__ dS) {
-    __shared__ float red[CS_RL][33];
-    const int g = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, rl = threadIdx.x >> 5;
+    constexpr int RL = 1024 / CW;
+    __shared__ float red[16][33];
+    const int g = blockIdx.x, cl = threadIdx.x % CW, c = blockIdx.y * CW + cl, rl = threadIdx.x / CW;
     const int r0 = grp_off[g], r1 = grp_off[g + 1], n = r1 - r0;
     const bool live = c < TH && c < ld;
-    const bool fits = n <= CS_RL * (CS_KEEP / 2);
+    const bool fits = n <= RL * (CS_KEEP / 2);
     float a[CS_KEEP / 2], d[CS_KEEP / 2];
     float cd = 0.f;
     if (live) {
         if (fits) {
 #pragma unroll
             for (int i = 0; i < CS_KEEP / 2; ++i) {
-                const int row = r0 + rl + CS_RL * i;
+                const int row = r0 + rl + RL * i;
                 a[i] = row < r1 ? A[(size_t)row * ld + c] : 0.f;
                 d[i] = row < r1 ? dA[(size_t)row * ld + c] : 0.f;
                 cd += a[i] * d[i];
             }
         } else {
-            for (int row = r0 + rl; row < r1; row += CS_RL) cd += A[(size_t)row * ld + c] * dA[(size_t)row * ld + c];
+            for (int row = r0 + rl; row < r1; row += RL) cd += A[(size_t)row * ld + c] * dA[(size_t)row * ld + c];
         }
     }
-    red[rl][cl] = cd;
-    __syncthreads();
-    cd = 0.f;
-#pragma unroll
-    for (int i = 0; i < CS_RL; ++i) cd += red[i][cl];
+    cd = cs_reduce<CW, false>(cd, red, cl);
     if (c >= ld) return;
     if (live && fits) {
 #pragma unroll
         for (int i = 0; i < CS_KEEP / 2; ++i) {
-            const int row = r0 + rl + CS_RL * i;
+            const int row = r0 + rl + RL * i;
             if (row < r1) dS[(size_t)row * ld + c] = a[i] * (d[i] - cd);
         }
     } else {
-        for (int row = r0 + rl; row < r1; row += CS_RL) {
+        for (int row = r0 + rl; row < r1; row += RL) {
             const size_t o = (size_t)row * ld + c;
             dS[o] = live ? A[o] * (dA[o] - cd) : 0.f;
         }
@@ -594,20 +609,33 @@ extern "C" int mil_value_proj(const float* pooled, const float* Wv, const float*
     return MIL_OK;
 }
 
-extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int TH, void* stream) {
-    AP_CHECK(S && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld);
+extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH,
+                                   void* stream) {
+    AP_CHECK(S && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld && max_group_rows >= 0);
     if (G == 0) return MIL_OK;
-    hipLaunchKernelGGL(k_grp_col_softmax, dim3(G, (ld + 31) / 32), dim3(1024), 0, (hipStream_t)stream, S, ld, grp_off, TH);
+    hipStream_t st = (hipStream_t)stream;
+    // narrowest row-lane count whose registers hold the longest group (wider column blocks coalesce better)
+    if (max_group_rows > 8192 && max_group_rows <= 32768)
+        hipLaunchKernelGGL(k_grp_col_softmax<2>, dim3(G, (ld + 1) / 2), dim3(1024), 0, st, S, ld, grp_off, TH);
+    else if (max_group_rows > 2048 && max_group_rows <= 8192)
+        hipLaunchKernelGGL(k_grp_col_softmax<8>, dim3(G, (ld + 7) / 8), dim3(1024), 0, st, S, ld, grp_off, TH);
+    else
+        hipLaunchKernelGGL(k_grp_col_softmax<32>, dim3(G, (ld + 31) / 32), dim3(1024), 0, st, S, ld, grp_off, TH);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
-extern "C" int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int TH,
-                                       float* dS, void* stream) {
-    AP_CHECK(A && dA && dS && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld);
+extern "C" int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G,
+                                       int max_group_rows, int TH, float* dS, void* stream) {
+    AP_CHECK(A && dA && dS && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld && max_group_rows >= 0);
     if (G == 0) return MIL_OK;
-    hipLaunchKernelGGL(k_grp_col_softmax_bwd, dim3(G, (ld + 31) / 32), dim3(1024), 0, (hipStream_t)stream, A, dA, ld, grp_off,
-                       TH, dS);
+    hipStream_t st = (hipStream_t)stream;
+    if (max_group_rows > 4096 && max_group_rows <= 16384)
+        hipLaunchKernelGGL(k_grp_col_softmax_bwd<2>, dim3(G, (ld + 1) / 2), dim3(1024), 0, st, A, dA, ld, grp_off, TH, dS);
+    else if (max_group_rows > 1024 && max_group_rows <= 4096)
+        hipLaunchKernelGGL(k_grp_col_softmax_bwd<8>, dim3(G, (ld + 7) / 8), dim3(1024), 0, st, A, dA, ld, grp_off, TH, dS);
+    else
+        hipLaunchKernelGGL(k_grp_col_softmax_bwd<32>, dim3(G, (ld + 31) / 32), dim3(1024), 0, st, A, dA, ld, grp_off, TH, dS);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

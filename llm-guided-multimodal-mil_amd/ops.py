@@ -1169,14 +1169,15 @@ class _GrpColSoftmax(torch.autograd.Function):
     """Softmax over the rows of each group, per column (columns >= TH are padding: zeros)."""
 
     @staticmethod
-    def forward(ctx, S, grp_off, G: int, TH: int):
+    def forward(ctx, S, grp_off, G: int, TH: int, max_rows: int = 0):
+        """max_rows: length of the longest group (0 = unknown): picks the kernel shape that keeps a group in registers."""
         A = S if (S.is_contiguous() and S.dtype == torch.float32) else _f32c(S, "S").clone()
         if A is S:
             ctx.mark_dirty(S)              # in place: the scores are the fresh output of the product that formed them
-        rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(grp_off), G, TH, _stream())
+        rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(grp_off), G, max_rows, TH, _stream())
         _lib.check(rc, "mil_grp_col_softmax")
         ctx.save_for_backward(A, grp_off)
-        ctx.G, ctx.TH = G, TH
+        ctx.G, ctx.TH, ctx.max_rows = G, TH, max_rows
         return A
 
     @staticmethod
@@ -1184,9 +1185,10 @@ class _GrpColSoftmax(torch.autograd.Function):
         A, grp_off = ctx.saved_tensors
         dA = _f32c(dA, "dA")
         dS = torch.empty_like(A)
-        rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(grp_off), ctx.G, ctx.TH, _p(dS), _stream())
+        rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(grp_off), ctx.G, ctx.max_rows, ctx.TH, _p(dS),
+                                                _stream())
         _lib.check(rc, "mil_grp_col_softmax_bwd")
-        return dS, None, None, None
+        return dS, None, None, None, None
 
 
 class _RowSoftmaxT(torch.autograd.Function):
@@ -1237,7 +1239,7 @@ def multi_token_pool_attention(q_tok, keys, kin, segs, Wq, bq, Wk, Wv, bv, H: in
     qp = linear_act(q_tok, Wq, bq) * (1.0 / C ** 0.5)
     Qp = _pad_vectors(_AbsorbQuery.apply(qp, Wk, H), B, TH)                      # k_proj.bias is softmax-invariant
     S = _GroupedNT.apply(kin, Qp, None, segs.k_off, segs.Tk_max)
-    A = _GrpColSoftmax.apply(S, segs.k_off, B, TH)
+    A = _GrpColSoftmax.apply(S, segs.k_off, B, TH, segs.Tk_max)
     pooled = _GroupedTN.apply(A, keys, segs.k_off, B, segs.Tk_max)               # [B, THp, E]
     return _ValueProj.apply(pooled[:, :TH].reshape(B * T, H, keys.shape[1]), Wv, bv)
 

@@ -100,3 +100,28 @@ def test_column_and_row_softmax_stages():
     o, (gr,) = _grads(lambda s: ops._RowSoftmaxT.apply(s * 1.0, T, H), [S.to(DEV)], go.to(DEV))
     assert float((o.cpu() - o_ref).abs().max()) <= 1e-6 and float(o[:, TH:].abs().max()) == 0.0
     assert rel_err(gr.cpu(), g_ref) <= 1e-5
+
+
+@pytest.mark.parametrize("lens,hint", [([3000, 2500], 3000), ([4096], 4096), ([9000, 40], 9000), ([17000], 17000),
+                                       ([3000, 2500], 0), ([40000], 40000)])
+def test_column_softmax_long_groups(lens, hint):
+    """Bags longer than 2048 rows (the authors' reach ~15 000 patches): narrower column blocks keep the group in registers;
+    hint 0 (length unknown) and groups beyond every register shape take the re-reading loop."""
+    g = torch.Generator().manual_seed(2)
+    R, G, T, H, ld = sum(lens), len(lens), 10, 8, 96
+    TH = T * H
+    off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    S = torch.randn((R, ld), generator=g) * 3
+    go = torch.randn((R, ld), generator=g)
+    seg = [(int(off[i]), int(off[i + 1])) for i in range(G)]
+
+    def ref_col(S):
+        out = torch.zeros_like(S)
+        out[:, :TH] = torch.cat([torch.softmax(S[a:b, :TH], 0) for a, b in seg], 0)
+        return out
+
+    o_ref, (g_ref,) = _grads(ref_col, [S], go)
+    o, (gr,) = _grads(lambda s: ops._GrpColSoftmax.apply(s * 1.0, off.to(DEV), G, TH, hint), [S.to(DEV)], go.to(DEV))
+    # fp32 sums over up to 40 000 rows in a different order than the reference: a few 1e-5 relative
+    assert float((o.cpu() - o_ref).abs().max()) <= 5e-5 and rel_err(o.cpu(), o_ref) <= 5e-5 and float(o[:, TH:].abs().max()) == 0.0
+    assert rel_err(gr.cpu(), g_ref) <= 5e-5
