@@ -485,6 +485,8 @@ extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B,
                      workspace_floats, aux, ldaux, aux_mode, stream);
 }
 
+#include "skinny_gemm.h"
+
 // C_g = sum over the row chunks of a split grouped contraction (fixed order)
 __global__ __launch_bounds__(256) void k_grouped_fold(const float* __restrict__ part, int splits, size_t per, float* __restrict__ C,
                                                       size_t total) {
@@ -518,7 +520,19 @@ extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float
         // C[rows_g, :N] = A[rows_g, :K] . B_g   (b_mode 0: B_g [N, K];  b_mode 1: B_g [K, N]);  K % 32 == 0
         if (K <= 0 || (K % LG_BK) != 0 || (b_mode == 1 && (N & 3))) return MIL_EINVAL;
         const dim3 grid((N + 127) / 128, (max_group_rows + 127) / 128, G);
-        if (b_mode == 0)
+        if (b_mode == 0 && residual == nullptr && N <= 96 && (N % 32) == 0) {
+            // N = T x H absorbed vectors: 64-row workgroups, one MFMA tile per wave (skinny_gemm.h)
+            const dim3 gs((max_group_rows + 63) / 64, G);
+            if (N == 32) hipLaunchKernelGGL(k_skinny_nt<1>, gs, dim3(128), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
+            else if (N == 64) hipLaunchKernelGGL(k_skinny_nt<2>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
+            else hipLaunchKernelGGL(k_skinny_nt<3>, gs, dim3(384), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
+        } else if (b_mode == 1 && K <= 96 && (N % 128) == 0 && (bias == nullptr || strideBias == 0)) {
+            // K = T x H: the whole contraction staged at once
+            const dim3 gs(N / 128, (max_group_rows + 63) / 64, G);
+            if (K == 32) hipLaunchKernelGGL(k_skinny_nn<32>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr);
+            else if (K == 64) hipLaunchKernelGGL(k_skinny_nn<64>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr);
+            else hipLaunchKernelGGL(k_skinny_nn<96>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr);
+        } else if (b_mode == 0)
             hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, 0, N, K, K, bias, 0, residual, ldr, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
         else
             hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, 0, N, K, K, bias, 0, residual, ldr, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);

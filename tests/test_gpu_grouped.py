@@ -24,9 +24,10 @@ def _grads(fn, ins, go):
     return out.detach(), [t.grad for t in ins]
 
 
-def test_grouped_products_and_their_backwards():
+@pytest.mark.parametrize("N", [96, 64, 32, 128])          # 32 / 64 / 96: the skinny kernels (skinny_gemm.h); 128: k_gemm groups
+def test_grouped_products_and_their_backwards(N):
     g = torch.Generator().manual_seed(0)
-    R, G, N, K = sum(LENS), len(LENS), 96, 512
+    R, G, K = sum(LENS), len(LENS), 512
     off = _off()
     A = torch.randn((R, K), generator=g)
     B = torch.randn((G, N, K), generator=g) / K ** 0.5
