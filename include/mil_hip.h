@@ -194,6 +194,18 @@ size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
              int accumulate, float* workspace, size_t workspace_floats, void* stream);
+/* Parameter half of a Linear layer's backward (every nn.Linear (+Tanh / ReLU) of aggregator.py:44-68 and
+ * sam/transformer.py:413-416, sam/common.py:21-26 above MIL_SMALL_ROWS rows) in one product launch + split-K fold:
+ *   dW[n_out, k_in] (+)= (dY (.) act'(Y))^T . X        db[n_out] (+)= column sums of dY (.) act'(Y)
+ * dY [rows, n_out] upstream gradient, Y the layer's saved output (needed for act 1 tanh / 2 relu; NULL for act 0),
+ * X [rows, k_in] the layer input; db may be NULL.  The activation derivative is applied while dY is staged and the bias
+ * gradient is accumulated from the staged operand, so no activation-backward or column-sum pass is launched.
+ * workspace: mil_linear_bwd_params_workspace_floats(rows, n_out, k_in) floats. */
+size_t mil_linear_bwd_params_workspace_floats(int rows, int n_out, int k_in);
+int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows,
+                          int n_out, int k_in, float* dW, int lddw, float* db, int accumulate, float* workspace,
+                          size_t workspace_floats, void* stream);
+
 /* mil_gemm (a_mode 0) with one auxiliary [M, N] tensor touched in the epilogue:
  *   aux_mode 1: aux = the pre-activation (product + bias, before act) is stored too - QuickGELU's backward needs it;
  *   aux_mode 2: the result is multiplied by QuickGELU'(aux) - the activation backward of clip/model.py:162-164 fused

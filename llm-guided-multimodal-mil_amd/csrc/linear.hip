@@ -32,6 +32,16 @@ struct GemmGroups {
     int mode, splits;
 };
 
+// Weight-gradient extras (a_mode 1 only, template flag AX): the A operand is dY (.) act'(Y) formed while it is staged
+// (a_aux = the layer's saved output Y, a_act = ACT_TANH / ACT_RELU / ACT_NONE), and the column sums of that operand -
+// the bias gradient - are accumulated by the workgroups of the first column tile into a_colsum[split][M].  One launch
+// (+ the split-K fold) then yields dW and db without a stand-alone activation-backward or column-sum pass.
+struct GemmExtra {
+    const float* a_aux;
+    float* a_colsum;
+    int ld_aux, a_act;
+};
+
 // aux_mode 1: also store the pre-activation (bias added, before act) to aux - the backward of QuickGELU needs it;
 // aux_mode 2: multiply by QuickGELU'(aux[row][j]) - the activation backward fused into the epilogue of the product
 // that forms the gradient (clip/model.py:162-164 inside the MLP of :176-178).
@@ -91,12 +101,14 @@ struct OperandTile {
     }
 };
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, bool AX = false>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K, int kchunk,
                                               const float* __restrict__ bias, int act, const float* __restrict__ residual,
                                               int ldr, int accumulate, float* __restrict__ partial,
-                                              float* __restrict__ aux, int ldaux, int aux_mode, GemmGroups gg) {
+                                              float* __restrict__ aux, int ldaux, int aux_mode, GemmGroups gg,
+                                              GemmExtra ex = GemmExtra{nullptr, nullptr, 0, 0}) {
+    static_assert(!AX || AMODE == 1, "operand extras are defined for the k-major A operand only");
     constexpr int ASZ = AMODE == 0 ? 128 * LG_KS : LG_BK * 128;
     constexpr int BSZ = BMODE == 0 ? 128 * LG_KS : LG_BK * 128;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
@@ -148,6 +160,32 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     // the K seen by the loaders is this block's chunk end (so the zero mask also cuts the split-K chunk)
     ta.init(A, lda, i0, M, kend, tid);
     tb.init(B, ldb, j0, N, kend, tid);
+    OperandTile<AMODE> tx;                          // AX: the saved layer output, same tile as A
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};              // AX: column sums of the staged A operand (this thread's 4 columns)
+    const bool ax_act = AX && ex.a_aux != nullptr;
+    if (ax_act) tx.init(ex.a_aux, ex.ld_aux, i0, M, kend, tid);
+    auto a_load = [&](int i, int k0) {
+        ta.load(i, k0);
+        if (AX) { if (ax_act) tx.load(i, k0); }
+    };
+    auto a_store = [&](int i, float* lds) {
+        if (AX) {
+            f32x4 v = ta.reg[i] * ta.mask[i];
+            if (ax_act) {
+                const f32x4 y = tx.reg[i];
+                if (ex.a_act == ACT_TANH) {
+                    v = v * (1.0f - y * y);
+                } else if (ex.a_act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(lds + ta.lds_off[i]) = v;
+            csum += v;
+        } else {
+            ta.store(i, lds);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -159,12 +197,12 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 
     if (nslice > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ta.load(i, kbeg); tb.load(i, kbeg); }
+        for (int i = 0; i < 4; ++i) { a_load(i, kbeg); tb.load(i, kbeg); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ta.store(i, as); tb.store(i, bs); }
+        for (int i = 0; i < 4; ++i) { a_store(i, as); tb.store(i, bs); }
         const int k1 = kbeg + min(1, nslice - 1) * LG_BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ta.load(i, k1); tb.load(i, k1); }
+        for (int i = 0; i < 4; ++i) { a_load(i, k1); tb.load(i, k1); }
     }
     __syncthreads();
     for (int s = 0; s < nslice; ++s) {
@@ -200,7 +238,12 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                 const int g = 4 * t + jj;
                 if (g >= 2 && g < 10) {            // staging piece g-2: next slice into LDS, reload with the slice after
                     const int pc = g - 2;
-                    if (pc < 4) { ta.store(pc, an); ta.load(pc, k2); }
+                    if (pc < 4) {
+                        // AX: the registers of the last iteration hold a second copy of the final slice - it must not
+                        // enter the column sums (its LDS image is never read)
+                        if (!AX || s + 1 < nslice) a_store(pc, an);
+                        a_load(pc, k2);
+                    }
                     else { tb.store(pc - 4, bn); tb.load(pc - 4, k2); }
                 }
                 if (t < 3) {                        // next k-group's fragments: one tile per MFMA group
@@ -217,6 +260,22 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
             }
         }
         __syncthreads();
+    }
+
+    if (AX) {
+        if (ex.a_colsum != nullptr && blockIdx.x == 0) {
+            // fold the 8 k-row groups of threads (tid >> 5) that share the column quad tid & 31
+            __syncthreads();
+            float* red = smem;                       // [8][128]
+            *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + 4 * (tid & 31)) = csum;
+            __syncthreads();
+            if (tid < 128 && i0 + tid < M) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v += red[q * 128 + tid];
+                ex.a_colsum[(size_t)blockIdx.z * M + i0 + tid] = v;
+            }
+        }
     }
 
     // epilogue: lane holds column j, 16 rows per tile.  The residual / auxiliary / accumulate operands of a tile are
@@ -271,8 +330,15 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int S, float* __restrict__ C,
                                                        int ldc, int M, int N, const float* __restrict__ bias, int act,
                                                        const float* __restrict__ residual, int ldr, int accumulate,
-                                                       float* __restrict__ aux, int ldaux, int aux_mode) {
+                                                       float* __restrict__ aux, int ldaux, int aux_mode,
+                                                       const float* __restrict__ cs_part = nullptr,
+                                                       float* __restrict__ cs_out = nullptr, int cs_accumulate = 0) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (cs_part != nullptr && idx < (size_t)M) {         // bias gradient: fold the per-split column sums of the A operand
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += cs_part[(size_t)s * M + idx];
+        cs_out[idx] = cs_accumulate ? cs_out[idx] + v : v;
+    }
     if (idx >= (size_t)M * N) return;
     const int row = (int)(idx / N), j = (int)(idx % N);
     float v = 0.f;
@@ -483,6 +549,44 @@ extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B,
         return MIL_EINVAL;
     return gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
                      workspace_floats, aux, ldaux, aux_mode, stream);
+}
+
+// dW[N_out, K_in] (+)= (dY (.) act'(Y))^T . X,   db[N_out] (+)= column sums of dY (.) act'(Y):  the parameter half of a
+// Linear layer's backward in one product launch + its split-K fold.
+extern "C" size_t mil_linear_bwd_params_workspace_floats(int rows, int n_out, int k_in) {
+    if (rows <= 0 || n_out <= 0 || k_in <= 0) return 0;
+    int kc;
+    int S = splitk_plan(n_out, k_in, rows, 1, &kc);
+    if (S < 1) S = 1;
+    return (size_t)S * n_out * k_in + (size_t)S * n_out;
+}
+
+extern "C" int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx,
+                                     int rows, int n_out, int k_in, float* dW, int lddw, float* db, int accumulate,
+                                     float* workspace, size_t workspace_floats, void* stream) {
+    if (!dY || !X || !dW || !workspace || rows <= 0 || n_out < 4 || (n_out & 3) || k_in < 4 || (k_in & 3)) return MIL_EINVAL;
+    if ((lddy & 3) || (ldx & 3) || (Y != nullptr && (ldy & 3))) return MIL_EINVAL;
+    if (act != ACT_NONE && act != ACT_TANH && act != ACT_RELU) return MIL_EINVAL;
+    if (act != ACT_NONE && Y == nullptr) return MIL_EINVAL;
+    if (workspace_floats < mil_linear_bwd_params_workspace_floats(rows, n_out, k_in)) return MIL_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk;
+    int S = splitk_plan(n_out, k_in, rows, 1, &kchunk);
+    if (S < 1) { S = 1; kchunk = rows; }
+    float* partial = workspace;
+    float* cs_part = db != nullptr ? workspace + (size_t)S * n_out * k_in : nullptr;
+    const GemmExtra ex{act != ACT_NONE ? Y : nullptr, cs_part, ldy, act};
+    const dim3 grid((k_in + 127) / 128, (n_out + 127) / 128, S);
+    hipLaunchKernelGGL((k_gemm<1, 1, true>), grid, dim3(256), 0, st, dY, lddy, X, ldx, dW, lddw, n_out, k_in, rows, kchunk,
+                       (const float*)nullptr, 0, (const float*)nullptr, 0, accumulate, partial, (float*)nullptr, 0, 0,
+                       GemmGroups{nullptr, 0, 0, 0, GRP_NONE, 1}, ex);
+    MIL_CHECK_LAUNCH();
+    const size_t n = (size_t)n_out * k_in;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, S, dW, lddw, n_out, k_in,
+                       (const float*)nullptr, 0, (const float*)nullptr, 0, accumulate, (float*)nullptr, 0, 0,
+                       (const float*)cs_part, db, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
 }
 
 #include "skinny_gemm.h"

@@ -324,6 +324,23 @@ def gemm_aux(A, B, b_mode: int, M: int, N: int, K: int, aux, aux_mode: int, bias
     return out
 
 
+def linear_bwd_params(dy, y, act: int, x, dW_out=None, db_out=None, want_db: bool = True):
+    """dW = (dy (.) act'(y))^T x and db = its column sums in one product launch + fold (mil_linear_bwd_params).
+    y may be None for act 0.  Returns (dW [N, K], db [N] or None)."""
+    rows, N = dy.shape
+    K = x.shape[1]
+    dW = dW_out if dW_out is not None else torch.empty((N, K), device=dy.device, dtype=torch.float32)
+    db = None
+    if want_db:
+        db = db_out if db_out is not None else torch.empty(N, device=dy.device, dtype=torch.float32)
+    nws = _lib.lib().mil_linear_bwd_params_workspace_floats(rows, N, K)
+    ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
+    rc = _lib.lib().mil_linear_bwd_params(_p(dy), dy.stride(0), _p(y), y.stride(0) if y is not None else 0, act, _p(x),
+                                          x.stride(0), rows, N, K, _p(dW), dW.stride(0), _p(db), 0, _p(ws), nws, _stream())
+    _lib.check(rc, "mil_linear_bwd_params")
+    return dW, db
+
+
 def colsum(Y, out=None, accumulate: bool = False):
     M, N = Y.shape
     if out is None:
@@ -440,7 +457,18 @@ class _LinearAct(torch.autograd.Function):
             rc = _lib.lib().mil_quickgelu(_p(y), _p(dy), _p(dpre), dy.numel(), _stream())     # y holds the pre-activation
             _lib.check(rc, "mil_quickgelu")
         else:
+            fused = ctx.needs_input_grad[1] and N % 4 == 0 and K % 4 == 0
+            if fused and not ctx.needs_input_grad[0]:
+                # parameters only (fc_pathology: the bag features carry no gradient): act' is applied while dy is staged
+                # for the weight-gradient product, which also yields the bias gradient - no dpre tensor at all
+                dW, db = linear_bwd_params(dy, y if ctx.act else None, ctx.act, x, W_slot, b_slot,
+                                           ctx.has_b and ctx.needs_input_grad[2])
+                return None, dW, db, None, (dy if ctx.has_res else None)
             dpre = act_bwd(dy, y, ctx.act)
+            if fused:
+                dx = gemm(dpre, 0, W, 1, M, K, N)
+                dW, db = linear_bwd_params(dpre, None, 0, x, W_slot, b_slot, ctx.has_b and ctx.needs_input_grad[2])
+                return dx, dW, db, None, (dy if ctx.has_res else None)
         dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
         dW = gemm(dpre, 1, x, 1, N, K, M, out=W_slot, split_k=True) if ctx.needs_input_grad[1] else None
         db = colsum(dpre, out=b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None

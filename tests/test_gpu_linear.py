@@ -91,3 +91,31 @@ def test_fused_quickgelu_mlp_matches_torch():
     assert rel_err(out.detach().cpu(), ref.detach()) <= 3e-6
     for a, b, name in zip(dev_in, ref_in, ("x", "W1", "b1", "W2", "b2", "residual")):
         assert rel_err(a.grad.cpu(), b.grad) <= 1e-5, name
+
+
+@pytest.mark.parametrize("M,K,N,act,x_grad", [(300, 768, 512, "tanh", False), (4099, 768, 512, "tanh", False),
+                                              (130, 2048, 512, "none", False), (1000, 512, 2048, "relu", False),
+                                              (65, 64, 132, "tanh", False), (300, 768, 512, "tanh", True),
+                                              (33000, 512, 256, "relu", False)])
+def test_parameter_backward_with_fused_activation_and_bias_gradient(M, K, N, act, x_grad):
+    """mil_linear_bwd_params: dW and db from one product launch (+ fold); with no input gradient wanted (fc_pathology: the
+    bag features carry none) the activation derivative is applied while dy is staged.  Row counts cover one slice, odd
+    tails, a clamped column tile (N = 132) and many splits."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    go = torch.randn(M, N, generator=g)
+    dev = torch.device("cuda")
+    xd = x.to(dev).requires_grad_(x_grad)
+    Wd, bd = (t.to(dev).requires_grad_(True) for t in (W, b))
+    y = ops.linear_act(xd, Wd, bd, act)
+    (y * go.to(dev)).sum().backward()
+    xr, Wr, br = (t.clone().double().requires_grad_(True) for t in (x, W, b))
+    pre = F.linear(xr, Wr, br)
+    ref = {"none": pre, "tanh": torch.tanh(pre), "relu": torch.relu(pre)}[act]
+    (ref * go.double()).sum().backward()
+    assert rel_err(Wd.grad.cpu(), Wr.grad.float()) <= 1e-5
+    assert rel_err(bd.grad.cpu(), br.grad.float()) <= 1e-5
+    if x_grad:
+        assert rel_err(xd.grad.cpu(), xr.grad.float()) <= 1e-5

@@ -78,3 +78,21 @@ def test_flat_sgd_tracks_torch_sgd():
     for (k, a), b in zip(ref.named_parameters(), ours.parameters()):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), k
     assert o_our.exp_avg.numel() == 0
+
+
+def test_flat_adam_large_buffer_path():
+    """More than 2^21 parameters take the four-float4-per-thread Adam kernel (and its scalar tail)."""
+    torch.manual_seed(4)
+    ref = torch.nn.Linear(2048, 1101).to(DEV)            # 2 255 949 parameters: not a multiple of the 4096-element block
+    ours = copy.deepcopy(ref)
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-7)
+    o_our = FlatAdam(ours.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-7)
+    g = torch.Generator().manual_seed(0)
+    for step in range(3):
+        x = torch.randn((7, 2048), generator=g).to(DEV)
+        for m, o in ((ref, o_ref), (ours, o_our)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            o.step()
+    for (k, a), b in zip(ref.named_parameters(), ours.parameters()):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(a.detach().abs().max())), k
