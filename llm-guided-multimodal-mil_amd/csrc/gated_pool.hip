@@ -922,14 +922,18 @@ extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, co
 // dx[row][j] += sum_d dPreV[row][d] Wv[d][j] + dPreU[row][d] Wu[d][j]     (M = R, N = L, K = 384).
 // K-slices of 32 = 16 d's x {V, U} so one (V, U) load pair yields both dPre terms.
 // Workgroup 256 threads, tile 128 rows x 128 cols, wave (wi, wj) owns 64 x 64.
-// LDS: A [128][32] padded to 33 words (lane i reads word 33 i + k: conflict-free), B [32][128].
-#define GX_AS 33
+#define GX_KS 36       // k-contiguous A image row stride (words), as in k_gemm
+// Same pipeline as k_gemm (csrc/linear.hip): 128 x 128 x 32 tiles, 2 x 2 waves of 64 x 64, the A image k-contiguous
+// ([128][36], ds_read_b128 fragments: lane (r, h) takes k = 8t + 4h + jj), the weights k-major ([32][128]); registers
+// carry the slice after next and the staging is issued in pieces between MFMA groups.  A slice of 32 k's is 16 gate units:
+// local k 0..15 = dPreV_d, 16..31 = dPreU_d (d = 16 kk + k), built from (V, U, ds, w) when the slice is written to LDS.
 __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ gates, const float* __restrict__ ds,
                                                      const float* __restrict__ wvec, const float* __restrict__ Wv,
                                                      const float* __restrict__ Wu, float* __restrict__ dx, int R, int L) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (128 * GX_AS + 32 * 128)];
-    float* as = smem;                       // [2][128][33]
-    float* bs = smem + 2 * 128 * GX_AS;     // [2][32][128]
+    constexpr int ASZ = 128 * GX_KS, BSZ = 32 * 128;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
+    float* as = smem;
+    float* bs = smem + 2 * ASZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -937,53 +941,36 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
     const int jt = blockIdx.x % NJ, rt = blockIdx.x / NJ;
     const int row0 = rt * 128, j0 = jt * 128;
 
-    // staging: A: thread -> row (tid >> 1), 8 d's: (tid & 1) * 8 .. +7 ; B: k row (tid >> 5) + 8 i, chunk (tid & 31)
-    const int arow = tid >> 1, ad0 = (tid & 1) * 8;
-    const int brow = tid >> 5, bc4 = tid & 31;
-    const int garow = row0 + arow;
-    const float dsr = garow < R ? ds[garow] : 0.f;
-    f32x4 rv[2], ru[2], rb[4];
-
-    auto gload = [&](int kk) {   // kk: slice index, d0 = 16 kk
-        const int d0 = 16 * kk;
+    // A producer: thread -> unit quad dq = tid & 3 (d = 16 kk + 4 dq ..+3), rows (tid >> 2) + 64 i (i < 2)
+    const int dq = tid & 3, arow = tid >> 2;
+    const float* gsrc[2];
+    float dsr[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (garow < R) {
-                const float* gp = gates + (size_t)garow * GF_NG + d0 + ad0 + 4 * i;
-                rv[i] = *reinterpret_cast<const f32x4*>(gp);
-                ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
-            } else {
-                rv[i] = f32x4{0, 0, 0, 0};
-                ru[i] = f32x4{0, 0, 0, 0};
-            }
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int gr = row0 + arow + 64 * i;
+        gsrc[i] = gates + (size_t)min(gr, R - 1) * GF_NG + 4 * dq;
+        dsr[i] = gr < R ? ds[gr] : 0.f;                       // rows past the end contribute zeros
+    }
+    // B: k row (tid >> 5) + 8 i (i < 2: Wv rows, i >= 2: Wu rows), 16-byte chunk tid & 31
+    const int bk = tid >> 5, bc4 = tid & 31;
+    const float* bsrc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = brow + 8 * i;    // 0..31: k < 16 -> Wv[d0 + k], else Wu[d0 + k - 16]
-            const float* base = (i < 2) ? Wv + (size_t)(d0 + k) * L : Wu + (size_t)(d0 + k - 16) * L;
-            rb[i] = *reinterpret_cast<const f32x4*>(base + j0 + 4 * bc4);
-        }
+    for (int i = 0; i < 4; ++i) bsrc[i] = ((i < 2) ? Wv : Wu) + (size_t)(bk + 8 * (i & 1)) * L + j0 + 4 * bc4;
+    f32x4 rv[2], ru[2], rw[2], rb[4];
+    auto a_load = [&](int i, int kk) {
+        rv[i] = *reinterpret_cast<const f32x4*>(gsrc[i] + 16 * kk);
+        ru[i] = *reinterpret_cast<const f32x4*>(gsrc[i] + 192 + 16 * kk);
+        rw[i] = *reinterpret_cast<const f32x4*>(wvec + 16 * kk + 4 * dq);
     };
-    auto swrite = [&](int buf, int kk) {
-        const int d0 = 16 * kk;
-        float* ad = as + (buf * 128 + arow) * GX_AS;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + d0 + ad0 + 4 * i);
-            const f32x4 v = rv[i], u = ru[i];
-            const f32x4 dsw = dsr * w4;
-            const f32x4 pv = dsw * u * (1.0f - v * v);
-            const f32x4 pu = dsw * v * u * (1.0f - u);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ad[ad0 + 4 * i + e] = pv[e];
-                ad[16 + ad0 + 4 * i + e] = pu[e];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(bs + (buf * 32 + brow + 8 * i) * 128 + 4 * bc4) = rb[i];
+    auto a_store = [&](int i, float* dst) {
+        const f32x4 v = rv[i], u = ru[i];
+        const f32x4 dsw = dsr[i] * rw[i];
+        float* ad = dst + (arow + 64 * i) * GX_KS + 4 * dq;
+        *reinterpret_cast<f32x4*>(ad) = dsw * u * (1.0f - v * v);            // dPreV
+        *reinterpret_cast<f32x4*>(ad + 16) = dsw * v * u * (1.0f - u);       // dPreU
     };
+    auto b_load = [&](int i, int kk) { rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + (size_t)(16 * kk) * L); };
+    auto b_store = [&](int i, float* dst) { *reinterpret_cast<f32x4*>(dst + (bk + 8 * i) * 128 + 4 * bc4) = rb[i]; };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -993,36 +980,74 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    const int nslice = MIL_GATE_D / 16;   // 12
-    gload(0);
-    swrite(0, 0);
-    __syncthreads();
-    for (int sl = 0; sl < nslice; ++sl) {
-        const int buf = sl & 1;
-        if (sl + 1 < nslice) gload(sl + 1);
-        const float* ap = as + (buf * 128 + 64 * wi + r) * GX_AS + h;
-        const float* bp = bs + (buf * 32 + h) * 128 + 64 * wj + r;
+    constexpr int nslice = MIL_GATE_D / 16;   // 12
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const float a0 = ap[2 * ks], a1 = ap[32 * GX_AS + 2 * ks];
-            const float b0 = bp[ks * 256], b1 = bp[ks * 256 + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int i = 0; i < 2; ++i) a_load(i, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_load(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_store(i, as);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_store(i, bs);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_load(i, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_load(i, 1);
+    __syncthreads();
+    for (int s = 0; s < nslice; ++s) {
+        const int buf = s & 1;
+        const int k2 = min(s + 2, nslice - 1);
+        const float* ab = as + buf * ASZ;
+        const float* bb = bs + buf * BSZ;
+        float* an = as + (buf ^ 1) * ASZ;
+        float* bn = bs + (buf ^ 1) * BSZ;
+        f32x4 fa[2][2], fb[2][2];     // [register set][tile]
+        auto frag_a = [&](int t, int q, int a) {
+            fa[q][a] = *reinterpret_cast<const f32x4*>(ab + (64 * wi + 32 * a + r) * GX_KS + 8 * t + 4 * h);
+        };
+        auto frag_b = [&](int t, int q, int b) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fb[q][b][jj] = bb[(8 * t + 4 * h + jj) * 128 + 64 * wj + 32 * b + r];
+        };
+        frag_a(0, 0, 0); frag_a(0, 0, 1); frag_b(0, 0, 0); frag_b(0, 0, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = t & 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int g = 4 * t + jj;
+                // staging pieces between MFMA groups: the next slice into LDS, registers reloaded with the slice after
+                if (g == 2 || g == 4) { const int i = (g - 2) >> 1; a_store(i, an); a_load(i, k2); }
+                if (g >= 6 && g < 10) { const int i = g - 6; b_store(i, bn); b_load(i, k2); }
+                if (t < 3) {
+                    if (jj == 0) frag_a(t + 1, q ^ 1, 0);
+                    if (jj == 1) frag_a(t + 1, q ^ 1, 1);
+                    if (jj == 2) frag_b(t + 1, q ^ 1, 0);
+                    if (jj == 3) frag_b(t + 1, q ^ 1, 1);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0][jj], fb[q][0][jj], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0][jj], fb[q][1][jj], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1][jj], fb[q][0][jj], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1][jj], fb[q][1][jj], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (sl + 1 < nslice) swrite(buf ^ 1, sl + 1);
         __syncthreads();
     }
+    // dx += tile: the 16 old values of a tile column are loaded as one batch before the adds
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int gr = row0 + 64 * wi + 32 * a + mfma32_row(i, h);
-            if (gr < R) {
-                float* o = dx + (size_t)gr * L + j0 + 64 * wj + r;
-                o[0] += acc[a][0][i];
-                o[32] += acc[a][1][i];
+        for (int b = 0; b < 2; ++b) {
+            float* o = dx + j0 + 64 * wj + 32 * b + r;
+            const int rbase = row0 + 64 * wi + 32 * a;
+            float cv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cv[i] = o[(size_t)min(rbase + mfma32_row(i, h), R - 1) * L];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gr = rbase + mfma32_row(i, h);
+                if (gr < R) o[(size_t)gr * L] = cv[i] + acc[a][b][i];
             }
         }
 }

@@ -117,12 +117,29 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    int i0 = blockIdx.y * 128;
-    const int j0 = blockIdx.x * 128;
-    int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    // XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
+    // L2), so the column tiles of one row tile - which read the same A rows - would land on different XCDs and every A
+    // row would come from HBM once per column tile.  Logical id = (id % 8) * share + id / 8 (bijective for any grid)
+    // keeps consecutive logical tiles on one XCD, dispatched within a few slots of each other.  (Times are unchanged on
+    // MI355X - the Infinity Cache already absorbs the cross-XCD re-reads; the order only spares L2 -> fabric traffic.)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#if !defined(LG_NOXCD)
+    {
+        const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        int lin = bx + gx * (by + gy * bz);
+        const int q = nwg >> 3, rem = nwg & 7, xcd = lin & 7;
+        lin = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+        bx = lin % gx;
+        by = (lin / gx) % gy;
+        bz = lin / (gx * gy);
+    }
+#endif
+    int i0 = by * 128;
+    const int j0 = bx * 128;
+    int kbeg = bz * kchunk, kend = min(K, kbeg + kchunk);
     if (gg.mode != GRP_NONE) {
-        // grouped launch: blockIdx.z is the group (bag); no split-K
-        const int g = blockIdx.z, goff = gg.off[g], gn = gg.off[g + 1] - goff;
+        // grouped launch: bz is the group (bag); no split-K
+        const int g = bz, goff = gg.off[g], gn = gg.off[g + 1] - goff;
         if (gg.mode == GRP_ROWS) {                 // rows of A / C belong to groups, B (and bias) are per group
             M = gn;
             if (i0 >= M) return;
@@ -140,9 +157,9 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
             kbeg = 0;
             kend = K;
             if (gg.splits > 1) {
-                // M <= 128: blockIdx.y is a chunk of the group's rows instead of a row tile; partial C tiles go to
+                // M <= 128: by is a chunk of the group's rows instead of a row tile; partial C tiles go to
                 // C[(g * splits + chunk)] (a workspace) and are summed by k_grouped_fold
-                const int sidx = blockIdx.y;
+                const int sidx = by;
                 const int chunk = ((gn + gg.splits - 1) / gg.splits + LG_BK - 1) / LG_BK * LG_BK;
                 kbeg = min(gn, sidx * chunk);
                 kend = min(gn, kbeg + chunk);
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     }
 
     if (AX) {
-        if (ex.a_colsum != nullptr && blockIdx.x == 0) {
+        if (ex.a_colsum != nullptr && bx == 0) {
             // fold the 8 k-row groups of threads (tid >> 5) that share the column quad tid & 31
             __syncthreads();
             float* red = smem;                       // [8][128]
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                 float v = 0.f;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v += red[q * 128 + tid];
-                ex.a_colsum[(size_t)blockIdx.z * M + i0 + tid] = v;
+                ex.a_colsum[(size_t)bz * M + i0 + tid] = v;
             }
         }
     }
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = rbase + mfma32_row(i, h);
-                    if (row < M) partial[((size_t)blockIdx.z * M + row) * N + j] = acc[a][b][i];
+                    if (row < M) partial[((size_t)bz * M + row) * N + j] = acc[a][b][i];
                 }
                 continue;
             }
