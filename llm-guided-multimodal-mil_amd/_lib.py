@@ -114,12 +114,14 @@ def header_symbols() -> List[str]:
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # MIL_HIP_LIB: load another build of the same library (tools/variants/*.so: A/B timing of kernel variants)
+        path = os.environ.get("MIL_HIP_LIB") or LIB_PATH
+        if not os.path.exists(path):
             raise MilHipError(
-                f"{LIB_PATH} is missing: the HIP library is not built and there is no fallback path. "
+                f"{path} is missing: the HIP library is not built and there is no fallback path. "
                 "Run __graft_entry__.build() or `make -C llm-guided-multimodal-mil_amd/csrc`.")
         import torch  # noqa: F401  (loads torch's libamdhip64 first so the kernels share its runtime/streams)
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

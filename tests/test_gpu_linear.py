@@ -119,3 +119,40 @@ def test_parameter_backward_with_fused_activation_and_bias_gradient(M, K, N, act
     assert rel_err(bd.grad.cpu(), br.grad.float()) <= 1e-5
     if x_grad:
         assert rel_err(xd.grad.cpu(), xr.grad.float()) <= 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,b_mode,extras", [(66000, 512, 64, 0, "bias_tanh"), (40001, 640, 96, 0, "residual"),
+                                                 (33000, 512, 128, 1, "accumulate"), (70000, 520, 32, 1, "plain"),
+                                                 (66000, 2048, 64, 0, "aux")])
+def test_tall_gemm_over_several_rounds(M, N, K, b_mode, extras):
+    """Several rounds of the chip (more than 512 tiles, no split-K): ragged last row tile, a clamped last column tile,
+    one-slice and multi-slice contractions, every epilogue flavour."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dev = torch.device("cuda")
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5          # y = A W^T
+    ref = A.double() @ W.double().t()
+    Ad = A.to(dev)
+    Bd = (W if b_mode == 0 else W.t().contiguous()).to(dev)
+    if extras == "bias_tanh":
+        b = torch.randn(N, generator=g)
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K, bias=b.to(dev), act=ops.ACT["tanh"])
+        ref = torch.tanh(ref + b.double())
+    elif extras == "residual":
+        res = torch.randn(M, N, generator=g)
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K, residual=res.to(dev))
+        ref = ref + res.double()
+    elif extras == "accumulate":
+        out = torch.ones(M, N, device=dev)
+        ops.gemm(Ad, 0, Bd, b_mode, M, N, K, out=out, accumulate=True)
+        ref = ref + 1
+    elif extras == "aux":
+        b = torch.randn(N, generator=g)
+        pre = torch.empty(M, N, device=dev)
+        out = ops.gemm_aux(Ad, Bd, b_mode, M, N, K, pre, 1, bias=b.to(dev), act=ops.ACT["quickgelu"])
+        p = ref + b.double()
+        assert rel_err(pre.cpu(), p.float()) <= 2e-6
+        ref = p * torch.sigmoid(1.702 * p)
+    else:
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K)
+    assert rel_err(out.cpu(), ref.float()) <= 2e-6
