@@ -67,11 +67,17 @@ __global__ __launch_bounds__(256) void k_absorb_query_bwd_q(const float* __restr
 }
 
 // dWk[hc + c'][j] = sum_b qp[b][hc + c'] dQp[b][h][j];   grid H*C, block E/4
+// grid H * C rows, block 4 x (E / 4) threads: the four thread groups take every fourth batch of 8 b's (with T text
+// tokens per bag B is bags x T = a few hundred: one group walking all of them was 32 us of dependent latency) and
+// fold through LDS in a fixed order.
+#define AQ_GROUPS 4
 __global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* __restrict__ dQp, int B, int H, int C,
                                      int E, float* __restrict__ dWk) {
-    const int row = blockIdx.x, h = row / C, j4 = threadIdx.x, I = H * C;
+    __shared__ __attribute__((aligned(16))) float red[(AQ_GROUPS - 1) * 1024];        // E <= 1024
+    const int E4 = E / 4;
+    const int row = blockIdx.x, h = row / C, j4 = threadIdx.x % E4, grp = threadIdx.x / E4, I = H * C;
     f32x4 acc = {0, 0, 0, 0};
-    for (int b0 = 0; b0 < B; b0 += 8) {
+    for (int b0 = 8 * grp; b0 < B; b0 += 8 * AQ_GROUPS) {
         f32x4 gv[8];
         float q[8];
 #pragma unroll
@@ -83,7 +89,13 @@ __global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* 
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += q[u] * gv[u];
     }
-    *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
+    if (grp > 0) *reinterpret_cast<f32x4*>(red + (grp - 1) * 1024 + 4 * j4) = acc;
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < AQ_GROUPS - 1; ++g) acc += *reinterpret_cast<const f32x4*>(red + g * 1024 + 4 * j4);
+        *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- absorbed pool, forward
@@ -543,14 +555,14 @@ extern "C" int mil_absorb_query(const float* qp, const float* Wk, int B, int H, 
 
 extern "C" int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E,
                                     float* dqp, float* dWk, void* stream) {
-    AP_CHECK(qp && Wk && dQp && B > 0 && H > 0 && (C == 32 || C == 64) && E > 0 && (E & 3) == 0 && E <= 4096);
+    AP_CHECK(qp && Wk && dQp && B > 0 && H > 0 && (C == 32 || C == 64) && E > 0 && (E & 3) == 0 && E <= 1024);
     hipStream_t st = (hipStream_t)stream;
     if (dqp != nullptr) {
         hipLaunchKernelGGL(k_absorb_query_bwd_q, dim3(B, H), dim3(256), 0, st, dQp, Wk, H, C, E, dqp);
         MIL_CHECK_LAUNCH();
     }
     if (dWk != nullptr) {
-        hipLaunchKernelGGL(k_absorb_query_bwd_w, dim3(H * C), dim3(E / 4), 0, st, qp, dQp, B, H, C, E, dWk);
+        hipLaunchKernelGGL(k_absorb_query_bwd_w, dim3(H * C), dim3(AQ_GROUPS * (E / 4)), 0, st, qp, dQp, B, H, C, E, dWk);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;

@@ -52,10 +52,11 @@ class Attention(nn.Module):
 
     def multi_token_pool(self, q, keys, kin, segs: AttnSegs, residual=None):
         """Token->image attention with T > 1 text tokens per bag, K / V projections absorbed (ops.multi_token_pool_attention):
-        q [B*T, E] queries (+pe), keys [R, E] (values), kin [R, E] = keys + pe (scores)."""
-        o = ops.multi_token_pool_attention(q, keys, kin, segs, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight,
-                                           self.v_proj.weight, self.v_proj.bias, self.num_heads)
-        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
+        q [B*T, E] queries (+pe), keys [R, E] (values), kin [R, E] = keys + pe (scores).  Returns (output, keys alias):
+        later uses of the keys go through the alias so that all their gradients are folded inside one node."""
+        o, keys_pass = ops.multi_token_pool_attention(q, keys, kin, segs, self.q_proj.weight, self.q_proj.bias,
+                                                      self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads)
+        return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual), keys_pass
 
     def multi_token_rows(self, kin, k_tok, v_tok, segs: AttnSegs, residual=None):
         """Image->token attention with T > 1 tokens per bag, q / out projections absorbed: returns out_proj(attn) + residual."""
@@ -127,7 +128,8 @@ class TwoWayAttentionBlock(nn.Module):
             queries = self.norm2(att)
         elif multi:
             k = keys_pe_fn(keys)
-            queries = self.norm2(self.cross_attn_token_to_image.multi_token_pool(q, keys, k, s_ti, residual=queries))
+            att, keys = self.cross_attn_token_to_image.multi_token_pool(q, keys, k, s_ti, residual=queries)
+            queries = self.norm2(att)
         else:
             k = keys_pe_fn(keys)
             queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
@@ -189,7 +191,7 @@ class TwoWayTransformer(nn.Module):
         if one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
             out, keys = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
         elif ops.multi_token_ok(self.embedding_dim, self.num_heads, s_ti.q_lengths):
-            out = self.final_attn_token_to_image.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=queries)
+            out, keys = self.final_attn_token_to_image.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=queries)
         else:
             out = self.final_attn_token_to_image.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=queries)
         return self.norm_final_attn(out), keys

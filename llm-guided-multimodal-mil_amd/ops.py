@@ -1256,20 +1256,96 @@ def multi_token_ok(E: int, H: int, t_lengths) -> bool:
     return E == 512 and H == 8 and 1 < T <= 12 and all(t == T for t in t_lengths)
 
 
+class _MultiTokenPoolCore(torch.autograd.Function):
+    """pooled[b] = softmax_rows(kin_b Qp_b^T)^T keys_b  - the three image-side stages of the multi-token token->image
+    attention as ONE autograd node.  kin must be keys + (a constant): its gradient is folded into the keys' here, and the
+    node also hands the keys back as an alias for their later consumers, so every contribution to d(keys) - values,
+    scores, whatever arrives through the alias - is accumulated by the `residual` operand of the skinny products
+    instead of [N, 512] elementwise adds of autograd (8 x 30 us per step at 32 bags x 1024 patches)."""
+
+    @staticmethod
+    def forward(ctx, keys, kin, Qp, segs, TH: int):
+        keys_in = keys
+        keys, kin, Qp = _f32c(keys, "keys"), _f32c(kin.detach(), "kin"), _f32c(Qp, "Qp")
+        B, off, mr = segs.B, segs.k_off, segs.Tk_max
+        A = _gg_nt(kin, Qp, None, off, mr)                                       # scores [R, THp]
+        rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(off), B, mr, TH, _stream())
+        _lib.check(rc, "mil_grp_col_softmax")
+        pooled = _gg_tn(A, keys, off, B, mr)                                     # [B, THp, E]
+        ctx.segs, ctx.TH = segs, TH
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(keys, kin, Qp, A)
+        return pooled, keys_in.view_as(keys_in)
+
+    @staticmethod
+    def backward(ctx, dpooled, dkeys_pass):
+        keys, kin, Qp, A = ctx.saved_tensors
+        segs, TH = ctx.segs, ctx.TH
+        B, off, mr = segs.B, segs.k_off, segs.Tk_max
+        if dpooled is None:
+            return dkeys_pass, None, None, None, None
+        dpooled = _f32c(dpooled, "dpooled")
+        acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
+        dA = _gg_nt(keys, dpooled, None, off, mr)                                # dA = keys . dpooled^T
+        dS = torch.empty_like(A)
+        rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(off), B, mr, TH, _p(dS), _stream())
+        _lib.check(rc, "mil_grp_col_softmax_bwd")
+        dkeys = None
+        if ctx.needs_input_grad[0]:
+            dkeys = _gg_nn(A, dpooled, None, acc, off, mr)                       # values path (+ what came through the alias)
+            dkeys = _gg_nn(dS, Qp, None, dkeys, off, mr)                         # + scores path (d kin = d keys)
+        dQp = _gg_tn(dS, kin, off, B, mr) if ctx.needs_input_grad[2] else None
+        return dkeys, None, dQp, None, None
+
+
+class _MultiTokenRowsCore(torch.autograd.Function):
+    """out = softmax_T(kin Kp_b^T + cb_b) Vp_b + bo + keys  - the image->token attention with absorbed projections and its
+    residual as one node; kin = keys + (a constant), so d(keys) = dout + dS Kp comes out of one product launch."""
+
+    @staticmethod
+    def forward(ctx, keys, kin, Kp, cb, Vp, bo, segs, T: int, H: int):
+        keys, kin = _f32c(keys, "keys"), _f32c(kin.detach(), "kin")
+        Kp, cb, Vp, bo = _f32c(Kp, "Kp"), _f32c(cb, "cb"), _f32c(Vp, "Vp"), _f32c(bo, "bo")
+        off, mr = segs.q_off, segs.Tq_max
+        A = _gg_nt(kin, Kp, cb, off, mr)
+        rc = _lib.lib().mil_row_softmax_t(_p(A), A.stride(0), A.shape[0], T, H, _stream())
+        _lib.check(rc, "mil_row_softmax_t")
+        out = _gg_nn(A, Vp, bo, keys, off, mr)
+        ctx.segs, ctx.T, ctx.H = segs, T, H
+        ctx.save_for_backward(kin, Kp, Vp, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        kin, Kp, Vp, A = ctx.saved_tensors
+        segs, T, H = ctx.segs, ctx.T, ctx.H
+        off, mr, B = segs.q_off, segs.Tq_max, segs.B
+        dout = _f32c(dout, "dout")
+        dA = _gg_nt(dout, Vp, None, off, mr)                                     # [R, THp]
+        dS = torch.empty_like(A)
+        rc = _lib.lib().mil_row_softmax_t_bwd(_p(A), _p(dA), A.stride(0), A.shape[0], T, H, _p(dS), _stream())
+        _lib.check(rc, "mil_row_softmax_t_bwd")
+        dkeys = _gg_nn(dS, Kp, None, dout, off, mr) if ctx.needs_input_grad[0] else None      # residual + scores path
+        dKp = _gg_tn(dS, kin, off, B, mr) if ctx.needs_input_grad[2] else None
+        dcb = _seg_colsum(dS, off, B, mr) if ctx.needs_input_grad[3] else None
+        dVp = _gg_tn(A, dout, off, B, mr) if ctx.needs_input_grad[4] else None
+        dbo = colsum(dout) if ctx.needs_input_grad[5] else None
+        return dkeys, None, dKp, dcb, dVp, dbo, None, None, None
+
+
 def multi_token_pool_attention(q_tok, keys, kin, segs, Wq, bq, Wk, Wv, bv, H: int):
     """Token -> image attention for T text tokens per bag with the K / V projections absorbed
     (model/sam/transformer.py:291-295,113-118): the image side is three skinny grouped products around a column
     softmax instead of two [N, 512] x [512, 256] projections and an attention core.  segs: queries = tokens, keys = patches.
-    Returns the pre-out_proj output [B * T, H * C]."""
+    kin must be keys + positional rows (a constant): its gradient is folded into the keys'.
+    Returns (pre-out_proj output [B * T, H * C], keys alias - later consumers of the keys must use the alias)."""
     B, T = segs.B, segs.Tq_max
     TH = T * H
     C = Wq.shape[0] // H
     qp = linear_act(q_tok, Wq, bq) * (1.0 / C ** 0.5)
     Qp = _pad_vectors(_AbsorbQuery.apply(qp, Wk, H), B, TH)                      # k_proj.bias is softmax-invariant
-    S = _GroupedNT.apply(kin, Qp, None, segs.k_off, segs.Tk_max)
-    A = _GrpColSoftmax.apply(S, segs.k_off, B, TH, segs.Tk_max)
-    pooled = _GroupedTN.apply(A, keys, segs.k_off, B, segs.Tk_max)               # [B, THp, E]
-    return _ValueProj.apply(pooled[:, :TH].reshape(B * T, H, keys.shape[1]), Wv, bv)
+    pooled, keys_pass = _MultiTokenPoolCore.apply(keys, kin, Qp.contiguous(), segs, TH)      # [B, THp, E]
+    return _ValueProj.apply(pooled[:, :TH].reshape(B * T, H, keys.shape[1]), Wv, bv), keys_pass
 
 
 def multi_token_rows_attention(kin, k_tok, v_tok, segs, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H: int, residual=None):
@@ -1286,10 +1362,12 @@ def multi_token_rows_attention(kin, k_tok, v_tok, segs, Wq, bq, Wk, bk, Wv, bv, 
     cb = ((kp.view(B * T, H, C) * bq.view(1, H, C)).sum(-1) * scale).reshape(B, TH)
     pad = (-TH) % 32
     cb = torch.nn.functional.pad(cb, (0, pad)) if pad else cb
-    S = _GroupedNT.apply(kin, Kp, cb.contiguous(), segs.q_off, segs.Tq_max)
-    A = _RowSoftmaxT.apply(S, T, H)
     Vp = _pad_vectors(_AbsorbQuery.apply(vp, Wo.t().contiguous(), H), B, TH)      # Vp[t, h] = Wo[:, hC:(h+1)C] v_th
-    return _GroupedNN.apply(A, Vp, bo, residual, segs.q_off, segs.Tq_max)
+    if residual is None:
+        S = _GroupedNT.apply(kin, Kp, cb.contiguous(), segs.q_off, segs.Tq_max)
+        return _GroupedNN.apply(_RowSoftmaxT.apply(S, T, H), Vp, bo, None, segs.q_off, segs.Tq_max)
+    # with the keys as residual (the block form, sam/transformer.py:303-309) kin = keys + pe: one fused node
+    return _MultiTokenRowsCore.apply(residual, kin, Kp.contiguous(), cb.contiguous(), Vp.contiguous(), bo, segs, T, H)
 
 
 # --------------------------------------------------------------------------- split-bf16 products for frozen weights (opt-in)
