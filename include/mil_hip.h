@@ -34,7 +34,9 @@ extern "C" {
 
 #define MIL_GATE_D 192     /* gate width D of ABMIL (model/dim1/ABMIL.py:7), fixed by the reference */
 #define MIL_POOL_TILE 32   /* rows per attention-pool tile (tile map granularity) */
+#ifndef MIL_SMALL_ROWS
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
+#endif
 
 /* Library/ABI version, for the host mirror's load-time check. */
 int mil_abi_version(void);
@@ -194,6 +196,17 @@ size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
              int accumulate, float* workspace, size_t workspace_floats, void* stream);
+/* nn.Linear on 65 .. ~1000 rows (T text tokens x bags on the token side of sam/transformer.py:413-416 / common.py:21-26,
+ * the few-hundred-row text tower of a one-bag learnable-prompt step, clip/model.py:171-178): one launch per product, the
+ * workgroup of a 32 x 32 / 64 x 64 output tile contracts all of K (csrc/mid_linear.hip), no workspace.
+ *   fwd: y = act(x W^T + b) + residual       x [M, K], W [N, K]; K % 8 == 0; act 0 none, 1 tanh, 2 relu, 3 QuickGELU
+ *   bwd: dx = dpre W (needs N % 8 == 0), dW = dpre^T x, db = column sums of dpre, dpre = dy (.) act'(yv) (act 0..2; yv =
+ *        the saved OUTPUT, NULL for act 0).  dx / dW / db may be NULL (db needs dW). */
+int mil_linear_mid_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias, int act, const float* residual,
+                       int ldr, float* y, int ldy, int M, int N, int K, void* stream);
+int mil_linear_mid_bwd(const float* dy, int lddy, const float* yv, int ldyv, int act, const float* x, int ldx, const float* W,
+                       int ldw, float* dx, int lddx, float* dW, int lddw, float* db, int M, int N, int K, void* stream);
+
 /* Parameter half of a Linear layer's backward (every nn.Linear (+Tanh / ReLU) of aggregator.py:44-68 and
  * sam/transformer.py:413-416, sam/common.py:21-26 above MIL_SMALL_ROWS rows) in one product launch + split-K fold:
  *   dW[n_out, k_in] (+)= (dY (.) act'(Y))^T . X        db[n_out] (+)= column sums of dY (.) act'(Y)

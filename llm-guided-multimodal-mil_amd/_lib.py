@@ -92,6 +92,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
     "mil_adam_step_counted": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
     "mil_sgd_step": (c_int, [_P, _P, c_size_t] + [c_float] * 3 + [_P]),
+    "mil_linear_mid_fwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "mil_linear_mid_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int,
+                                   c_int, _P]),
     "mil_linear_bwd_params_workspace_floats": (c_size_t, [c_int] * 3),
     "mil_linear_bwd_params": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
                                       c_size_t, _P]),

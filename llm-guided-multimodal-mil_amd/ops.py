@@ -361,12 +361,49 @@ def act_bwd(dy, y, act: int):
     return dpre
 
 
-SMALL_ROWS = 64        # include/mil_hip.h: MIL_SMALL_ROWS
+SMALL_ROWS = int(__import__('os').environ.get('MIL_SMALL_ROWS_EXPERIMENT', 64))        # include/mil_hip.h: MIL_SMALL_ROWS
 
 
 def _small_ok(M: int, N: int, K: int, *tensors) -> bool:
     return (0 < M <= SMALL_ROWS and K % 16 == 0 and N % 16 == 0
             and all(t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0) for t in tensors))
+
+
+MID_ROWS = 1024            # csrc/mid_linear.hip: one-launch products for layers between the few-rows and the tiled regime
+MID_WORK = 340_000_000     # M * N * K up to which they beat the tiled GEMM + split-K fold (tools/kbench_mid.py)
+
+
+def _mid_ok(M: int, N: int, K: int, *tensors) -> bool:
+    return (SMALL_ROWS < M <= MID_ROWS and M * N * K <= MID_WORK and K % 8 == 0 and N % 8 == 0
+            and all(t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0) for t in tensors))
+
+
+def linear_mid_fwd(x, W, b, act: int, residual=None):
+    """nn.Linear on 65..1024 rows in one launch (include/mil_hip.h: mil_linear_mid_fwd)."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mil_linear_mid_fwd(_p(x), x.stride(0), _p(W), W.stride(0), _p(b), act, _p(residual),
+                                       residual.stride(0) if residual is not None else 0, _p(y), y.stride(0), M, N, K,
+                                       _stream())
+    _lib.check(rc, "mil_linear_mid_fwd")
+    return y
+
+
+def linear_mid_bwd(dy, y, act: int, x, W, need_dx: bool, need_dW: bool, need_db: bool, dW_out=None, db_out=None):
+    """Backward of the same layer, one launch per product (mil_linear_mid_bwd): dx, dW (+ db from the same pass)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dev = dy.device
+    dx = torch.empty((M, K), device=dev, dtype=torch.float32) if need_dx else None
+    need_dW = need_dW or need_db
+    dW = (dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)) if need_dW else None
+    db = (db_out if db_out is not None else torch.empty(N, device=dev, dtype=torch.float32)) if need_db else None
+    rc = _lib.lib().mil_linear_mid_bwd(_p(dy), dy.stride(0), _p(y) if act else None, y.stride(0) if act else 0, act, _p(x),
+                                       x.stride(0), _p(W), W.stride(0), _p(dx), K, _p(dW), dW.stride(0) if need_dW else 0,
+                                       _p(db), M, N, K, _stream())
+    _lib.check(rc, "mil_linear_mid_bwd")
+    return dx, dW, db
 
 
 def linear_small_fwd(x, W, b, act: int, residual=None):
@@ -417,9 +454,13 @@ class _LinearAct(torch.autograd.Function):
         res = _f32c(residual, "residual") if residual is not None else None
         pre = None
         ctx.small = _small_ok(M, N, K, x, W)
+        ctx.mid = (not ctx.small) and _mid_ok(M, N, K, x, W, res) and \
+            not (act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3]))
         if residual is not None and act != 0:
             raise _lib.MilHipError("linear_act: residual is only supported with act='none'")
-        if ctx.small and not (act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3])):
+        if ctx.mid:
+            y = linear_mid_fwd(x, W, b, act, res)
+        elif ctx.small and not (act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3])):
             y = linear_small_fwd(x, W, b, act, res)
         elif act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3]):
             # QuickGELU's derivative needs the pre-activation: keep it (learnable-prompt path only; the frozen
@@ -446,6 +487,12 @@ class _LinearAct(torch.autograd.Function):
         N = W.shape[0]
         W_slot = grad_slot(W)
         b_slot = grad_slot(ctx.b_param) if ctx.b_param is not None else None
+        if ctx.mid and ctx.act != ACT["quickgelu"]:
+            if dy.data_ptr() % 16 or dy.stride(0) % 4:
+                dy = dy.clone()
+            dx, dW, db = linear_mid_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                        ctx.has_b and ctx.needs_input_grad[2], W_slot, b_slot)
+            return dx, (dW if ctx.needs_input_grad[1] else None), db, None, (dy if ctx.has_res else None)
         if ctx.small:
             if dy.data_ptr() % 16:
                 dy = dy.clone()

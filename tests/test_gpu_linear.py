@@ -156,3 +156,40 @@ def test_tall_gemm_over_several_rounds(M, N, K, b_mode, extras):
     else:
         out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K)
     assert rel_err(out.cpu(), ref.float()) <= 2e-6
+
+
+@pytest.mark.parametrize("M,K,N,act,mode", [(333, 512, 512, "tanh", "all"), (65, 256, 64, "relu", "all"),
+                                            (1000, 512, 512, "none", "residual"), (320, 512, 2048, "relu", "all"),
+                                            (320, 2048, 512, "none", "frozen"), (999, 64, 136, "tanh", "all")])
+def test_mid_size_layers_one_launch_per_product(M, K, N, act, mode):
+    """65..1024 rows take csrc/mid_linear.hip (32 x 32 / 64 x 64 tiles, K contracted inside the workgroup): ragged row
+    counts (the weight gradient contracts over M in groups of 8), clamped tiles, residual, frozen weights (dx only)."""
+    assert ops._mid_ok(M, N, K)
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g)
+    go = torch.randn(M, N, generator=g)
+    dev = torch.device("cuda")
+    frozen = mode == "frozen"
+    xd = x.to(dev).requires_grad_(True)
+    Wd, bd = (t.to(dev).requires_grad_(not frozen) for t in (W, b))
+    rd = res.to(dev).requires_grad_(True) if mode == "residual" else None
+    y = ops.linear_act(xd, Wd, bd, act, residual=rd)
+    (y * go.to(dev)).sum().backward()
+    xr, Wr, br, rr = (t.clone().double().requires_grad_(True) for t in (x, W, b, res))
+    pre = F.linear(xr, Wr, br)
+    ref = {"none": pre, "tanh": torch.tanh(pre), "relu": torch.relu(pre)}[act]
+    if mode == "residual":
+        ref = ref + rr
+    (ref * go.double()).sum().backward()
+    assert rel_err(y.detach().cpu(), ref.detach().float()) <= 2e-6
+    assert rel_err(xd.grad.cpu(), xr.grad.float()) <= 1e-5
+    if frozen:
+        assert Wd.grad is None and bd.grad is None
+    else:
+        assert rel_err(Wd.grad.cpu(), Wr.grad.float()) <= 1e-5
+        assert rel_err(bd.grad.cpu(), br.grad.float()) <= 1e-5
+    if mode == "residual":
+        assert rel_err(rd.grad.cpu(), rr.grad.float()) <= 1e-6
