@@ -26,6 +26,9 @@ __device__ __forceinline__ float ml_dact(float g, float yv, int act) {
 }
 
 #define ML_TRIP 8          // k-groups (of 8) per trip: 16 operand loads in flight per lane (k-contiguous operands)
+#ifndef ML_T32_LIMIT
+#define ML_T32_LIMIT (4 * MIL_NUM_CU)
+#endif
 
 // TQ x TQ quadrants of 32 x 32 per workgroup, KS waves per quadrant splitting K: TQ * TQ * KS waves
 template <bool AKM, bool BKM, int TQ, int KS>
@@ -135,7 +138,7 @@ static void ml_launch(const float* A, int lda, const float* B, int ldb, float* C
                       const float* bias, int act, const float* residual, int ldr, const float* aux, int ldaux, int a_act,
                       float* colsum, hipStream_t st) {
     const long t32 = (long)((M + 31) / 32) * ((N + 31) / 32);
-    if (t32 <= 4 * MIL_NUM_CU) {
+    if (t32 <= ML_T32_LIMIT) {
         hipLaunchKernelGGL((k_mid<AKM, BKM, 1, 8>), dim3((N + 31) / 32, (M + 31) / 32), dim3(512), 0, st, A, lda, B, ldb, C, ldc,
                            M, N, K, bias, act, residual, ldr, aux, ldaux, a_act, colsum);
     } else {
