@@ -1,0 +1,160 @@
+// 64-row tile of the fp32 GEMM for tall products whose 128 x 128 tiles do not fill a round of the chip:
+//   C[M,N] (+)= epilogue( A[M,K] . B_op[K,N] )      b_mode 0: B [N, K] (y = x W^T),  b_mode 1: B [K, N] (dx = dy W)
+// The text tower under learnable prompts multiplies ~10 k rows by N = 512 weights: 324 tiles of 128 x 128 for 512
+// resident workgroups (0.63 of a round; mil_gemm then splits K three ways and pays a 23 us fold per product).  With
+// 64 x 128 tiles the same product is 648 tiles, and with an UNPADDED LDS image (48 KB for both stages instead of 55)
+// three workgroups fit a CU: 768 slots, one round, no split.  The k-contiguous images are [rows][32] with the 16-byte
+// chunk index XOR-swizzled by (row >> 1) & 7 - the 16 lanes served together by a ds_read_b128 then cover all 64 banks -
+// instead of k_gemm's 36-word row stride.  Workgroup 256 threads = 2 x 2 waves, wave tile 32 x 64 (two 32 x 32 MFMA
+// tiles); pipeline, fragment convention (lane (r, h) takes k = 8t + 4h + jj) and epilogue as in k_gemm.  K % 32 == 0.
+// Included by linear.hip.
+#pragma once
+
+__device__ __forceinline__ int g64_swz(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7)); }
+
+template <int BMODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_gemm64(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+              int M, int N, int K, const float* __restrict__ bias, int act, const float* __restrict__ residual, int ldr,
+              int accumulate, float* __restrict__ aux, int ldaux, int aux_mode) {
+    constexpr int ASZ = 64 * 32;
+    constexpr int BSZ = BMODE == 0 ? 128 * 32 : LG_BK * 128;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];       // 48 KB
+    float* as = smem;
+    float* bs = smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 128;
+    const int nslice = K / LG_BK;
+
+    // staging maps.  A: rows (tid >> 3) + 32 i (i < 2), chunk tid & 7.  B (NT): rows (tid >> 3) + 32 i (i < 4), chunk tid & 7.
+    // B (NN): k row (tid >> 5) + 8 i (i < 4), 16-byte column chunk tid & 31.
+    const int srow = tid >> 3, sch = tid & 7;
+    const float* asrc[2];
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = srow + 32 * i;
+        asrc[i] = A + (size_t)min(i0 + row, M - 1) * lda + 4 * sch;
+        aoff[i] = g64_swz(row, sch);
+    }
+    const float* bsrc[4];
+    int boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (BMODE == 0) {
+            const int row = srow + 32 * i;
+            bsrc[i] = B + (size_t)min(j0 + row, N - 1) * ldb + 4 * sch;
+            boff[i] = g64_swz(row, sch);
+        } else {
+            const int kr = (tid >> 5) + 8 * i, c4 = tid & 31;
+            bsrc[i] = B + (size_t)kr * ldb + min(j0 + 4 * c4, max(N - 4, 0));
+            boff[i] = kr * 128 + 4 * c4;
+        }
+    }
+    f32x4 ra[2], rb[4];
+    auto a_load = [&](int i, int k0) { ra[i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0); };
+    auto b_load = [&](int i, int k0) {
+        rb[i] = *reinterpret_cast<const f32x4*>(BMODE == 0 ? bsrc[i] + k0 : bsrc[i] + (size_t)k0 * ldb);
+    };
+    auto a_store = [&](int i, float* dst) { *reinterpret_cast<f32x4*>(dst + aoff[i]) = ra[i]; };
+    auto b_store = [&](int i, float* dst) { *reinterpret_cast<f32x4*>(dst + boff[i]) = rb[i]; };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_load(i, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_load(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_store(i, as);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_store(i, bs);
+    {
+        const int k1 = min(1, nslice - 1) * LG_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_load(i, k1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_load(i, k1);
+    }
+    __syncthreads();
+    const int arow = 32 * wi + r;
+    for (int s = 0; s < nslice; ++s) {
+        const int buf = s & 1;
+        const int k2 = min(s + 2, nslice - 1) * LG_BK;
+        const float* ab = as + buf * ASZ;
+        const float* bb = bs + buf * BSZ;
+        float* an = as + (buf ^ 1) * ASZ;
+        float* bn = bs + (buf ^ 1) * BSZ;
+        f32x4 fa[2], fb[2][2];                      // [register set] / [register set][tile]
+        auto frag_a = [&](int t, int q) { fa[q] = *reinterpret_cast<const f32x4*>(ab + g64_swz(arow, 2 * t + h)); };
+        auto frag_b = [&](int t, int q, int b) {
+            if (BMODE == 0) {
+                fb[q][b] = *reinterpret_cast<const f32x4*>(bb + g64_swz(64 * wj + 32 * b + r, 2 * t + h));
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fb[q][b][jj] = bb[(8 * t + 4 * h + jj) * 128 + 64 * wj + 32 * b + r];
+            }
+        };
+        frag_a(0, 0); frag_b(0, 0, 0); frag_b(0, 0, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = t & 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int g = 4 * t + jj;
+                if (g >= 2 && g < 8) {              // six staging pieces: next slice into LDS, reload with the slice after
+                    const int pc = g - 2;
+                    if (pc < 2) { a_store(pc, an); a_load(pc, k2); }
+                    else { b_store(pc - 2, bn); b_load(pc - 2, k2); }
+                }
+                if (t < 3) {
+                    if (jj == 0) frag_a(t + 1, q ^ 1);
+                    if (jj == 1) frag_b(t + 1, q ^ 1, 0);
+                    if (jj == 2) frag_b(t + 1, q ^ 1, 1);
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][jj], fb[q][0][jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][jj], fb[q][1][jj], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int rbase = i0 + 32 * wi;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + 64 * wj + 32 * b + r;
+        if (j >= N) continue;
+        const float bj = bias != nullptr ? bias[j] : 0.f;
+        float rv[16], pv[16], cv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rc = min(rbase + mfma32_row(i, h), M - 1);
+            rv[i] = residual != nullptr ? residual[(size_t)rc * ldr + j] : 0.f;
+            pv[i] = aux_mode == AUX_MUL_DGELU ? aux[(size_t)rc * ldaux + j] : 0.f;
+            cv[i] = accumulate ? C[(size_t)rc * ldc + j] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = rbase + mfma32_row(i, h);
+            if (row >= M) continue;
+            float v = acc[b][i] + bj;
+            if (aux_mode == AUX_STORE_PRE) {
+                aux[(size_t)row * ldaux + j] = v;
+            } else if (aux_mode == AUX_MUL_DGELU) {
+                const float sg = 1.0f / (1.0f + __expf(-1.702f * pv[i]));
+                v *= sg * (1.0f + 1.702f * pv[i] * (1.0f - sg));
+            }
+            if (act == ACT_TANH) v = tanhf(v);
+            else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
+            C[(size_t)row * ldc + j] = v + rv[i] + cv[i];
+        }
+    }
+}

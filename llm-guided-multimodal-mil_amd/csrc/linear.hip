@@ -410,6 +410,8 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, c
     dpre[i] = act == ACT_TANH ? g * (1.0f - yy * yy) : act == ACT_RELU ? (yy > 0.f ? g : 0.f) : g;
 }
 
+#include "gemm64.h"
+
 // Split-K policy.  Weight gradients (a_mode 1: K = number of rows) always split to fill the chip.  The other forms
 // split only when the output is a handful of tiles (token-side projections: M = bags x text tokens <= a few dozen
 // rows), where a single 128 x 128 workgroup per tile would walk all of K alone: 30-60 us of latency for <0.1 GFLOP.
@@ -501,6 +503,24 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
     if (b_mode == 1 && (N < 4 || (N & 3))) return MIL_EINVAL;
     if (a_mode == 1 && b_mode == 0) return MIL_EINVAL;             // TT form is never needed
     hipStream_t st = (hipStream_t)stream;
+#if !defined(LG_NO_TILE64)
+    if (a_mode == 0) {
+        // 64-row tiles (gemm64.h: 768 slots) when they waste clearly less of their last round than 128-row tiles (512 slots)
+        const long ct = (N + 127) / 128, t128 = ((M + 127) / 128) * ct, t64 = ((M + 63) / 64) * ct;
+        const int s128 = 2 * MIL_NUM_CU, s64 = 3 * MIL_NUM_CU;
+        const double w128 = (double)((t128 + s128 - 1) / s128) * s128 / (double)t128;
+        const double w64 = (double)((t64 + s64 - 1) / s64) * s64 / (double)t64;
+        if (t64 >= s64 / 2 && K >= 256 && 1.08 * w64 < w128) {
+            const dim3 grid((unsigned)ct, (M + 63) / 64);
+            if (b_mode == 0)
+                hipLaunchKernelGGL(k_gemm64<0>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+            else
+                hipLaunchKernelGGL(k_gemm64<1>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+            MIL_CHECK_LAUNCH();
+            return MIL_OK;
+        }
+    }
+#endif
     {
         int rows_main, S_tail, kc_tail;
         if (workspace != nullptr && tail_plan(M, N, K, a_mode, &rows_main, &S_tail, &kc_tail) &&

@@ -193,3 +193,40 @@ def test_mid_size_layers_one_launch_per_product(M, K, N, act, mode):
         assert rel_err(bd.grad.cpu(), br.grad.float()) <= 1e-5
     if mode == "residual":
         assert rel_err(rd.grad.cpu(), rr.grad.float()) <= 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,b_mode,extras", [(10300, 512, 512, 0, "bias_tanh"), (10300, 512, 2048, 1, "accumulate"),
+                                                 (10241, 520, 256, 1, "residual"), (9000, 512, 512, 0, "aux"),
+                                                 (19000, 512, 256, 0, "plain")])
+def test_64_row_tiles_for_partial_rounds(M, N, K, b_mode, extras):
+    """Tall products whose 128-row tiles fill a round poorly (about 10 k text-tower rows x 512 outputs) take k_gemm64:
+    64 x 128 tiles in an unpadded, XOR-swizzled LDS image, three workgroups per CU, no split-K."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dev = torch.device("cuda")
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = A.double() @ W.double().t()
+    Ad = A.to(dev)
+    Bd = (W if b_mode == 0 else W.t().contiguous()).to(dev)
+    if extras == "bias_tanh":
+        b = torch.randn(N, generator=g)
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K, bias=b.to(dev), act=ops.ACT["tanh"])
+        ref = torch.tanh(ref + b.double())
+    elif extras == "residual":
+        res = torch.randn(M, N, generator=g)
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K, residual=res.to(dev))
+        ref = ref + res.double()
+    elif extras == "accumulate":
+        out = torch.ones(M, N, device=dev)
+        ops.gemm(Ad, 0, Bd, b_mode, M, N, K, out=out, accumulate=True)
+        ref = ref + 1
+    elif extras == "aux":
+        b = torch.randn(N, generator=g)
+        pre = torch.empty(M, N, device=dev)
+        out = ops.gemm_aux(Ad, Bd, b_mode, M, N, K, pre, 1, bias=b.to(dev), act=ops.ACT["quickgelu"])
+        p = ref + b.double()
+        assert rel_err(pre.cpu(), p.float()) <= 2e-6
+        ref = p * torch.sigmoid(1.702 * p)
+    else:
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K)
+    assert rel_err(out.cpu(), ref.float()) <= 2e-6
