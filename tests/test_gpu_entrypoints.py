@@ -51,3 +51,14 @@ def test_hip_graph_training_with_learnable_prompts(tmp_path):
     assert "Epoch: [0]" in out and "Loss" in out
     ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
     assert "clinic_extractor.ctx" in ck["state_dict"]
+
+
+def test_two_ranks_on_one_gpu_with_graph_replay_and_flat_optimizer(tmp_path):
+    """World size 2 rehearsed on ONE GPU (both ranks on device 0, gloo): the captured step body is replayed on each rank,
+    the single flat gradient all-reduce and the one-launch optimizer run outside the graph."""
+    out = run("train_ddp.py", "--synthetic", "[64, 768, 8]", "--clip_layers", "1", "--batch_size", "2",
+              "--multiprocessing_distributed", "--gpu", "0,0", "--dist_backend", "gloo", "--dist_url", "tcp://127.0.0.1:29641",
+              "--hip_graph", "1", "--n_epochs", "1", "--iter_per_epoch", "4", "--save_dir", str(tmp_path))
+    assert "Epoch: [0]" in out and "Loss" in out
+    ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
+    assert torch.isfinite(ck["state_dict"]["aggregator.attention_V.0.weight"]).all()
