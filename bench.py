@@ -68,8 +68,6 @@ def kernel_breakdown(tr, x, lay, y, iters=20):
     # with hrow the fused tail also writes the score gradient ds (the former k_pool_ds_from_h launch)
     out["merge_head_loss_ds"] = timed(lambda: ops.pool_merge_head(partials, lay, L, fp.p("fc.1.weight"), fp.p("fc.1.bias"),
                                                                   y, scale, scores=c["scores"], hrow=hrow), iters)
-    out["head_bwd_params"] = timed(lambda: ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"),
-                                                               c["loss_bag"], tr.loss_sum), iters)
     ds = c["ds"]
     g = {k: torch.empty_like(fp.p(k)) for k in fp.order}
     gargs = (g["aggregator.attention_V.0.weight"], g["aggregator.attention_V.0.bias"], g["aggregator.attention_U.0.weight"],
@@ -79,8 +77,10 @@ def kernel_breakdown(tr, x, lay, y, iters=20):
     lib = ops._lib.lib()
     out["gate_bwd_dw"] = timed(lambda: lib.mil_gate_bwd_partials(ops._p(x), ops._p(c["gates"]), ops._p(ds), ops._p(w), R, L,
                                                                  D_GATE, ops._p(ws), ws.numel(), ops._stream()), iters)
-    out["gate_bwd_reduce"] = timed(lambda: lib.mil_gate_bwd_reduce(ops._p(ws), R, L, *[ops._p(t) for t in gargs], 0,
-                                                                   ops._stream()), iters)
+    # the split-K fold; the head's parameter gradients (dWf, dbf, loss sum) ride on the same launch as appended workgroups
+    both = timed(lambda: ops.gate_bwd_params_head(x, c["gates"], ds, w, *gargs, c["dz"], c["M"], g["fc.1.weight"], g["fc.1.bias"],
+                                                  c["loss_bag"], tr.loss_sum, workspace=ws), iters)
+    out["gate_bwd_reduce_and_head_params"] = max(0.0, both - out["gate_bwd_dw"])
     out["adam"] = timed(lambda: ops.adam_step(fp.flat, fp.grad, fp.exp_avg, fp.exp_avg_sq, 1), iters)
     return out
 

@@ -149,6 +149,14 @@ int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, c
 int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
                         float* dw, float* db, int accumulate, void* stream);
 
+/* mil_gate_bwd_params with the head's parameter gradients (mil_head_bwd_params: dWf [C, L], dbf [C], loss_out = sum of
+ * loss_bag) computed by workgroups appended to the reduce launch - one launch less per training step; the bag
+ * embeddings M [B, L] have the gate's input width L (the image-only model, aggregator_clip.py:79-118). */
+int mil_gate_bwd_params_head(const float* x, const float* gates, const float* ds, const float* w, int R, int L, int D,
+                             float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu, float* dbu,
+                             float* dw, float* db, int accumulate, const float* dz, const float* M, float* dWf,
+                             float* dbf, int B, int C, const float* loss_bag, float* loss_out, void* stream);
+
 /* Input gradient through the gate (needed when the bag is itself a computed tensor, i.e.
  * the fused text+image path): dx += dPreV Wv + dPreU Wu. */
 int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,

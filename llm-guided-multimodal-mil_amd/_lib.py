@@ -35,6 +35,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_attn_pool_bwd": (c_int, [_P] * 6 + [c_int, c_int, _P, _P, _P]),
     "mil_gate_bwd_workspace_floats": (c_size_t, [c_int, c_int]),
     "mil_gate_bwd_params": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),
+    "mil_gate_bwd_params_head": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int] + [_P] * 4
+                                 + [c_int, c_int, _P, _P, _P]),
     "mil_gate_bwd_partials": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t, _P]),
     "mil_gate_bwd_reduce": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, _P]),
     "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P]),

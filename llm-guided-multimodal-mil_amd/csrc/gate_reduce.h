@@ -4,6 +4,46 @@
 #include "mil_common.h"
 #define GR_NG 384
 
+// Parameter gradients of the head (model/aggregator.py:128-131: z = M Wf^T + bf):  dWf[c][j] = sum_b dz[b][c] M[b][j],
+// dbf[c] = sum_b dz[b][c], plus the step's loss = sum_b loss_bag[b].  A handful of workgroups of latency-bound work that
+// depends only on the fused per-bag tail: it rides at the end of the gate reduce launch (blocks >= first) instead of
+// being a launch of its own.  Same arithmetic as k_head_bwd_params (head_loss.hip).
+struct HeadBwdArgs {
+    const float* dz;            // [B, C] or NULL (no head work in this launch)
+    const float* M;             // [B, L]
+    float* dWf;                 // [C, L]
+    float* dbf;                 // [C]
+    const float* loss_bag;      // [B] or NULL
+    float* loss_out;            // [1]
+    int B, L, C;
+};
+static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& a, int blk, float (*red)[64]) {
+    const int nlb = (a.L + 63) / 64;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (blk < a.C * nlb) {
+        const int c = blk / nlb, j = (blk % nlb) * 64 + lane;
+        float v = 0.f;
+        if (j < a.L)
+            for (int b = g; b < a.B; b += 4) v += a.dz[b * a.C + c] * a.M[(size_t)b * a.L + j];
+        red[g][lane] = v;
+        __syncthreads();
+        if (g == 0 && j < a.L) a.dWf[(size_t)c * a.L + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    } else {
+        if ((int)threadIdx.x < a.C) {
+            const int c = threadIdx.x;
+            float v = 0.f;
+            for (int b = 0; b < a.B; ++b) v += a.dz[b * a.C + c];
+            a.dbf[c] = v;
+        }
+        if (a.loss_bag != nullptr && g == 1) {
+            float v = 0.f;
+            for (int b = lane; b < a.B; b += 64) v += a.loss_bag[b];
+            v = wave_allsum(v);
+            if (lane == 0) a.loss_out[0] = v;
+        }
+    }
+}
+
 // Sum the split-K partials and un-permute the gate index.  One thread per output float4.
 // One thread per output float4 (8 independent 16-byte loads in flight), un-permuting the gate index; the last
 // 577 threads fold the bias / w / b partials.  (A 4-threads-per-output variant with 4x the workgroups measured
@@ -11,7 +51,13 @@
 static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __restrict__ part, const float* __restrict__ pbias,
                                                                 int S, int L, float* __restrict__ dWv, float* __restrict__ dbv,
                                                                 float* __restrict__ dWu, float* __restrict__ dbu,
-                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate,
+                                                                int head_first = 1 << 30, HeadBwdArgs head = HeadBwdArgs{}) {
+    if ((int)blockIdx.x >= head_first) {          // appended workgroups: the head's parameter gradients (uniform branch)
+        __shared__ float hred[4][64];
+        head_bwd_params_block(head, blockIdx.x - head_first, hred);
+        return;
+    }
     const int L4 = L / 4;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int nW = GR_NG * L4;

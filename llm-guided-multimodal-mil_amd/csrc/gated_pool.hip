@@ -886,6 +886,26 @@ extern "C" int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* 
     return MIL_OK;
 }
 
+extern "C" int mil_gate_bwd_params_head(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                                        int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
+                                        float* dWu, float* dbu, float* dw, float* db, int accumulate, const float* dz,
+                                        const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag,
+                                        float* loss_out, void* stream) {
+    if (!dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
+    if (B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
+    const int rc = mil_gate_bwd_partials(x, gates, ds, w, R, L, D, workspace, workspace_floats, stream);
+    if (rc != MIL_OK) return rc;
+    int kc;
+    const int S = split_plan(R, L, &kc);
+    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
+    const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C};
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
+                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate, nred, head);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
                                    int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
                                    float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {

@@ -199,6 +199,25 @@ def gate_bwd_params(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: boo
     return workspace
 
 
+def gate_bwd_params_head(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, dz, M, dWf, dbf, loss_bag=None, loss_out=None,
+                         workspace: Optional[torch.Tensor] = None):
+    """gate_bwd_params + head_bwd_params in two launches instead of three: the head's parameter gradients are computed by
+    workgroups appended to the reduce launch (mil_gate_bwd_params_head)."""
+    x = _f32c(x, "x")
+    R, L = x.shape
+    need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.float32)
+    B, C = dz.shape
+    if M.shape[1] != L:
+        raise _lib.MilHipError("gate_bwd_params_head: the bag embeddings must have the gate's input width")
+    rc = _lib.lib().mil_gate_bwd_params_head(_p(x), _p(gates), _p(ds), _p(_f32c(w, "w")), R, L, GATE_D, _p(workspace),
+                                             workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db), 0,
+                                             _p(dz), _p(M), _p(dWf), _p(dbf), B, C, _p(loss_bag), _p(loss_out), _stream())
+    _lib.check(rc, "mil_gate_bwd_params_head")
+    return workspace
+
+
 def gate_bwd_input(gates, ds, w, Wv, Wu, dx):
     R, L = dx.shape
     rc = _lib.lib().mil_gate_bwd_input(_p(gates), _p(ds), _p(_f32c(w, "w")), _p(_f32c(Wv, "Wv")), _p(_f32c(Wu, "Wu")),

@@ -133,8 +133,11 @@ class ImageOnlyTrainer:
     def backward(self):
         """Gradients of the (globally normalised) BCE loss into the flat grad buffer (overwrites it)."""
         c, fp = self.last, self.fp
-        ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum)
         b16 = c["x"].dtype == torch.bfloat16
+        # fp32 path: the head's parameter gradients ride on the gate reduce launch (below); bf16: their own launch
+        head_fused = (not b16) and c["M"].shape[1] == c["x"].shape[1]
+        if not head_fused:
+            ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum)
         if c.get("ds") is not None:
             ds = c["ds"]
         elif c.get("hrow") is not None:
@@ -143,6 +146,14 @@ class ImageOnlyTrainer:
             ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
         else:
             ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
+        if head_fused:
+            self._ws = ops.gate_bwd_params_head(
+                c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
+                fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
+                fp.g("aggregator.attention_U.0.weight"), fp.g("aggregator.attention_U.0.bias"),
+                fp.g("aggregator.attention_weights.weight").view(-1), fp.g("aggregator.attention_weights.bias"),
+                c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum, workspace=self._ws)
+            return self.loss_sum
         dw_fn = ops.gate_bwd_params
         if b16:
             dw_fn = ops.gate_bwd_params_bf16 if (self.bf16_grad_mfma and c["x"].shape[1] % 256 == 0) else ops.gate_bwd_params_x16
