@@ -389,15 +389,21 @@ __global__ __launch_bounds__(256) void k_pool_ds_from_h(const float* __restrict_
 typedef unsigned short gb_u16x8 __attribute__((ext_vector_type(8)));
 
 // XB16: x is stored as bf16 and widened to fp32 while it is staged (config-5 path; the product stays fp32 MFMA).
-template <bool XB16>
-__global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv, const float* __restrict__ gates,
+// KG: K groups per workgroup.  KG = 2 (tall inputs): 512 threads, the two halves of the workgroup run the same pipeline
+// on the two halves of the row chunk (own LDS stages, common barriers) and fold their accumulators through LDS before the
+// store, so a launch needs half as many row chunks for the same number of resident waves - half the partial tiles to
+// write here and to read in k_gate_bwd_reduce.
+template <bool XB16, int KG>
+__global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict__ xv, const float* __restrict__ gates,
                                                      const float* __restrict__ ds, const float* __restrict__ wvec,
                                                      float* __restrict__ part, float* __restrict__ pbias, int R, int L,
                                                      int KC, int NJ) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GB_BKR * 128];
+    __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * 2 * GB_BKR * 128];
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    float* smem = smem_all + grp * (2 * 2 * GB_BKR * 128);      // this K group's stages
     float* ab = smem;                         // [2][32][128] dPre
     float* xb = smem + 2 * GB_BKR * 128;      // [2][32][128] x
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware order: hardware deals workgroup ids round-robin over the 8 XCDs (id % 8 shares an L2).
@@ -412,8 +418,13 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
 #endif
     const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
     const int j0 = jt * 128;
-    const int rbeg = s * KC, rend = min(R, rbeg + KC);
+    // row chunk of the workgroup, then this K group's part of it (whole slices to group 0 first); the slice loop runs
+    // nloop times for everybody (common barriers): iterations past a group's own slices multiply dead copies (ds = 0)
+    const int cbeg = s * KC, cend = min(R, cbeg + KC);
+    const int half = KG == 1 ? cend - cbeg : ((cend - cbeg + 2 * GB_BKR - 1) / (2 * GB_BKR)) * GB_BKR;
+    const int rbeg = min(cend, cbeg + grp * half), rend = KG == 1 ? cend : min(cend, rbeg + half);
     const int nslice = (rend - rbeg + GB_BKR - 1) / GB_BKR;
+    const int nloop = (min(half, cend - cbeg) + GB_BKR - 1) / GB_BKR;
 
     const float* x = static_cast<const float*>(xv);
     const unsigned short* xh = static_cast<const unsigned short*>(xv);
@@ -433,11 +444,11 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
     auto xload = [&](int i, int rs) {
         if (XB16) {
             if (i < 2) {
-                const int gr = min(rs + hrow + 16 * i, rend - 1);
+                const int gr = max(min(rs + hrow + 16 * i, rend - 1), 0);
                 rh[i] = *reinterpret_cast<const gb_u16x8*>(xh + (size_t)gr * L + j0 + 8 * hc8);
             }
         } else {
-            const int gr = min(rs + xrow + 8 * i, rend - 1);
+            const int gr = max(min(rs + xrow + 8 * i, rend - 1), 0);
             rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4);
         }
     };
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
     };
     auto aload = [&](int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
-        const int gc = min(gr, rend - 1);
+        const int gc = max(min(gr, rend - 1), 0);
         const float* gp = gates + (size_t)gc * GF_NG + 64 * m + 4 * ad4;
         rv[i] = *reinterpret_cast<const f32x4*>(gp);
         ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
@@ -491,27 +502,27 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    if (nslice > 0) {
+    {
 #pragma unroll
         for (int i = 0; i < 4; ++i) xload(i, rbeg);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) aload(i, rbeg, true);
+        for (int i = 0; i < 2; ++i) aload(i, rbeg, nslice > 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xwrite(i, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) { awrite_v(i, 0); awrite_u(i, 0); }
-        const int rs1 = rbeg + min(1, nslice - 1) * GB_BKR;
+        const int rs1 = rbeg + max(min(1, nslice - 1), 0) * GB_BKR;
 #pragma unroll
         for (int i = 0; i < 4; ++i) xload(i, rs1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) aload(i, rs1, nslice > 1);   // a single-slice chunk must not count slice 0 twice
     }
     __syncthreads();
-    for (int sl = 0; sl < nslice; ++sl) {
+    for (int sl = 0; sl < nloop; ++sl) {
         const int buf = sl & 1;
-        // registers hold slice sl+1 (or, in the last iteration, a dead copy with ds forced to 0)
+        // registers hold slice sl+1 (or, past this group's last slice, a dead copy with ds forced to 0)
         const bool live2 = sl + 2 < nslice;
-        const int rs2 = rbeg + min(sl + 2, nslice - 1) * GB_BKR;
+        const int rs2 = rbeg + max(min(sl + 2, nslice - 1), 0) * GB_BKR;
         const float* ap = ab + buf * GB_BKR * 128 + h * 128 + 64 * wi + r;
         const float* bp = xb + buf * GB_BKR * 128 + h * 128 + 64 * wj + r;
         float fa[2][2], fb[2][2];
@@ -542,54 +553,81 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
         __syncthreads();
     }
 
+    // KG = 2: group 1 hands its accumulators to group 0 through its own (now dead) staging area - same lane, same register
+    // index, so no transpose - and group 0 alone stores the folded tile
+    if (KG == 2) {
+        __syncthreads();
+        float* fold = smem_all + (2 * 2 * GB_BKR * 128) + wave * (64 * 64);      // group 1's 64 KB: 16 KB per wave
+        if (grp == 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) fold[((a * 2 + b) * 16 + i) * 64 + lane] = acc[a][b][i];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] += fold[((a * 2 + b) * 16 + i) * 64 + lane];
+        }
+    }
+
     // partial tile -> part[s][128m + 64wi + row][j0 + 64wj + col].  The accumulators hold a column per lane
     // (16 rows each); going through LDS turns 64 four-byte stores per lane into 16 sixteen-byte ones
     // (each wave transposes its own 64 x 64 tile in its own 16 KB of the staging area; stride 64 is conflict-free both ways).
     {
         __syncthreads();                                  // the staging buffers are dead from here on
-        float* tw = smem + wave * (64 * 64);
+        if (grp == 0) {
+            float* tw = smem + wave * (64 * 64);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) tw[(32 * a + mfma32_row(i, h)) * 64 + 32 * b + r] = acc[a][b][i];
-        // same-wave write -> read: no barrier needed, the LDS ops of a wave complete in order (lgkmcnt)
-        float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj;
-        const int c4 = lane & 15, rr = lane >> 4;         // 16 float4 columns x 4 rows per pass
+                    for (int i = 0; i < 16; ++i) tw[(32 * a + mfma32_row(i, h)) * 64 + 32 * b + r] = acc[a][b][i];
+            // same-wave write -> read: no barrier needed, the LDS ops of a wave complete in order (lgkmcnt)
+            float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj;
+            const int c4 = lane & 15, rr = lane >> 4;         // 16 float4 columns x 4 rows per pass
 #pragma unroll
-        for (int pass = 0; pass < 16; ++pass) {
-            const int row = 4 * pass + rr;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * 64 + 4 * c4);
-            *reinterpret_cast<f32x4*>(pt + (size_t)row * L + 4 * c4) = v;
+            for (int pass = 0; pass < 16; ++pass) {
+                const int row = 4 * pass + rr;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tw + row * 64 + 4 * c4);
+                *reinterpret_cast<f32x4*>(pt + (size_t)row * L + 4 * c4) = v;
+            }
         }
     }
 
-    // bias / w partials (only the j-tile-0 workgroups publish them)
+    // bias / w partials (only the j-tile-0 workgroups publish them); both K groups contribute their row groups
     if (jt == 0) {
-        float* redf = smem;   // [16 row groups][3][64]
+        float* redf = smem_all;   // [16 KG row groups][3][64]
+        const int arow_all = arow + 16 * grp;
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            redf[(arow * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
-            redf[(arow * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
-            redf[(arow * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
+            redf[(arow_all * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
+            redf[(arow_all * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
+            redf[(arow_all * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
         }
         __syncthreads();
-        if (tid < 192) {
+        if (grp == 0 && tid < 192) {
             const int which = tid / 64, d = tid % 64;
             float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) v += redf[(g * 3 + which) * 64 + d];
+            for (int g = 0; g < 16 * KG; ++g) v += redf[(g * 3 + which) * 64 + d];
             pbias[((size_t)s * 4 + which) * 192 + 64 * m + d] = v;
         }
         if (m == 0) {
             __syncthreads();
-            redf[tid] = acc_ds;
+            redf[threadIdx.x] = acc_ds;
             __syncthreads();
-            if (tid == 0) {
+            if (threadIdx.x == 0) {
                 float v = 0.f;
-                for (int g = 0; g < 256; g += 16) v += redf[g];
+                for (int g = 0; g < 256 * KG; g += 16) v += redf[g];
                 pbias[((size_t)s * 4 + 3) * 192] = v;
             }
         }
@@ -599,9 +637,18 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dw(const void* __restrict__ xv
 #include "gate_reduce.h"
 
 // ================================================================================ host entry points
+// KG = 2 (two K groups per 512-thread workgroup, one workgroup per CU) once a row chunk is at least 512 rows deep
+static inline int split_kg(int R, int L) {
+#if defined(GB_NO_KG2)
+    return 1;
+#endif
+    const int NJ = L / 128;
+    const int smax = (MIL_NUM_CU) / (3 * NJ);
+    return (smax >= 1 && R / smax >= 512) ? 2 : 1;
+}
 static inline int split_plan(int R, int L, int* KC_out) {
     const int NJ = L / 128;
-    int smax = (2 * MIL_NUM_CU) / (3 * NJ);
+    int smax = (2 * MIL_NUM_CU / split_kg(R, L)) / (3 * NJ);
     if (smax < 1) smax = 1;
     int kc = ((R + smax - 1) / smax + GB_BKR - 1) / GB_BKR * GB_BKR;
     if (kc < GB_BKR) kc = GB_BKR;
@@ -867,8 +914,12 @@ extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const f
     const int S = split_plan(R, L, &kc);
     if (workspace_floats < (size_t)S * GF_NG * L + (size_t)S * 4 * 192) return MIL_ENOSPC;
     const int NJ = L / 128;
-    hipLaunchKernelGGL(k_gate_bwd_dw<false>, dim3(S * 3 * NJ), dim3(256), 0, (hipStream_t)stream, (const void*)x, gates, ds,
-                       w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ);
+    if (split_kg(R, L) == 2)
+        hipLaunchKernelGGL((k_gate_bwd_dw<false, 2>), dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, (const void*)x, gates, ds,
+                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ);
+    else
+        hipLaunchKernelGGL((k_gate_bwd_dw<false, 1>), dim3(S * 3 * NJ), dim3(256), 0, (hipStream_t)stream, (const void*)x, gates, ds,
+                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -928,7 +979,11 @@ extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, co
     float* pbias = workspace + (size_t)S * GF_NG * L;
     const int NJ = L / 128;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gate_bwd_dw<true>, dim3(S * 3 * NJ), dim3(256), 0, st, (const void*)x, gates, ds, w, part, pbias,
+    if (split_kg(R, L) == 2)
+        hipLaunchKernelGGL((k_gate_bwd_dw<true, 2>), dim3(S * 3 * NJ), dim3(512), 0, st, (const void*)x, gates, ds, w, part, pbias,
+                           R, L, kc, NJ);
+    else
+        hipLaunchKernelGGL((k_gate_bwd_dw<true, 1>), dim3(S * 3 * NJ), dim3(256), 0, st, (const void*)x, gates, ds, w, part, pbias,
                        R, L, kc, NJ);
     MIL_CHECK_LAUNCH();
     const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
