@@ -35,7 +35,7 @@ from mil_amd.trainer import ImageOnlyTrainer  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # HBM bytes per launch from rocprofv3 PMC passes of this same command at the default workload
 # (profiles/r01_bench_hbm_traffic_pmc.csv: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied)
-PMC_TRAFFIC_BYTES = {"gate_fwd": (70.5 + 48.1) * 2 ** 20, "gate_bwd_dw": (126.7 + 30.8) * 2 ** 20}
+PMC_TRAFFIC_BYTES = {"gate_fwd": (70.3 + 48.1) * 2 ** 20, "gate_bwd_dw": (130.7 + 15.8) * 2 ** 20}
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 D_GATE = 192
 
