@@ -34,9 +34,7 @@ extern "C" {
 
 #define MIL_GATE_D 192     /* gate width D of ABMIL (model/dim1/ABMIL.py:7), fixed by the reference */
 #define MIL_POOL_TILE 32   /* rows per attention-pool tile (tile map granularity) */
-#ifndef MIL_SMALL_ROWS
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
-#endif
 
 /* Library/ABI version, for the host mirror's load-time check. */
 int mil_abi_version(void);

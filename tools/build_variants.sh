@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/variants
 for v in "$@"; do
   name=$(echo "$v" | tr -c 'A-Za-z0-9\n' '_')
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -shared $v \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared $v \
      llm-guided-multimodal-mil_amd/csrc/gated_pool.hip llm-guided-multimodal-mil_amd/csrc/gated_pool_bf16.hip llm-guided-multimodal-mil_amd/csrc/head_loss.hip llm-guided-multimodal-mil_amd/csrc/linear.hip llm-guided-multimodal-mil_amd/csrc/linear_x.hip llm-guided-multimodal-mil_amd/csrc/small_linear.hip llm-guided-multimodal-mil_amd/csrc/mid_linear.hip llm-guided-multimodal-mil_amd/csrc/attention.hip llm-guided-multimodal-mil_amd/csrc/absorbed_attn.hip \
      -o tools/variants/lib$name.so &
 done
