@@ -644,7 +644,10 @@ extern "C" size_t mil_gemm_grouped_workspace_floats(int a_mode, int G, int max_g
     const int tiles = G * ((N + 127) / 128);
     int S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
     if (S > max_group_rows / 128) S = max_group_rows / 128;         // at least four 32-row slices per chunk
-    if (S > 8) S = 8;
+#ifndef LG_GRP_SMAX
+#define LG_GRP_SMAX 32      // one bag of 4096 patches: 4 column tiles x 32 row chunks = 128 workgroups (8 chunks: 55 -> 19 us)
+#endif
+    if (S > LG_GRP_SMAX) S = LG_GRP_SMAX;
     return S >= 2 ? (size_t)G * S * M * N : 0;
 }
 
