@@ -2,7 +2,7 @@
 
 The authors train with ONE bag per GPU (run_train.sh:81, `--batch_size` = number of GPUs): at that size the fusion step
 is a few hundred short launches and the host, not the GPU, sets the pace (measured on MI355X, 1 bag x 4096 patches:
-10 frozen prompts 8.8 ms per step eager, 3.3 ms replayed; learnable prompts 10.5 -> 7.9 ms; one note 5.6 -> 1.2 ms).  `GraphedStep` captures the step body the first time a shape
+10 frozen prompts 8.8 ms per step eager, 2.3 ms replayed; learnable prompts 10.5 -> 6.3 ms; one note 5.6 -> 1.2 ms).  `GraphedStep` captures the step body the first time a shape
 signature repeats and replays it afterwards:
 
   * the signature is the caller's key (bag lengths, prompt count, train/eval) plus the input shapes - a step with
