@@ -666,10 +666,13 @@ extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float
         const dim3 grid((N + 127) / 128, (max_group_rows + 127) / 128, G);
         if (b_mode == 0 && residual == nullptr && N <= 96 && (N % 32) == 0) {
             // N = T x H absorbed vectors: 64-row workgroups, one MFMA tile per wave (skinny_gemm.h)
-            const dim3 gs((max_group_rows + 63) / 64, G);
-            if (N == 32) hipLaunchKernelGGL(k_skinny_nt<1>, gs, dim3(128), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
-            else if (N == 64) hipLaunchKernelGGL(k_skinny_nt<2>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
-            else hipLaunchKernelGGL(k_skinny_nt<3>, gs, dim3(384), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
+            const bool narrow = (long)G * ((max_group_rows + 63) / 64) < MIL_NUM_CU;      // few bags: 32-row workgroups
+            const dim3 gs(narrow ? (max_group_rows + 31) / 32 : (max_group_rows + 63) / 64, G);
+#define SKINNY_NT(NCTV)                                                                                                  \
+    if (narrow) hipLaunchKernelGGL((k_skinny_nt<NCTV, 1>), gs, dim3(64 * NCTV), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias); \
+    else hipLaunchKernelGGL((k_skinny_nt<NCTV, 2>), gs, dim3(128 * NCTV), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
+            if (N == 32) { SKINNY_NT(1) } else if (N == 64) { SKINNY_NT(2) } else { SKINNY_NT(3) }
+#undef SKINNY_NT
         } else if (b_mode == 1 && K <= 96 && (N % 128) == 0 && (bias == nullptr || strideBias == 0)) {
             // K = T x H: the whole contraction staged at once
             const dim3 gs(N / 128, (max_group_rows + 63) / 64, G);

@@ -4,7 +4,7 @@
 // multiply padding and one bag of 4096 patches is 32 workgroups; with K = 96 its pipeline is three slices long and the
 // prologue / epilogue dominate (measured at 32 bags x 1024 patches: 61 and 75 us for 3.2 GFLOP = 20 us of MFMA time).
 //
-//   k_skinny_nt<NCT>:  C[rows_g, :32 NCT] = A[rows_g, :K] . B_g[32 NCT, K]^T + bias_g        (scores: K = 512)
+//   k_skinny_nt<NCT, RWT>:  C[rows_g, :32 NCT] = A[rows_g, :K] . B_g[32 NCT, K]^T + bias_g        (scores: K = 512)
 //       workgroup = 64 rows x 32 NCT columns, one 32 x 32 MFMA tile per wave (2 x NCT waves), K walked in 32-deep
 //       slices through a double-buffered LDS image, registers carry the next slice.
 //   k_skinny_nn<KP>:   C[rows_g, :N] = A[rows_g, :KP] . B_g[KP, N] + bias + residual          (values: KP = 32 / 64 / 96)
@@ -13,14 +13,17 @@
 // Same fragment conventions as k_gemm (32x32x2 fp32 MFMA, lane (r, h) takes k = 8t + 4h + jj).  Included by linear.hip.
 #pragma once
 
-template <int NCT>
-__global__ __launch_bounds__(128 * NCT) void k_skinny_nt(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                          int ldb, long strideB, float* __restrict__ C, int ldc,
-                                                          const int32_t* __restrict__ grp_off, int K,
-                                                          const float* __restrict__ bias, long strideBias) {
-    constexpr int T = 128 * NCT, P = 32 * NCT;
-    constexpr int NA = (512 + T - 1) / T;          // float4 pieces of the 64 x 32 A slice per thread
-    constexpr int ASZ = 64 * LG_KS, BSZ = P * LG_KS;
+// RWT = row blocks of 32 per workgroup: 2 (64 rows, 2 x NCT waves) in general, 1 (32 rows, NCT waves) when the launch
+// would otherwise be under ~one workgroup per CU (a single bag of 4096 patches: 64 -> 128 workgroups)
+template <int NCT, int RWT>
+__global__ __launch_bounds__(64 * RWT * NCT) void k_skinny_nt(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                               int ldb, long strideB, float* __restrict__ C, int ldc,
+                                                               const int32_t* __restrict__ grp_off, int K,
+                                                               const float* __restrict__ bias, long strideBias) {
+    constexpr int T = 64 * RWT * NCT, P = 32 * NCT, RW = 32 * RWT;
+    constexpr int NA = (RW * 8 + T - 1) / T;       // float4 pieces of the RW x 32 A slice per thread
+    constexpr int NB = (P * 8) / T;                // P x 8 pieces of the B slice: 4 / RWT per thread exactly
+    constexpr int ASZ = RW * LG_KS, BSZ = P * LG_KS;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
     float* as = smem;
     float* bs = smem + 2 * ASZ;
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(128 * NCT) void k_skinny_nt(const float* __restrict
     const int wr = wave / NCT, wc = wave % NCT;
     const int r = lane & 31, h = lane >> 5;
     const int g = blockIdx.y, goff = grp_off[g], M = grp_off[g + 1] - goff;
-    const int i0 = blockIdx.x * 64;
+    const int i0 = blockIdx.x * RW;
     if (i0 >= M) return;
     A += (size_t)goff * lda;
     C += (size_t)goff * ldc;
@@ -40,31 +43,31 @@ __global__ __launch_bounds__(128 * NCT) void k_skinny_nt(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int idx = tid + T * i;
-        alive[i] = idx < 512;
-        const int row = (idx >> 3) & 63, ch = idx & 7;
+        alive[i] = idx < RW * 8;
+        const int row = (idx >> 3) % RW, ch = idx & 7;
         asrc[i] = A + (size_t)min(i0 + row, M - 1) * lda + 4 * ch;
         aoff[i] = row * LG_KS + 4 * ch;
     }
-    const float* bsrc[2];
-    int boff[2];
+    const float* bsrc[NB];
+    int boff[NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                  // P x 8 pieces = 2 per thread exactly
+    for (int i = 0; i < NB; ++i) {
         const int idx = tid + T * i, col = idx >> 3, ch = idx & 7;
         bsrc[i] = B + (size_t)col * ldb + 4 * ch;
         boff[i] = col * LG_KS + 4 * ch;
     }
-    f32x4 ra[NA], rb[2];
+    f32x4 ra[NA], rb[NB];
     auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) if (alive[i]) ra[i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
     };
     auto store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) if (alive[i]) *reinterpret_cast<f32x4*>(as + buf * ASZ + aoff[i]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(bs + buf * BSZ + boff[i]) = rb[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(bs + buf * BSZ + boff[i]) = rb[i];
     };
 
     f32x16 acc;

@@ -126,3 +126,19 @@ def test_column_softmax_long_groups(lens, hint):
     # fp32 sums over up to 40 000 rows in a different order than the reference: a few 1e-5 relative
     assert float((o.cpu() - o_ref).abs().max()) <= 5e-5 and rel_err(o.cpu(), o_ref) <= 5e-5 and float(o[:, TH:].abs().max()) == 0.0
     assert rel_err(gr.cpu(), g_ref) <= 5e-5
+
+
+@pytest.mark.parametrize("G,rows,N", [(40, 500, 96), (3, 700, 64), (64, 260, 32)])
+def test_skinny_nt_wide_and_narrow_workgroups(G, rows, N):
+    """k_skinny_nt picks 32-row workgroups for a few bags and 64-row ones otherwise: both against torch, ragged last tiles."""
+    g = torch.Generator().manual_seed(G + rows)
+    lens = [rows - (i % 7) for i in range(G)]
+    off = torch.zeros(G + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.tensor(lens), 0)
+    R, K = sum(lens), 512
+    A = torch.randn((R, K), generator=g)
+    B = torch.randn((G, N, K), generator=g) / K ** 0.5
+    bias = torch.randn((G, N), generator=g)
+    out = ops._gg_nt(A.to(DEV), B.to(DEV), bias.to(DEV), off.to(DEV), max(lens))
+    ref = torch.cat([A[int(off[i]):int(off[i + 1])] @ B[i].t() + bias[i] for i in range(G)], 0)
+    assert rel_err(out.cpu(), ref) <= 2e-6
