@@ -1,9 +1,10 @@
-// 64-row tile of the fp32 GEMM for tall products whose 128 x 128 tiles do not fill a round of the chip:
+// 64-row tile of the fp32 GEMM - the default for tall products (a_mode 0) from half a round of the chip upwards:
 //   C[M,N] (+)= epilogue( A[M,K] . B_op[K,N] )      b_mode 0: B [N, K] (y = x W^T),  b_mode 1: B [K, N] (dx = dy W)
-// The text tower under learnable prompts multiplies ~10 k rows by N = 512 weights: 324 tiles of 128 x 128 for 512
-// resident workgroups (0.63 of a round; mil_gemm then splits K three ways and pays a 23 us fold per product).  With
-// 64 x 128 tiles the same product is 648 tiles, and with an UNPADDED LDS image (48 KB for both stages instead of 55)
-// three workgroups fit a CU: 768 slots, one round, no split.  The k-contiguous images are [rows][32] with the 16-byte
+// 64 x 128 tiles with an UNPADDED LDS image (48 KB for both stages instead of the 72 KB of k_gemm) fit THREE workgroups
+// per CU: 768 slots of half-size tiles waste less of a launch's last round than 512 slots of 128 x 128 tiles (the text
+// tower under learnable prompts multiplies ~10 k rows: 324 tiles for N = 512, 1296 for N = 2048), the third resident
+// workgroup hides more of each other's prologue / epilogue, and nothing needs split-K with its fold launch.
+// The k-contiguous images are [rows][32] with the 16-byte
 // chunk index XOR-swizzled by (row >> 1) & 7 - the 16 lanes served together by a ds_read_b128 then cover all 64 banks -
 // instead of k_gemm's 36-word row stride.  Workgroup 256 threads = 2 x 2 waves, wave tile 32 x 64 (two 32 x 32 MFMA
 // tiles); pipeline, fragment convention (lane (r, h) takes k = 8t + 4h + jj) and epilogue as in k_gemm.  K % 32 == 0.

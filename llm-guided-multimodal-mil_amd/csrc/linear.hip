@@ -505,12 +505,12 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
     hipStream_t st = (hipStream_t)stream;
 #if !defined(LG_NO_TILE64)
     if (a_mode == 0) {
-        // 64-row tiles (gemm64.h: 768 slots) when they waste clearly less of their last round than 128-row tiles (512 slots)
-        const long ct = (N + 127) / 128, t128 = ((M + 127) / 128) * ct, t64 = ((M + 63) / 64) * ct;
-        const int s128 = 2 * MIL_NUM_CU, s64 = 3 * MIL_NUM_CU;
-        const double w128 = (double)((t128 + s128 - 1) / s128) * s128 / (double)t128;
-        const double w64 = (double)((t64 + s64 - 1) / s64) * s64 / (double)t64;
-        if (t64 >= s64 / 2 && K >= 256 && 1.08 * w64 < w128) {
+        // Tall products take 64 x 128 tiles (gemm64.h: three workgroups per CU = 768 slots) as soon as those fill half
+        // of the chip: finer rounds and a third resident workgroup beat the 128-row tile on every shape measured
+        // (tools/kbench_gemm64.py, kbench_gemm_k.py: 10 300 x 2048 x 512 241 -> 199 us, x 512 x 512 85 -> 65, 32 768 x 512 x 384
+        // 137 -> 126, x 1536 equal), and no product of this kind needs split-K or the split last round any more.
+        const long ct = (N + 127) / 128, t64 = ((M + 63) / 64) * ct;
+        if (t64 >= 3 * MIL_NUM_CU / 2 && K >= 256) {
             const dim3 grid((unsigned)ct, (M + 63) / 64);
             if (b_mode == 0)
                 hipLaunchKernelGGL(k_gemm64<0>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);

@@ -199,8 +199,8 @@ def test_mid_size_layers_one_launch_per_product(M, K, N, act, mode):
                                                  (10241, 520, 256, 1, "residual"), (9000, 512, 512, 0, "aux"),
                                                  (19000, 512, 256, 0, "plain")])
 def test_64_row_tiles_for_partial_rounds(M, N, K, b_mode, extras):
-    """Tall products whose 128-row tiles fill a round poorly (about 10 k text-tower rows x 512 outputs) take k_gemm64:
-    64 x 128 tiles in an unpadded, XOR-swizzled LDS image, three workgroups per CU, no split-K."""
+    """Tall products (from half a round of the chip upwards) take k_gemm64: 64 x 128 tiles in an unpadded, XOR-swizzled
+    LDS image, three workgroups per CU, no split-K."""
     g = torch.Generator().manual_seed(M + N + K)
     dev = torch.device("cuda")
     A = torch.randn(M, K, generator=g)
