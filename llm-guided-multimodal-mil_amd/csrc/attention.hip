@@ -800,7 +800,7 @@ extern "C" int mil_layernorm_fwd(const float* x, const float* gamma, const float
 }
 
 extern "C" int mil_layernorm_bwd_blocks(int rows) {
-    int nb = (rows + 15) / 16;          // 16 rows per workgroup = two passes of its four waves, two rows each
+    int nb = (rows + 15) / 16;          // 16 rows per workgroup (four per wave): enough workgroups for a few hundred rows
     if (nb > 512) nb = 512;             // tall inputs: two workgroups per CU; more only adds partial-sum traffic
     return nb < 1 ? 1 : nb;
 }
