@@ -547,23 +547,31 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     }
 }
 
-// dgamma[c] = sum_b part[b][0][c], dbeta[c] = sum_b part[b][1][c]: workgroup = 64 columns of the 2 E, its four waves take
-// every fourth partial and fold through LDS (one launch instead of two column sums).
-__global__ __launch_bounds__(256) void k_layernorm_param_fold(const float* __restrict__ part, int nb, int E,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[4][64];
+// dgamma[c] = sum_b part[b][0][c], dbeta[c] = sum_b part[b][1][c]: workgroup = 64 columns of the 2 E, its 16 waves take
+// every 16th partial (four loads in flight each) and fold through LDS - one launch instead of two column sums.
+__global__ __launch_bounds__(1024) void k_layernorm_param_fold(const float* __restrict__ part, int nb, int E,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;              // column of the [2 E] row: < E -> dgamma, else dbeta
-    float v0 = 0.f, v1 = 0.f;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (c < 2 * E) {
+        const size_t st = (size_t)2 * E;
         int b = g;
-        for (; b + 4 < nb; b += 8) { v0 += part[(size_t)b * 2 * E + c]; v1 += part[(size_t)(b + 4) * 2 * E + c]; }
-        for (; b < nb; b += 4) v0 += part[(size_t)b * 2 * E + c];
+        for (; b + 48 < nb; b += 64) {
+            v0 += part[(size_t)b * st + c];
+            v1 += part[(size_t)(b + 16) * st + c];
+            v2 += part[(size_t)(b + 32) * st + c];
+            v3 += part[(size_t)(b + 48) * st + c];
+        }
+        for (; b < nb; b += 16) v0 += part[(size_t)b * st + c];
     }
-    red[g][lane] = v0 + v1;
+    red[g][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (g == 0 && c < 2 * E) {
-        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][lane];
         if (c < E) dgamma[c] = v; else dbeta[c - E] = v;
     }
 }
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(256) void k_layernorm_param_fold(const float* __res
 // The token stream has a few dozen rows: one workgroup of 16 waves, wave w takes rows w, w + 16, w + 32, w + 48 with
 // all loads issued up front, and the parameter gradients are folded in LDS and written directly (no partials, no
 // column-sum launches).
-template <int NE>
+template <int NE, bool RES>
 __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ dy, const float* __restrict__ stats,
                                                               const float* __restrict__ dres, int rows,
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __res
                                                               float* __restrict__ dbeta) {
     __shared__ float red[16][2][64 * NE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, E = 64 * NE;
-    float dg[NE], db[NE], gm[NE], xv[4][NE], dv[4][NE], rv[4][NE], mean[4], rstd[4];
+    float dg[NE], db[NE], gm[NE], xv[4][NE], dv[4][NE], rv[RES ? 4 : 1][RES ? NE : 1], mean[4], rstd[4];
 #pragma unroll
     for (int e = 0; e < NE; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[lane + 64 * e]; }
 #pragma unroll
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __res
         for (int e = 0; e < NE; ++e) {
             xv[i][e] = x[(size_t)row * E + lane + 64 * e];
             dv[i][e] = dy[(size_t)row * E + lane + 64 * e];
-            rv[i][e] = dres != nullptr ? dres[(size_t)row * E + lane + 64 * e] : 0.f;
+            if (RES) rv[i][e] = dres[(size_t)row * E + lane + 64 * e];
         }
     }
 #pragma unroll
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(1024) void k_layernorm_bwd_small(const float* __res
         s1 = wave_allsum(s1) / E;
         s2 = wave_allsum(s2) / E;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd[i] * (g[e] - s1 - xh[e] * s2) + rv[i][e];
+        for (int e = 0; e < NE; ++e) dx[(size_t)row * E + lane + 64 * e] = rstd[i] * (g[e] - s1 - xh[e] * s2) + (RES ? rv[i][e] : 0.f);
     }
     if (dgamma == nullptr) return;          // frozen parameters (uniform over the workgroup)
 #pragma unroll
@@ -820,11 +828,14 @@ extern "C" int mil_layernorm_bwd_res(const float* x, const float* gamma, const f
     hipStream_t st = (hipStream_t)stream;
     if (rows <= 64) {
         const dim3 g1(1), b1(1024);
+#define LNS_LAUNCH(NEV)                                                                                                   \
+    if (dres != nullptr) hipLaunchKernelGGL((k_layernorm_bwd_small<NEV, true>), g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); \
+    else hipLaunchKernelGGL((k_layernorm_bwd_small<NEV, false>), g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta);
         switch (E / 64) {
-            case 1: hipLaunchKernelGGL(k_layernorm_bwd_small<1>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
-            case 2: hipLaunchKernelGGL(k_layernorm_bwd_small<2>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
-            case 4: hipLaunchKernelGGL(k_layernorm_bwd_small<4>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
-            case 8: hipLaunchKernelGGL(k_layernorm_bwd_small<8>, g1, b1, 0, st, x, gamma, dy, stats, dres, rows, dx, dgamma, dbeta); break;
+            case 1: LNS_LAUNCH(1); break;
+            case 2: LNS_LAUNCH(2); break;
+            case 4: LNS_LAUNCH(4); break;
+            case 8: LNS_LAUNCH(8); break;
             default: return MIL_EINVAL;
         }
         MIL_CHECK_LAUNCH();
@@ -843,7 +854,7 @@ extern "C" int mil_layernorm_bwd_res(const float* x, const float* gamma, const f
     MIL_CHECK_LAUNCH();
     if (!params) return MIL_OK;
     // partials are [nb][2][E]: both parameter gradients folded by one launch (fixed order)
-    hipLaunchKernelGGL(k_layernorm_param_fold, dim3((2 * E + 63) / 64), dim3(256), 0, st, workspace, nb, E, dgamma, dbeta);
+    hipLaunchKernelGGL(k_layernorm_param_fold, dim3((2 * E + 63) / 64), dim3(1024), 0, st, workspace, nb, E, dgamma, dbeta);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
