@@ -24,5 +24,8 @@ python3 $ROOT/tools/bench_fusion.py --coop --steps 10 --warmup 3 > $OUT/coop_lin
 python3 $ROOT/tools/bench_fusion.py --graph --prompts 10 --steps 20 --warmup 3 > $OUT/p10_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --coop --clip_gemm_pieces 3 --steps 10 --warmup 3 > $OUT/coop3_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --coop --clip_gemm_pieces 2 --steps 10 --warmup 3 > $OUT/coop2_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --graph --bags 1 --patches 4096 --steps 50 --warmup 5 > $OUT/one_bag_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --graph --bags 1 --patches 4096 --prompts 10 --steps 50 --warmup 5 > $OUT/one_bag_p10_line.json 2>/dev/null
+python3 $ROOT/tools/bench_fusion.py --graph --bags 1 --patches 4096 --coop --steps 30 --warmup 5 > $OUT/one_bag_coop_line.json 2>/dev/null
 python3 $ROOT/tools/kbench_split.py > $OUT/kbench_split.txt 2>/dev/null
 echo done

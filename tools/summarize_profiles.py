@@ -74,7 +74,9 @@ with open(os.path.join(DST, f"{TAG}_bench_mfma_busy_pmc.csv"), "w") as o:
 lines = {}
 for key, fn in (("bench", "bench_line.json"), ("fusion", "fusion_line.json"), ("bf16", "bf16_line.json"),
                 ("fusion_coop", "coop_line.json"), ("fusion_10_prompts", "p10_line.json"),
-                ("fusion_coop_split3", "coop3_line.json"), ("fusion_coop_split2", "coop2_line.json")):
+                ("fusion_coop_split3", "coop3_line.json"), ("fusion_coop_split2", "coop2_line.json"),
+                ("one_bag_4096_hipgraph", "one_bag_line.json"), ("one_bag_4096_10_prompts_hipgraph", "one_bag_p10_line.json"),
+                ("one_bag_4096_learnable_prompts_hipgraph", "one_bag_coop_line.json")):
     try:
         txt = [l for l in open(os.path.join(SRC, fn)).read().splitlines() if l.startswith("{")][-1]
         lines[key] = json.loads(txt)
