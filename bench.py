@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bags/sec, forward+backward(+all-reduce+Adam), N=1024 patches, D=512 (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # starts N ranks itself when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch of synthetic bags resident in HBM:
@@ -9,39 +9,129 @@ per GPU 32 bags x 1024 patches x 512 dims (BASELINE config 2 at N=1; 8 GPUs x 32
 config 4), image-only branch: gate scores (fp32 MFMA) -> attention pool -> head -> BCE ->
 backward -> one flat-gradient RCCL all-reduce -> Adam.  Weak scaling: per-GPU work is fixed.
 
+Launching (reference: mp.spawn of one process per GPU, train_ddp.py:53-82,622-624).  With WORLD_SIZE in the
+environment this process IS one rank (torchrun).  Without it and with --gpus N > 1 this process starts N child
+ranks BEFORE touching a GPU (fresh python processes, rank r bound to GPU r, backend nccl = RCCL), waits for
+them and exits non-zero if any rank fails or fewer than N devices are visible: it never falls back to one rank.
+
 Rank 0 prints ONE JSON line.  Extra objects on it:
   roofline      dominant kernel (the gate GEMMs, fp32 MFMA bound), algorithmic flops / HIP-event time
   roofline_pool the HBM-bound attention-pool kernel at N=4096, D=512 (north_star's 30 % target)
-  cpu_baseline  the CPU oracle (torch fp32, one bag per forward as the reference runs) on this host
+  cpu_baseline  the CPU oracle (torch fp32, one bag per forward as the reference runs) on this host, at 1 thread
+                and at all physical cores
+  rccl          (N>1 or MIL_FORCE_COLLECTIVES=1) world size RCCL reports, measured all-reduce time of the step's buffer
+  configs       (N=1) BASELINE config 3 (CLIP-text fusion, 32 x 1024 x 768) and config 5 (bf16, 32 x 4096 x 1024):
+                ms/step, bags/s, dominant-kernel roofline, and a parity check of the SAME full-size batch against
+                the oracle on 2 of the 32 bags (outside the timed region)
 """
 import argparse
+import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import mil_amd  # noqa: E402,F401
-from mil_amd import ops, synthetic as syn  # noqa: E402
-from mil_amd.bags import BagLayout  # noqa: E402
-from mil_amd.trainer import ImageOnlyTrainer  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# HBM bytes per launch from rocprofv3 PMC passes of this same command at the default workload
-# (profiles/r01_bench_hbm_traffic_pmc.csv: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied)
-PMC_TRAFFIC_BYTES = {"gate_fwd": (70.3 + 48.1) * 2 ** 20, "gate_bwd_dw": (130.7 + 15.8) * 2 ** 20}
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 D_GATE = 192
+# HBM bytes per launch from rocprofv3 PMC passes of this same command at the default workload
+# (profiles/*_hbm_traffic_pmc.csv: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied)
+PMC_TRAFFIC_FILE = os.path.join(REPO, "profiles", "pmc_traffic.json")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--prime", type=int, default=300, help="untimed forward passes before the warm-up steps (clock ramp)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--bags-per-gpu", type=int, default=32)
+    ap.add_argument("--patches", type=int, default=1024)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: BASELINE config 5 variant (x and gate weights stored bf16, fp32 accumulate); use with "
+                         "--patches 4096 --dim 1024.  The headline metric is f32.")
+    ap.add_argument("--train-mode", type=int, default=1, help="1: a true model.train() step - dropout(0.5) on the patches "
+                    "(ABMIL.py:49) and dropout(0.25) before the head (aggregator.py:129), masks generated in-kernel; "
+                    "0: the eval-mode (parity) step of round 1")
+    ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step (gradient accumulation): "
+                    "one all-reduce + Adam every ACCUM passes; a 'step' stays one pass over one batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 objects")
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (default: eager; "
+                    "the step is GPU-bound either way)")
+    ap.add_argument("--dump", default="", help="(tests) rank 0 saves loss + flat gradient of the first step here")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0)
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args) -> int:
+    """Parent of an N-rank run: starts the ranks, never touches a GPU itself (device_count() does not initialise
+    HIP on this image).  Returns the exit code for the whole job."""
+    import torch
+    rehearsal = os.environ.get("MIL_BENCH_REHEARSAL") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not rehearsal:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible; refusing to run fewer ranks "
+              f"(set MIL_BENCH_REHEARSAL=1 for the one-GPU gloo rehearsal of the N>1 code path)", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.1)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+        if (rc != 0 or time.time() > deadline) and live:
+            if rc == 0:
+                rc = 124
+                print("bench.py: launch timeout; stopping the ranks", file=sys.stderr)
+            for p in live:                      # exactly the processes started above, by handle
+                p.terminate()
+            t_end = time.time() + 10
+            for p in live:
+                try:
+                    p.wait(max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            live = []
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- helpers
 def timed(fn, iters, warm=2):
     """Average duration (ms) of fn() on the current stream, measured with HIP events."""
+    import torch
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,42 +143,26 @@ def timed(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
+def _pmc_traffic(name):
+    try:
+        return json.load(open(PMC_TRAFFIC_FILE)).get(name)
+    except (OSError, ValueError):
+        return None
+
+
 def kernel_breakdown(tr, x, lay, y, iters=20):
-    """HIP-event time of each launch group of one step (separate pass, outside the timed region)."""
-    fp = tr.fp
-    R, L = x.shape
-    tr.forward(x, lay, y)
-    c = dict(tr.last)
-    w = fp.p("aggregator.attention_weights.weight").view(-1)
-    out = {}
-    out["gate_fwd"] = timed(lambda: tr._gate_fwd(x, True), iters)
-    out["pool_partial"] = timed(lambda: ops.attn_pool_partial_h(x, c["scores"], lay, fp.p("fc.1.weight")), iters)
-    partials, hrow = ops.attn_pool_partial_h(x, c["scores"], lay, fp.p("fc.1.weight"))
-    scale = 1.0 / c["prob"].numel()
-    # with hrow the fused tail also writes the score gradient ds (the former k_pool_ds_from_h launch)
-    out["merge_head_loss_ds"] = timed(lambda: ops.pool_merge_head(partials, lay, L, fp.p("fc.1.weight"), fp.p("fc.1.bias"),
-                                                                  y, scale, scores=c["scores"], hrow=hrow), iters)
-    ds = c["ds"]
-    g = {k: torch.empty_like(fp.p(k)) for k in fp.order}
-    gargs = (g["aggregator.attention_V.0.weight"], g["aggregator.attention_V.0.bias"], g["aggregator.attention_U.0.weight"],
-             g["aggregator.attention_U.0.bias"], g["aggregator.attention_weights.weight"].view(-1),
-             g["aggregator.attention_weights.bias"])
-    ws = ops.gate_bwd_params(x, c["gates"], ds, w, *gargs)
-    lib = ops._lib.lib()
-    out["gate_bwd_dw"] = timed(lambda: lib.mil_gate_bwd_partials(ops._p(x), ops._p(c["gates"]), ops._p(ds), ops._p(w), R, L,
-                                                                 D_GATE, ops._p(ws), ws.numel(), ops._stream()), iters)
-    # the split-K fold; the head's parameter gradients (dWf, dbf, loss sum) ride on the same launch as appended workgroups
-    both = timed(lambda: ops.gate_bwd_params_head(x, c["gates"], ds, w, *gargs, c["dz"], c["M"], g["fc.1.weight"], g["fc.1.bias"],
-                                                  c["loss_bag"], tr.loss_sum, workspace=ws), iters)
-    out["gate_bwd_reduce_and_head_params"] = max(0.0, both - out["gate_bwd_dw"])
-    out["adam"] = timed(lambda: ops.adam_step(fp.flat, fp.grad, fp.exp_avg, fp.exp_avg_sq, 1), iters)
-    return out
+    """HIP-event time of each launch group of one step (separate pass, outside the timed region).  Each group is timed
+    through the library's stand-alone C entry points in one call per launch (tr.time_pieces)."""
+    return tr.time_pieces(x, lay, y, iters)
 
 
 def pool_roofline(dev, iters=20):
     """The HBM-bound attention-pool stage at the north_star point N=4096, D=512: one pass reads x once
     (N*L*4 B), the scores (4 N) and writes M (4 L).  Enough bags to exceed the 256 MiB Infinity Cache
     so the bytes really come from HBM."""
+    import torch
+    from mil_amd import ops
+    from mil_amd.bags import BagLayout
     N, L, B = 4096, 512, 64            # 512 MiB of x
     x = torch.randn(B * N, L, device=dev)
     scores = torch.randn(B * N, device=dev)
@@ -98,38 +172,42 @@ def pool_roofline(dev, iters=20):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_pool_partial+k_pool_merge", "workload": f"{B} bags x {N} x {L} fp32",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
-            "traffic": None, "ms_per_launch": round(ms, 4), "passes_per_s": round(B / (ms * 1e-3), 1)}
+            "traffic": _pmc_traffic("pool_4096x512"), "bytes_per_launch": alg_bytes,
+            "ms_per_launch": round(ms, 4), "passes_per_s": round(B / (ms * 1e-3), 1)}
 
 
-def cpu_baseline(N, L, budget_s=12.0):
-    """The reference's CPU arithmetic (oracle restatement) timed on this host: one bag per forward,
-    fp32, eval, fwd + BCE + bwd."""
-    from oracle import mil_oracle as orc
-    threads = max(1, min(16, os.cpu_count() or 1))
-    torch.set_num_threads(threads)
-    p = syn.image_only_params(1234, L=L)
-    names = list(p.keys())
-    y = syn.make_labels(1, 1)
-    bags = [torch.randn(N, L) for _ in range(4)]
-
-    def one(xb):
-        leaves = {k: p[k].clone().requires_grad_(True) for k in names}
-        o = orc.image_only_forward(xb, leaves)
-        loss = orc.bce_loss(o["prob"], y)
-        loss.backward()
-
-    for xb in bags[:3]:
-        one(xb)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(bags[n % 4])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return {"value": round(n / el, 2), "unit": "bags/s", "cores": threads, "kind": "port",
-            "sample": f"{n} bags of {N}x{L} fp32, one bag per fwd+loss+bwd, torch-CPU oracle, {el:.1f} s",
-            "cpu": _cpu_model()}
+def _physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        n = len(seen)
+    except OSError:
+        n = 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota): threads beyond it only time-slice
+    quota = avail
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n or avail, avail, quota))
 
 
 def _cpu_model():
@@ -142,50 +220,222 @@ def _cpu_model():
     return "unknown"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--prime", type=int, default=300, help="untimed forward passes before the warm-up steps (clock ramp)")
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--bags-per-gpu", type=int, default=32)
-    ap.add_argument("--patches", type=int, default=1024)
-    ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="bf16: BASELINE config 5 variant (x and gate weights stored bf16, fp32 accumulate); use with "
-                         "--patches 4096 --dim 1024.  The headline metric is f32.")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (default: eager; "
-                    "the step is GPU-bound either way: 0.306 vs 0.299 ms measured)")
-    args = ap.parse_args()
+def cpu_baseline(N, L, budget_s=8.0):
+    """The reference's CPU arithmetic (oracle restatement) timed on this host: one bag per forward,
+    fp32, eval, fwd + BCE + bwd, at 1 thread and at all physical cores this process may use."""
+    import torch
+    from mil_amd import synthetic as syn
+    from oracle import mil_oracle as orc
+    p = syn.image_only_params(1234, L=L)
+    names = list(p.keys())
+    y = syn.make_labels(1, 1)
+    bags = [torch.randn(N, L) for _ in range(4)]
+
+    def one(xb):
+        leaves = {k: p[k].clone().requires_grad_(True) for k in names}
+        o = orc.image_only_forward(xb, leaves)
+        loss = orc.bce_loss(o["prob"], y)
+        loss.backward()
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        for xb in bags[:3]:
+            one(xb)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one(bags[n % 4])
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                return n, el
+
+    cores = _physical_cores()
+    n1, e1 = run(1)
+    # "all cores": the physical cores this process may use; torch's intra-op pool stops scaling on a 1024 x 512 bag long
+    # before 64+ threads, so 16 threads (the best count measured on the EPYC 9575F host) is tried too and the faster kept
+    best = None
+    for c in sorted({cores, min(cores, 16)}):
+        nc_, ec_ = run(c)
+        if best is None or nc_ / ec_ > best[1] / best[2]:
+            best = (c, nc_, ec_)
+    cores_used, nc, ec = best
+    return {"value": round(nc / ec, 2), "unit": "bags/s", "cores": cores_used, "cores_available": cores, "kind": "port",
+            "sample": f"{nc} bags of {N}x{L} fp32, one bag per fwd+loss+bwd, torch-CPU oracle, {ec:.1f} s",
+            "one_thread": {"value": round(n1 / e1, 2), "unit": "bags/s", "cores": 1,
+                           "sample": f"{n1} bags in {e1:.1f} s"},
+            "cpu": _cpu_model()}
+
+
+# ----------------------------------------------------------------------------------------------- extra configs (N=1)
+def config5_bf16(dev, steps=60, warmup=5):
+    """BASELINE config 5: 32 bags x 4096 patches x 1024 dims, x and gate weights stored bf16, fp32 accumulate."""
+    import torch
+    from mil_amd import ops, synthetic as syn
+    from mil_amd.bags import BagLayout
+    from mil_amd.trainer import ImageOnlyTrainer
+    from oracle import mil_oracle as orc
+    B, N, L = 32, 4096, 1024
+    p = syn.image_only_params(1234, L=L)
+    tr = ImageOnlyTrainer(p, dev)
+    x32 = syn.make_bags(4321, B, N, L)
+    x = x32.reshape(B * N, L).to(dev).to(torch.bfloat16)
+    y = syn.make_labels(99, B).to(dev)
+    lay = BagLayout.uniform(B, N, dev)
+    # parity of THIS batch, before any update: 2 of the 32 bags against the oracle on the same bf16-rounded inputs
+    prob, z = tr.forward(x, lay, None)
+    pr = dict(p)
+    for k in ("aggregator.attention_V.0.weight", "aggregator.attention_U.0.weight"):
+        pr[k] = p[k].to(torch.bfloat16).float()
+    dl, top1 = 0.0, True
+    for b in (0, B - 1):
+        o = orc.image_only_forward(x32[b].to(torch.bfloat16).float(), pr)
+        dl = max(dl, float((z[b].cpu() - o["logits"][0]).abs().max()))
+        top1 = top1 and bool(torch.equal(prob[b].cpu().argmax(-1), o["prob"][0].argmax(-1)))
+    for _ in range(30):
+        tr.forward(x, lay, y)
+    for _ in range(warmup):
+        tr.train_step(x, lay, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(x, lay, y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    R = B * N
+    kb = tr.time_pieces(x, lay, y, 20)
+    dom = max(("gate_fwd", "gate_bwd_dw"), key=lambda k: kb[k])
+    flops = 4.0 * R * L * D_GATE
+    hbm = R * L * 2 / (kb["gate_fwd"] * 1e-3) / 1e9
+    return {"workload": f"{B} bags x {N} x {L}, bf16 storage / fp32 accumulate, image-only fwd+BCE+bwd+Adam (BASELINE config 5)",
+            "ms_per_step": round(ms, 4), "bags_per_s": round(B / (ms * 1e-3), 1), "dtype": "bf16",
+            "step_algorithmic_bytes": 2 * R * L * 2, "step_hbm_frac": round(2 * R * L * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "roofline": {"bound": "mfma", "kernel": "k_gate_fwd_bf16_deep" if dom == "gate_fwd" else "k_gate_bwd_dw_bf16",
+                         "achieved": round(flops / (kb[dom] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(flops / (kb[dom] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "flops_per_launch": flops, "ms_per_launch": round(kb[dom], 4),
+                         "traffic": _pmc_traffic("cfg5_" + dom)},
+            "roofline_hbm_gate_fwd": {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": round(hbm / PEAK_HBM_GBS, 4), "bytes_per_launch": R * L * 2},
+            "kernels_ms": {k: round(v, 4) for k, v in kb.items()},
+            "parity": {"bags_checked": [0, B - 1], "max_abs_dlogit": dl, "top1_equal": top1,
+                       "oracle": "fp32 oracle on the same bf16-rounded x and gate weights", "tolerance": 1e-3}}
+
+
+def config3_fusion(dev, steps=30, warmup=4):
+    """BASELINE config 3: 32 bags x 1024 patches x 768 dims + one 77-token note per bag through aggregator(args):
+    fc_pathology -> CLIP ViT-B/32 text tower (frozen) -> fc_CI2Pth -> TwoWayTransformer -> multi-modal bag -> ABMIL ->
+    head -> BCE -> backward -> FlatAdam; trainable part replayed from a hipGraph (frozen text tower outside)."""
+    import torch
+    from types import SimpleNamespace
+    from mil_amd import synthetic as syn
+    from mil_amd.model.utils import get_model
+    from mil_amd.optim import FlatAdam
+    from oracle import mil_oracle as orc
+    B, N = 32, 1024
+    args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL",
+                           num_classes=2, learnablePrompt=0, n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI",
+                           model_CT="resnetMC3_18", clip_layers=12, cache_text=0)
+    torch.manual_seed(1234)
+    model = get_model(args).to(dev).eval()          # eval: the parity mode (dropout off); gradients still flow
+    x = syn.make_bags(1, B, N, 768).to(dev)
+    ids = syn.make_token_ids(2, B, 1).to(dev)
+    y = syn.make_labels(3, B).to(dev)
+    # parity of THIS batch on 2 of the 32 bags (before any update)
+    with torch.no_grad():
+        prob, _ = model([x], ids)
+        z = model.last_logits.detach().cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    dl, top1 = 0.0, True
+    for b in (0, B - 1):
+        with torch.no_grad():
+            o = orc.fused_forward(x[b].cpu(), ids[b].cpu(), sd)
+        dl = max(dl, float((z[b] - o["logits"][0]).abs().max()))
+        top1 = top1 and bool(torch.equal(prob[b].cpu().argmax(-1), o["prob"][0].argmax(-1)))
+    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7, counted=True)
+    crit = torch.nn.BCELoss()
+    with torch.no_grad():
+        tfeat = model.clinic_extractor(ids)         # frozen tower: cached per note in training (dim1/CLIP.py cache_text)
+
+    def gstep():
+        p_, _ = model([x], ids, text_features=tfeat)
+        loss = crit(p_, y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            gstep()
+    torch.cuda.current_stream().wait_stream(side)
+    opt.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gstep()
+    for _ in range(warmup):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    R = B * N
+    # algorithmic flops of the trainable path per step (SURVEY 8d): fc_pathology fwd + dW (2 x 2*R*768*512),
+    # ABMIL gate fwd + dW + dx (3 x 4*R*512*192); the absorbed one-token attention sites are HBM-bound streams
+    flops = 2 * 2.0 * R * 768 * 512 + 3 * 4.0 * R * 512 * D_GATE
+    return {"workload": f"{B} bags x {N} x 768 + one 77-token note per bag, aggregator(args) fwd+BCE+bwd+Adam "
+                        "(BASELINE config 3; text embeddings of the frozen ViT-B/32 tower cached per note)",
+            "ms_per_step": round(ms, 4), "bags_per_s": round(B / (ms * 1e-3), 1), "dtype": "f32", "launch": "hipGraph",
+            "roofline": {"bound": "mfma", "kernel": "step (fc_pathology + gate GEMMs)", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                         "flops_per_step": flops, "traffic": None},
+            "parity": {"bags_checked": [0, B - 1], "max_abs_dlogit": dl, "top1_equal": top1,
+                       "oracle": "fp32 oracle fused_forward (model/aggregator.py:134-209 wiring)", "tolerance": 1e-3}}
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+    import mil_amd  # noqa: F401
+    from mil_amd import synthetic as syn
+    from mil_amd.bags import BagLayout
+    from mil_amd.trainer import ImageOnlyTrainer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         f"(torchrun --nproc-per-node {args.gpus}, or plain `python bench.py --gpus {args.gpus}`)")
     # MIL_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo - a one-GPU rehearsal of the N>1 code path
     # (RCCL refuses two ranks on one device); never used for reported numbers.
     rehearsal = os.environ.get("MIL_BENCH_REHEARSAL") == "1"
-    gpu = 0 if rehearsal else local_rank % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if not rehearsal and local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {ndev} are visible")
+    gpu = 0 if rehearsal else local_rank
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     force = os.environ.get("MIL_FORCE_COLLECTIVES") == "1"      # world size 1 through RCCL: checks init + collectives
-    if world > 1 or force:
+    use_dist = world > 1 or force
+    backend = "gloo" if rehearsal else "nccl"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if force and world == 1:
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        kw = {} if rehearsal else {"device_id": dev}
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=300), **kw)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, {args.gpus} expected")
 
     B, N, L, C = args.bags_per_gpu, args.patches, args.dim, 2
     params = syn.image_only_params(1234, L=L)
-    tr = ImageOnlyTrainer(params, dev, world_size=world)
+    tr = ImageOnlyTrainer(params, dev, world_size=world, train_mode=bool(args.train_mode), accum=args.accum)
     x = syn.make_bags(4321 + rank, B, N, L).reshape(B * N, L).to(dev)       # resident in HBM before timing
     if args.dtype == "bf16":
         x = x.to(torch.bfloat16)
@@ -194,9 +444,18 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1 or force:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.dump:
+        tr.forward(x, lay, y)
+        tr.backward()
+        tr.reduce_only()
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"grad": tr.fp.grad.detach().cpu().clone(), "loss": float(tr.loss_sum.item())}, args.dump)
+        tr.reset_dropout_stream()
 
     if not args.graph:
         step = lambda: tr.train_step(x, lay, y)     # noqa: E731
@@ -204,9 +463,8 @@ def main():
         tr.capture(x, lay, y)                        # forward+backward as one hipGraph on static buffers
         step = tr.replay_step
     # Clock priming (every rank, before the W warm-up steps): the chip needs ~10-30 ms of sustained load to reach its
-    # steady clock, and a short run (50 steps = 13 ms) otherwise reads 8 % slower than a long one of the very same loop
-    # (0.287 vs 0.263 ms/step at 50 / 1000 steps).  Forward passes only: no optimizer update, so the parameter trajectory
-    # of "W warm-up steps + K timed steps" is untouched.
+    # steady clock, and a short run (50 steps = 13 ms) otherwise reads 8 % slower than a long one of the very same loop.
+    # Forward passes only: no optimizer update, so the parameter trajectory of "W warm-up + K timed steps" is untouched.
     for _ in range(args.prime):
         tr.forward(x, lay, y)
     for _ in range(args.warmup):
@@ -217,15 +475,34 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1 or force:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(tr.loss_sum.item())
 
+    rccl = None
+    if use_dist:
+        # the step's one collective, alone: the flat gradient + loss buffer (0.79 MB), HIP events on the compute stream
+        # (torch's all_reduce makes the current stream wait for the collective, so the events bracket it)
+        buf = torch.zeros_like(tr.fp.grad_ext)
+        ar_ms = timed(lambda: dist.all_reduce(buf), 50, warm=10)
+        t = torch.tensor([ar_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:       # noqa: BLE001
+                ver = None
+        rccl = {"backend": backend, "world_size": dist.get_world_size(), "allreduce_bytes": buf.numel() * 4,
+                "allreduce_us": round(float(t.item()) * 1e3, 2), "version": ver,
+                "collectives_per_step": round(1.0 / args.accum, 4)}
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
+        mode = "train (dropout 0.5 on patches + 0.25 before the head, in-kernel masks)" if args.train_mode else "eval (no dropout)"
         line = {
             "metric": "bags/sec fwd+bwd, N=1024 patches D=512", "value": round(value, 1), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -233,60 +510,56 @@ def main():
             "config": {"workload": f"{B} bags/GPU x {N} patches x {L} dims, image-only gated-attention MIL "
                                    f"fwd+BCE+bwd+allreduce+Adam (BASELINE config 2; x{world} GPUs = {world * B} bags)",
                        "bags_per_gpu": B, "patches": N, "dim": L, "global_bags": world * B,
-                       "parallelism": f"dp{world}", "loss": round(loss, 6),
+                       "parallelism": f"dp{world}", "loss": round(loss, 6), "mode": mode, "accum": args.accum,
                        "launch": "eager" if not args.graph else "hipGraph(fwd+bwd)+eager(allreduce,adam)"},
         }
-        if not args.no_breakdown and args.dtype == "bf16":
-            sb = 2                                    # bytes per stored x element
-            fwd_ms = timed(lambda: tr._gate_fwd(x, True), 20)
-            sc, _ = tr._gate_fwd(x, True)
-            pp_ms = timed(lambda: ops.attn_pool_partial_bf16(x, sc, lay), 20)
-            R = B * N
-            line["roofline"] = {"bound": "hbm", "kernel": "k_gate_fwd_bf16", "achieved": round(R * L * sb / (fwd_ms * 1e-3) / 1e9, 1),
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(R * L * sb / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                "traffic": None, "ms_per_launch": round(fwd_ms, 4),
-                                "mfma_tflops": round(4.0 * R * L * D_GATE / (fwd_ms * 1e-3) / 1e12, 1)}
-            tr.forward(x, lay, y)
-            c = dict(tr.last)
-            ds = ops.attn_pool_bwd_bf16(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay)
-            ds_ms = timed(lambda: ops.attn_pool_bwd_bf16(x, c["scores"], c["lse"], c["dM"], c["cdot"], lay), 20)
-            fp = tr.fp
-            g = {k: torch.empty_like(fp.p(k)) for k in fp.order}
-            gargs = (g["aggregator.attention_V.0.weight"], g["aggregator.attention_V.0.bias"],
-                     g["aggregator.attention_U.0.weight"], g["aggregator.attention_U.0.bias"],
-                     g["aggregator.attention_weights.weight"].view(-1), g["aggregator.attention_weights.bias"])
-            wv = fp.p("aggregator.attention_weights.weight").view(-1)
-            ws = ops.gate_bwd_params_bf16(x, c["gates"], ds, wv, *gargs)
-            dw_ms = timed(lambda: ops.gate_bwd_params_bf16(x, c["gates"], ds, wv, *gargs, False, ws), 20)
-            line["kernels_ms"] = {"gate_fwd_bf16": round(fwd_ms, 4), "pool_partial_bf16": round(pp_ms, 4),
-                                  "pool_bwd_ds_bf16": round(ds_ms, 4), "gate_bwd_dw_bf16(+reduce)": round(dw_ms, 4)}
-            line["kernels_gbs"] = {"pool_partial_bf16": round(R * L * sb / (pp_ms * 1e-3) / 1e9, 1),
-                                   "pool_bwd_ds_bf16": round(R * L * sb / (ds_ms * 1e-3) / 1e9, 1)}
-            line["kernels_tflops"] = {"gate_fwd_bf16": round(4.0 * R * L * D_GATE / (fwd_ms * 1e-3) / 1e12, 1),
-                                      "gate_bwd_dw_bf16": round(4.0 * R * L * D_GATE / (dw_ms * 1e-3) / 1e12, 1)}
-        elif not args.no_breakdown:
+        if rccl is not None:
+            line["rccl"] = rccl
+        if not args.no_breakdown:
             kb = kernel_breakdown(tr, x, lay, y)
             R = B * N
             flops = {"gate_fwd": 4.0 * R * L * D_GATE, "gate_bwd_dw": 4.0 * R * L * D_GATE}
             dom = max(("gate_fwd", "gate_bwd_dw"), key=lambda k: kb[k])
             ach = flops[dom] / (kb[dom] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd" if dom == "gate_fwd" else "k_gate_bwd_dw",
-                                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                                "traffic": PMC_TRAFFIC_BYTES[dom] if (B, N, L) == (32, 1024, 512) else None,
-                                "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
+            if args.dtype == "bf16":
+                line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd_bf16" if dom == "gate_fwd" else "k_gate_bwd_dw_bf16",
+                                    "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
+                                    "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
+            else:
+                line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd" if dom == "gate_fwd" else "k_gate_bwd_dw",
+                                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                                    "traffic": _pmc_traffic("cfg2_" + dom) if (B, N, L) == (32, 1024, 512) else None,
+                                    "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
             line["kernels_ms"] = {k: round(v, 4) for k, v in kb.items()}
             line["kernels_tflops"] = {k: round(flops[k] / (kb[k] * 1e-3) / 1e12, 2) for k in flops}
-            pool_bytes = R * L * 4 + 4 * R + 4 * L * B
-            line["kernels_gbs"] = {"pool_partial": round(pool_bytes / (kb["pool_partial"] * 1e-3) / 1e9, 1),
-                                   }
-            line["roofline_pool"] = pool_roofline(dev)
+            if world == 1 and args.dtype == "f32":
+                line["roofline_pool"] = pool_roofline(dev)
+        if world == 1 and not args.no_configs and args.dtype == "f32":
+            cfgs = {}
+            for name, fn in (("cfg5", config5_bf16), ("cfg3", config3_fusion)):
+                try:
+                    cfgs[name] = fn(dev)
+                except Exception as e:      # noqa: BLE001  (the headline line must still be printed)
+                    cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            line["configs"] = cfgs
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(N, L)
         print(json.dumps(line), flush=True)
-    if world > 1 or force:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -37,7 +37,25 @@ extern "C" {
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
 
 /* Library/ABI version, for the host mirror's load-time check. */
-int mil_abi_version(void);
+int mil_abi_version(void);   /* 2 */
+
+/* ---- dropout keep bits (train mode) -------------------------------------------------------
+ * model.train() upstream drops the bag rows with p = 0.5 BEFORE the gate and pools the dropped rows
+ * (model/dim1/ABMIL.py:26,49,59) and drops the bag embedding with p = 0.25 in front of the head
+ * (model/aggregator.py:128-131).  Here a keep mask is a packed bit tensor, uint32 [rows][cols/32], bit (col & 31) of
+ * word (col >> 5) set = element kept; every entry point below that consumes x (or M) takes such a tensor (NULL = eval
+ * mode, no dropout) plus the survivors' scale 1/(1-p).  The backward reads the same bits, so it sees the forward's mask
+ * by construction, and a caller (or a parity test) may supply any mask.
+ * mil_dropout_keep_bits fills a tensor from Philox4x32-10: key = seed, counter = (128-bit block index, stream offset);
+ * offset_dev (nullable) is a device int32 added to `offset`, so a hipGraph replay draws a fresh mask when the counter
+ * moves (the trainer points it at its device step counter).  p_drop = 0.5 uses one random bit per element, 0.25 two,
+ * anything else a 32-bit threshold.  cols % 32 == 0. */
+int mil_dropout_keep_bits(uint32_t* bits, int rows, int cols, float p_drop, uint64_t seed, uint64_t offset,
+                          const int32_t* offset_dev, void* stream);
+/* counter[0] += v on the stream (a device-side pass counter that a replayed hipGraph advances: dropout offsets). */
+int mil_counter_add(int32_t* counter, int v, void* stream);
+/* t[row][col] = keep ? t * scale : 0, in place (dropout backward for a consumer that cannot fold the mask in). */
+int mil_dropout_apply_bits(float* t, const uint32_t* bits, int rows, int cols, float scale, void* stream);
 
 /* ---- tile map ---------------------------------------------------------------------------
  * The attention-pool kernels split every bag into tiles of MIL_POOL_TILE rows.
@@ -52,7 +70,7 @@ int mil_abi_version(void);
  * Requires L % 32 == 0, D == 192. */
 int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu,
                         const float* bu, const float* w, const float* b, float* scores,
-                        float* gates, int R, int L, int D, void* stream);
+                        float* gates, int R, int L, int D, const uint32_t* xbits, float xscale, void* stream);
 
 /* ---- K1b: attention pool ----------------------------------------------------------------
  * A = softmax over the rows of each bag of s; M[b] = sum_i A_i x_i; lse[b] = logsumexp(s).
@@ -61,19 +79,22 @@ int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const 
  * partials workspace: [T, L + 2] floats.  M: [B, L]; lse: [B]. */
 int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_map,
                       const int32_t* bag_tile_off, int T, int B, int L, float* partials,
-                      float* M, float* lse, void* stream);
+                      float* M, float* lse, const uint32_t* xbits, float xscale, void* stream);
 
 /* The two halves of mil_attn_pool_fwd as separate entry points, so a training step can replace
  * the plain merge by the fused tail below.  mil_attn_pool_partial writes the tile partials only. */
 int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
-                          float* partials, void* stream);
+                          float* partials, const uint32_t* xbits, float xscale, void* stream);
 
 /* Pool partial pass that also emits the head's projection of every patch, hrow[row][c] = x_row . Wf[c] (C <= 4):
  * when ABMIL feeds the linear head directly (model/aggregator.py:199-200), dM = dz Wf, so the backward's
  * x_i . dM equals sum_c dz[bag][c] hrow[i][c] and mil_attn_pool_bwd_from_h yields ds WITHOUT re-reading x
  * (replaces mil_attn_pool_bwd: ds_i = A_i (sum_c dz[bag][c] hrow[i][c] - cdot[bag])). */
+/* Train mode: xbits / xscale as above; mbits [B][L/32] / mscale = the head's dropout on the bag embedding, folded into
+ * the head rows (hrow[row][c] = x_row^dropped . (Wf[c] * keepM[bag] * mscale)) so the identity above still holds. */
 int mil_attn_pool_partial_h(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
-                            float* partials, const float* Wf, int C, float* hrow, void* stream);
+                            float* partials, const float* Wf, int C, float* hrow, const uint32_t* xbits, float xscale,
+                            const uint32_t* mbits, float mscale, void* stream);
 int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float* hrow, const float* dz,
                              const float* cdot, const int32_t* tile_map, int T, int C, float* ds, void* stream);
 
@@ -87,7 +108,10 @@ int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float*
 int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
                         const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                         float* lse, float* z, float* p, float* loss_bag, float* dz, float* dM, float* cdot,
-                        const int32_t* tile_map, const float* scores, const float* hrow, float* ds, void* stream);
+                        const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
+                        const uint32_t* mbits, float mscale, float* Mdrop, void* stream);
+/* mbits / mscale (nullable / 1): keep bits of the head's Dropout(.25); M stays the un-dropped pool output, the head
+ * reads M * keep * mscale (also written to Mdrop [B, L] when given: it is the M of dWf = dz^T M), dM carries the mask. */
 
 /* ---- K3b: per-bag head ------------------------------------------------------------------
  * z = M Wf^T + bf (logits), p = sigmoid(z).  model/aggregator.py:128-131,200 (eval: the
@@ -111,6 +135,9 @@ int mil_head_bwd(const float* dz_or_dp, const float* p, const float* M, const fl
  * loss_bag [B] is given it also writes loss_out[0] = sum_b loss_bag[b] (overwrite: no memset, no atomics). */
 int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
                         const float* loss_bag, float* loss_out, void* stream);
+/* The same with accumulate != 0 adding to dWf, dbf and loss_out (gradient accumulation over micro-batches). */
+int mil_head_bwd_params_acc(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
+                            const float* loss_bag, float* loss_out, int accumulate, void* stream);
 
 /* CLIP-as-loss of the image-only variant (reference utils.py:247-284 CLIPloss_v1, forward :261-284):
  * out [b, E] bag embeddings, feat [b, F, E] frozen CLIP text features of the F per-feature prompts of each sample;
@@ -127,7 +154,7 @@ int mil_rowdot(const float* a, const float* c, float* out, int B, int L, void* s
  * If dx != NULL also writes the pool term dx_i = A_i dM[bag] (overwrites dx). */
 int mil_attn_pool_bwd(const float* x, const float* scores, const float* lse, const float* dM,
                       const float* cdot, const int32_t* tile_map, int T, int L, float* ds,
-                      float* dx, void* stream);
+                      float* dx, const uint32_t* xbits, float xscale, void* stream);
 
 /* Gate parameter gradients from the saved gates and ds:
  * dWv = dPreV^T x, dWu = dPreU^T x, dbv, dbu, dw = sum_i ds_i V_i U_i, db = sum_i ds_i,
@@ -138,14 +165,14 @@ size_t mil_gate_bwd_workspace_floats(int R, int L);
 int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, const float* w,
                         int R, int L, int D, float* workspace, size_t workspace_floats,
                         float* dWv, float* dbv, float* dWu, float* dbu, float* dw, float* db,
-                        int accumulate, void* stream);
+                        int accumulate, const uint32_t* xbits, float xscale, void* stream);
 
 /* The two launches of mil_gate_bwd_params on their own: the split-K MFMA kernel (fills the workspace) and the
  * reduce (workspace -> outputs). */
 int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
-                          int D, float* workspace, size_t workspace_floats, void* stream);
+                          int D, float* workspace, size_t workspace_floats, const uint32_t* xbits, void* stream);
 int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
-                        float* dw, float* db, int accumulate, void* stream);
+                        float* dw, float* db, int accumulate, float xscale, void* stream);
 
 /* mil_gate_bwd_params with the head's parameter gradients (mil_head_bwd_params: dWf [C, L], dbf [C], loss_out = sum of
  * loss_bag) computed by workgroups appended to the reduce launch - one launch less per training step; the bag
@@ -153,12 +180,20 @@ int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float*
 int mil_gate_bwd_params_head(const float* x, const float* gates, const float* ds, const float* w, int R, int L, int D,
                              float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu, float* dbu,
                              float* dw, float* db, int accumulate, const float* dz, const float* M, float* dWf,
-                             float* dbf, int B, int C, const float* loss_bag, float* loss_out, void* stream);
+                             float* dbf, int B, int C, const float* loss_bag, float* loss_out, const uint32_t* xbits,
+                             float xscale, void* stream);
+
+/* The reduce launch of mil_gate_bwd_params_head on its own (after mil_gate_bwd_partials). */
+int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                             float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
+                             float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out, void* stream);
 
 /* Input gradient through the gate (needed when the bag is itself a computed tensor, i.e.
  * the fused text+image path): dx += dPreV Wv + dPreU Wu. */
+/* With xbits this launch, the last writer of dx, also applies the backward of the patch dropout: dx = keep ? dx * xscale : 0. */
 int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,
-                       const float* Wu, int R, int L, int D, float* dx, void* stream);
+                       const float* Wu, int R, int L, int D, float* dx, const uint32_t* xbits, float xscale,
+                       void* stream);
 
 /* ---- K1, bf16-storage variant (BASELINE config 5: N=4096, D=1024) -------------------------------
  * x and the gate weights are stored as bf16 (uint16_t bit patterns); all accumulation is fp32.  Same
@@ -185,7 +220,8 @@ int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, const float*
 /* mil_gate_bwd_params with x stored as bf16 (widened while staged; fp32 MFMA product: exact on the rounded x). */
 int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R, int L,
                             int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,
-                            float* dbu, float* dw, float* db, int accumulate, void* stream);
+                            float* dbu, float* dw, float* db, int accumulate, const uint32_t* xbits, float xscale,
+                            void* stream);
 
 /* ---- K3a: generic fp32-MFMA GEMM with fused epilogue -----------------------------------------
  * C[M,N] (+)= act(A_op[M,K] . B_op[K,N] + bias) + residual
@@ -405,6 +441,80 @@ int mil_adam_step_counted(float* param, const float* grad, float* exp_avg, float
  * flat fp32 buffer: g = grad_scale * grad + weight_decay * param;  param -= lr * g.  Both buffers 16-byte aligned. */
 int mil_sgd_step(float* param, const float* grad, size_t n, float lr, float weight_decay, float grad_scale,
                  void* stream);
+
+/* ---- the image-only training step as ONE call -------------------------------------------------------------
+ * Replaces, for the image-only branch (BASELINE configs 2/4/5), the reference's per-step sequence
+ *     out = generator(x); loss = criterion(out, y); optimizer.zero_grad(); loss.backward(); optimizer.step()
+ * (train_ddp.py:295-348) with one host call that enqueues every launch of the step on `stream`:
+ *   MIL_STAGE_DROPBITS   keep bits for the patches (p = .5, ABMIL.py:49) and the bag embeddings (p = .25, aggregator.py:129)
+ *   MIL_STAGE_GATE_FWD   gate scores (+ saved gates)                                  ABMIL.py:52-54
+ *   MIL_STAGE_POOL       attention-pool tile partials (+ head projections)            ABMIL.py:56-59
+ *   MIL_STAGE_TAIL       per-bag merge, head, sigmoid, BCE, dz, dM, ds                aggregator.py:128-131,200; train_ddp.py:323
+ *   MIL_STAGE_GATE_BWD   split-K weight gradient of the gate                          autograd of ABMIL.py:52-54
+ *   MIL_STAGE_REDUCE     split-K fold + head parameter gradients + loss sum
+ *   MIL_STAGE_ADAM       Adam over the flat parameter buffer                          train_ddp.py:115-118,348
+ * The host mirror fills the struct once per (model, batch layout) and re-submits it every step: the per-step host cost
+ * is one foreign call.  With world size > 1 the gradient all-reduce sits between REDUCE and ADAM: run the step with
+ * stages = ALL & ~ADAM, all-reduce `grad_flat`, then run stages = ADAM.
+ * All pointers are device pointers owned by the caller.  y == NULL: inference (stages up to TAIL, no gradients).
+ * x_bf16 != 0: x, Wv16, Wu16 are bf16 bit patterns (BASELINE config 5); eval-mode only (train != 0 is rejected). */
+#define MIL_STAGE_DROPBITS 0x01u
+#define MIL_STAGE_GATE_FWD 0x02u
+#define MIL_STAGE_POOL     0x04u
+#define MIL_STAGE_TAIL     0x08u
+#define MIL_STAGE_GATE_BWD 0x10u
+#define MIL_STAGE_REDUCE   0x20u
+#define MIL_STAGE_ADAM     0x40u
+#define MIL_STAGE_ALL      0x7fu
+typedef struct mil_image_only_step {
+    uint32_t struct_bytes;          /* sizeof(mil_image_only_step): ABI check */
+    uint32_t stages;                /* MIL_STAGE_* to run */
+    /* batch */
+    const void* x;                  /* [R, L] fp32 (or bf16 bits) */
+    const float* y;                 /* [B, C] one-hot labels, or NULL */
+    const int32_t* tile_map;        /* [T, 4] */
+    const int32_t* bag_tile_off;    /* [B + 1] */
+    int32_t R, L, B, C, T;
+    int32_t x_bf16;
+    float loss_scale;               /* 1 / (C * global bags) */
+    int32_t accumulate;             /* != 0: add this batch's gradients to the buffers (gradient accumulation) */
+    /* parameters (fp32 masters; views of one flat buffer in the host mirror) */
+    const float *Wv, *bv, *Wu, *bu, *w, *b, *Wf, *bf;
+    const uint16_t *Wv16, *Wu16;    /* bf16 shadows of Wv, Wu (x_bf16 only) */
+    /* gradients */
+    float *dWv, *dbv, *dWu, *dbu, *dw, *db, *dWf, *dbf;
+    float* loss_out;                /* [1]: sum over the bags of loss_scale * BCE */
+    /* per-step state kept for the backward, caller-allocated */
+    float* scores;                  /* [R] */
+    float* gates;                   /* [R, 384] */
+    float* partials;                /* [T, L + 2] */
+    float* hrow;                    /* [R, C] (C <= 4) or NULL: the backward then re-reads x */
+    float* ds;                      /* [R] */
+    float* dw_ws;                   /* split-K workspace of the weight gradient */
+    uint64_t dw_ws_floats;
+    float *M, *Mdrop, *lse, *logits, *prob, *loss_bag, *dz, *dM, *cdot;   /* [B, L] x2, [B], [B, C] x2, [B], [B, C], [B, L], [B] */
+    /* dropout (train != 0) */
+    int32_t train;
+    int32_t bf16_grad_mfma;         /* x_bf16: weight gradient on the bf16 MFMA (else fp32 MFMA on the widened x) */
+    uint32_t* xbits;                /* [R, L/32] */
+    uint32_t* mbits;                /* [B, L/32] */
+    uint64_t seed, offset;          /* Philox key / stream position of this pass */
+    const int32_t* offset_dev;      /* nullable device counter added to offset (hipGraph replay) */
+    /* optimizer (MIL_STAGE_ADAM) */
+    float *param_flat, *grad_flat, *exp_avg, *exp_avg_sq;
+    uint64_t n_param;
+    int32_t adam_step;              /* 1-based step number (host bias corrections) ... */
+    int32_t* adam_step_dev;         /* ... or a device counter of steps already taken (incremented by the launch) */
+    float lr, beta1, beta2, eps, weight_decay, grad_scale;
+} mil_image_only_step;
+
+int mil_image_only_step_run(const mil_image_only_step* a, void* stream);
+/* Measurement helper: runs the given stage subset `iters` times back to back on `stream` between two HIP events (after
+ * `warm` untimed runs) and returns the average duration of one run in *ms_out.  Synchronises the stream.  The state a
+ * stage reads must exist (run the whole step once first).  bench.py's per-kernel figures come from here: the launches
+ * are issued from C, so a 10 us kernel is not timed behind 30 us of interpreter. */
+int mil_image_only_step_time(const mil_image_only_step* a, uint32_t stages, int warm, int iters, float* ms_out,
+                             void* stream);
 
 #ifdef __cplusplus
 }

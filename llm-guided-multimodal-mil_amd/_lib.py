@@ -8,38 +8,46 @@ from __future__ import annotations
 import ctypes
 import os
 import re
-from ctypes import c_long, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_long, c_float, c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mil_hip.h")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/mil_hip.h one to one
 SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_abi_version": (c_int, []),
-    "mil_gate_scores_fwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
-    "mil_attn_pool_fwd": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, _P, _P]),
-    "mil_attn_pool_partial": (c_int, [_P] * 3 + [c_int, c_int, _P, _P]),
-    "mil_attn_pool_partial_h": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_int, _P, _P]),
+    "mil_dropout_keep_bits": (c_int, [_P, c_int, c_int, c_float, c_uint64, c_uint64, _P, _P]),
+    "mil_dropout_apply_bits": (c_int, [_P, _P, c_int, c_int, c_float, _P]),
+    "mil_counter_add": (c_int, [_P, c_int, _P]),
+    "mil_gate_scores_fwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, c_float, _P]),
+    "mil_attn_pool_fwd": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
+    "mil_attn_pool_partial": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_float, _P]),
+    "mil_attn_pool_partial_h": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_int, _P, _P, c_float, _P, c_float, _P]),
     "mil_attn_pool_bwd_from_h": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
-    "mil_pool_merge_head": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12 + [_P]),
+    "mil_pool_merge_head": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12
+                            + [_P, c_float, _P, _P]),
     "mil_head_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P]),
     "mil_bce_fwd_bwd": (c_int, [_P] * 4 + [c_int, c_int, c_float, _P]),
     "mil_head_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
     "mil_head_bwd_params": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, _P]),
+    "mil_head_bwd_params_acc": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, c_int, _P]),
     "mil_clip_contrastive_loss": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "mil_rowdot": (c_int, [_P] * 3 + [c_int, c_int, _P]),
-    "mil_attn_pool_bwd": (c_int, [_P] * 6 + [c_int, c_int, _P, _P, _P]),
+    "mil_attn_pool_bwd": (c_int, [_P] * 6 + [c_int, c_int, _P, _P, _P, c_float, _P]),
     "mil_gate_bwd_workspace_floats": (c_size_t, [c_int, c_int]),
-    "mil_gate_bwd_params": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),
+    "mil_gate_bwd_params": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P, c_float, _P]),
     "mil_gate_bwd_params_head": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int] + [_P] * 4
-                                 + [c_int, c_int, _P, _P, _P]),
-    "mil_gate_bwd_partials": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t, _P]),
-    "mil_gate_bwd_reduce": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, _P]),
-    "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P]),
+                                 + [c_int, c_int, _P, _P, _P, c_float, _P]),
+    "mil_gate_bwd_partials": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "mil_gate_bwd_reduce": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float, _P]),
+    "mil_gate_bwd_reduce_head": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float] + [_P] * 4 + [c_int, c_int, _P, _P, _P]),
+    "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
+    "mil_image_only_step_run": (c_int, [_P, _P]),
+    "mil_image_only_step_time": (c_int, [_P, c_uint32, c_int, c_int, _P, _P]),
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
     "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P]),
@@ -47,7 +55,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_attn_pool_bwd_bf16": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
     "mil_gate_bwd_workspace_floats_bf16": (c_size_t, [c_int, c_int]),
     "mil_gate_bwd_params_bf16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),
-    "mil_gate_bwd_params_x16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),
+    "mil_gate_bwd_params_x16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P, c_float, _P]),
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
@@ -101,6 +109,29 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_linear_bwd_params": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
                                       c_size_t, _P]),
 }
+
+STAGE_DROPBITS, STAGE_GATE_FWD, STAGE_POOL, STAGE_TAIL, STAGE_GATE_BWD, STAGE_REDUCE, STAGE_ADAM = 1, 2, 4, 8, 16, 32, 64
+STAGE_ALL = 0x7f
+
+
+class ImageOnlyStep(ctypes.Structure):
+    """`mil_image_only_step` of include/mil_hip.h, field for field."""
+    _fields_ = (
+        [("struct_bytes", c_uint32), ("stages", c_uint32),
+         ("x", _P), ("y", _P), ("tile_map", _P), ("bag_tile_off", _P),
+         ("R", c_int32), ("L", c_int32), ("B", c_int32), ("C", c_int32), ("T", c_int32),
+         ("x_bf16", c_int32), ("loss_scale", c_float), ("accumulate", c_int32)]
+        + [(n, _P) for n in ("Wv", "bv", "Wu", "bu", "w", "b", "Wf", "bf", "Wv16", "Wu16")]
+        + [(n, _P) for n in ("dWv", "dbv", "dWu", "dbu", "dw", "db", "dWf", "dbf", "loss_out")]
+        + [(n, _P) for n in ("scores", "gates", "partials", "hrow", "ds", "dw_ws")]
+        + [("dw_ws_floats", c_uint64)]
+        + [(n, _P) for n in ("M", "Mdrop", "lse", "logits", "prob", "loss_bag", "dz", "dM", "cdot")]
+        + [("train", c_int32), ("bf16_grad_mfma", c_int32), ("xbits", _P), ("mbits", _P), ("seed", c_uint64),
+           ("offset", c_uint64), ("offset_dev", _P)]
+        + [(n, _P) for n in ("param_flat", "grad_flat", "exp_avg", "exp_avg_sq")]
+        + [("n_param", c_uint64), ("adam_step", c_int32), ("adam_step_dev", _P)]
+        + [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")])
+
 
 _lib = None
 

@@ -1,0 +1,118 @@
+// Dropout keep-masks as packed bit tensors (train mode of the hot path).
+//
+// Reference: model/dim1/ABMIL.py:26,49 (`self.dropout1 = nn.Dropout(0.5)`, applied to the bag x before the gate AND before
+// the pooled sum, :59) and model/aggregator.py:128-131 (`nn.Dropout(0.25)` in front of the head's Linear).  torch draws
+// these masks from its Philox stream; which stream position an element gets is an implementation detail of ATen, so the
+// contract kept here is the distribution (independent Bernoulli keeps, survivors scaled by 1/(1-p)) and Philox4x32-10 as
+// the generator - the masks themselves are an explicit input/output (bit tensors), so the oracle can be run on exactly
+// the mask the kernels used (tests/test_gpu_dropout.py) and a caller can supply its own.
+//
+// Layout: bits[row * (cols/32) + (col >> 5)], bit (col & 31) set = element kept.  One bit per element: the three kernels
+// that consume the patches (k_gate_fwd, k_pool_partial, k_gate_bwd_dw) re-read 1/32 of the bytes of x (2 MiB for
+// 32 x 1024 x 512) instead of a materialised dropped copy (64 MiB written and read), and the backward sees the forward's
+// mask by construction.
+//
+// Philox4x32-10 (Salmon et al., SC'11; Random123 reference constants), key = (seed_lo, seed_hi), counter =
+// (block_lo, block_hi, offset_lo, offset_hi): `offset` is the stream position (the trainer uses the step number, host
+// scalar or a device counter so a hipGraph replay draws fresh masks), `block` the index of the 128-bit output block:
+//   p_drop = 0.5 : word w of the bit tensor = output word (w & 3) of block (w >> 2)            (1 random bit / element)
+//   p_drop = 0.25: word w = ~(out[2 (w & 1)] & out[2 (w & 1) + 1]) of block (w >> 1)          (dropped iff 2 bits set)
+//   otherwise    : element e kept iff out[e & 3] of block (e >> 2) >= p_drop * 2^32            (32 random bits / element)
+#include "mil_common.h"
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+struct philox4 { uint32_t v[4]; };
+
+__device__ __forceinline__ philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
+        const uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    return philox4{{c0, c1, c2, c3}};
+}
+
+// mode 0: p = 0.5, mode 1: p = 0.25, mode 2: generic threshold.  One thread per 128-bit Philox block.
+__global__ __launch_bounds__(256) void k_dropout_keep_bits(uint32_t* __restrict__ bits, size_t nwords, int mode,
+                                                           uint32_t thr, uint32_t seed_lo, uint32_t seed_hi,
+                                                           uint64_t offset, const int32_t* __restrict__ offset_dev) {
+    const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (offset_dev != nullptr) offset += (uint64_t)(uint32_t)offset_dev[0];
+    const uint32_t o_lo = (uint32_t)offset, o_hi = (uint32_t)(offset >> 32);
+    if (mode == 0) {
+        const size_t w0 = blk * 4;
+        if (w0 >= nwords) return;
+        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), o_lo, o_hi, seed_lo, seed_hi);
+        if (w0 + 4 <= nwords) {
+            *reinterpret_cast<uint4*>(bits + w0) = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        } else {
+            for (int i = 0; i < 4 && w0 + i < nwords; ++i) bits[w0 + i] = r.v[i];
+        }
+    } else if (mode == 1) {
+        const size_t w0 = blk * 2;
+        if (w0 >= nwords) return;
+        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), o_lo, o_hi, seed_lo, seed_hi);
+        bits[w0] = ~(r.v[0] & r.v[1]);
+        if (w0 + 1 < nwords) bits[w0 + 1] = ~(r.v[2] & r.v[3]);
+    } else {
+        // one output word = 32 elements = 8 Philox blocks; thread = word
+        if (blk >= nwords) return;
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint64_t b = (uint64_t)blk * 8 + q;
+            const philox4 r = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), o_lo, o_hi, seed_lo, seed_hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) word |= (r.v[e] >= thr ? 1u : 0u) << (4 * q + e);
+        }
+        bits[blk] = word;
+    }
+}
+
+extern "C" int mil_dropout_keep_bits(uint32_t* bits, int rows, int cols, float p_drop, uint64_t seed, uint64_t offset,
+                                     const int32_t* offset_dev, void* stream) {
+    if (!bits || rows < 0 || cols <= 0 || (cols % 32) != 0 || !(p_drop >= 0.f) || !(p_drop < 1.f)) return MIL_EINVAL;
+    const size_t nwords = (size_t)rows * (cols / 32);
+    if (nwords == 0) return MIL_OK;
+    int mode = 2;
+    size_t nthreads = nwords;
+    if (p_drop == 0.5f) { mode = 0; nthreads = (nwords + 3) / 4; }
+    else if (p_drop == 0.25f) { mode = 1; nthreads = (nwords + 1) / 2; }
+    const double t = (double)p_drop * 4294967296.0;
+    const uint32_t thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    hipLaunchKernelGGL(k_dropout_keep_bits, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits,
+                       nwords, mode, thr, (uint32_t)seed, (uint32_t)(seed >> 32), offset, offset_dev);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// dx[row][col] = keep ? dx * scale : 0 in place (autograd route: backward through the patch dropout when the gradient
+// of the bag rows is needed and no consumer kernel can fold the mask in).
+__global__ __launch_bounds__(256) void k_dropout_apply_bits(float* __restrict__ t, const uint32_t* __restrict__ bits,
+                                                            size_t n4, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index: 8 per bits word
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<f32x4*>(t)[i];
+    const uint32_t m = bits[i >> 3] >> (4 * (i & 7));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ((m >> e) & 1u) ? v[e] * scale : 0.f;
+    reinterpret_cast<f32x4*>(t)[i] = v;
+}
+
+extern "C" int mil_dropout_apply_bits(float* t, const uint32_t* bits, int rows, int cols, float scale, void* stream) {
+    if (!t || !bits || rows < 0 || cols <= 0 || (cols % 32) != 0) return MIL_EINVAL;
+    const size_t n4 = (size_t)rows * cols / 4;
+    if (n4 == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_dropout_apply_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, bits, n4,
+                       scale);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

@@ -16,6 +16,7 @@ struct HeadBwdArgs {
     const float* loss_bag;      // [B] or NULL
     float* loss_out;            // [1]
     int B, L, C;
+    int accumulate;             // != 0: add to dWf / dbf / loss_out (gradient accumulation over micro-batches)
 };
 static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& a, int blk, float (*red)[64]) {
     const int nlb = (a.L + 63) / 64;
@@ -27,19 +28,23 @@ static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& 
             for (int b = g; b < a.B; b += 4) v += a.dz[b * a.C + c] * a.M[(size_t)b * a.L + j];
         red[g][lane] = v;
         __syncthreads();
-        if (g == 0 && j < a.L) a.dWf[(size_t)c * a.L + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (g == 0 && j < a.L) {
+            float* o = a.dWf + (size_t)c * a.L + j;
+            const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            *o = a.accumulate ? *o + t : t;
+        }
     } else {
         if ((int)threadIdx.x < a.C) {
             const int c = threadIdx.x;
             float v = 0.f;
             for (int b = 0; b < a.B; ++b) v += a.dz[b * a.C + c];
-            a.dbf[c] = v;
+            a.dbf[c] = a.accumulate ? a.dbf[c] + v : v;
         }
         if (a.loss_bag != nullptr && g == 1) {
             float v = 0.f;
             for (int b = lane; b < a.B; b += 64) v += a.loss_bag[b];
             v = wave_allsum(v);
-            if (lane == 0) a.loss_out[0] = v;
+            if (lane == 0) a.loss_out[0] = a.accumulate ? a.loss_out[0] + v : v;
         }
     }
 }
@@ -52,7 +57,8 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
                                                                 int S, int L, float* __restrict__ dWv, float* __restrict__ dbv,
                                                                 float* __restrict__ dWu, float* __restrict__ dbu,
                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate,
-                                                                int head_first = 1 << 30, HeadBwdArgs head = HeadBwdArgs{}) {
+                                                                float wscale, int head_first = 1 << 30,
+                                                                HeadBwdArgs head = HeadBwdArgs{}) {
     if ((int)blockIdx.x >= head_first) {          // appended workgroups: the head's parameter gradients (uniform branch)
         __shared__ float hred[4][64];
         head_bwd_params_block(head, blockIdx.x - head_first, hred);
@@ -75,6 +81,7 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
             for (int e = 0; e < 8; ++e) v += t[e];
         }
         for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
+        v *= wscale;             // train mode: the 1/(1-p) of the patch dropout (x entered the product as keep-masked x)
         const int m = gi >> 7, ii = gi & 127;
         float* dst = (ii < 64 ? dWv + (size_t)(64 * m + ii) * L : dWu + (size_t)(64 * m + ii - 64) * L) + 4 * c4;
         if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);

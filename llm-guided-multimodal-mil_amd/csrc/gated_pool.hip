@@ -27,11 +27,22 @@
 #define GF_NG 384
 
 typedef __attribute__((address_space(3))) void lds_void;
+// all-ones if bit `b` of m is set, else 0 (v_bfe_i32: a one-bit signed field)
+__device__ __forceinline__ unsigned bitmask1(unsigned m, int b) { return (unsigned)__builtin_amdgcn_sbfe((int)m, b, 1); }
+__device__ __forceinline__ float keep_if(float v, unsigned m, int b) {
+    return __uint_as_float(__float_as_uint(v) & bitmask1(m, b));
+}
+// DROP: train mode (ABMIL.py:49).  xbits [R][L/32] keep bits (csrc/dropout.hip); a K-slice is 32 columns = ONE word per
+// row, loaded one slice ahead next to the DMA pieces; the A fragment of lane (r, h) holds k = 8t + 4h + j, so the word is
+// shifted by 4h once and element (t, j) is kept by bit 8t + j (two VALU per element, under the MFMAs).  The survivors'
+// scale 1/(1-p) is applied to the accumulators in the epilogue.
+template <bool DROP>
 __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, const float* __restrict__ Wv,
                                                        const float* __restrict__ bv, const float* __restrict__ Wu,
                                                        const float* __restrict__ bu, const float* __restrict__ wvec,
                                                        const float* __restrict__ battn, float* __restrict__ scores,
-                                                       float* __restrict__ gates, int R, int L) {
+                                                       float* __restrict__ gates, int R, int L,
+                                                       const uint32_t* __restrict__ xbits, float xscale) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * 32];
     float* xs = smem;                      // [2][128][32]
     float* ws = smem + 2 * GF_TM * 32;     // [2][384][32]
@@ -71,6 +82,12 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
     const int nslice = L / GF_BK;
     // (starting each workgroup's K loop at a different slice, to de-correlate the L2 requests for the shared gate
     //  weights, measured no gain: 107.4 vs 106.2 us fp32, 172 vs 171 us bf16 - the slices stay in natural order)
+    const uint32_t* mrow = nullptr;                    // keep bits of this lane's fragment row
+    unsigned mnext = 0;
+    if (DROP) {
+        mrow = xbits + (size_t)min(row0 + 32 * wr + r, R - 1) * nslice;
+        mnext = mrow[0];
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_piece(i, 0, 0);
     __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
@@ -78,6 +95,11 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
     for (int s = 0; s < nslice; ++s) {
         const int buf = s & 1;
         const int k1 = min(s + 1, nslice - 1) * GF_BK;
+        unsigned mcur = 0;
+        if (DROP) {
+            mcur = mnext >> (4 * h);
+            mnext = mrow[min(s + 1, nslice - 1)];
+        }
         const float* xa = xs + (buf * GF_TM + 32 * wr + r) * 32;
         const float* wb = ws + (buf * GF_NG + 32 * 3 * wc + r) * 32;
         f32x4 a[2], b[2][3][2];
@@ -103,11 +125,12 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
                     frag_piece(t + 1, q ^ 1, 2 * j);
                     if (2 * j + 1 < 7) frag_piece(t + 1, q ^ 1, 2 * j + 1);
                 }
+                const float av = DROP ? keep_if(a[q][j], mcur, 8 * t + j) : a[q][j];
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
-                        acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b[q][c][u][j], acc[c][u], 0, 0, 0);
+                        acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[q][c][u][j], acc[c][u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -123,8 +146,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
         const float bvd = bv[d], bud = bu[d], wd = wvec[d];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float v = fast_tanh(acc[c][0][i] + bvd);
-            const float u = fast_sigmoid(acc[c][1][i] + bud);
+            const float v = fast_tanh(DROP ? fmaf(acc[c][0][i], xscale, bvd) : acc[c][0][i] + bvd);
+            const float u = fast_sigmoid(DROP ? fmaf(acc[c][1][i], xscale, bud) : acc[c][1][i] + bud);
             part[i] += wd * v * u;
             if (gates != nullptr) {
                 const int gr = row0 + 32 * wr + mfma32_row(i, h);
@@ -156,11 +179,16 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
 // Optional by-product (Wf != NULL, C <= 4): h[row][c] = x_row . Wf[c], the head's projection of every patch.  The
 // backward then needs no second pass over x: x_i . dM = sum_c dz[bag][c] h[i][c] because dM = dz Wf
 // (k_pool_ds_from_h replaces the 64 MiB read of k_pool_bwd_ds).
+// Train mode: xbits keeps (ABMIL.py:49: the DROPPED x is what gets pooled, :59) - lane l owns columns 4l + 256q, i.e. bits
+// 4 (l & 7).. of word 8q + (l >> 3) of its row; the survivors' scale rides on the softmax weight.  mbits / mscale: the
+// head's Dropout(.25) on the bag embedding (aggregator.py:129) folds into the head rows used for the by-product
+// h[row][c] = x_row . (Wf[c] * keepM[bag] * mscale), so that x_i . dM = sum_c dz_c h[i][c] still holds in the backward.
 template <int NQ>
 __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ x, const float* __restrict__ scores,
                                                       const int32_t* __restrict__ tile_map, float* __restrict__ partials,
                                                       int L, const float* __restrict__ Wf, int C,
-                                                      float* __restrict__ hrow) {
+                                                      float* __restrict__ hrow, const uint32_t* __restrict__ xbits,
+                                                      float xscale, const uint32_t* __restrict__ mbits, float mscale) {
     __shared__ float p_lds[MIL_POOL_TILE];
     __shared__ float ml_lds[2];
     __shared__ __attribute__((aligned(16))) float red[3 * NQ * 256];
@@ -184,19 +212,49 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
     // Rows past the tile end are clamped to its last row and carry weight 0 (p_lds is 0 there): the
     // loop is branch-free, so all 8 x NQ 16-byte loads of a wave are in flight together.
     f32x4 v[MIL_POOL_TILE / 4][NQ];
+    unsigned mk[MIL_POOL_TILE / 4][NQ];
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
         const int rr = min(wave + 4 * i, nrows - 1);
         const float* xr = x + (size_t)(row0 + rr) * L + 4 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+        if (xbits != nullptr) {
+            const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 3);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mk[i][q] = mr[8 * q];
+        }
+    }
+    if (xbits != nullptr) {
+        const int sh = 4 * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < MIL_POOL_TILE / 4; ++i)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned m = mk[i][q] >> sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][q][e] = keep_if(v[i][q][e], m, e);
+            }
+    } else {
+        xscale = 1.0f;
     }
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const float p = p_lds[wave + 4 * i];
+        const float p = p_lds[wave + 4 * i] * xscale;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] += p * v[i][q];
     }
+    // head rows as this tile's bag sees them: x scale and the head's dropout mask folded in
+    const int bag_ = tile_map[4 * t];
+    auto head_row = [&](int c, int q) {
+        f32x4 w = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 256 * q + 4 * lane) * xscale;
+        if (mbits != nullptr) {
+            const unsigned m = mbits[(size_t)bag_ * (L >> 5) + 8 * q + (lane >> 3)] >> (4 * (lane & 7));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = keep_if(w[e], m, e) * mscale;
+        }
+        return w;
+    };
     if (Wf != nullptr && C == 2) {
         // two classes (the usual head): the tile's 8 x 2 dot products of this wave go through ONE 16-value reduction
         float d16[16];
@@ -204,7 +262,7 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
         for (int c = 0; c < 2; ++c) {
             f32x4 wf[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) wf[q] = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 256 * q + 4 * lane);
+            for (int q = 0; q < NQ; ++q) wf[q] = head_row(c, q);
 #pragma unroll
             for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
                 float d = 0.f;
@@ -221,7 +279,7 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
         for (int c = 0; c < C; ++c) {
             f32x4 wf[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) wf[q] = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 256 * q + 4 * lane);
+            for (int q = 0; q < NQ; ++q) wf[q] = head_row(c, q);
 #pragma unroll
             for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
                 float d = 0.f;
@@ -321,23 +379,31 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
                                                      const float* __restrict__ lse, const float* __restrict__ dM,
                                                      const float* __restrict__ cdot,
                                                      const int32_t* __restrict__ tile_map, float* __restrict__ ds,
-                                                     float* __restrict__ dx, int L) {
+                                                     float* __restrict__ dx, int L, const uint32_t* __restrict__ xbits,
+                                                     float xscale) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int bag = tile_map[4 * t], row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
+    if (xbits == nullptr) xscale = 1.0f;
     f32x4 g[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) g[q] = *reinterpret_cast<const f32x4*>(dM + (size_t)bag * L + 256 * q + 4 * lane);
     const float lse_b = lse[bag], c_b = cdot[bag];
     // branch-free loads (rows past the tile end clamp to its last row), guarded stores
     f32x4 v[MIL_POOL_TILE / 4][NQ];
+    unsigned mk[MIL_POOL_TILE / 4][NQ];
     float sc[MIL_POOL_TILE / 4];
+    const int sh = 4 * (lane & 7);
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
         const size_t row = (size_t)(row0 + min(wave + 4 * i, nrows - 1));
         const float* xr = x + row * L + 4 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+        if (xbits != nullptr) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mk[i][q] = xbits[row * (L >> 5) + 8 * q + (lane >> 3)] >> sh;
+        }
         sc[i] = scores[row];
     }
 #pragma unroll
@@ -345,14 +411,22 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
         const int rr = wave + 4 * i;
         float dot = 0.f;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            dot += v[i][q][0] * g[q][0] + v[i][q][1] * g[q][1] + v[i][q][2] * g[q][2] + v[i][q][3] * g[q][3];
-        dot = wave_allsum(dot);
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 xv = v[i][q];
+            if (xbits != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = keep_if(xv[e], mk[i][q], e);
+            }
+            dot += xv[0] * g[q][0] + xv[1] * g[q][1] + xv[2] * g[q][2] + xv[3] * g[q][3];
+        }
+        dot = wave_allsum(dot) * xscale;
         const float a = expf(sc[i] - lse_b);
         if (rr < nrows) {
             const size_t row = (size_t)(row0 + rr);
             if (lane == 0) ds[row] = a * (dot - c_b);
             if (dx != nullptr) {
+                // the pool term of the gradient of the (dropped) rows; the dropout's own backward (mask, scale) is applied
+                // once, by the last writer of dx (k_gate_bwd_dx)
                 float* dr = dx + row * L + 4 * lane;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dr + 256 * q) = a * g[q];
@@ -397,7 +471,7 @@ template <bool XB16, int KG>
 __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict__ xv, const float* __restrict__ gates,
                                                      const float* __restrict__ ds, const float* __restrict__ wvec,
                                                      float* __restrict__ part, float* __restrict__ pbias, int R, int L,
-                                                     int KC, int NJ) {
+                                                     int KC, int NJ, const uint32_t* __restrict__ xbits) {
     __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * 2 * GB_BKR * 128];
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
     float* smem = smem_all + grp * (2 * 2 * GB_BKR * 128);      // this K group's stages
@@ -435,21 +509,25 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
     const int arow = tid >> 4, ad4 = tid & 15;    // gates: rows arow + 16i (i < 2), d = 64m + 4*ad4
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
     f32x4 rx[4], rv[2], ru[2];
+    unsigned rm[4] = {0, 0, 0, 0};   // train mode: keep bits of the staged x chunks (the forward's mask, csrc/dropout.hip)
     float rds[2], rmask[2];      // raw ds value and its validity mask (applied at use, never at load)
     f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
     float acc_ds = 0.f;
 
     // Branch-free staging pieces (rows past the chunk end are clamped to its last row and get ds = 0, so they
     // add nothing): the loop body is one basic block and every piece sits between two MFMA groups.
+    const int LW = L >> 5;
     auto xload = [&](int i, int rs) {
         if (XB16) {
             if (i < 2) {
                 const int gr = max(min(rs + hrow + 16 * i, rend - 1), 0);
                 rh[i] = *reinterpret_cast<const gb_u16x8*>(xh + (size_t)gr * L + j0 + 8 * hc8);
+                if (xbits != nullptr) rm[i] = xbits[(size_t)gr * LW + ((j0 + 8 * hc8) >> 5)];
             }
         } else {
             const int gr = max(min(rs + xrow + 8 * i, rend - 1), 0);
             rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4);
+            if (xbits != nullptr) rm[i] = xbits[(size_t)gr * LW + ((j0 + 4 * xc4) >> 5)];
         }
     };
     auto xwrite = [&](int i, int buf) {
@@ -462,11 +540,22 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
                     lo[e] = __uint_as_float(((unsigned)rh[i][e]) << 16);
                     hi[e] = __uint_as_float(((unsigned)rh[i][4 + e]) << 16);
                 }
+                if (xbits != nullptr) {
+                    const unsigned mm = rm[i] >> (8 * (hc8 & 3));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lo[e] = keep_if(lo[e], mm, e); hi[e] = keep_if(hi[e], mm, 4 + e); }
+                }
                 *reinterpret_cast<f32x4*>(dst) = lo;
                 *reinterpret_cast<f32x4*>(dst + 4) = hi;
             }
         } else {
-            *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = rx[i];
+            f32x4 v = rx[i];
+            if (xbits != nullptr) {
+                const unsigned mm = rm[i] >> (4 * (xc4 & 7));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = keep_if(v[e], mm, e);
+            }
+            *reinterpret_cast<f32x4*>(xb + (buf * GB_BKR + xrow + 8 * i) * 128 + 4 * xc4) = v;
         }
     };
     auto aload = [&](int i, int rs, bool live) {
@@ -656,7 +745,7 @@ static inline int split_plan(int R, int L, int* KC_out) {
     return (R + kc - 1) / kc;
 }
 
-extern "C" int mil_abi_version(void) { return 1; }
+extern "C" int mil_abi_version(void) { return 2; }
 
 // Small batches (the authors train with ONE bag per GPU: R = 1 000 - 15 000 rows): 128-row tiles would leave most CUs
 // idle (8 workgroups for 1024 patches, each walking all of K: the kernel takes its full ~100 us for 1/32 of the
@@ -668,11 +757,13 @@ extern "C" int mil_abi_version(void) { return 1; }
 #define GS_TM 32
 #define GS_LS 36
 #define GS_THREADS 768
+template <bool DROP>
 __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __restrict__ x, const float* __restrict__ Wv,
                                                              const float* __restrict__ bv, const float* __restrict__ Wu,
                                                              const float* __restrict__ bu, const float* __restrict__ wvec,
                                                              const float* __restrict__ battn, float* __restrict__ scores,
-                                                             float* __restrict__ gates, int R, int L) {
+                                                             float* __restrict__ gates, int R, int L,
+                                                             const uint32_t* __restrict__ xbits, float xscale) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (GS_TM + GF_NG) * GS_LS];
     float* xs = smem;                            // [2][32][36]
     float* ws = smem + 2 * GS_TM * GS_LS;        // [2][384][36]
@@ -690,17 +781,28 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
     }
     const int xrow = (tid & 255) >> 3, xch = tid & 7;
     const float* xsrc = x + (size_t)min(row0 + xrow, R - 1) * L + 4 * xch;
+    const uint32_t* msrc = DROP ? xbits + (size_t)min(row0 + xrow, R - 1) * (L / 32) : nullptr;
     const int xdst = xrow * GS_LS + 4 * xch;
     f32x4 wreg[2][4], xreg[2];
+    unsigned mreg[2] = {0, 0};
     auto gload = [&](int set, int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wreg[set][i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
         xreg[set] = *reinterpret_cast<const f32x4*>(xsrc + k0);
+        if (DROP) mreg[set] = msrc[k0 >> 5];                     // a slice = 32 columns = one word of keep bits per row
     };
     auto swrite = [&](int set, int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ws + buf * GF_NG * GS_LS + wdst[i]) = wreg[set][i];
-        if (tid < 256) *reinterpret_cast<f32x4*>(xs + buf * GS_TM * GS_LS + xdst) = xreg[set];
+        if (tid < 256) {
+            f32x4 v = xreg[set];
+            if (DROP) {
+                const unsigned m = mreg[set] >> (4 * xch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = keep_if(v[e], m, e) * xscale;
+            }
+            *reinterpret_cast<f32x4*>(xs + buf * GS_TM * GS_LS + xdst) = v;
+        }
     };
     f32x16 acc;
 #pragma unroll
@@ -796,25 +898,45 @@ static inline int gate_tail_rows(int R, int tiles_per_round) {
     return (tail >= 1 && tail <= MIL_SMALL_ROWS && full >= tiles_per_round && full % tiles_per_round == 0) ? tail : 0;
 }
 
+static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                               const float* w, const float* b, float* scores, float* gates, int R, int L,
+                               const uint32_t* xbits, float xscale, hipStream_t st) {
+    if (xbits)
+        hipLaunchKernelGGL(k_gate_fwd_r32<true>, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b,
+                           scores, gates, R, L, xbits, xscale);
+    else
+        hipLaunchKernelGGL(k_gate_fwd_r32<false>, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b,
+                           scores, gates, R, L, xbits, 1.0f);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                    const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
-                                   void* stream) {
+                                   const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
     if ((R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4) {
         // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
-        hipLaunchKernelGGL(k_gate_fwd_r32, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b, scores,
-                           gates, R, L);
-        MIL_CHECK_LAUNCH();
-        return MIL_OK;
+        return launch_gate_fwd_r32(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xscale, st);
     }
     const int tail = gates != nullptr ? gate_tail_rows(R, MIL_NUM_CU) : 0;       // the tail path keeps V, U in `gates`
     const int Rm = R - tail;
     const int grid = (Rm + GF_TM - 1) / GF_TM;
-    hipLaunchKernelGGL(k_gate_fwd, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L);
+    if (xbits)
+        hipLaunchKernelGGL(k_gate_fwd<true>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
+                           xscale);
+    else
+        hipLaunchKernelGGL(k_gate_fwd<false>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
+                           1.0f);
     MIL_CHECK_LAUNCH();
+    if (tail > 0 && xbits) {
+        // train mode: the few rows beyond whole rounds go through the 32-row kernel (it applies the keep bits while staging)
+        return launch_gate_fwd_r32(x + (size_t)Rm * L, Wv, bv, Wu, bu, w, b, scores + Rm, gates + (size_t)Rm * GF_NG, tail, L,
+                                   xbits + (size_t)Rm * (L / 32), xscale, st);
+    }
     if (tail > 0) {
         const float* xt = x + (size_t)Rm * L;
         float* gt = gates + (size_t)Rm * GF_NG;
@@ -830,23 +952,27 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
 }
 
 static int launch_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
-                               float* partials, const float* Wf, int C, float* hrow, hipStream_t st) {
+                               float* partials, const float* Wf, int C, float* hrow, hipStream_t st,
+                               const uint32_t* xbits = nullptr, float xscale = 1.0f, const uint32_t* mbits = nullptr,
+                               float mscale = 1.0f) {
     if (T <= 0) return MIL_OK;
     switch (L / 256) {
-        case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
-        case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
-        case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
-        default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow); break;
+        case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
+        case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
+        case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
+        default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
     }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_attn_pool_partial_h(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
-                                       float* partials, const float* Wf, int C, float* hrow, void* stream) {
+                                       float* partials, const float* Wf, int C, float* hrow, const uint32_t* xbits,
+                                       float xscale, const uint32_t* mbits, float mscale, void* stream) {
     if (!x || !scores || !tile_map || !partials || !Wf || !hrow) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0 || C <= 0 || C > 4) return MIL_EINVAL;
-    return launch_pool_partial(x, scores, tile_map, T, L, partials, Wf, C, hrow, (hipStream_t)stream);
+    return launch_pool_partial(x, scores, tile_map, T, L, partials, Wf, C, hrow, (hipStream_t)stream, xbits, xscale, mbits,
+                               mscale);
 }
 
 extern "C" int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, const float* hrow, const float* dz,
@@ -860,19 +986,19 @@ extern "C" int mil_attn_pool_bwd_from_h(const float* scores, const float* lse, c
 }
 
 extern "C" int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
-                                     float* partials, void* stream) {
+                                     float* partials, const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !scores || !tile_map || !partials) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
-    return launch_pool_partial(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, (hipStream_t)stream);
+    return launch_pool_partial(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, (hipStream_t)stream, xbits, xscale);
 }
 
 extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_map,
                                  const int32_t* bag_tile_off, int T, int B, int L, float* partials, float* M,
-                                 float* lse, void* stream) {
+                                 float* lse, const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !scores || !tile_map || !bag_tile_off || !partials || !M || !lse) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || B < 0 || T < 0) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = launch_pool_partial(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, st);
+    const int rc = launch_pool_partial(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, st, xbits, xscale);
     if (rc != MIL_OK) return rc;
     if (B > 0) {
         hipLaunchKernelGGL(k_pool_merge, dim3(B, L / 128), dim3(256), 0, st, partials, bag_tile_off, M, lse, L, T);
@@ -883,16 +1009,16 @@ extern "C" int mil_attn_pool_fwd(const float* x, const float* scores, const int3
 
 extern "C" int mil_attn_pool_bwd(const float* x, const float* scores, const float* lse, const float* dM,
                                  const float* cdot, const int32_t* tile_map, int T, int L, float* ds, float* dx,
-                                 void* stream) {
+                                 const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !scores || !lse || !dM || !cdot || !tile_map || !ds) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (L / 256) {
-        case 1: hipLaunchKernelGGL(k_pool_bwd_ds<1>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
-        case 2: hipLaunchKernelGGL(k_pool_bwd_ds<2>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
-        case 3: hipLaunchKernelGGL(k_pool_bwd_ds<3>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
-        default: hipLaunchKernelGGL(k_pool_bwd_ds<4>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L); break;
+        case 1: hipLaunchKernelGGL(k_pool_bwd_ds<1>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L, xbits, xscale); break;
+        case 2: hipLaunchKernelGGL(k_pool_bwd_ds<2>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L, xbits, xscale); break;
+        case 3: hipLaunchKernelGGL(k_pool_bwd_ds<3>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L, xbits, xscale); break;
+        default: hipLaunchKernelGGL(k_pool_bwd_ds<4>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, dx, L, xbits, xscale); break;
     }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
@@ -907,7 +1033,8 @@ extern "C" size_t mil_gate_bwd_workspace_floats(int R, int L) {
 
 // The two launches of mil_gate_bwd_params as separate entry points (bench.py times the MFMA kernel alone).
 extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
-                                     int D, float* workspace, size_t workspace_floats, void* stream) {
+                                     int D, float* workspace, size_t workspace_floats, const uint32_t* xbits,
+                                     void* stream) {
     if (!x || !gates || !ds || !w || !workspace) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
@@ -916,23 +1043,23 @@ extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const f
     const int NJ = L / 128;
     if (split_kg(R, L) == 2)
         hipLaunchKernelGGL((k_gate_bwd_dw<false, 2>), dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, (const void*)x, gates, ds,
-                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ);
+                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ, xbits);
     else
         hipLaunchKernelGGL((k_gate_bwd_dw<false, 1>), dim3(S * 3 * NJ), dim3(256), 0, (hipStream_t)stream, (const void*)x, gates, ds,
-                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ);
+                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ, xbits);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
-                                   float* dw, float* db, int accumulate, void* stream) {
+                                   float* dw, float* db, int accumulate, float xscale, void* stream) {
     if (!workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
     if (L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
     const int S = split_plan(R, L, &kc);
     const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
-                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate);
+                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xscale);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -941,34 +1068,56 @@ extern "C" int mil_gate_bwd_params_head(const float* x, const float* gates, cons
                                         int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
                                         float* dWu, float* dbu, float* dw, float* db, int accumulate, const float* dz,
                                         const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag,
-                                        float* loss_out, void* stream) {
+                                        float* loss_out, const uint32_t* xbits, float xscale, void* stream) {
     if (!dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
     if (B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
-    const int rc = mil_gate_bwd_partials(x, gates, ds, w, R, L, D, workspace, workspace_floats, stream);
+    const int rc = mil_gate_bwd_partials(x, gates, ds, w, R, L, D, workspace, workspace_floats, xbits, stream);
     if (rc != MIL_OK) return rc;
     int kc;
     const int S = split_plan(R, L, &kc);
     const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
     const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
-    const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C};
+    const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
-                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate, nred, head);
+                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate,
+                       xbits ? xscale : 1.0f, nred, head);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// The reduce launch of mil_gate_bwd_params_head alone (split-K fold + the head's parameter gradients as appended
+// workgroups), for a caller that issued mil_gate_bwd_partials itself (csrc/step.hip).
+extern "C" int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                                        float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
+                                        float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                                        void* stream) {
+    if (!workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
+    if (L <= 0 || (L % 128) != 0 || R <= 0 || B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
+    int kc;
+    const int S = split_plan(R, L, &kc);
+    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
+    const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
+                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xscale, nred, head);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
                                    int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
-                                   float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
+                                   float* dWu, float* dbu, float* dw, float* db, int accumulate, const uint32_t* xbits,
+                                   float xscale, void* stream) {
     if (!dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
-    const int rc = mil_gate_bwd_partials(x, gates, ds, w, R, L, D, workspace, workspace_floats, stream);
+    const int rc = mil_gate_bwd_partials(x, gates, ds, w, R, L, D, workspace, workspace_floats, xbits, stream);
     if (rc != MIL_OK) return rc;
-    return mil_gate_bwd_reduce(workspace, R, L, dWv, dbv, dWu, dbu, dw, db, accumulate, stream);
+    return mil_gate_bwd_reduce(workspace, R, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xbits ? xscale : 1.0f, stream);
 }
 
 extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R,
                                        int L, int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
-                                       float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
+                                       float* dWu, float* dbu, float* dw, float* db, int accumulate, const uint32_t* xbits,
+                                       float xscale, void* stream) {
     if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
@@ -981,14 +1130,14 @@ extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, co
     hipStream_t st = (hipStream_t)stream;
     if (split_kg(R, L) == 2)
         hipLaunchKernelGGL((k_gate_bwd_dw<true, 2>), dim3(S * 3 * NJ), dim3(512), 0, st, (const void*)x, gates, ds, w, part, pbias,
-                           R, L, kc, NJ);
+                           R, L, kc, NJ, xbits);
     else
         hipLaunchKernelGGL((k_gate_bwd_dw<true, 1>), dim3(S * 3 * NJ), dim3(256), 0, st, (const void*)x, gates, ds, w, part, pbias,
-                       R, L, kc, NJ);
+                       R, L, kc, NJ, xbits);
     MIL_CHECK_LAUNCH();
     const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
-                       dbu, dw, db, accumulate);
+                       dbu, dw, db, accumulate, xbits ? xscale : 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1004,7 +1153,8 @@ extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, co
 // local k 0..15 = dPreV_d, 16..31 = dPreU_d (d = 16 kk + k), built from (V, U, ds, w) when the slice is written to LDS.
 __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ gates, const float* __restrict__ ds,
                                                      const float* __restrict__ wvec, const float* __restrict__ Wv,
-                                                     const float* __restrict__ Wu, float* __restrict__ dx, int R, int L) {
+                                                     const float* __restrict__ Wu, float* __restrict__ dx, int R, int L,
+                                                     const uint32_t* __restrict__ xbits, float xscale) {
     constexpr int ASZ = 128 * GX_KS, BSZ = 32 * 128;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
     float* as = smem;
@@ -1119,10 +1269,24 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
             float cv[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) cv[i] = o[(size_t)min(rbase + mfma32_row(i, h), R - 1) * L];
+            if (xbits != nullptr) {
+                // this launch is the last writer of dx: the backward of the patch dropout (ABMIL.py:49) is applied here,
+                // dx = keep ? (pool term + gate term) / (1 - p) : 0
+                const int col = j0 + 64 * wj + 32 * b + r;
+                unsigned mw[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int gr = rbase + mfma32_row(i, h);
-                if (gr < R) o[(size_t)gr * L] = cv[i] + acc[a][b][i];
+                for (int i = 0; i < 16; ++i) mw[i] = xbits[(size_t)min(rbase + mfma32_row(i, h), R - 1) * (L >> 5) + (col >> 5)];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int gr = rbase + mfma32_row(i, h);
+                    if (gr < R) o[(size_t)gr * L] = ((mw[i] >> (col & 31)) & 1u) ? (cv[i] + acc[a][b][i]) * xscale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int gr = rbase + mfma32_row(i, h);
+                    if (gr < R) o[(size_t)gr * L] = cv[i] + acc[a][b][i];
+                }
             }
         }
 }
@@ -1131,7 +1295,8 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
 // per row, thread = four columns, d looped (W is L2-resident).
 __global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restrict__ gates, const float* __restrict__ ds,
                                                           const float* __restrict__ wvec, const float* __restrict__ Wv,
-                                                          const float* __restrict__ Wu, float* __restrict__ dx, int L) {
+                                                          const float* __restrict__ Wu, float* __restrict__ dx, int L,
+                                                          const uint32_t* __restrict__ xbits, float xscale) {
     __shared__ float pv[MIL_GATE_D], pu[MIL_GATE_D];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float dsr = ds[row];
@@ -1149,12 +1314,18 @@ __global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restric
             acc += pv[d] * *reinterpret_cast<const f32x4*>(Wv + (size_t)d * L + j) +
                    pu[d] * *reinterpret_cast<const f32x4*>(Wu + (size_t)d * L + j);
         f32x4* o = reinterpret_cast<f32x4*>(dx + (size_t)row * L + j);
-        *o += acc;
+        f32x4 v = *o + acc;
+        if (xbits != nullptr) {
+            const unsigned m = xbits[(size_t)row * (L >> 5) + (j >> 5)] >> (j & 31);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((m >> e) & 1u) ? v[e] * xscale : 0.f;
+        }
+        *o = v;
     }
 }
 
 extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu,
-                                  int R, int L, int D, float* dx, void* stream) {
+                                  int R, int L, int D, float* dx, const uint32_t* xbits, float xscale, void* stream) {
     if (!gates || !ds || !w || !Wv || !Wu || !dx) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
@@ -1163,11 +1334,11 @@ extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const flo
     const int tail = per_round > 0 ? gate_tail_rows(R, per_round) : 0;
     const int Rm = R - tail;
     const int grid = ((Rm + 127) / 128) * (L / 128);
-    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, st, gates, ds, w, Wv, Wu, dx, Rm, L);
+    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, st, gates, ds, w, Wv, Wu, dx, Rm, L, xbits, xscale);
     MIL_CHECK_LAUNCH();
     if (tail > 0) {
         hipLaunchKernelGGL(k_gate_bwd_dx_tail, dim3(tail), dim3(128), 0, st, gates + (size_t)Rm * GF_NG, ds + Rm, w, Wv, Wu,
-                           dx + (size_t)Rm * L, L);
+                           dx + (size_t)Rm * L, L, xbits ? xbits + (size_t)Rm * (L >> 5) : nullptr, xscale);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;

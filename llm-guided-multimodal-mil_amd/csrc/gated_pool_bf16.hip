@@ -802,7 +802,7 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, c
     MIL_CHECK_LAUNCH();
     const int nthreads = HB_NG * (L / 4) + 3 * 192 + 1;
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
-                       dbu, dw, db, accumulate);
+                       dbu, dw, db, accumulate, 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void k_head_bwd_dm(const float* __restrict__ d
 __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict__ dz_or_dp, const float* __restrict__ p,
                                                          const float* __restrict__ M, float* __restrict__ dWf,
                                                          float* __restrict__ dbf, int B, int L, int C,
-                                                         const float* __restrict__ loss_bag, float* __restrict__ loss_out) {
+                                                         const float* __restrict__ loss_bag, float* __restrict__ loss_out,
+                                                         int accumulate) {
     __shared__ float red[4][64];
     const int nlb = (L + 63) / 64;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
             }
         red[g][lane] = v;
         __syncthreads();
-        if (g == 0 && j < L) dWf[(size_t)c * L + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (g == 0 && j < L) {
+            const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            dWf[(size_t)c * L + j] = accumulate ? dWf[(size_t)c * L + j] + t : t;
+        }
     } else {
         // bias gradients: thread t < C sums over the bags; the loss: wave 1 sums loss_bag
         if ((int)threadIdx.x < C) {
@@ -103,13 +107,13 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
                 if (p != nullptr) { const float pp = p[b * C + c]; gz = gz * pp * (1.0f - pp); }
                 v += gz;
             }
-            dbf[c] = v;
+            dbf[c] = accumulate ? dbf[c] + v : v;
         }
         if (loss_bag != nullptr && g == 1) {
             float v = 0.f;
             for (int b = lane; b < B; b += 64) v += loss_bag[b];
             v = wave_allsum(v);
-            if (lane == 0) loss_out[0] = v;
+            if (lane == 0) loss_out[0] = accumulate ? loss_out[0] + v : v;
         }
     }
 }
@@ -180,6 +184,13 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const f
     }
 }
 __global__ void k_step_inc(int* step_dev) { *step_dev += 1; }
+__global__ void k_counter_add(int* ctr, int v) { *ctr += v; }
+extern "C" int mil_counter_add(int32_t* counter, int v, void* stream) {
+    if (!counter) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, v);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fused per-bag tail of the forward and head of the backward (one workgroup per bag):
@@ -198,15 +209,21 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
                                                          float* __restrict__ dM, float* __restrict__ cdot,
                                                          const int32_t* __restrict__ tile_map,
                                                          const float* __restrict__ scores, const float* __restrict__ hrow,
-                                                         float* __restrict__ ds) {
+                                                         float* __restrict__ ds, const uint32_t* __restrict__ mbits,
+                                                         float mscale, float* __restrict__ Mdrop) {
+    // mbits [B][L/32]: keep bits of the head's Dropout(.25) on the bag embedding (aggregator.py:129; train mode).  M stays
+    // the un-dropped ABMIL output, Mdrop = M * keep * mscale feeds the head (and dWf); dM = d loss / d M carries the mask.
     __shared__ float red[4];
     __shared__ float scale_lds[1024];
     __shared__ __attribute__((aligned(16))) float m_lds[1024];
     __shared__ __attribute__((aligned(16))) float part_lds[4 * 1024];
+    __shared__ float keep_lds[1024];
     __shared__ float dzs[32];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
     const float* ml = partials + (size_t)T * L;
+    for (int j = tid; j < L; j += 256)
+        keep_lds[j] = mbits == nullptr ? 1.0f : (((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f);
     // global max / normaliser over the bag's tiles
     float m = -INFINITY;
     for (int t = t0 + tid; t < t1; t += 256) m = fmaxf(m, ml[2 * t]);
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
         v *= inv;
         m_lds[j] = v;
         M[(size_t)b * L + j] = v;
+        if (Mdrop != nullptr) Mdrop[(size_t)b * L + j] = v * keep_lds[j];
     }
     if (tid == 0) lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
     __syncthreads();
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     float lossacc = 0.f;
     for (int c = 0; c < C; ++c) {
         float v = 0.f;
-        for (int j = tid; j < L; j += 256) v += m_lds[j] * Wf[(size_t)c * L + j];
+        for (int j = tid; j < L; j += 256) v += m_lds[j] * keep_lds[j] * Wf[(size_t)c * L + j];
         v = block_allsum_256(v, red);
         if (tid == 0) {
             const float zz = v + bf[c];
@@ -279,6 +297,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     for (int j = tid; j < L; j += 256) {
         float v = 0.f;
         for (int c = 0; c < C; ++c) v += dzs[c] * Wf[(size_t)c * L + j];
+        v *= keep_lds[j];
         dM[(size_t)b * L + j] = v;
         dot += v * m_lds[j];
     }
@@ -304,14 +323,14 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
                                    const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                                    float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
                                    const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
-                                   void* stream) {
+                                   const uint32_t* mbits, float mscale, float* Mdrop, void* stream) {
     if (!partials || !bag_tile_off || !Wf || !bf || !M || !lse || !z || !p) return MIL_EINVAL;
     if (y && (!loss_sum || !dz || !dM || !cdot)) return MIL_EINVAL;
     if (ds && (!y || !tile_map || !scores || !hrow)) return MIL_EINVAL;
     if (!(L == 256 || L == 512 || L == 768 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     hipLaunchKernelGGL(k_pool_merge_head, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
-                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds);
+                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -343,19 +362,23 @@ extern "C" int mil_head_bwd(const float* dz_or_dp, const float* p, const float* 
     hipLaunchKernelGGL(k_head_bwd_dm, dim3(B), dim3(256), 0, st, dz_or_dp, p, M, Wf, dM, cdot, L, C);
     MIL_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_head_bwd_params, dim3(C * ((L + 63) / 64) + 1), dim3(256), 0, st, dz_or_dp, p, M, dWf, dbf, B, L,
-                       C, (const float*)nullptr, (float*)nullptr);
+                       C, (const float*)nullptr, (float*)nullptr, 0);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
-extern "C" int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
-                                   const float* loss_bag, float* loss_out, void* stream) {
+extern "C" int mil_head_bwd_params_acc(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
+                                       const float* loss_bag, float* loss_out, int accumulate, void* stream) {
     if (!dz || !M || !dWf || !dbf) return MIL_EINVAL;
     if (B <= 0 || L <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
     hipLaunchKernelGGL(k_head_bwd_params, dim3(C * ((L + 63) / 64) + 1), dim3(256), 0, (hipStream_t)stream, dz,
-                       (const float*)nullptr, M, dWf, dbf, B, L, C, loss_bag, loss_out);
+                       (const float*)nullptr, M, dWf, dbf, B, L, C, loss_bag, loss_out, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+extern "C" int mil_head_bwd_params(const float* dz, const float* M, float* dWf, float* dbf, int B, int L, int C,
+                                   const float* loss_bag, float* loss_out, void* stream) {
+    return mil_head_bwd_params_acc(dz, M, dWf, dbf, B, L, C, loss_bag, loss_out, 0, stream);
 }
 
 // small buffers (the image-only step: 0.2 M parameters) want many workgroups, large ones (fusion: 9.8 M) loads in flight

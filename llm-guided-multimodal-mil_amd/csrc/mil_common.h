@@ -10,7 +10,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MIL_WAVE 64
-#define MIL_NUM_CU 256
+// Compute units of the current device, read once per process (256 on MI355X).  Host code only: grid sizing,
+// split-K cost models, tile-quantisation thresholds.
+static inline int mil_num_cu() {
+    static int cached = 0;
+    if (cached <= 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cached = n;
+        else
+            return 256;                     // no device visible (host-only sizing queries): the MI355X value
+    }
+    return cached;
+}
+#define MIL_NUM_CU (mil_num_cu())
 
 #define MIL_CHECK_LAUNCH()                               \
     do {                                                 \

@@ -1,0 +1,162 @@
+// The image-only training step as one host call (include/mil_hip.h: mil_image_only_step).
+//
+// Reference: train_ddp.py:295-348 runs, per step, generator(x) -> criterion -> zero_grad -> backward -> optimizer.step
+// through the Python interpreter and ATen's dispatcher (dozens of implicit launches).  Here the step is a fixed
+// sequence of eight launches issued from C on the caller's stream; nothing is allocated, nothing synchronises, so the
+// call is capture-safe (the host mirror replays it from a hipGraph for tiny one-bag steps) and costs one foreign call.
+#include "mil_common.h"
+
+static int step_check(const mil_image_only_step* a) {
+    if (!a || a->struct_bytes != sizeof(mil_image_only_step)) return MIL_EINVAL;
+    if (!a->x || !a->tile_map || !a->bag_tile_off) return MIL_EINVAL;
+    if (a->R < 0 || a->B < 0 || a->T < 0 || a->L <= 0 || a->C <= 0 || a->C > 32) return MIL_EINVAL;
+    if (!a->Wv || !a->bv || !a->Wu || !a->bu || !a->w || !a->b || !a->Wf || !a->bf) return MIL_EINVAL;
+    if (!a->scores || !a->partials || !a->M || !a->lse || !a->logits || !a->prob) return MIL_EINVAL;
+    if (a->x_bf16 && (!a->Wv16 || !a->Wu16)) return MIL_EINVAL;
+    if (a->x_bf16 && a->train) return MIL_EINVAL;               // in-kernel dropout exists on the fp32 path only
+    if (a->train && (!a->xbits || !a->mbits || !a->Mdrop)) return MIL_EINVAL;
+    if (a->y) {
+        if (!a->gates || !a->ds || !a->loss_bag || !a->dz || !a->dM || !a->cdot) return MIL_EINVAL;
+    }
+    return MIL_OK;
+}
+
+extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* stream) {
+    int rc = step_check(a);
+    if (rc != MIL_OK) return rc;
+    const uint32_t st = a->stages;
+    const bool train = a->train != 0;
+    const bool grads = a->y != nullptr;
+    const float xscale = train ? 2.0f : 1.0f;                   // 1 / (1 - 0.5)   ABMIL.py:26
+    const float mscale = train ? 1.0f / 0.75f : 1.0f;           // 1 / (1 - 0.25)  aggregator.py:129
+    const uint32_t* xbits = train ? a->xbits : nullptr;
+    const uint32_t* mbits = train ? a->mbits : nullptr;
+    const bool use_h = a->hrow != nullptr && grads && a->C <= 4;
+
+    if ((st & MIL_STAGE_DROPBITS) && train) {
+        rc = mil_dropout_keep_bits(a->xbits, a->R, a->L, 0.5f, a->seed, a->offset, a->offset_dev, stream);
+        if (rc != MIL_OK) return rc;
+        // a second key for the head's mask: same stream position, different Philox key
+        rc = mil_dropout_keep_bits(a->mbits, a->B, a->L, 0.25f, a->seed ^ 0x9E3779B97F4A7C15ull, a->offset, a->offset_dev,
+                                   stream);
+        if (rc != MIL_OK) return rc;
+    }
+    if (st & MIL_STAGE_GATE_FWD) {
+        float* gates = grads ? a->gates : nullptr;
+        if (a->x_bf16)
+            rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores, gates,
+                                          a->R, a->L, MIL_GATE_D, stream);
+        else
+            rc = mil_gate_scores_fwd((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R, a->L,
+                                     MIL_GATE_D, xbits, xscale, stream);
+        if (rc != MIL_OK) return rc;
+    }
+    if (st & MIL_STAGE_POOL) {
+        if (a->x_bf16) {
+            rc = use_h ? mil_attn_pool_partial_h_bf16((const uint16_t*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials,
+                                                      a->Wf, a->C, a->hrow, stream)
+                       : mil_attn_pool_partial_bf16((const uint16_t*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials,
+                                                    stream);
+        } else {
+            rc = use_h ? mil_attn_pool_partial_h((const float*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials, a->Wf,
+                                                 a->C, a->hrow, xbits, xscale, mbits, mscale, stream)
+                       : mil_attn_pool_partial((const float*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials, xbits,
+                                               xscale, stream);
+        }
+        if (rc != MIL_OK) return rc;
+    }
+    if (st & MIL_STAGE_TAIL) {
+        rc = mil_pool_merge_head(a->partials, a->bag_tile_off, a->T, a->B, a->L, a->Wf, a->bf, a->C, a->y, a->loss_scale, a->M,
+                                 a->lse, a->logits, a->prob, grads ? a->loss_bag : nullptr, grads ? a->dz : nullptr,
+                                 grads ? a->dM : nullptr, grads ? a->cdot : nullptr, use_h ? a->tile_map : nullptr,
+                                 use_h ? a->scores : nullptr, use_h ? a->hrow : nullptr, use_h ? a->ds : nullptr, mbits, mscale,
+                                 train ? a->Mdrop : nullptr, stream);
+        if (rc != MIL_OK) return rc;
+        if (grads && !use_h) {          // no head projections: the score gradient takes a second pass over x
+            rc = a->x_bf16 ? mil_attn_pool_bwd_bf16((const uint16_t*)a->x, a->scores, a->lse, a->dM, a->cdot, a->tile_map, a->T,
+                                                    a->L, a->ds, stream)
+                           : mil_attn_pool_bwd((const float*)a->x, a->scores, a->lse, a->dM, a->cdot, a->tile_map, a->T, a->L,
+                                               a->ds, nullptr, xbits, xscale, stream);
+            if (rc != MIL_OK) return rc;
+        }
+    }
+    if (!grads) return MIL_OK;
+    if (!a->dWv || !a->dbv || !a->dWu || !a->dbu || !a->dw || !a->db || !a->dWf || !a->dbf || !a->loss_out || !a->dw_ws)
+        return (st & (MIL_STAGE_GATE_BWD | MIL_STAGE_REDUCE)) ? MIL_EINVAL : MIL_OK;
+    const float* Mhead = train ? a->Mdrop : a->M;               // the M the head saw (dWf = dz^T M)
+    if (a->x_bf16) {
+        // bf16 storage: one entry point per weight-gradient flavour (its launch pair), then the head's parameter gradients
+        if (st & (MIL_STAGE_GATE_BWD | MIL_STAGE_REDUCE)) {
+            if (a->bf16_grad_mfma && (a->L % 256) == 0)
+                rc = mil_gate_bwd_params_bf16((const uint16_t*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
+                                              (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
+                                              a->accumulate, stream);
+            else
+                rc = mil_gate_bwd_params_x16((const uint16_t*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
+                                             (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
+                                             a->accumulate, nullptr, 1.0f, stream);
+            if (rc != MIL_OK) return rc;
+        }
+        if (st & MIL_STAGE_REDUCE) {
+            rc = mil_head_bwd_params_acc(a->dz, Mhead, a->dWf, a->dbf, a->B, a->L, a->C, a->loss_bag, a->loss_out, a->accumulate,
+                                         stream);
+            if (rc != MIL_OK) return rc;
+        }
+    } else {
+        if (st & MIL_STAGE_GATE_BWD) {
+            rc = mil_gate_bwd_partials((const float*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
+                                       (size_t)a->dw_ws_floats, xbits, stream);
+            if (rc != MIL_OK) return rc;
+        }
+        if (st & MIL_STAGE_REDUCE) {
+            rc = mil_gate_bwd_reduce_head(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db, a->accumulate,
+                                          xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag, a->loss_out, stream);
+            if (rc != MIL_OK) return rc;
+        }
+    }
+    if (st & MIL_STAGE_ADAM) {
+        if (!a->param_flat || !a->grad_flat || !a->exp_avg || !a->exp_avg_sq) return MIL_EINVAL;
+        if (a->adam_step_dev)
+            rc = mil_adam_step_counted(a->param_flat, a->grad_flat, a->exp_avg, a->exp_avg_sq, (size_t)a->n_param,
+                                       a->adam_step_dev, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale,
+                                       stream);
+        else
+            rc = mil_adam_step(a->param_flat, a->grad_flat, a->exp_avg, a->exp_avg_sq, (size_t)a->n_param, a->adam_step, a->lr,
+                               a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale, stream);
+        if (rc != MIL_OK) return rc;
+        if (a->x_bf16) {
+            // the bf16 shadows of the gate weights follow their fp32 masters here, once per update, instead of being
+            // re-cast in front of every forward (two launches per pass in round 1)
+            rc = mil_cast_bf16(a->Wv, const_cast<uint16_t*>(a->Wv16), (size_t)MIL_GATE_D * a->L, stream);
+            if (rc != MIL_OK) return rc;
+            rc = mil_cast_bf16(a->Wu, const_cast<uint16_t*>(a->Wu16), (size_t)MIL_GATE_D * a->L, stream);
+            if (rc != MIL_OK) return rc;
+        }
+    }
+    return MIL_OK;
+}
+
+extern "C" int mil_image_only_step_time(const mil_image_only_step* a, uint32_t stages, int warm, int iters, float* ms_out,
+                                        void* stream) {
+    if (!a || !ms_out || iters <= 0 || warm < 0) return MIL_EINVAL;
+    mil_image_only_step s = *a;
+    s.stages = stages;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return MIL_EINVAL;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MIL_EINVAL; }
+    int rc = MIL_OK;
+    for (int i = 0; i < warm && rc == MIL_OK; ++i) rc = mil_image_only_step_run(&s, stream);
+    if (rc == MIL_OK) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == MIL_OK; ++i) rc = mil_image_only_step_run(&s, stream);
+        (void)hipEventRecord(e1, st);
+        const hipError_t e = hipEventSynchronize(e1);
+        if (rc == MIL_OK && e != hipSuccess) rc = (int)e;
+        float ms = 0.f;
+        if (rc == MIL_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *ms_out = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

@@ -26,6 +26,7 @@ class CLIP(nn.Module):
         # opt-in: split-bf16 products for the frozen tower's GEMMs (clip/model.py: set_gemm_pieces); default fp32
         self.model.set_gemm_pieces(int(getattr(args, "clip_gemm_pieces", 0)))
         self._cache = {}
+        self.cache_limit = int(getattr(args, "cache_text_limit", 65536))     # notes kept (2 KB each)
         if getattr(args, "learnablePrompt", 0):
             self.ctx_dim = self.model.ln_final.weight.shape[0]
             n_prompts = len(getattr(args, "clinical_features", [])) + 1                   # CLIP.py:19
@@ -69,6 +70,8 @@ class CLIP(nn.Module):
             idx = torch.tensor(list(first.values()), device=x.device)
             with torch.no_grad():
                 new = self.model.encode_text(flat.index_select(0, idx))
+            if len(self._cache) + len(first) > self.cache_limit:      # bounded: a cohort larger than the limit re-encodes
+                self._cache = {k: v for k, v in self._cache.items() if k in set(keys)}
             for j, k in enumerate(first.keys()):
                 self._cache[k] = new[j].clone()
         return torch.stack([self._cache[k] for k in keys], 0).reshape(B, P, -1)

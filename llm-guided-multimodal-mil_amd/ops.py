@@ -37,20 +37,50 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- plain operators
-def gate_scores_fwd(x, Wv, bv, Wu, bu, w, b, save_gates: bool = True):
-    """scores [R], gates [R, 384] (or None).  ABMIL.py:52-54."""
+X_DROP_P, X_DROP_SCALE = 0.5, 2.0            # ABMIL.py:26,49
+M_DROP_P, M_DROP_SCALE = 0.25, 1.0 / 0.75    # aggregator.py:129
+
+
+def dropout_keep_bits(rows: int, cols: int, p_drop: float, seed: int, offset: int, device, out=None, offset_dev=None):
+    """uint32-packed keep mask [rows, cols // 32] (stored as int32) from Philox4x32-10 (csrc/dropout.hip)."""
+    if cols % 32:
+        raise _lib.MilHipError("dropout_keep_bits: cols must be a multiple of 32")
+    if out is None:
+        out = torch.empty((rows, cols // 32), device=device, dtype=torch.int32)
+    rc = _lib.lib().mil_dropout_keep_bits(_p(out), rows, cols, float(p_drop), int(seed) & (2 ** 64 - 1),
+                                          int(offset) & (2 ** 64 - 1), _p(offset_dev), _stream())
+    _lib.check(rc, "mil_dropout_keep_bits")
+    return out
+
+
+def counter_add(counter, v: int = 1):
+    """counter[0] += v on the current stream (device int32)."""
+    rc = _lib.lib().mil_counter_add(_p(counter), int(v), _stream())
+    _lib.check(rc, "mil_counter_add")
+
+
+def dropout_apply_bits(t, bits, scale: float):
+    """t = keep ? t * scale : 0 in place."""
+    rows, cols = t.shape
+    rc = _lib.lib().mil_dropout_apply_bits(_p(t), _p(bits), rows, cols, float(scale), _stream())
+    _lib.check(rc, "mil_dropout_apply_bits")
+    return t
+
+
+def gate_scores_fwd(x, Wv, bv, Wu, bu, w, b, save_gates: bool = True, xbits=None, xscale: float = 1.0):
+    """scores [R], gates [R, 384] (or None).  ABMIL.py:52-54.  xbits: keep bits of the patch dropout (train mode)."""
     x = _f32c(x, "x")
     R, L = x.shape
     scores = torch.empty(R, device=x.device, dtype=torch.float32)
     gates = torch.empty((R, 2 * GATE_D), device=x.device, dtype=torch.float32) if save_gates else None
     rc = _lib.lib().mil_gate_scores_fwd(_p(x), _p(_f32c(Wv, "Wv")), _p(_f32c(bv, "bv")), _p(_f32c(Wu, "Wu")),
                                         _p(_f32c(bu, "bu")), _p(_f32c(w, "w")), _p(_f32c(b, "b")), _p(scores),
-                                        _p(gates), R, L, Wv.shape[0], _stream())
+                                        _p(gates), R, L, Wv.shape[0], _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_gate_scores_fwd")
     return scores, gates
 
 
-def attn_pool_fwd(x, scores, layout: BagLayout):
+def attn_pool_fwd(x, scores, layout: BagLayout, xbits=None, xscale: float = 1.0):
     """M [B, L], lse [B].  ABMIL.py:56-59 per bag."""
     x = _f32c(x, "x")
     R, L = x.shape
@@ -60,24 +90,25 @@ def attn_pool_fwd(x, scores, layout: BagLayout):
     M = torch.empty((layout.B, L), device=x.device, dtype=torch.float32)
     lse = torch.empty(layout.B, device=x.device, dtype=torch.float32)
     rc = _lib.lib().mil_attn_pool_fwd(_p(x), _p(scores), _p(layout.tile_map), _p(layout.bag_tile_off), layout.T,
-                                      layout.B, L, _p(partials), _p(M), _p(lse), _stream())
+                                      layout.B, L, _p(partials), _p(M), _p(lse), _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_attn_pool_fwd")
     return M, lse
 
 
-def attn_pool_partial(x, scores, layout: BagLayout):
+def attn_pool_partial(x, scores, layout: BagLayout, xbits=None, xscale: float = 1.0):
     """Tile partials only ([T*L] weighted sums then [T*2] (max, sum) pairs); merged by pool_merge_head."""
     x = _f32c(x, "x")
     R, L = x.shape
     if R != layout.R:
         raise _lib.MilHipError(f"attn_pool_partial: x has {R} rows but the bag layout covers {layout.R}")
     partials = torch.empty(layout.T * (L + 2), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().mil_attn_pool_partial(_p(x), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials), _stream())
+    rc = _lib.lib().mil_attn_pool_partial(_p(x), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials), _p(xbits),
+                                          float(xscale), _stream())
     _lib.check(rc, "mil_attn_pool_partial")
     return partials
 
 
-def attn_pool_partial_h(x, scores, layout: BagLayout, Wf):
+def attn_pool_partial_h(x, scores, layout: BagLayout, Wf, xbits=None, xscale: float = 1.0, mbits=None, mscale: float = 1.0):
     """Tile partials plus hrow [R, C] = x Wf^T (head projection of every patch; lets the backward skip x)."""
     x = _f32c(x, "x")
     R, L = x.shape
@@ -85,7 +116,8 @@ def attn_pool_partial_h(x, scores, layout: BagLayout, Wf):
     partials = torch.empty(layout.T * (L + 2), device=x.device, dtype=torch.float32)
     hrow = torch.empty((R, C), device=x.device, dtype=torch.float32)
     rc = _lib.lib().mil_attn_pool_partial_h(_p(x), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials),
-                                            _p(_f32c(Wf, "Wf")), C, _p(hrow), _stream())
+                                            _p(_f32c(Wf, "Wf")), C, _p(hrow), _p(xbits), float(xscale), _p(mbits),
+                                            float(mscale), _stream())
     _lib.check(rc, "mil_attn_pool_partial_h")
     return partials, hrow
 
@@ -98,7 +130,8 @@ def attn_pool_bwd_from_h(scores, lse, hrow, dz, cdot, layout: BagLayout):
     return ds
 
 
-def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0, scores=None, hrow=None):
+def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0, scores=None, hrow=None,
+                    mbits=None, mscale: float = 1.0):
     """Fused per-bag tail: returns dict(M, lse, logits, prob[, loss_bag, dz, dM, cdot[, ds]]); with labels it also
     produces each bag's scaled BCE loss and the head's backward inputs for the pool, and with the forward's head
     projections `hrow` (attn_pool_partial_h) the score gradient ds of every row as well."""
@@ -110,12 +143,15 @@ def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: 
                    cdot=torch.empty(B, device=dev), loss_bag=torch.empty(B, device=dev))
         if hrow is not None and scores is not None:
             out["ds"] = torch.empty(scores.shape[0], device=dev)
+    if mbits is not None:
+        out["Mdrop"] = torch.empty((B, L), device=dev)
     rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
                                         _p(_f32c(bf, "bf")), C, _p(y), float(scale), _p(out["M"]), _p(out["lse"]),
                                         _p(out["logits"]), _p(out["prob"]), _p(out.get("loss_bag")), _p(out.get("dz")),
                                         _p(out.get("dM")), _p(out.get("cdot")),
                                         _p(layout.tile_map) if "ds" in out else None, _p(scores) if "ds" in out else None,
-                                        _p(hrow) if "ds" in out else None, _p(out.get("ds")), _stream())
+                                        _p(hrow) if "ds" in out else None, _p(out.get("ds")), _p(mbits), float(mscale),
+                                        _p(out.get("Mdrop")), _stream())
     _lib.check(rc, "mil_pool_merge_head")
     return out
 
@@ -173,20 +209,20 @@ def rowdot(a, c):
     return out
 
 
-def attn_pool_bwd(x, scores, lse, dM, cdot, layout: BagLayout, want_dx: bool):
+def attn_pool_bwd(x, scores, lse, dM, cdot, layout: BagLayout, want_dx: bool, xbits=None, xscale: float = 1.0):
     """ds [R] and, if requested, the pool term of dx ([R, L] = A_i dM)."""
     x = _f32c(x, "x")
     R, L = x.shape
     ds = torch.empty(R, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x) if want_dx else None
     rc = _lib.lib().mil_attn_pool_bwd(_p(x), _p(scores), _p(lse), _p(_f32c(dM, "dM")), _p(cdot), _p(layout.tile_map),
-                                      layout.T, L, _p(ds), _p(dx), _stream())
+                                      layout.T, L, _p(ds), _p(dx), _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_attn_pool_bwd")
     return ds, dx
 
 
 def gate_bwd_params(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False,
-                    workspace: Optional[torch.Tensor] = None):
+                    workspace: Optional[torch.Tensor] = None, xbits=None, xscale: float = 1.0):
     x = _f32c(x, "x")
     R, L = x.shape
     need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
@@ -194,13 +230,13 @@ def gate_bwd_params(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: boo
         workspace = torch.empty(need, device=x.device, dtype=torch.float32)
     rc = _lib.lib().mil_gate_bwd_params(_p(x), _p(gates), _p(ds), _p(_f32c(w, "w")), R, L, GATE_D, _p(workspace),
                                         workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
-                                        1 if accumulate else 0, _stream())
+                                        1 if accumulate else 0, _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_gate_bwd_params")
     return workspace
 
 
 def gate_bwd_params_head(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, dz, M, dWf, dbf, loss_bag=None, loss_out=None,
-                         workspace: Optional[torch.Tensor] = None):
+                         workspace: Optional[torch.Tensor] = None, xbits=None, xscale: float = 1.0):
     """gate_bwd_params + head_bwd_params in two launches instead of three: the head's parameter gradients are computed by
     workgroups appended to the reduce launch (mil_gate_bwd_params_head)."""
     x = _f32c(x, "x")
@@ -213,15 +249,16 @@ def gate_bwd_params_head(x, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, dz, M, dWf
         raise _lib.MilHipError("gate_bwd_params_head: the bag embeddings must have the gate's input width")
     rc = _lib.lib().mil_gate_bwd_params_head(_p(x), _p(gates), _p(ds), _p(_f32c(w, "w")), R, L, GATE_D, _p(workspace),
                                              workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db), 0,
-                                             _p(dz), _p(M), _p(dWf), _p(dbf), B, C, _p(loss_bag), _p(loss_out), _stream())
+                                             _p(dz), _p(M), _p(dWf), _p(dbf), B, C, _p(loss_bag), _p(loss_out), _p(xbits),
+                                             float(xscale), _stream())
     _lib.check(rc, "mil_gate_bwd_params_head")
     return workspace
 
 
-def gate_bwd_input(gates, ds, w, Wv, Wu, dx):
+def gate_bwd_input(gates, ds, w, Wv, Wu, dx, xbits=None, xscale: float = 1.0):
     R, L = dx.shape
     rc = _lib.lib().mil_gate_bwd_input(_p(gates), _p(ds), _p(_f32c(w, "w")), _p(_f32c(Wv, "Wv")), _p(_f32c(Wu, "Wu")),
-                                       R, L, GATE_D, _p(dx), _stream())
+                                       R, L, GATE_D, _p(dx), _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_gate_bwd_input")
     return dx
 
@@ -251,12 +288,13 @@ def sgd_step(param, grad, lr: float = 1e-3, weight_decay: float = 1e-7, grad_sca
 # --------------------------------------------------------------------------- autograd wrappers
 class _GatedAttentionPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, Wv, bv, Wu, bu, w, b, layout: BagLayout):
+    def forward(ctx, x, Wv, bv, Wu, bu, w, b, layout: BagLayout, xbits=None):
         x = _f32c(x, "x")
         need_grad = any(ctx.needs_input_grad[:7])
-        scores, gates = gate_scores_fwd(x, Wv, bv, Wu, bu, w.reshape(-1), b, save_gates=need_grad)
-        M, lse = attn_pool_fwd(x, scores, layout)
-        ctx.layout = layout
+        xs = X_DROP_SCALE if xbits is not None else 1.0
+        scores, gates = gate_scores_fwd(x, Wv, bv, Wu, bu, w.reshape(-1), b, save_gates=need_grad, xbits=xbits, xscale=xs)
+        M, lse = attn_pool_fwd(x, scores, layout, xbits=xbits, xscale=xs)
+        ctx.layout, ctx.xbits, ctx.xs = layout, xbits, xs
         ctx.save_for_backward(x, Wv, Wu, w, scores, gates if gates is not None else torch.empty(0, device=x.device), lse, M)
         ctx.mark_non_differentiable(scores)
         return M, scores
@@ -267,7 +305,8 @@ class _GatedAttentionPool(torch.autograd.Function):
         dM = _f32c(dM, "dM")
         cdot = rowdot(M, dM)
         want_dx = ctx.needs_input_grad[0]
-        ds, dx = attn_pool_bwd(x, scores, lse, dM, cdot, ctx.layout, want_dx)
+        xbits, xs = ctx.xbits, ctx.xs
+        ds, dx = attn_pool_bwd(x, scores, lse, dM, cdot, ctx.layout, want_dx, xbits=xbits, xscale=xs)
         dWv = torch.empty_like(Wv)
         dWu = torch.empty_like(Wu)
         dbv = torch.empty(GATE_D, device=x.device, dtype=torch.float32)
@@ -275,15 +314,16 @@ class _GatedAttentionPool(torch.autograd.Function):
         dw = torch.empty_like(dbv)
         db = torch.empty(1, device=x.device, dtype=torch.float32)
         wflat = w.reshape(-1)
-        gate_bwd_params(x, gates, ds, wflat, dWv, dbv, dWu, dbu, dw, db)
+        gate_bwd_params(x, gates, ds, wflat, dWv, dbv, dWu, dbu, dw, db, xbits=xbits, xscale=xs)
         if want_dx:
-            gate_bwd_input(gates, ds, wflat, Wv, Wu, dx)
-        return dx, dWv, dbv, dWu, dbu, dw.reshape(w.shape), db, None
+            gate_bwd_input(gates, ds, wflat, Wv, Wu, dx, xbits=xbits, xscale=xs)      # also applies the dropout backward
+        return dx, dWv, dbv, dWu, dbu, dw.reshape(w.shape), db, None, None
 
 
-def gated_attention_pool(x, Wv, bv, Wu, bu, w, b, layout: BagLayout) -> Tuple[torch.Tensor, torch.Tensor]:
-    """M [B, L] (differentiable) and the raw attention scores [R] (not differentiable)."""
-    return _GatedAttentionPool.apply(x, Wv, bv, Wu, bu, w, b, layout)
+def gated_attention_pool(x, Wv, bv, Wu, bu, w, b, layout: BagLayout, xbits=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """M [B, L] (differentiable) and the raw attention scores [R] (not differentiable).  xbits: keep bits of the
+    patch dropout (train mode, ABMIL.py:49): the kernels read x through the mask, no dropped copy is made."""
+    return _GatedAttentionPool.apply(x, Wv, bv, Wu, bu, w, b, layout, xbits)
 
 
 class _HeadSigmoid(torch.autograd.Function):
@@ -970,7 +1010,7 @@ def gate_bwd_params_x16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulat
         workspace = torch.empty(need, device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_gate_bwd_params_x16(_p(x16), _p(gates), _p(ds), _p(w), R, L, GATE_D, _p(workspace),
                                             workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
-                                            1 if accumulate else 0, _stream())
+                                            1 if accumulate else 0, None, 1.0, _stream())
     _lib.check(rc, "mil_gate_bwd_params_x16")
     return workspace
 

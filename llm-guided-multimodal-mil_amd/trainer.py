@@ -16,7 +16,9 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops
+import ctypes
+
+from . import _lib, ops
 from .bags import BagLayout
 from .dist_utils import allreduce_flat, broadcast_flat
 
@@ -72,8 +74,15 @@ class FlatParams:
 
 
 class ImageOnlyTrainer:
+    """The image-only training step on the one-call C entry point `mil_image_only_step_run` (csrc/step.hip).
+
+    train_mode=True is a real `model.train()` step: dropout(0.5) on the patches before the gate and the pool
+    (ABMIL.py:49,59) and dropout(0.25) in front of the head (aggregator.py:129), masks drawn in-kernel from Philox keep
+    bits (csrc/dropout.hip) and re-read by the backward.  train_mode=False is the eval-mode (parity) step."""
+
     def __init__(self, params: Dict[str, torch.Tensor], device, lr: float = 1e-5, betas=(0.9, 0.999),
-                 weight_decay: float = 1e-7, eps: float = 1e-8, world_size: int = 1, bf16_grad_mfma: bool = True):
+                 weight_decay: float = 1e-7, eps: float = 1e-8, world_size: int = 1, bf16_grad_mfma: bool = True,
+                 train_mode: bool = False, accum: int = 1, seed: int = 1234, counted: bool = False):
         self.device = device
         self.fp = FlatParams(params, device, PARAM_ORDER)
         self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
@@ -84,121 +93,251 @@ class ImageOnlyTrainer:
         self.bf16_grad_mfma = bf16_grad_mfma
         self.step_count = 0
         self.loss_sum = self.fp.loss_slot
-        self._ws: Optional[torch.Tensor] = None
+        self.train_mode = bool(train_mode)
+        self.seed, self.drop_pass = int(seed), 0
+        self.accum = max(1, int(accum))          # micro-batches per optimizer step (one all-reduce + Adam per `accum`)
+        self._micro = 0
+        # counted: the step number lives on the device (Adam's bias corrections and the dropout stream position read it),
+        # so the whole step - optimizer included - is the same launch sequence every time and can be replayed from a hipGraph
+        self.step_counter = torch.zeros(1, device=device, dtype=torch.int32) if counted else None
+        self._ws: Dict[str, torch.Tensor] = {}   # grow-only per-step state (scores, gates, partials, ...)
+        self._args: Optional[_lib.ImageOnlyStep] = None
+        self._args_key = None
+        self._keep = None                        # tensors the current struct points at (x, y, layout)
+        self._w16: Optional[Dict[str, torch.Tensor]] = None
+        self._w16_version, self._param_version = -1, 0
+        self._graph = None
         self.last = {}
         if self.world > 1:      # DDP broadcasts rank 0's parameters at wrap time (train_ddp.py:79)
             broadcast_flat(self.fp.flat, src=0)
 
-    # ------------------------------------------------------------------ pieces (also timed one by one by bench.py)
-    def _gate_fwd(self, x, save_gates=True):
-        fp = self.fp
-        if x.dtype == torch.bfloat16:       # config-5 path: bf16 storage of x and of the gate weights, fp32 accumulate
-            Wv16 = ops.cast_bf16(fp.p("aggregator.attention_V.0.weight"))
-            Wu16 = ops.cast_bf16(fp.p("aggregator.attention_U.0.weight"))
-            return ops.gate_scores_fwd_bf16(x, Wv16, fp.p("aggregator.attention_V.0.bias"), Wu16,
-                                            fp.p("aggregator.attention_U.0.bias"),
-                                            fp.p("aggregator.attention_weights.weight").view(-1),
-                                            fp.p("aggregator.attention_weights.bias"), save_gates=save_gates)
-        return ops.gate_scores_fwd(
-            x, fp.p("aggregator.attention_V.0.weight"), fp.p("aggregator.attention_V.0.bias"),
-            fp.p("aggregator.attention_U.0.weight"), fp.p("aggregator.attention_U.0.bias"),
-            fp.p("aggregator.attention_weights.weight").view(-1), fp.p("aggregator.attention_weights.bias"),
-            save_gates=save_gates)
+    # ------------------------------------------------------------------ the step descriptor
+    def _buf(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            # grow-only; a captured graph keeps its own references to the buffers it was recorded with (self._graph)
+            t = self._ws[name] = torch.empty(max(1, numel), device=self.device, dtype=dtype)
+        return t
 
+    def _shadows(self):
+        fp = self.fp
+        if self._w16 is None:
+            self._w16 = {k: torch.empty(fp.p(k).shape, device=self.device, dtype=torch.bfloat16)
+                         for k in ("aggregator.attention_V.0.weight", "aggregator.attention_U.0.weight")}
+        if self._w16_version != self._param_version:
+            for k, t in self._w16.items():
+                ops.cast_bf16(fp.p(k), out=t)
+            self._w16_version = self._param_version
+        return self._w16
+
+    def _fill(self, x: torch.Tensor, layout: BagLayout, y: Optional[torch.Tensor], global_bags: Optional[int]):
+        """(Re)build the C struct for this batch; cached while the same tensors / layout come back."""
+        b16 = x.dtype == torch.bfloat16
+        if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.MilHipError("ImageOnlyTrainer: x must be a float32 / bfloat16 tensor on the MI355X (no CPU path)")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        R, L = x.shape
+        if R != layout.R:
+            raise _lib.MilHipError(f"ImageOnlyTrainer: x has {R} rows but the bag layout covers {layout.R}")
+        fp = self.fp
+        C = fp.p("fc.1.weight").shape[0]
+        if fp.p("fc.1.weight").shape[1] != L:
+            raise _lib.MilHipError("ImageOnlyTrainer: the head's input width must equal the patch width L")
+        train = self.train_mode and y is not None and not b16
+        key = (x.data_ptr(), R, L, b16, id(layout), None if y is None else y.data_ptr(), global_bags, train)
+        if self._args is not None and key == self._args_key:
+            return self._args
+        B, T = layout.B, layout.T
+        a = _lib.ImageOnlyStep()
+        a.struct_bytes = ctypes.sizeof(_lib.ImageOnlyStep)
+        pv = lambda t: None if t is None else t.data_ptr()      # noqa: E731
+        a.x, a.y, a.tile_map, a.bag_tile_off = pv(x), pv(y), pv(layout.tile_map), pv(layout.bag_tile_off)
+        a.R, a.L, a.B, a.C, a.T, a.x_bf16 = R, L, B, C, T, int(b16)
+        nb = global_bags if global_bags is not None else B * self.world
+        a.loss_scale = 1.0 / (max(1, nb) * C * self.accum)
+        names = {"Wv": "aggregator.attention_V.0.weight", "bv": "aggregator.attention_V.0.bias",
+                 "Wu": "aggregator.attention_U.0.weight", "bu": "aggregator.attention_U.0.bias",
+                 "w": "aggregator.attention_weights.weight", "b": "aggregator.attention_weights.bias",
+                 "Wf": "fc.1.weight", "bf": "fc.1.bias"}
+        for f, k in names.items():
+            setattr(a, f, fp.p(k).data_ptr())
+            setattr(a, "d" + f, fp.g(k).data_ptr())
+        if b16:
+            w16 = self._shadows()
+            a.Wv16, a.Wu16 = w16[names["Wv"]].data_ptr(), w16[names["Wu"]].data_ptr()
+        a.loss_out = self.loss_sum.data_ptr()
+        grads = y is not None
+        st = dict(scores=self._buf("scores", R), partials=self._buf("partials", T * (L + 2)),
+                  M=self._buf("M", B * L), lse=self._buf("lse", B), logits=self._buf("logits", B * C),
+                  prob=self._buf("prob", B * C))
+        if grads:
+            if b16:
+                need = _lib.lib().mil_gate_bwd_workspace_floats_bf16(R, L) if (self.bf16_grad_mfma and L % 256 == 0) else \
+                    _lib.lib().mil_gate_bwd_workspace_floats(R, L)
+            else:
+                need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
+            st.update(gates=self._buf("gates", R * 2 * ops.GATE_D), ds=self._buf("ds", R),
+                      hrow=self._buf("hrow", R * C) if C <= 4 else None, dw_ws=self._buf("dw_ws", need),
+                      Mdrop=self._buf("Mdrop", B * L), loss_bag=self._buf("loss_bag", B), dz=self._buf("dz", B * C),
+                      dM=self._buf("dM", B * L), cdot=self._buf("cdot", B))
+            a.dw_ws_floats = st["dw_ws"].numel()
+        if train:
+            st.update(xbits=self._buf("xbits", R * (L // 32), torch.int32), mbits=self._buf("mbits", B * (L // 32), torch.int32))
+        for k, t in st.items():
+            setattr(a, k, pv(t))
+        a.train, a.bf16_grad_mfma, a.seed = int(train), int(self.bf16_grad_mfma), self.seed
+        a.offset_dev = pv(self.step_counter)
+        a.param_flat, a.grad_flat = fp.flat.data_ptr(), fp.grad.data_ptr()
+        a.exp_avg, a.exp_avg_sq, a.n_param = fp.exp_avg.data_ptr(), fp.exp_avg_sq.data_ptr(), fp.flat.numel()
+        a.adam_step_dev = pv(self.step_counter)
+        a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale = self.betas[0], self.betas[1], self.eps, self.wd, 1.0
+        self._args, self._args_key = a, key
+        self._keep = (x, y, layout, dict(st), self._w16)
+        # host-visible views of the step's outputs (valid until the next forward)
+        self.last = dict(x=x, layout=layout, scores=st["scores"][:R], M=st["M"][:B * L].view(B, L), lse=st["lse"][:B],
+                         logits=st["logits"][:B * C].view(B, C), prob=st["prob"][:B * C].view(B, C))
+        if grads:
+            self.last.update(gates=st["gates"][:R * 2 * ops.GATE_D].view(R, 2 * ops.GATE_D), ds=st["ds"][:R],
+                             hrow=None if st["hrow"] is None else st["hrow"][:R * C].view(R, C),
+                             dz=st["dz"][:B * C].view(B, C), dM=st["dM"][:B * L].view(B, L), cdot=st["cdot"][:B],
+                             loss_bag=st["loss_bag"][:B], Mdrop=st["Mdrop"][:B * L].view(B, L))
+        if train:
+            self.last.update(xbits=st["xbits"][:R * (L // 32)].view(R, L // 32), mbits=st["mbits"][:B * (L // 32)].view(B, L // 32))
+        return a
+
+    def _run(self, a, stages: int):
+        a.stages = stages
+        a.accumulate = int(self._micro > 0)
+        a.lr = self.lr
+        a.adam_step = self.step_count + 1
+        # dropout stream position: (micro-batch index of this optimizer step) << 32 | pass count; in counted mode the device
+        # step counter is added on the device, so a replayed graph moves on by itself
+        a.offset = (self._micro << 32) | (0 if self.step_counter is not None else (self.drop_pass & 0xFFFFFFFF))
+        rc = _lib.lib().mil_image_only_step_run(ctypes.byref(a), ops._stream())
+        _lib.check(rc, "mil_image_only_step_run")
+
+    # ------------------------------------------------------------------ pieces
     def forward(self, x: torch.Tensor, layout: BagLayout, y: Optional[torch.Tensor] = None,
                 global_bags: Optional[int] = None):
-        """Inference when y is None; with labels the fused tail also produces loss, dz, dM, cdot."""
-        fp = self.fp
-        scores, gates = self._gate_fwd(x, save_gates=y is not None)
-        hrow = None
-        if x.dtype == torch.bfloat16 and y is not None and fp.p("fc.1.weight").shape[0] <= 4:
-            partials, hrow = ops.attn_pool_partial_h_bf16(x, scores, layout, fp.p("fc.1.weight"))
-        elif x.dtype == torch.bfloat16:
-            partials = ops.attn_pool_partial_bf16(x, scores, layout)
-        elif y is not None and fp.p("fc.1.weight").shape[0] <= 4:
-            # training: the pool pass also projects every patch on the head (x_i . Wf[c]); the backward then
-            # needs no second pass over x (ops.attn_pool_bwd_from_h)
-            partials, hrow = ops.attn_pool_partial_h(x, scores, layout, fp.p("fc.1.weight"))
-        else:
-            partials = ops.attn_pool_partial(x, scores, layout)
-        scale = 1.0
-        if y is not None:
-            nb = global_bags if global_bags is not None else layout.B * self.world
-            scale = 1.0 / (nb * fp.p("fc.1.weight").shape[0])
-        t = ops.pool_merge_head(partials, layout, x.shape[1], fp.p("fc.1.weight"), fp.p("fc.1.bias"), y, scale,
-                                scores=scores, hrow=hrow)                 # with hrow: ds comes out of this launch too
-        self.last = dict(x=x, layout=layout, scores=scores, gates=gates, hrow=hrow, **t)
-        return t["prob"], t["logits"]
+        """Inference when y is None (eval semantics); with labels the fused tail also produces loss, dz, dM, ds and, in
+        train mode, the pass draws fresh dropout masks."""
+        a = self._fill(x, layout, y, global_bags)
+        if a.train:
+            self.drop_pass += 1
+        self._run(a, _lib.STAGE_DROPBITS | _lib.STAGE_GATE_FWD | _lib.STAGE_POOL | _lib.STAGE_TAIL)
+        return self.last["prob"], self.last["logits"]
 
     def backward(self):
-        """Gradients of the (globally normalised) BCE loss into the flat grad buffer (overwrites it)."""
-        c, fp = self.last, self.fp
-        b16 = c["x"].dtype == torch.bfloat16
-        # fp32 path: the head's parameter gradients ride on the gate reduce launch (below); bf16: their own launch
-        head_fused = (not b16) and c["M"].shape[1] == c["x"].shape[1]
-        if not head_fused:
-            ops.head_bwd_params(c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum)
-        if c.get("ds") is not None:
-            ds = c["ds"]
-        elif c.get("hrow") is not None:
-            ds = ops.attn_pool_bwd_from_h(c["scores"], c["lse"], c["hrow"], c["dz"], c["cdot"], c["layout"])
-        elif b16:
-            ds = ops.attn_pool_bwd_bf16(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"])
-        else:
-            ds, _ = ops.attn_pool_bwd(c["x"], c["scores"], c["lse"], c["dM"], c["cdot"], c["layout"], want_dx=False)
-        if head_fused:
-            self._ws = ops.gate_bwd_params_head(
-                c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
-                fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
-                fp.g("aggregator.attention_U.0.weight"), fp.g("aggregator.attention_U.0.bias"),
-                fp.g("aggregator.attention_weights.weight").view(-1), fp.g("aggregator.attention_weights.bias"),
-                c["dz"], c["M"], fp.g("fc.1.weight"), fp.g("fc.1.bias"), c["loss_bag"], self.loss_sum, workspace=self._ws)
-            return self.loss_sum
-        dw_fn = ops.gate_bwd_params
-        if b16:
-            dw_fn = ops.gate_bwd_params_bf16 if (self.bf16_grad_mfma and c["x"].shape[1] % 256 == 0) else ops.gate_bwd_params_x16
-        self._ws = dw_fn(
-            c["x"], c["gates"], ds, fp.p("aggregator.attention_weights.weight").view(-1),
-            fp.g("aggregator.attention_V.0.weight"), fp.g("aggregator.attention_V.0.bias"),
-            fp.g("aggregator.attention_U.0.weight"), fp.g("aggregator.attention_U.0.bias"),
-            fp.g("aggregator.attention_weights.weight").view(-1), fp.g("aggregator.attention_weights.bias"),
-            accumulate=False, workspace=self._ws)
+        """Gradients of the (globally normalised) BCE loss into the flat grad buffer (overwrites it, or adds to it for
+        the 2nd.. micro-batch of an accumulation window)."""
+        if self._args is None or not self._args.y:
+            raise _lib.MilHipError("ImageOnlyTrainer.backward: call forward(x, layout, y) with labels first")
+        self._run(self._args, _lib.STAGE_GATE_BWD | _lib.STAGE_REDUCE)
         return self.loss_sum
+
+    def reduce_only(self):
+        """The step's single collective: one all-reduce(sum) of gradients + loss over RCCL."""
+        if self.world > 1 or self.force_collectives:
+            allreduce_flat(self.fp.grad_ext)
+
+    def _adam(self):
+        self._run(self._args, _lib.STAGE_ADAM)
+        self.step_count += 1
+        self._param_version += 1
+        if self._args.x_bf16:
+            self._w16_version = self._param_version     # step.hip re-cast the shadows right after the update
 
     def reduce_and_step(self):
         """One all-reduce(sum) of the flat gradient over RCCL, then Adam.  The local loss was already
         normalised by the global bag count, so the sum IS DDP's mean-of-ranks gradient."""
-        if self.world > 1 or self.force_collectives:
-            allreduce_flat(self.fp.grad_ext)        # gradients + loss in one collective
-        self.step_count += 1
-        ops.adam_step(self.fp.flat, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, self.step_count, self.lr,
-                      self.betas, self.eps, self.wd, 1.0)
+        self.reduce_only()
+        self._adam()
 
     def train_step(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
-        prob, z = self.forward(x, layout, y)
-        self.backward()
-        self.reduce_and_step()
-        return self.loss_sum, prob
+        """forward + backward (+ all-reduce + Adam once every `accum` calls).  World size 1, accum 1: ONE C call."""
+        a = self._fill(x, layout, y, None)
+        if a.train:
+            self.drop_pass += 1
+        last = self._micro == self.accum - 1
+        fused_adam = last and not (self.world > 1 or self.force_collectives)
+        self._run(a, _lib.STAGE_ALL if fused_adam else _lib.STAGE_ALL & ~_lib.STAGE_ADAM)
+        if fused_adam:
+            self.step_count += 1
+            self._param_version += 1
+            if a.x_bf16:
+                self._w16_version = self._param_version
+        elif last:
+            self.reduce_and_step()
+        self._micro = 0 if last else self._micro + 1
+        return self.loss_sum, self.last["prob"]
+
+    def reset_dropout_stream(self):
+        self.drop_pass = 0
+
+    # ------------------------------------------------------------------ measurement
+    def time_pieces(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor, iters: int = 20, warm: int = 3):
+        """HIP-event duration (ms) of each launch group of the step, issued from C (mil_image_only_step_time)."""
+        a = self._fill(x, layout, y, None)
+        self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)          # state every stage reads exists
+        groups = [("gate_fwd", _lib.STAGE_GATE_FWD), ("pool_partial", _lib.STAGE_POOL),
+                  ("merge_head_loss_ds", _lib.STAGE_TAIL), ("gate_bwd_dw", _lib.STAGE_GATE_BWD),
+                  ("gate_bwd_reduce_and_head_params", _lib.STAGE_REDUCE)]
+        if a.train:
+            groups.insert(0, ("dropout_bits", _lib.STAGE_DROPBITS))
+        if a.x_bf16:        # the bf16 weight gradient's launch pair is one entry point: time it as a whole
+            groups = [g for g in groups if g[0] not in ("gate_bwd_dw", "gate_bwd_reduce_and_head_params")]
+            groups.append(("gate_bwd_dw", _lib.STAGE_GATE_BWD | _lib.STAGE_REDUCE))
+        out = {}
+        ms = ctypes.c_float(0.0)
+        for name, stg in groups:
+            a.accumulate = 0
+            rc = _lib.lib().mil_image_only_step_time(ctypes.byref(a), stg, warm, iters, ctypes.byref(ms), ops._stream())
+            _lib.check(rc, "mil_image_only_step_time")
+            out[name] = float(ms.value)
+        # Adam on scratch copies of the parameters and moments, so timing it does not train
+        fp = self.fp
+        a2 = _lib.ImageOnlyStep.from_buffer_copy(a)
+        scratch = [fp.flat.clone(), fp.exp_avg.clone(), fp.exp_avg_sq.clone()]
+        a2.param_flat, a2.exp_avg, a2.exp_avg_sq = (t.data_ptr() for t in scratch)
+        a2.adam_step_dev, a2.adam_step, a2.lr, a2.x_bf16 = None, 1, self.lr, 0
+        rc = _lib.lib().mil_image_only_step_time(ctypes.byref(a2), _lib.STAGE_ADAM, warm, iters, ctypes.byref(ms), ops._stream())
+        _lib.check(rc, "mil_image_only_step_time")
+        out["adam"] = float(ms.value)
+        return out
 
     # ------------------------------------------------------------------ hipGraph replay of the launch-bound part
     def capture(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
-        """Capture forward+backward (8 launches on static buffers) into one hipGraph.  ``x`` and ``y`` become
-        the static input buffers: copy new bags into them, then call ``replay_step()``.  The all-reduce and the
-        Adam launch stay eager (Adam's bias corrections are per-step host scalars)."""
+        """Capture forward+backward (static buffers) into one hipGraph.  ``x`` and ``y`` become the static input
+        buffers: copy new bags into them, then call ``replay_step()``.  With counted=True the Adam launch (device step
+        counter) is inside the graph as well when no all-reduce is needed.  The graph entry keeps references to every
+        tensor its launches point at (layout, workspace, bf16 shadows), so later growth of the trainer's buffers or
+        eviction from BagLayout's cache cannot free memory a replay reads."""
+        a = self._fill(x, layout, y, None)
+        if a.train and self.step_counter is None:
+            raise _lib.MilHipError("ImageOnlyTrainer.capture in train mode needs counted=True: the dropout stream position "
+                                   "must live on the device, or every replay would draw the same mask")
+        in_graph_adam = self.step_counter is not None and not (self.world > 1 or self.force_collectives) and self.accum == 1
+        stages = _lib.STAGE_ALL if in_graph_adam else _lib.STAGE_ALL & ~_lib.STAGE_ADAM
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):
-                self.forward(x, layout, y)
-                self.backward()
+            self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)
         torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self.forward(x, layout, y)
-            self.backward()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._run(a, stages)
+        self._graph = dict(graph=graph, keep=self._keep, args=a, adam=in_graph_adam, last=dict(self.last))
         return self
 
     def replay_step(self):
-        self._graph.replay()
-        self.reduce_and_step()
+        g = self._graph
+        g["graph"].replay()
+        self.last = g["last"]
+        if g["adam"]:
+            self.step_count += 1
+            self._param_version += 1
+        else:
+            self._args = g["args"]
+            self.reduce_and_step()
         return self.loss_sum, self.last["prob"]

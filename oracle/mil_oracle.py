@@ -29,14 +29,19 @@ Params = Dict[str, Tensor]
 
 
 # --------------------------------------------------------------------------- ABMIL
-def abmil_forward(x: Tensor, p: Params, prefix: str = "aggregator.") -> Tuple[Tensor, Tensor, Tensor]:
-    """Gated-attention MIL pool, eval mode (dropout off).
+def abmil_forward(x: Tensor, p: Params, prefix: str = "aggregator.",
+                  keep: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """Gated-attention MIL pool.  keep=None: eval mode (dropout off).
 
     Follows model/dim1/ABMIL.py:47-59: V = tanh(x Wv^T + bv), U = sigmoid(x Wu^T + bu),
     s = (V*U) w^T + b, A = softmax over the N instances, M = A x.
+    Train mode (ABMIL.py:26,49: x = Dropout(0.5)(x) in front of everything, so the DROPPED x is pooled too, :59): pass
+    the 0/1 keep mask [N, L]; x becomes x * keep / (1 - 0.5) exactly as F.dropout scales the survivors.
 
     x: [N, L] one bag.  Returns (M [1, L], A [1, N], s [N]).
     """
+    if keep is not None:
+        x = x * keep * 2.0                           # ABMIL.py:49
     Wv, bv = p[prefix + "attention_V.0.weight"], p[prefix + "attention_V.0.bias"]
     Wu, bu = p[prefix + "attention_U.0.weight"], p[prefix + "attention_U.0.bias"]
     w, b = p[prefix + "attention_weights.weight"], p[prefix + "attention_weights.bias"]
@@ -63,11 +68,13 @@ def abmil_forward_batched_quirk(x: Tensor, p: Params, prefix: str = "aggregator.
 
 
 # --------------------------------------------------------------------------- head + loss
-def head_forward(M: Tensor, p: Params) -> Tuple[Tensor, Tensor]:
-    """Per-bag classifier head, eval mode: z = M Wf^T + bf (logits), p = sigmoid(z).
+def head_forward(M: Tensor, p: Params, keep: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Per-bag classifier head: z = Dropout(.25)(M) Wf^T + bf (logits), p = sigmoid(z).  keep=None: eval mode.
 
-    model/aggregator.py:128-131,200.  M: [B, L] -> (z [B, C], prob [B, C]).
+    model/aggregator.py:128-131,200.  M: [B, L] -> (z [B, C], prob [B, C]).  keep: 0/1 mask [B, L] of the head's dropout.
     """
+    if keep is not None:
+        M = M * keep * (1.0 / 0.75)                  # aggregator.py:129
     z = F.linear(M, p["fc.1.weight"], p["fc.1.bias"])
     return z, torch.sigmoid(z)
 
@@ -229,11 +236,13 @@ def clip_learnable_prompts(ids: Tensor, ctx_vectors: Tensor, p: Params, heads: i
 
 
 # --------------------------------------------------------------------------- full recipes
-def image_only_forward(x: Tensor, p: Params) -> Dict[str, Tensor]:
+def image_only_forward(x: Tensor, p: Params, keep_x: Optional[Tensor] = None,
+                       keep_m: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """BASELINE config 2 for one bag x [N, L=512]: ABMIL -> fc -> sigmoid
-    (model/aggregator.py:199-200 with the bag fed directly)."""
-    M, A, s = abmil_forward(x, p)
-    z, prob = head_forward(M, p)
+    (model/aggregator.py:199-200 with the bag fed directly).  keep_x [N, L] / keep_m [1, L]: the
+    dropout masks of a model.train() pass (None = eval)."""
+    M, A, s = abmil_forward(x, p, keep=keep_x)
+    z, prob = head_forward(M, p, keep=keep_m)
     return {"M": M, "A": A, "scores": s, "logits": z, "prob": prob}
 
 

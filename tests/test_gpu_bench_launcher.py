@@ -1,0 +1,70 @@
+"""GPU: bench.py's own launcher.  `python bench.py --gpus N` without torchrun must start N ranks itself (reference:
+mp.spawn of one process per GPU, train_ddp.py:53-82,622-624), never fall back to one rank, and the N>1 step must equal
+the single-process step on the union of the ranks' bags."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import rel_err
+from mil_amd import synthetic as syn
+from mil_amd.bags import BagLayout
+from mil_amd.trainer import ImageOnlyTrainer
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "1", "--prime", "2", "--bags-per-gpu", "4", "--patches", "128", "--no-cpu-baseline",
+         "--no-configs", "--no-breakdown"]
+
+
+def bench(*argv, env=None, expect_ok=True):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], capture_output=True, text=True, timeout=600, env=e)
+    if expect_ok:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    return r
+
+
+def test_one_rank_through_rccl_reports_the_collective():
+    line = bench("--gpus", "1", *SMALL, env={"MIL_FORCE_COLLECTIVES": "1"})
+    assert line["n_gpus"] == 1 and line["rccl"]["backend"] == "nccl" and line["rccl"]["world_size"] == 1
+    assert line["rccl"]["allreduce_bytes"] > 700000          # the flat gradient + loss slot (0.79 MB)
+    assert line["rccl"]["allreduce_us"] > 0
+
+
+def test_two_ranks_rehearsal_equals_the_single_process_step(tmp_path):
+    dump = str(tmp_path / "g.pt")
+    line = bench("--gpus", "2", *SMALL, "--train-mode", "0", "--dump", dump, env={"MIL_BENCH_REHEARSAL": "1"})
+    assert line["n_gpus"] == 2 and line["config"]["global_bags"] == 8
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"          # rehearsal: both ranks on GPU 0
+    got = torch.load(dump, weights_only=True)
+    # the same 8 bags (rank r draws make_bags(4321 + r) / make_labels(99 + r)) in ONE process
+    dev = torch.device("cuda")
+    B, N, L = 4, 128, 512
+    x = torch.cat([syn.make_bags(4321 + r, B, N, L).reshape(B * N, L) for r in range(2)], 0).to(dev)
+    y = torch.cat([syn.make_labels(99 + r, B, 2) for r in range(2)], 0).to(dev)
+    tr = ImageOnlyTrainer(syn.image_only_params(1234, L=L), dev)
+    tr.forward(x, BagLayout.uniform(2 * B, N, dev), y)
+    tr.backward()
+    assert abs(float(tr.loss_sum.item()) - got["loss"]) <= 1e-6
+    assert rel_err(got["grad"], tr.fp.grad.cpu()) <= 1e-5
+
+
+def test_more_ranks_than_gpus_is_refused_not_downgraded():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    r = bench("--gpus", "2", *SMALL, expect_ok=False)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not r.stdout.strip()                       # no JSON line with a wrong n_gpus
+
+
+def test_gpus_flag_must_match_torchrun_world_size():
+    r = bench("--gpus", "2", *SMALL, env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_ok=False)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
