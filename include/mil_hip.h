@@ -34,6 +34,9 @@ extern "C" {
 
 #define MIL_GATE_D 192     /* gate width D of ABMIL (model/dim1/ABMIL.py:7), fixed by the reference */
 #define MIL_POOL_TILE 32   /* rows per attention-pool tile (tile map granularity) */
+#define MIL_LOSS_BCE 0            /* BCELoss on the sigmoid outputs, mean over B x C  (train_ddp.py:98: num_classes <= 2) */
+#define MIL_LOSS_CE_ON_SIGMOID 1  /* CrossEntropyLoss applied to the sigmoid outputs with the one-hot float labels as
+                                     class probabilities, mean over B (train_ddp.py:95-96: num_classes > 2) */
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
 
 /* Library/ABI version, for the host mirror's load-time check. */
@@ -109,7 +112,7 @@ int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int 
                         const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                         float* lse, float* z, float* p, float* loss_bag, float* dz, float* dM, float* cdot,
                         const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
-                        const uint32_t* mbits, float mscale, float* Mdrop, void* stream);
+                        const uint32_t* mbits, float mscale, float* Mdrop, int loss_kind, void* stream);
 /* mbits / mscale (nullable / 1): keep bits of the head's Dropout(.25); M stays the un-dropped pool output, the head
  * reads M * keep * mscale (also written to Mdrop [B, L] when given: it is the M of dWf = dz^T M), dM carries the mask. */
 
@@ -436,6 +439,11 @@ int mil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int mil_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                           int32_t* step_counter, float lr, float beta1, float beta2, float eps, float weight_decay,
                           float grad_scale, void* stream);
+/* The same launch without the increment, for a buffer updated in several segments (parameters without a gradient are
+ * skipped, as torch.optim.Adam skips them); advance the counter once afterwards with mil_counter_add. */
+int mil_adam_step_counted_noinc(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                const int32_t* step_counter, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float grad_scale, void* stream);
 
 /* torch.optim.SGD step without momentum (train_ddp.py:103-108: the optimizer of the learnable-prompt runs) over a
  * flat fp32 buffer: g = grad_scale * grad + weight_decay * param;  param -= lr * g.  Both buffers 16-byte aligned. */
@@ -476,7 +484,8 @@ typedef struct mil_image_only_step {
     const int32_t* bag_tile_off;    /* [B + 1] */
     int32_t R, L, B, C, T;
     int32_t x_bf16;
-    float loss_scale;               /* 1 / (C * global bags) */
+    float loss_scale;               /* 1 / (C * global bags) for MIL_LOSS_BCE, 1 / global bags for MIL_LOSS_CE_ON_SIGMOID */
+    int32_t loss_kind;              /* MIL_LOSS_* */
     int32_t accumulate;             /* != 0: add this batch's gradients to the buffers (gradient accumulation) */
     /* parameters (fp32 masters; views of one flat buffer in the host mirror) */
     const float *Wv, *bv, *Wu, *bu, *w, *b, *Wf, *bf;

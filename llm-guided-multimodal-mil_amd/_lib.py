@@ -29,7 +29,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_attn_pool_partial_h": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_int, _P, _P, c_float, _P, c_float, _P]),
     "mil_attn_pool_bwd_from_h": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
     "mil_pool_merge_head": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12
-                            + [_P, c_float, _P, _P]),
+                            + [_P, c_float, _P, c_int, _P]),
     "mil_head_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P]),
     "mil_bce_fwd_bwd": (c_int, [_P] * 4 + [c_int, c_int, c_float, _P]),
     "mil_head_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
@@ -101,6 +101,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gather_eot": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
     "mil_adam_step_counted": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
+    "mil_adam_step_counted_noinc": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
     "mil_sgd_step": (c_int, [_P, _P, c_size_t] + [c_float] * 3 + [_P]),
     "mil_linear_mid_fwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "mil_linear_mid_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int,
@@ -120,7 +121,7 @@ class ImageOnlyStep(ctypes.Structure):
         [("struct_bytes", c_uint32), ("stages", c_uint32),
          ("x", _P), ("y", _P), ("tile_map", _P), ("bag_tile_off", _P),
          ("R", c_int32), ("L", c_int32), ("B", c_int32), ("C", c_int32), ("T", c_int32),
-         ("x_bf16", c_int32), ("loss_scale", c_float), ("accumulate", c_int32)]
+         ("x_bf16", c_int32), ("loss_scale", c_float), ("loss_kind", c_int32), ("accumulate", c_int32)]
         + [(n, _P) for n in ("Wv", "bv", "Wu", "bu", "w", "b", "Wf", "bf", "Wv16", "Wu16")]
         + [(n, _P) for n in ("dWv", "dbv", "dWu", "dbu", "dw", "db", "dWf", "dbf", "loss_out")]
         + [(n, _P) for n in ("scores", "gates", "partials", "hrow", "ds", "dw_ws")]

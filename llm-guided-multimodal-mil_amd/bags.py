@@ -3,10 +3,14 @@ attention-pool kernels iterate over (include/mil_hip.h, "tile map")."""
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Sequence
+from typing import ClassVar, List, Sequence
+
+from collections import OrderedDict
 
 import numpy as np
 import torch
+
+from . import lifetime
 
 POOL_TILE = 32
 
@@ -43,22 +47,37 @@ class BagLayout:
     bag_tile_off: torch.Tensor   # int32 [B+1]
     bag_off: torch.Tensor        # int32 [B+1]
 
-    _cache = {}
+    _cache: ClassVar["OrderedDict[tuple, BagLayout]"] = OrderedDict()
+    CACHE_ENTRIES: ClassVar[int] = 256
+
+    @classmethod
+    def _get(cls, key):
+        hit = cls._cache.get(key)
+        if hit is not None:
+            cls._cache.move_to_end(key)
+            lifetime.note(hit)           # a graph being captured keeps the layout it points at (lifetime.py)
+        return hit
+
+    @classmethod
+    def _put(cls, key, lay):
+        # LRU, bounded: one ragged bag per step means a new key almost every step.  Eviction drops only the cache's
+        # reference; captured graphs hold their own.
+        cls._cache[key] = lay
+        while len(cls._cache) > cls.CACHE_ENTRIES:
+            cls._cache.popitem(last=False)
+        return lifetime.note(lay)
 
     @classmethod
     def make(cls, lengths: Sequence[int], device) -> "BagLayout":
         key = (tuple(int(v) for v in lengths), str(device))
-        hit = cls._cache.get(key)
+        hit = cls._get(key)
         if hit is not None:
             return hit
         tm, bto, bo = build_tile_map(lengths)
         lay = cls(lengths=list(key[0]), R=int(bo[-1]), B=len(key[0]), T=int(tm.shape[0]),
                   tile_map=torch.from_numpy(tm).to(device), bag_tile_off=torch.from_numpy(bto).to(device),
                   bag_off=torch.from_numpy(bo).to(device))
-        if len(cls._cache) > 64:
-            cls._cache.clear()
-        cls._cache[key] = lay
-        return lay
+        return cls._put(key, lay)
 
     @classmethod
     def uniform(cls, B: int, N: int, device) -> "BagLayout":
@@ -71,7 +90,7 @@ class BagLayout:
         how the fused model pools over (text tokens + patches) without materialising the per-bag concatenation
         of model/aggregator.py:192."""
         key = ("2seg", tuple(int(v) for v in n_lengths), tuple(int(v) for v in t_lengths), str(device))
-        hit = cls._cache.get(key)
+        hit = cls._get(key)
         if hit is not None:
             return hit
         n = np.asarray(key[1], dtype=np.int64)
@@ -90,7 +109,4 @@ class BagLayout:
         lay = cls(lengths=[int(a + c) for a, c in zip(n, t)], R=int(bo_n[-1] + bo_t[-1]), B=B, T=int(tm.shape[0]),
                   tile_map=torch.from_numpy(np.ascontiguousarray(tm)).to(device),
                   bag_tile_off=torch.from_numpy(bto).to(device), bag_off=torch.from_numpy(bo_n).to(device))
-        if len(cls._cache) > 64:
-            cls._cache.clear()
-        cls._cache[key] = lay
-        return lay
+        return cls._put(key, lay)

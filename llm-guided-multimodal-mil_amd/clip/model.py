@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import lifetime, ops
 from ..segments import AttnSegs
 
 
@@ -140,7 +140,7 @@ class CLIPText(nn.Module):
     def _proj(self, device):
         if self._proj_t is None or self._proj_t.device != device:
             self._proj_t = self.text_projection.detach().t().contiguous()     # frozen: [embed, W] = nn.Linear layout
-        return self._proj_t
+        return lifetime.note(self._proj_t)
 
     def set_gemm_pieces(self, pieces: int):
         """0 = fp32 MFMA GEMMs (default, the parity path); 2 or 3 = split-bf16 products for the frozen block weights

@@ -62,6 +62,8 @@ def create_arg_parser(argv=None):
     p.add_argument("--ragged", action="store_true", help="draw a different patch count per bag")
     p.add_argument("--clip_layers", type=int, default=12)
     p.add_argument("--fused_step", action="store_true", help="image_only: fused trainer instead of autograd + DDP")
+    p.add_argument("--no_dropout", action="store_true", help="--fused_step: eval-mode arithmetic (no dropout) while training; "
+                   "the default is a true model.train() step with in-kernel dropout masks")
     p.add_argument("--clip_gemm_pieces", type=int, default=0, choices=[0, 2, 3],
                    help="frozen CLIP text tower: 0 = fp32 MFMA GEMMs (parity path); 2 / 3 = split-bf16 products "
                         "(3 / 6 cross terms: ~3e-6 / fp32-level relative error, 2.3x / 1.45x the fp32 GEMM rate)")

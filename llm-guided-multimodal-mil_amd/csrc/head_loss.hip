@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
                                                          const int32_t* __restrict__ tile_map,
                                                          const float* __restrict__ scores, const float* __restrict__ hrow,
                                                          float* __restrict__ ds, const uint32_t* __restrict__ mbits,
-                                                         float mscale, float* __restrict__ Mdrop) {
+                                                         float mscale, float* __restrict__ Mdrop, int loss_kind) {
     // mbits [B][L/32]: keep bits of the head's Dropout(.25) on the bag embedding (aggregator.py:129; train mode).  M stays
     // the un-dropped ABMIL output, Mdrop = M * keep * mscale feeds the head (and dWf); dM = d loss / d M carries the mask.
     __shared__ float red[4];
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     if (tid == 0) lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
     __syncthreads();
     // head
+    __shared__ float ps[32];
     float lossacc = 0.f;
     for (int c = 0; c < C; ++c) {
         float v = 0.f;
@@ -281,10 +282,35 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
             const float pp = 1.0f / (1.0f + expf(-zz));
             z[b * C + c] = zz;
             p[b * C + c] = pp;
-            if (y != nullptr) {
-                const float yy = y[b * C + c];
+            ps[c] = pp;
+        }
+    }
+    if (y != nullptr && tid == 0) {
+        if (loss_kind == 0) {
+            // BCELoss on the sigmoid outputs vs one-hot float labels (train_ddp.py:98,323-324); log clamped at -100
+            for (int c = 0; c < C; ++c) {
+                const float pp = ps[c], yy = y[b * C + c];
                 lossacc += -(yy * fmaxf(logf(pp), -100.0f) + (1.0f - yy) * fmaxf(logf(1.0f - pp), -100.0f));
                 const float d = (pp - yy) * scale;
+                dz[b * C + c] = d;
+                dzs[c] = d;
+            }
+        } else {
+            // num_classes > 2: the reference switches to CrossEntropyLoss and applies it to the module's SIGMOID outputs
+            // with the float one-hot labels as class probabilities (train_ddp.py:95-96,323-324):
+            //   loss_b = -sum_c y_c log softmax(p)_c;  d loss / d p_c = softmax(p)_c sum_k y_k - y_c;  dz = dp p (1 - p)
+            float mx = -INFINITY, se = 0.f, sy = 0.f;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, ps[c]);
+            for (int c = 0; c < C; ++c) se += expf(ps[c] - mx);
+            const float lse_p = mx + logf(se);
+            for (int c = 0; c < C; ++c) {
+                const float yy = y[b * C + c];
+                sy += yy;
+                lossacc += -yy * (ps[c] - lse_p);
+            }
+            for (int c = 0; c < C; ++c) {
+                const float pp = ps[c], q = expf(pp - lse_p);
+                const float d = (q * sy - y[b * C + c]) * scale * pp * (1.0f - pp);
                 dz[b * C + c] = d;
                 dzs[c] = d;
             }
@@ -323,14 +349,16 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
                                    const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                                    float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
                                    const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
-                                   const uint32_t* mbits, float mscale, float* Mdrop, void* stream) {
+                                   const uint32_t* mbits, float mscale, float* Mdrop, int loss_kind, void* stream) {
     if (!partials || !bag_tile_off || !Wf || !bf || !M || !lse || !z || !p) return MIL_EINVAL;
+    if (loss_kind != MIL_LOSS_BCE && loss_kind != MIL_LOSS_CE_ON_SIGMOID) return MIL_EINVAL;
     if (y && (!loss_sum || !dz || !dM || !cdot)) return MIL_EINVAL;
     if (ds && (!y || !tile_map || !scores || !hrow)) return MIL_EINVAL;
     if (!(L == 256 || L == 512 || L == 768 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
     hipLaunchKernelGGL(k_pool_merge_head, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
-                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop);
+                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop,
+                       loss_kind);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -408,6 +436,22 @@ extern "C" int mil_adam_step(float* param, const float* grad, float* exp_avg, fl
     return MIL_OK;
 }
 
+// The Adam launch of mil_adam_step_counted WITHOUT the counter increment: a flat buffer updated in several contiguous
+// segments (optim.FlatAdam skips parameters that received no gradient, as torch.optim.Adam does) reads the same step
+// number in every segment; the caller advances the counter once (mil_counter_add).
+extern "C" int mil_adam_step_counted_noinc(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                           const int32_t* step_counter, float lr, float beta1, float beta2, float eps,
+                                           float weight_decay, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale, 1.f, 1.f,
+                (const int*)step_counter, (hipStream_t)stream);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
 extern "C" int mil_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                                      int32_t* step_counter, float lr, float beta1, float beta2, float eps,
                                      float weight_decay, float grad_scale, void* stream) {

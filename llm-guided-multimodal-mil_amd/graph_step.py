@@ -21,9 +21,11 @@ from typing import Callable, Dict, List, Sequence, Tuple
 
 import torch
 
+from . import lifetime
+
 
 class _Entry:
-    __slots__ = ("graph", "inputs", "outputs", "grads")
+    __slots__ = ("graph", "inputs", "outputs", "grads", "keep")
 
 
 class GraphedStep:
@@ -39,6 +41,7 @@ class GraphedStep:
     def _drop_grads(self):
         for p in self.params:
             p.grad = None
+            p._mil_slot_used = False      # ops.grad_slot hands a parameter's flat slot out once per backward pass
 
     def _eager(self, inputs, body):
         # Every execution of the body - eager, warm-up, capture - runs on ONE side stream: autograd binds a parameter's
@@ -60,17 +63,22 @@ class GraphedStep:
         ent = _Entry()
         ent.inputs = [t.clone() for t in inputs]
         cur = torch.cuda.current_stream()
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            for _ in range(self.warmup):          # caches (segment maps, positional rows, split weights) fill here
-                self._drop_grads()
-                body(*ent.inputs)[0].backward()
-        cur.wait_stream(self.stream)
-        self._drop_grads()                        # backward inside the capture then allocates / adopts, never accumulates
-        ent.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ent.graph, stream=self.stream):
-            out = body(*ent.inputs)
-            out[0].backward()
+        # Everything a cache hands out from here on (tile maps, segment maps, positional rows, transposed / split frozen
+        # weights) is referenced by raw pointer inside the captured launches: the entry keeps those objects alive, so cache
+        # eviction or a table that is re-allocated larger can never free memory a replay reads (lifetime.py).
+        with lifetime.recording() as keep:
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                for _ in range(self.warmup):      # caches (segment maps, positional rows, split weights) fill here
+                    self._drop_grads()
+                    body(*ent.inputs)[0].backward()
+            cur.wait_stream(self.stream)
+            self._drop_grads()                    # backward inside the capture then allocates / adopts, never accumulates
+            ent.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent.graph, stream=self.stream):
+                out = body(*ent.inputs)
+                out[0].backward()
+        ent.keep = keep
         ent.outputs = tuple(o.detach() for o in out)
         ent.grads = [p.grad for p in self.params]
         return ent

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import lifetime, ops
 from ..bags import BagLayout
 from .sam.transformer import TwoWayTransformer
 
@@ -80,7 +80,7 @@ class aggregator(nn.Module):
             pe[:, 0::2] = torch.sin(position.float() * div_term)
             pe[:, 1::2] = torch.cos(position.float() * div_term)
             self._pe = pe.to(device)
-        return self._pe
+        return lifetime.note(self._pe)            # a captured graph keeps the table it saw when a larger one replaces it
 
     def _lin_tanh(self, seq: nn.Sequential, x):
         return ops.linear_act(x, seq[0].weight, seq[0].bias, "tanh")

@@ -46,6 +46,7 @@ class Attention(nn.Module):
         the keys instead of two [N, E] x [E, I] GEMMs.  keys come WITHOUT positional encoding (added on the fly).
         Returns (attention output, keys alias): later uses of the keys must go through the alias so that their
         gradient is folded inside the pool's backward."""
+        _zero_grad_params(self.k_proj.bias)
         o, keys_pass = ops.one_token_attention(q, keys, pe_table, segs, self.q_proj.weight, self.q_proj.bias,
                                                self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads)
         return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual), keys_pass
@@ -54,6 +55,7 @@ class Attention(nn.Module):
         """Token->image attention with T > 1 text tokens per bag, K / V projections absorbed (ops.multi_token_pool_attention):
         q [B*T, E] queries (+pe), keys [R, E] (values), kin [R, E] = keys + pe (scores).  Returns (output, keys alias):
         later uses of the keys go through the alias so that all their gradients are folded inside one node."""
+        _zero_grad_params(self.k_proj.bias)
         o, keys_pass = ops.multi_token_pool_attention(q, keys, kin, segs, self.q_proj.weight, self.q_proj.bias,
                                                       self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads)
         return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual), keys_pass
@@ -71,6 +73,16 @@ class Attention(nn.Module):
         segs = AttnSegs.make([Tq] * B, [Tk] * B, q.device)
         form = "pool" if (Tq <= 16 and Tk > 16) else "rows"
         return self.flat(q.reshape(B * Tq, E), k.reshape(B * Tk, E), v.reshape(B * Tk, E), segs, form).reshape(B, Tq, E)
+
+
+def _zero_grad_params(*params):
+    """Parameters a fast path leaves out of the graph although the reference's graph contains them with a
+    mathematically zero gradient (q / k projections of a one-key softmax, k_proj.bias under any softmax): upstream their
+    .grad is a dense zero tensor, so torch.optim.Adam still applies weight decay to them, whereas a parameter whose .grad
+    is None is skipped.  optim.FlatAdam reads this mark to tell the two cases apart."""
+    for p in params:
+        if p is not None:
+            p._mil_zero_grad = True
 
 
 def one_token_ok(attn: "Attention", s_ti: AttnSegs, pe_table) -> bool:
@@ -108,6 +120,7 @@ class TwoWayAttentionBlock(nn.Module):
             # are (softmax of one score = 1), so :282-287 reduce to out_proj(v_proj(queries)) and q_proj / k_proj
             # get exactly zero gradient, as they do upstream.
             a = self.self_attn
+            _zero_grad_params(a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias)
             vp = ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias)
             queries = ops.linear_act(vp, a.out_proj.weight, a.out_proj.bias, "none",
                                      residual=None if self.skip_first_layer_pe else queries)
@@ -140,6 +153,7 @@ class TwoWayAttentionBlock(nn.Module):
             # out_proj(v_proj(token)) and q_proj / k_proj get exactly zero gradient (as upstream).  Skips two
             # [N, 512] projections and the attention core; bit-for-bit the general path's result up to rounding.
             a = self.cross_attn_image_to_token
+            _zero_grad_params(a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias)
             o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
             keys = self.norm4(ops.add_bag_row(keys, o, s_it), keys_tail_rows)
         elif multi:

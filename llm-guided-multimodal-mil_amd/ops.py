@@ -131,7 +131,7 @@ def attn_pool_bwd_from_h(scores, lse, hrow, dz, cdot, layout: BagLayout):
 
 
 def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: float = 1.0, scores=None, hrow=None,
-                    mbits=None, mscale: float = 1.0):
+                    mbits=None, mscale: float = 1.0, loss_kind: int = 0):
     """Fused per-bag tail: returns dict(M, lse, logits, prob[, loss_bag, dz, dM, cdot[, ds]]); with labels it also
     produces each bag's scaled BCE loss and the head's backward inputs for the pool, and with the forward's head
     projections `hrow` (attn_pool_partial_h) the score gradient ds of every row as well."""
@@ -151,7 +151,7 @@ def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: 
                                         _p(out.get("dM")), _p(out.get("cdot")),
                                         _p(layout.tile_map) if "ds" in out else None, _p(scores) if "ds" in out else None,
                                         _p(hrow) if "ds" in out else None, _p(out.get("ds")), _p(mbits), float(mscale),
-                                        _p(out.get("Mdrop")), _stream())
+                                        _p(out.get("Mdrop")), int(loss_kind), _stream())
     _lib.check(rc, "mil_pool_merge_head")
     return out
 
@@ -277,6 +277,15 @@ def adam_step_counted(param, grad, exp_avg, exp_avg_sq, step_counter, lr: float 
                                           _p(step_counter), lr, betas[0], betas[1], eps, weight_decay, grad_scale,
                                           _stream())
     _lib.check(rc, "mil_adam_step_counted")
+
+
+def adam_step_counted_noinc(param, grad, exp_avg, exp_avg_sq, step_counter, lr: float = 1e-5, betas=(0.9, 0.999),
+                            eps: float = 1e-8, weight_decay: float = 1e-7, grad_scale: float = 1.0):
+    """One segment of a counted Adam step; the caller advances the counter once (counter_add)."""
+    rc = _lib.lib().mil_adam_step_counted_noinc(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
+                                                _p(step_counter), lr, betas[0], betas[1], eps, weight_decay, grad_scale,
+                                                _stream())
+    _lib.check(rc, "mil_adam_step_counted_noinc")
 
 
 def sgd_step(param, grad, lr: float = 1e-3, weight_decay: float = 1e-7, grad_scale: float = 1.0):
@@ -481,8 +490,17 @@ def grad_slot(param):
     """The flat-gradient view optim.FlatAdam reserved for this parameter (None without FlatAdam): a backward that
     writes its result there and returns it hands autograd the final storage, so no gather copy is needed."""
     slot = getattr(param, "_mil_grad", None)
+    if slot is None or slot.shape != param.shape:
+        return None
+    # Only the FIRST backward node of a pass may write the slot in place: were the same parameter used by a second node
+    # (a shared Linear), its kernel would overwrite the first result before autograd's AccumulateGrad adds the two.  The
+    # flag is cleared by FlatAdam.zero_grad() / GraphedStep; a second request in the same pass gets None, i.e. a fresh
+    # tensor that autograd then accumulates into the slot.
+    if getattr(param, "_mil_slot_used", False):
+        return None
+    param._mil_slot_used = True
     # a fresh alias: autograd adopts a returned gradient without copying only if nothing else references that tensor
-    return slot.detach() if (slot is not None and slot.shape == param.shape) else None
+    return slot.detach()
 
 
 def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool, dW_out=None, db_out=None):

@@ -8,8 +8,8 @@ views of one contiguous buffer, so that per step there is
   * one Adam launch (mil_adam_step / mil_adam_step_counted) over everything.
 Backward kernels that know a parameter's slot (ops.grad_slot: the Linear layers) write the gradient there directly,
 so the gather only moves what the other ops produced.  Same arithmetic as torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected, eps outside the
-sqrt); a parameter whose gradient is None (the q/k projections of a one-key attention) takes a zero gradient, i.e.
-only the weight-decay term, exactly like a dense zero gradient upstream."""
+sqrt); a parameter whose gradient is None is skipped altogether (no moments, no weight decay), as torch.optim.Adam
+skips it: the update runs over the contiguous live ranges of the flat buffer."""
 from typing import Iterable, List
 
 import torch
@@ -47,6 +47,8 @@ class FlatAdam:
                 self._gviews.append(self.grad[off:off + p.numel()].view(p.shape))
                 p._mil_grad = self._gviews[-1]                 # ops.grad_slot: backward kernels write here directly
         self._is_zero = [True] * len(self.params)              # slot known to hold zeros (never-written / re-zeroed)
+        self._live = None
+        self._seg_cache = {}
         self.defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}
         self.param_groups = [dict(self.defaults, params=self.params)]    # lr schedulers write param_groups[0]["lr"]
         self.world = world_size
@@ -58,14 +60,19 @@ class FlatAdam:
         """Gradients are dropped (autograd then hands over fresh tensors without an accumulate kernel)."""
         for p in self.params:
             p.grad = None
+            p._mil_slot_used = False          # ops.grad_slot: the slot may be written in place once per backward pass
 
     @torch.no_grad()
     def gather(self):
         """Bring every gradient into the flat buffer: nothing to do for those a backward kernel already wrote in
         place (p.grad IS the slot), one foreach copy for the rest, zeros for parameters without a gradient."""
         dst, src = [], []
+        live = []
         for i, (slot, p) in enumerate(zip(self._gviews, self.params)):
             g = p.grad
+            # live: received a gradient, or was left out of the graph by a fast path although upstream it carries a dense
+            # zero gradient (model/sam/transformer.py: _zero_grad_params) - then the zero slot IS its gradient
+            live.append(g is not None or getattr(p, "_mil_zero_grad", False))
             if g is None:
                 if not self._is_zero[i]:
                     slot.zero_()
@@ -77,6 +84,32 @@ class FlatAdam:
                 src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
+        self._live = tuple(live)
+
+    def _segments(self):
+        """Contiguous [begin, end) ranges of the flat buffer whose parameters received a gradient this step.
+        torch.optim.Adam skips a parameter whose .grad is None - no moment update, no weight decay - so modules that are
+        constructed but never used (TwoWayTransformer_CT / _Both, fc_CI2CT, prompt_embedding ...: model/aggregator.py:36-70)
+        keep their initial values upstream; updating them with a zero gradient would decay them through the
+        Adam-normalised weight-decay term.  The update therefore runs on the live ranges only (cached per liveness
+        pattern; usually one or two ranges)."""
+        live = getattr(self, "_live", None)
+        if live is None or all(live):
+            return [(0, self.flat.numel())]
+        hit = self._seg_cache.get(live)
+        if hit is None:
+            hit, start = [], None
+            ends = self.offsets[1:] + [self.flat.numel()]
+            for i, ok in enumerate(live):
+                if ok and start is None:
+                    start = self.offsets[i]
+                if not ok and start is not None:
+                    hit.append((start, self.offsets[i]))
+                    start = None
+            if start is not None:
+                hit.append((start, ends[-1]))
+            self._seg_cache[live] = hit
+        return hit
 
     @torch.no_grad()
     def reduce(self) -> float:
@@ -91,13 +124,21 @@ class FlatAdam:
     def step(self):
         scale = self.reduce()
         g = self.param_groups[0]
+        segs = self._segments()
         if self.counted:
-            ops.adam_step_counted(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_counter, g["lr"],
-                                  g["betas"], g["eps"], g["weight_decay"], scale)
+            if len(segs) == 1 and segs[0] == (0, self.flat.numel()):
+                ops.adam_step_counted(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_counter, g["lr"],
+                                      g["betas"], g["eps"], g["weight_decay"], scale)
+            else:
+                for a, b in segs:
+                    ops.adam_step_counted_noinc(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
+                                                self.step_counter, g["lr"], g["betas"], g["eps"], g["weight_decay"], scale)
+                ops.counter_add(self.step_counter, 1)
         else:
             self.step_count += 1
-            ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"], g["betas"],
-                          g["eps"], g["weight_decay"], scale)
+            for a, b in segs:
+                ops.adam_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.step_count,
+                              g["lr"], g["betas"], g["eps"], g["weight_decay"], scale)
 
     def state_dict(self):
         step = int(self.step_counter.item()) if self.counted else self.step_count
@@ -127,7 +168,8 @@ class FlatSGD(FlatAdam):
     def step(self):
         scale = self.reduce()
         g = self.param_groups[0]
-        ops.sgd_step(self.flat, self.grad, g["lr"], g["weight_decay"], scale)
+        for a, b in self._segments():            # parameters without a gradient are skipped, as torch.optim.SGD does
+            ops.sgd_step(self.flat[a:b], self.grad[a:b], g["lr"], g["weight_decay"], scale)
 
     def state_dict(self):
         return {"param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}

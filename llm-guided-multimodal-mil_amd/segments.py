@@ -4,8 +4,12 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+from collections import OrderedDict
+
 import numpy as np
 import torch
+
+from . import lifetime
 
 POOL_KEYS_PER_TILE = 64
 ROWS_PER_BLOCK = 32
@@ -33,7 +37,8 @@ def _tiles(lengths: np.ndarray, off: np.ndarray, tile: int):
 
 class AttnSegs:
     """Queries of bag b (q_lengths[b] rows) attend to the keys of bag b (k_lengths[b] rows)."""
-    _cache = {}
+    _cache: "OrderedDict[tuple, AttnSegs]" = OrderedDict()
+    CACHE_ENTRIES = 512
 
     def __init__(self, q_lengths: Sequence[int], k_lengths: Sequence[int], device):
         ql = np.asarray(q_lengths, dtype=np.int64)
@@ -59,7 +64,9 @@ class AttnSegs:
         key = (tuple(int(v) for v in q_lengths), tuple(int(v) for v in k_lengths), str(device))
         hit = cls._cache.get(key)
         if hit is None:
-            if len(cls._cache) > 256:
-                cls._cache.clear()
             hit = cls._cache[key] = cls(q_lengths, k_lengths, device)
-        return hit
+            while len(cls._cache) > cls.CACHE_ENTRIES:          # LRU; captured graphs keep their own references
+                cls._cache.popitem(last=False)
+        else:
+            cls._cache.move_to_end(key)
+        return lifetime.note(hit)

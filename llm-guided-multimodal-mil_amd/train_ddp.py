@@ -69,13 +69,21 @@ def main_worker(local_rank: int, nprocs: int, args):
         from .trainer import ImageOnlyTrainer
         sd = model.state_dict()
         params = {k.replace("extractor_pathology.", "aggregator."): v for k, v in sd.items()}
-        tr = ImageOnlyTrainer(params, dev, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
+        # a true model.train() step: dropout on the patches and in front of the head, masks drawn in-kernel (Philox)
+        tr = ImageOnlyTrainer(params, dev, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world,
+                              train_mode=not getattr(args, "no_dropout", False), seed=args.seed)
+        if args.resume:
+            ck = torch.load(args.resume, map_location=dev, weights_only=True)
+            tr.load_model_state_dict(ck["state_dict"])
+            tr.load_optimizer_state_dict(ck["optimizer"])
+            args.start_epoch = ck["epoch"]
     else:
         generator = model
         flat_opt = bool(getattr(args, "flat_adam", 1))
         if world > 1 and not flat_opt:
             generator = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)
-        criterion = torch.nn.BCELoss()
+        # train_ddp.py:95-98: CrossEntropyLoss above two classes (applied to the sigmoid outputs, float one-hot targets)
+        criterion = torch.nn.CrossEntropyLoss() if args.num_classes > 2 else torch.nn.BCELoss()
         trainable = [p for p in model.parameters() if p.requires_grad]
         if args.learnablePrompt:                                                         # train_ddp.py:104-109
             lr0 = args.lr = 1e-3
@@ -163,10 +171,11 @@ def main_worker(local_rank: int, nprocs: int, args):
             end = time.time()
         if rank == 0 and args.save_dir:
             os.makedirs(args.save_dir, exist_ok=True)
-            sd = tr.fp.state_dict() if fused else model.state_dict()
-            state = {"epoch": epoch + 1, "state_dict": sd}
-            if not fused:
-                state["optimizer"] = optimizer.state_dict()
+            # same key schema either way (the model's own names), optimizer state included: a fused-step checkpoint
+            # loads strictly into the model / test_ddp.py and resumes like the autograd route's
+            sd = tr.model_state_dict() if fused else model.state_dict()
+            state = {"epoch": epoch + 1, "state_dict": sd,
+                     "optimizer": tr.optimizer_state_dict() if fused else optimizer.state_dict()}
             save_checkpoint(state, True, args.save_dir, f"checkpoint_{epoch:04d}.pth.tar")
     if world > 1:
         dist.barrier()

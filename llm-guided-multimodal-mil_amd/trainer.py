@@ -82,7 +82,8 @@ class ImageOnlyTrainer:
 
     def __init__(self, params: Dict[str, torch.Tensor], device, lr: float = 1e-5, betas=(0.9, 0.999),
                  weight_decay: float = 1e-7, eps: float = 1e-8, world_size: int = 1, bf16_grad_mfma: bool = True,
-                 train_mode: bool = False, accum: int = 1, seed: int = 1234, counted: bool = False):
+                 train_mode: bool = False, accum: int = 1, seed: int = 1234, counted: bool = False,
+                 loss: Optional[str] = None):
         self.device = device
         self.fp = FlatParams(params, device, PARAM_ORDER)
         self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
@@ -92,6 +93,12 @@ class ImageOnlyTrainer:
         # bf16 x only: weight gradient on the bf16 MFMA (dPre rounded to bf16) or on the fp32 MFMA (exact on the rounded x)
         self.bf16_grad_mfma = bf16_grad_mfma
         self.step_count = 0
+        # criterion as train_ddp.py:95-98 picks it: BCELoss for <= 2 classes, CrossEntropyLoss (on the sigmoid outputs,
+        # one-hot float targets) above
+        C = int(params["fc.1.weight"].shape[0])
+        self.loss = loss if loss is not None else ("ce" if C > 2 else "bce")
+        if self.loss not in ("bce", "ce"):
+            raise ValueError("loss must be 'bce' or 'ce'")
         self.loss_sum = self.fp.loss_slot
         self.train_mode = bool(train_mode)
         self.seed, self.drop_pass = int(seed), 0
@@ -155,7 +162,8 @@ class ImageOnlyTrainer:
         a.x, a.y, a.tile_map, a.bag_tile_off = pv(x), pv(y), pv(layout.tile_map), pv(layout.bag_tile_off)
         a.R, a.L, a.B, a.C, a.T, a.x_bf16 = R, L, B, C, T, int(b16)
         nb = global_bags if global_bags is not None else B * self.world
-        a.loss_scale = 1.0 / (max(1, nb) * C * self.accum)
+        a.loss_kind = 1 if self.loss == "ce" else 0
+        a.loss_scale = 1.0 / (max(1, nb) * (C if self.loss == "bce" else 1) * self.accum)
         names = {"Wv": "aggregator.attention_V.0.weight", "bv": "aggregator.attention_V.0.bias",
                  "Wu": "aggregator.attention_U.0.weight", "bu": "aggregator.attention_U.0.bias",
                  "w": "aggregator.attention_weights.weight", "b": "aggregator.attention_weights.bias",
@@ -275,6 +283,45 @@ class ImageOnlyTrainer:
     def reset_dropout_stream(self):
         self.drop_pass = 0
 
+    # ------------------------------------------------------------------ checkpoints (train_ddp.py:217-244 schema)
+    def model_state_dict(self, prefix_map=(("aggregator.", "extractor_pathology."),)):
+        """Parameters under the MODULE's key names (model/aggregator_clip.py keeps ABMIL as `extractor_pathology`), so a
+        checkpoint written by the fused step loads strictly into the model and into test_ddp.py."""
+        out = {}
+        for k, v in self.fp.state_dict().items():
+            for a, b in prefix_map:
+                if k.startswith(a):
+                    k = b + k[len(a):]
+                    break
+            out[k] = v
+        return out
+
+    def load_model_state_dict(self, sd, prefix_map=(("extractor_pathology.", "aggregator."),)):
+        for k, v in sd.items():
+            for a, b in prefix_map:
+                if k.startswith(a):
+                    k = b + k[len(a):]
+                    break
+            if k in self.fp.offsets:
+                self.fp.p(k).copy_(v)
+        self._param_version += 1
+
+    def optimizer_state_dict(self):
+        step = int(self.step_counter.item()) if self.step_counter is not None else self.step_count
+        return {"step": step, "exp_avg": self.fp.exp_avg.clone(), "exp_avg_sq": self.fp.exp_avg_sq.clone(),
+                "order": list(self.fp.order), "drop_pass": self.drop_pass,
+                "param_groups": [{"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd}]}
+
+    def load_optimizer_state_dict(self, sd):
+        if list(sd.get("order", self.fp.order)) != list(self.fp.order):
+            raise ValueError("optimizer state was saved for another parameter order")
+        self.fp.exp_avg.copy_(sd["exp_avg"])
+        self.fp.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        self.drop_pass = int(sd.get("drop_pass", 0))
+        if self.step_counter is not None:
+            self.step_counter.fill_(self.step_count)
+
     # ------------------------------------------------------------------ measurement
     def time_pieces(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor, iters: int = 20, warm: int = 3):
         """HIP-event duration (ms) of each launch group of the step, issued from C (mil_image_only_step_time)."""
@@ -327,7 +374,7 @@ class ImageOnlyTrainer:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._run(a, stages)
-        self._graph = dict(graph=graph, keep=self._keep, args=a, adam=in_graph_adam, last=dict(self.last))
+        self._graph = dict(graph=graph, keep=(self._keep, dict(self._ws)), args=a, adam=in_graph_adam, last=dict(self.last))
         return self
 
     def replay_step(self):

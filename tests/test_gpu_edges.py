@@ -45,7 +45,7 @@ def test_raw_768_wide_features_and_three_classes():
     p = syn.image_only_params(102, L=L, C=3)
     bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(10 + i)) for i, n in enumerate([130, 64, 5])]
     y = syn.make_labels(4, 3, C=3)
-    tr, prob, z = _step(p, bags, y, L)
+    tr, prob, z = _step(p, bags, y, L, loss="bce")
     loss, logits, rprob, grads = orc.batch_loss_and_grads(bags, y, p)
     assert float((z.cpu() - logits).abs().max()) <= 2e-5
     assert abs(float(tr.loss_sum.item()) - float(loss)) <= 1e-5
@@ -106,3 +106,24 @@ def test_rows_beyond_a_whole_round_of_tiles_take_the_few_rows_path():
     ops.gate_bwd_input(g_ref, ds[R - T:].contiguous(), gp[4], gp[0], gp[2], dx_ref)
     assert rel_err(dx[R - T:].cpu(), dx_ref.cpu()) <= 2e-6
     assert float(dx[:R - T].abs().sum()) > 0
+
+
+def test_more_than_two_classes_use_cross_entropy_on_the_sigmoid_outputs():
+    """num_classes > 2: the reference's criterion is CrossEntropyLoss applied to the module's sigmoid outputs with the
+    float one-hot labels as class probabilities (train_ddp.py:95-96,323-324)."""
+    L = 512
+    p = syn.image_only_params(104, L=L, C=3)
+    bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(20 + i)) for i, n in enumerate([90, 33, 64, 7])]
+    y = syn.make_labels(5, 4, C=3)
+    tr, prob, z = _step(p, bags, y, L)                      # default criterion for C = 3
+    assert tr.loss == "ce"
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    outs = [orc.image_only_forward(b, leaves) for b in bags]
+    rprob = torch.cat([o["prob"] for o in outs], 0)
+    rloss = torch.nn.CrossEntropyLoss()(rprob, y)
+    rloss.backward()
+    assert abs(float(tr.loss_sum.item()) - float(rloss)) <= 1e-5
+    assert torch.equal(prob.cpu().argmax(-1), rprob.argmax(-1))
+    for k in leaves:
+        if leaves[k].grad is not None and float(leaves[k].grad.norm()) > 1e-7:
+            assert rel_err(tr.fp.g(k).cpu(), leaves[k].grad) <= 2e-4, k

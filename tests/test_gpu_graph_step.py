@@ -104,3 +104,59 @@ def test_new_shape_runs_eagerly_then_gets_its_own_graph():
         opt.step()
         assert torch.isfinite(loss).all() and tuple(prob.shape) == (1, 2)
     assert gs.eager_steps == 2 and gs.replays == 4
+
+
+def test_captured_graph_survives_cache_eviction_and_table_growth(monkeypatch):
+    """A captured step holds raw pointers to cached tile / segment maps and to the positional table.  Evicting those
+    cache entries (many other ragged shapes) and re-allocating the table larger must not change what a replay computes:
+    the graph entry keeps its own references (lifetime.py).  The freed-and-reused case is provoked by filling new
+    allocations with garbage before the replay."""
+    from mil_amd.bags import BagLayout
+    from mil_amd.segments import AttnSegs
+    monkeypatch.setattr(BagLayout, "CACHE_ENTRIES", 4)
+    monkeypatch.setattr(AttnSegs, "CACHE_ENTRIES", 4)
+    BagLayout._cache.clear()
+    AttnSegs._cache.clear()
+    m = _model(0, layers=1)
+    crit = torch.nn.BCELoss()
+    params = [p for p in m.parameters() if p.requires_grad]
+    gs = GraphedStep(params, max_graphs=1)
+    lengths = [40, 64]
+
+    def run(seed, graphed):
+        x = syn.make_bags(seed, 2, 64, 768).to(DEV)
+        t = m.clinic_extractor(syn.make_token_ids(seed, 2, 1).to(DEV))
+        y = syn.make_labels(seed, 2).to(DEV)
+        def body(x_, t_, y_):
+            prob = m([x_], None, lengths, text_features=t_)[0]
+            return crit(prob, y_), prob
+        if graphed:
+            out = gs.run(tuple(lengths), (x, t, y), body)
+            return float(out[0]), [None if p.grad is None else p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        loss = body(x, t, y)[0]
+        loss.backward()
+        return float(loss.detach()), [None if p.grad is None else p.grad.clone() for p in params]
+
+    run(1, True)                      # first sight: eager
+    run(2, True)                      # second: captured + replayed
+    assert gs.replays == 1
+    # other shapes, eagerly: evict every cache entry the graph used; one bag longer than the table: it is re-allocated
+    for i, n in enumerate([33, 47, 52, 61, 38, 45, 2500]):
+        x = syn.make_bags(50 + i, 1, n, 768).to(DEV)
+        t = m.clinic_extractor(syn.make_token_ids(i, 1, 1).to(DEV))
+        crit(m([x], None, None, text_features=t)[0], syn.make_labels(i, 1).to(DEV)).backward()
+    assert len(BagLayout._cache) <= 4 and len(AttnSegs._cache) <= 4
+    junk = [torch.full((4096,), 0x7fffffff, device=DEV, dtype=torch.int32) for _ in range(256)]   # reuse freed blocks
+    torch.cuda.synchronize()
+    l_g, g_g = run(3, True)
+    assert gs.replays == 2
+    l_e, g_e = run(3, False)
+    del junk
+    assert abs(l_g - l_e) <= 1e-6
+    assert sum(g is not None for g in g_e) > 10
+    for a, b in zip(g_g, g_e):
+        assert (a is None) == (b is None)
+        if b is not None:
+            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))

@@ -31,14 +31,50 @@ def test_flat_adam_tracks_torch_adam(counted):
         for m, o in ((ref, o_ref), (ours, o_our)):
             o.zero_grad()
             m(x).square().mean().backward()
-            if m is ref and m.extra.grad is None:
-                m.extra.grad = torch.zeros_like(m.extra)       # upstream semantics of a dense zero gradient
-            o.step()
+            o.step()           # `extra` never receives a gradient: torch.optim.Adam skips it, and so does FlatAdam
     for (k, a), b in zip(ref.named_parameters(), ours.parameters()):
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), k
     assert all(p.data_ptr() >= o_our.flat.data_ptr() for p in ours.parameters())     # still views of the flat buffer
     sd = o_our.state_dict()
     assert sd["step"] == 6
+    torch.manual_seed(3)
+    assert torch.equal(ours.extra.detach().cpu(), _model().extra.detach().cpu())      # untouched: no weight-decay drift
+
+
+def test_zero_gradient_mark_keeps_upstream_weight_decay():
+    """A parameter a fast path leaves out of the graph although upstream it gets a dense ZERO gradient (q / k projections
+    of a one-key attention) is marked `_mil_zero_grad`: torch.optim.Adam decays it, so FlatAdam must too."""
+    ref = _model()
+    ours = copy.deepcopy(ref)
+    ours.extra._mil_zero_grad = True
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-2)
+    o_our = FlatAdam(ours.parameters(), lr=1e-3, weight_decay=1e-2)
+    x = torch.randn((11, 37), device=DEV)
+    for _ in range(3):
+        for m, o in ((ref, o_ref), (ours, o_our)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            if m is ref:
+                m.extra.grad = torch.zeros_like(m.extra)
+            o.step()
+    assert float((ref.extra - ours.extra).abs().max()) <= 2e-6
+    assert float((ours.extra - _model().extra).abs().max()) > 1e-4                     # it did move
+
+
+def test_grad_slot_is_handed_out_once_per_backward_pass():
+    """A weight used by TWO nodes in one step: only the first backward may write the flat slot in place, the second
+    gets a fresh tensor and autograd accumulates, so p.grad = g1 + g2 (not 2 g2)."""
+    from mil_amd import ops
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(512, 256).to(DEV)
+    ref = copy.deepcopy(lin)
+    opt = FlatAdam(list(lin.parameters()), lr=1e-3)
+    x1, x2 = torch.randn((32, 512), device=DEV), torch.randn((32, 512), device=DEV)
+    opt.zero_grad()
+    (ops.linear_act(x1, lin.weight, lin.bias, "tanh").sum() + 3.0 * ops.linear_act(x2, lin.weight, lin.bias, "tanh").sum()).backward()
+    (torch.tanh(ref(x1)).sum() + 3.0 * torch.tanh(ref(x2)).sum()).backward()
+    assert float((lin.weight.grad - ref.weight.grad).abs().max()) <= 1e-3 * float(ref.weight.grad.abs().max())
+    assert float((lin.bias.grad - ref.bias.grad).abs().max()) <= 1e-3 * float(ref.bias.grad.abs().max())
 
 
 def test_linear_gradients_land_in_the_flat_slots_without_a_copy():
@@ -72,9 +108,7 @@ def test_flat_sgd_tracks_torch_sgd():
         for m, o in ((ref, o_ref), (ours, o_our)):
             o.zero_grad()
             m(x).square().mean().backward()
-            if m is ref and m.extra.grad is None:
-                m.extra.grad = torch.zeros_like(m.extra)
-            o.step()
+            o.step()           # `extra` has no gradient: skipped by torch.optim.SGD and by FlatSGD alike
     for (k, a), b in zip(ref.named_parameters(), ours.parameters()):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), k
     assert o_our.exp_avg.numel() == 0
