@@ -3,6 +3,7 @@
 #pragma once
 #include "mil_common.h"
 #define GR_NG 384
+#define GR_NB 16          // lanes per bias / w / b output in the reduce
 
 // Parameter gradients of the head (model/aggregator.py:128-131: z = M Wf^T + bf):  dWf[c][j] = sum_b dz[b][c] M[b][j],
 // dbf[c] = sum_b dz[b][c], plus the step's loss = sum_b loss_bag[b].  A handful of workgroups of latency-bound work that
@@ -53,8 +54,10 @@ static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& 
 // One thread per output float4 (8 independent 16-byte loads in flight), un-permuting the gate index; the last
 // 577 threads fold the bias / w / b partials.  (A 4-threads-per-output variant with 4x the workgroups measured
 // slower: 14.3 vs 12.1 us for the 31 MB of partials at L = 512.)
+// SB: number of bias slabs [4][192] in pbias (S for kernels whose jt == 0 workgroups publish a chunk's sums, S * NJ for
+// k_gate_bwd_dw2, where every column-tile workgroup publishes its share).
 static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __restrict__ part, const float* __restrict__ pbias,
-                                                                int S, int L, float* __restrict__ dWv, float* __restrict__ dbv,
+                                                                int S, int SB, int L, float* __restrict__ dWv, float* __restrict__ dbv,
                                                                 float* __restrict__ dWu, float* __restrict__ dbu,
                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate,
                                                                 float wscale, int head_first = 1 << 30,
@@ -86,11 +89,16 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
         float* dst = (ii < 64 ? dWv + (size_t)(64 * m + ii) * L : dWu + (size_t)(64 * m + ii - 64) * L) + 4 * c4;
         if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
-    } else if (idx < nW + 3 * 192 + 1) {
-        const int k = idx - nW;
+    } else if (idx < nW + GR_NB * (3 * 192 + 1)) {
+        // bias / w / b: GR_NB lanes per output, each sums every GR_NB-th slab (loads in flight), then a fixed-order
+        // shuffle fold.  (One thread per output walked the S * NJ slabs of the low-VALU kernel serially: 9.5 us.)
+        const int k = (idx - nW) / GR_NB, sub = (idx - nW) % GR_NB;
         const int which = k / 192, d = k % 192;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += pbias[((size_t)s * 4 + which) * 192 + d];
+        for (int s = sub; s < SB; s += GR_NB) v += pbias[((size_t)s * 4 + which) * 192 + d];
+#pragma unroll
+        for (int mm = GR_NB / 2; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm);
+        if (sub != 0) return;
         float* dst = which == 0 ? dbv + d : which == 1 ? dbu + d : which == 2 ? dw + d : db;
         if (accumulate) v += *dst;
         *dst = v;

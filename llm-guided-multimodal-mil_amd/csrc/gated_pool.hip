@@ -6,6 +6,7 @@
 //     dense fp32 contractions: v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s roof).
 //   * scores -> softmax over the bag -> A.x (and ds in the backward) stream x once: HBM-bound.
 #include "mil_common.h"
+#include <type_traits>
 
 // ================================================================================ K1a gate forward
 // Workgroup: 512 threads = 8 waves, tile = 128 rows x all 384 gate columns, K-slices of 32, double-buffered in LDS.
@@ -467,7 +468,7 @@ typedef unsigned short gb_u16x8 __attribute__((ext_vector_type(8)));
 // on the two halves of the row chunk (own LDS stages, common barriers) and fold their accumulators through LDS before the
 // store, so a launch needs half as many row chunks for the same number of resident waves - half the partial tiles to
 // write here and to read in k_gate_bwd_reduce.
-template <bool XB16, int KG>
+template <bool XB16, int KG, bool DROP>
 __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict__ xv, const float* __restrict__ gates,
                                                      const float* __restrict__ ds, const float* __restrict__ wvec,
                                                      float* __restrict__ part, float* __restrict__ pbias, int R, int L,
@@ -522,12 +523,12 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
             if (i < 2) {
                 const int gr = max(min(rs + hrow + 16 * i, rend - 1), 0);
                 rh[i] = *reinterpret_cast<const gb_u16x8*>(xh + (size_t)gr * L + j0 + 8 * hc8);
-                if (xbits != nullptr) rm[i] = xbits[(size_t)gr * LW + ((j0 + 8 * hc8) >> 5)];
+                if (DROP) rm[i] = xbits[(size_t)gr * LW + ((j0 + 8 * hc8) >> 5)];
             }
         } else {
             const int gr = max(min(rs + xrow + 8 * i, rend - 1), 0);
             rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)gr * L + j0 + 4 * xc4);
-            if (xbits != nullptr) rm[i] = xbits[(size_t)gr * LW + ((j0 + 4 * xc4) >> 5)];
+            if (DROP) rm[i] = xbits[(size_t)gr * LW + ((j0 + 4 * xc4) >> 5)];
         }
     };
     auto xwrite = [&](int i, int buf) {
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
                     lo[e] = __uint_as_float(((unsigned)rh[i][e]) << 16);
                     hi[e] = __uint_as_float(((unsigned)rh[i][4 + e]) << 16);
                 }
-                if (xbits != nullptr) {
+                if (DROP) {
                     const unsigned mm = rm[i] >> (8 * (hc8 & 3));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { lo[e] = keep_if(lo[e], mm, e); hi[e] = keep_if(hi[e], mm, 4 + e); }
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
             }
         } else {
             f32x4 v = rx[i];
-            if (xbits != nullptr) {
+            if (DROP) {
                 const unsigned mm = rm[i] >> (4 * (xc4 & 7));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = keep_if(v[e], mm, e);
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
         rds[i] = ds[gc];                                  // unconditional load: keeps the body branch-free
         rmask[i] = (live && gr < rend) ? 1.f : 0.f;
     };
+#if defined(GB_OLD_DPRE)
     auto awrite_v = [&](int i, int buf) {           // dPreV = ds w U (1 - V^2)
         const f32x4 v = rv[i], u = ru[i];
         const f32x4 pv = (rds[i] * rmask[i] * w4) * u * (1.0f - v * v);
@@ -582,6 +584,30 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
         acc_w += dsv * v * u;
         if (ad4 == 0) acc_ds += dsv;
     };
+#else
+    // dPreV = ds w U (1 - V^2) = a - (a V) V and dPreU = ds w V U (1 - U) = t - t U with a = ds w U, t = a V: four VALU
+    // per (V, U) pair instead of seven.  (The bias / w / b sums stay unconditional: a wave-uniform `jt == 0` branch around
+    // them splits the k-step into basic blocks and costs more than the six VALU it saves.)
+    f32x4 rt[2];
+    auto awrite_v = [&](int i, int buf) {
+        const f32x4 v = rv[i];
+        const f32x4 a = ((rds[i] * rmask[i]) * w4) * ru[i];
+        const f32x4 t = a * v;
+        const f32x4 pv = a - t * v;
+        rt[i] = t;
+        *reinterpret_cast<f32x4*>(ab + (buf * GB_BKR + arow + 16 * i) * 128 + 4 * ad4) = pv;
+        acc_bv += pv;
+    };
+    auto awrite_u = [&](int i, int buf) {
+        const f32x4 t = rt[i], u = ru[i];
+        const f32x4 pu = t - t * u;
+        *reinterpret_cast<f32x4*>(ab + (buf * GB_BKR + arow + 16 * i) * 128 + 64 + 4 * ad4) = pu;
+        const float dsv = rds[i] * rmask[i];
+        acc_bu += pu;
+        acc_w += (dsv * rv[i]) * u;
+        if (ad4 == 0) acc_ds += dsv;
+    };
+#endif
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -607,7 +633,18 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
         for (int i = 0; i < 2; ++i) aload(i, rs1, nslice > 1);   // a single-slice chunk must not count slice 0 twice
     }
     __syncthreads();
-    for (int sl = 0; sl < nloop; ++sl) {
+#if defined(GB_STAMP)
+    const uint64_t st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Issue order inside a k-step.  The two waves of a SIMD (w and w + 4) share its matrix pipe and the older one wins every
+    // arbitration: measured with in-kernel stamps (tools/kbench_clock.py), waves 0-3 spent 29 % of the loop parked at the
+    // slice barrier while waves 4-7, starved until then, finished the slice ALONE.  A wave on its own only keeps the pipe
+    // busy if its non-matrix instructions sit in the shadow of its own MFMAs, so the k-step is laid out as
+    //     MFMA . fragment reads . MFMA . staging part a . MFMA . staging part b . MFMA . staging part c
+    // (one v_mfma_f32_32x32x2_f32 occupies the pipe for 64 cycles; a part is a handful of VALU / one LDS write / one or
+    // two global loads), each boundary pinned with sched_barrier: hipcc otherwise gathers the staging in front of a
+    // block of four MFMAs, behind which the wave sits blocked for 3 x 64 cycles with nothing else to issue.
+    auto slice_body = [&](int sl) {
         const int buf = sl & 1;
         // registers hold slice sl+1 (or, past this group's last slice, a dead copy with ds forced to 0)
         const bool live2 = sl + 2 < nslice;
@@ -616,32 +653,96 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
         const float* bp = xb + buf * GB_BKR * 128 + h * 128 + 64 * wj + r;
         float fa[2][2], fb[2][2];
         fa[0][0] = ap[0]; fa[0][1] = ap[32]; fb[0][0] = bp[0]; fb[0][1] = bp[32];
+        // staging parts of k-step ks (p = 0, 1, 2): LDS image of slice sl+1 from the registers, registers reloaded with sl+2
+        auto part = [&](int ks, int p) {
+#if defined(GB_ABL_NOLD)
+            if (ks >= 1 && ks <= 4 && p == 0) xwrite(ks - 1, buf ^ 1);
+            if (ks == 5 && p == 0) awrite_v(0, buf ^ 1);
+            if (ks == 6 && p == 0) awrite_u(0, buf ^ 1);
+            if (ks == 7 && p == 0) awrite_v(1, buf ^ 1);
+            if (ks == 8 && p == 0) awrite_u(1, buf ^ 1);
+            (void)rs2; (void)live2;
+#elif defined(GB_ABL_NOWR)
+            if (ks >= 1 && ks <= 4 && p == 1) { asm volatile("" ::"v"(rx[ks - 1])); xload(ks - 1, rs2); }
+            if (ks == 6 && p == 1) { asm volatile("" ::"v"(rv[0]), "v"(ru[0]), "v"(rds[0])); aload(0, rs2, live2); }
+            if (ks == 8 && p == 1) { asm volatile("" ::"v"(rv[1]), "v"(ru[1]), "v"(rds[1])); aload(1, rs2, live2); }
+#else
+#if !defined(GB_ABL_NOX)
+            if (ks >= 1 && ks <= 4) {
+                if (p == 0) xwrite(ks - 1, buf ^ 1);
+                if (p == 1) xload(ks - 1, rs2);
+            }
+#endif
+#if !defined(GB_ABL_NOA)
+            if (ks == 5 && p == 0) awrite_v(0, buf ^ 1);
+            if (ks == 6 && p == 0) awrite_u(0, buf ^ 1);
+            if (ks == 6 && p == 1) aload(0, rs2, live2);
+            if (ks == 7 && p == 0) awrite_v(1, buf ^ 1);
+            if (ks == 8 && p == 0) awrite_u(1, buf ^ 1);
+            if (ks == 8 && p == 1) aload(1, rs2, live2);
+#endif
+#endif
+        };
 #pragma unroll
         for (int ks = 0; ks < GB_BKR / 2; ++ks) {
             const int q = ks & 1;
+#if defined(GB_OLD_ORDER)
             if (ks + 1 < GB_BKR / 2) {
                 fa[q ^ 1][0] = ap[(ks + 1) * 256]; fa[q ^ 1][1] = ap[(ks + 1) * 256 + 32];
                 fb[q ^ 1][0] = bp[(ks + 1) * 256]; fb[q ^ 1][1] = bp[(ks + 1) * 256 + 32];
             }
-            // one staging piece per k-step: LDS image of slice sl+1, then reload the registers with slice sl+2
-#if !defined(GB_ABL_NOX)
-            if (ks >= 1 && ks <= 4) { xwrite(ks - 1, buf ^ 1); xload(ks - 1, rs2); }
-#endif
-#if !defined(GB_ABL_NOA)
-            if (ks == 5) awrite_v(0, buf ^ 1);
-            if (ks == 6) { awrite_u(0, buf ^ 1); aload(0, rs2, live2); }
-            if (ks == 7) awrite_v(1, buf ^ 1);
-            if (ks == 8) { awrite_u(1, buf ^ 1); aload(1, rs2, live2); }
-#endif
+            part(ks, 0); part(ks, 1); part(ks, 2);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#else
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < GB_BKR / 2) {
+                fa[q ^ 1][0] = ap[(ks + 1) * 256]; fa[q ^ 1][1] = ap[(ks + 1) * 256 + 32];
+                fb[q ^ 1][0] = bp[(ks + 1) * 256]; fb[q ^ 1][1] = bp[(ks + 1) * 256 + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            part(ks, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            part(ks, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            part(ks, 2);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
-        __syncthreads();
+    };
+#if defined(GB_STAMP)
+    uint64_t st_bar = 0;
+#define GB_SYNC() do { const uint64_t b0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); st_bar += __builtin_amdgcn_s_memtime() - b0_; } while (0)
+#else
+#define GB_SYNC() __syncthreads()
+#endif
+    for (int sl = 0; sl < nloop; ++sl) {
+        slice_body(sl);
+        GB_SYNC();
     }
 
+#if defined(GB_STAMP)
+    // diagnostic build only: shader-clock and 100 MHz real-time ticks across the main loop, into unused pbias slots
+    if (threadIdx.x == 0) {
+        const uint64_t st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        float* dbg = pbias + ((size_t)s * 4 + 3) * 192 + 8 + 2 * (m * NJ + jt);
+        dbg[0] = (float)(st_t1 - st_t0);
+        dbg[1] = (float)(st_r1 - st_r0);
+    }
+    if ((threadIdx.x & 63) == 0 && m == 0 && jt == 0)      // per-wave cycles spent inside the slice barriers
+        pbias[((size_t)s * 4 + 3) * 192 + 64 + (threadIdx.x >> 6)] = (float)st_bar;
+#endif
+#if defined(GB_OLD_STORE)
     // KG = 2: group 1 hands its accumulators to group 0 through its own (now dead) staging area - same lane, same register
     // index, so no transpose - and group 0 alone stores the folded tile
     if (KG == 2) {
@@ -690,6 +791,36 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
             }
         }
     }
+#else
+    // partial tile -> part[s][128m + 64wi + row][j0 + 64wj + col].  The accumulators hold a column per lane (16 rows
+    // each); going through LDS turns 64 four-byte stores per lane into sixteen-byte ones: every wave writes its 64 x 64
+    // tile row-major into its own 16 KB of its group's (now dead) staging area (stride 64 is conflict-free both ways).
+    // KG = 2: both K groups do that, then the two waves that own the same tile (one per group) each fold and store HALF
+    // of its rows - one LDS round trip and all eight waves storing, instead of fold -> transpose -> store by four.
+    {
+        __syncthreads();                                  // the staging buffers are dead from here on
+        float* tw = smem + wave * (64 * 64);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tw[(32 * a + mfma32_row(i, h)) * 64 + 32 * b + r] = acc[a][b][i];
+        if (KG == 2) __syncthreads();                     // KG = 1: same-wave write -> read, ordered by lgkmcnt
+        float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj;
+        const int c4 = lane & 15, rr = lane >> 4;         // 16 float4 columns x 4 rows per pass
+        const float* t0 = smem_all + wave * (64 * 64);
+        const float* t1 = smem_all + (2 * 2 * GB_BKR * 128) + wave * (64 * 64);
+        constexpr int NP = 16 / KG;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int row = 4 * (pass + NP * grp) + rr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(t0 + row * 64 + 4 * c4);
+            if (KG == 2) v += *reinterpret_cast<const f32x4*>(t1 + row * 64 + 4 * c4);
+            *reinterpret_cast<f32x4*>(pt + (size_t)row * L + 4 * c4) = v;
+        }
+    }
+#endif
 
     // bias / w partials (only the j-tile-0 workgroups publish them); both K groups contribute their row groups
     if (jt == 0) {
@@ -718,6 +849,266 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
                 float v = 0.f;
                 for (int g = 0; g < 256 * KG; g += 16) v += redf[g];
                 pbias[((size_t)s * 4 + 3) * 192] = v;
+            }
+        }
+    }
+}
+
+
+// ================================================================================ K1 backward: gate dW, "VALU diet" form
+// Same product, tiling, split-K layout, k order and outputs (bit for bit) as k_gate_bwd_dw<false, 2, *>; what changes is
+// how little VECTOR-ALU work the main loop carries.  Measured on MI355X (tools/mfma_valu_mix.hip): unlike the bf16 MFMAs,
+// v_mfma_f32_32x32x2_f32 does NOT hide VALU instructions issued around it - it runs at the f32 VALU rate and every
+// v_fma / v_and between two of them costs 3-5 cycles of matrix time, at one or two waves per SIMD alike (4 fillers per
+// MFMA: 64 -> 84 cycles; LDS reads, scalar ALU and s_nop fillers are free).  The first kernel spent ~230 VALU
+// instructions per wave and 32-row slice (64 MFMAs) on 64-bit address arithmetic, row clamps, LDS addresses, masks:
+// 27 % of the loop.  Here
+//   * global operands come through buffer resources whose base / size live in SGPRs and advance by scalar ALU: the
+//     per-lane offset is a loop invariant, rows beyond the K group's end read as ZERO by the hardware range check (no
+//     clamps, no validity masks - a zero ds row contributes nothing);
+//   * both LDS images store their four 32-column blocks in the order {0, 2, 1, 3}, so the two operand values a lane
+//     needs per k-step are 64 dwords apart and ONE ds_read2st64_b32 with immediate offsets fetches them (no address
+//     VALU; the buffer index is a compile-time constant: the slice loop is unrolled by two);
+//   * the bias / w / b sums are spread over the NJ column-tile workgroups of a row chunk (slice sl is summed by the
+//     workgroup with jt == sl % NJ, scalar branch) instead of being summed by all of them and published by one.
+// What is left is the arithmetic itself: dPre (20 VALU per (V, U) float4 pair) and, in train mode, the keep mask of x.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define MIL_SRD_FLAGS 0x00020000      /* raw buffer, 32-bit data format field as hipcc expects for gfx950 */
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void k_gate_bwd_dw2(const float* __restrict__ x, const float* __restrict__ gates,
+                                                      const float* __restrict__ ds, const float* __restrict__ wvec,
+                                                      float* __restrict__ part, float* __restrict__ pbias, int R, int L,
+                                                      int KC, int NJ, const uint32_t* __restrict__ xbits) {
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * 2 * 2 * GB_BKR * 128];
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    float* smem = smem_all + grp * (2 * 2 * GB_BKR * 128);      // this K group's stages: [2][32][128] dPre, [2][32][128] x
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
+    const int j0 = jt * 128;
+    const int cbeg = s * KC, cend = min(R, cbeg + KC);
+    const int half = ((cend - cbeg + 2 * GB_BKR - 1) / (2 * GB_BKR)) * GB_BKR;
+    const int rbeg = min(cend, cbeg + grp * half), rend = min(cend, rbeg + half);
+    const int nloop = (min(half, cend - cbeg) + GB_BKR - 1) / GB_BKR;      // common to both groups (shared barriers)
+
+    // per-lane byte offsets inside a slice (loop invariants)
+    const int xrow = tid >> 5, xc4 = tid & 31;    // x: rows xrow + 8i (i < 4), 16-byte chunk xc4 of the 128-column tile
+    const int arow = tid >> 4, ad4 = tid & 15;    // gates: rows arow + 16i (i < 2), d = 64m + 4 ad4
+    const int LW = L >> 5;
+    int vx[4], vm[4], vg[2], vd[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        vx[i] = ((xrow + 8 * i) * L + j0 + 4 * xc4) * 4;
+        vm[i] = ((xrow + 8 * i) * LW + ((j0 + 4 * xc4) >> 5)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        vg[i] = ((arow + 16 * i) * GF_NG + 64 * m + 4 * ad4) * 4;
+        vd[i] = (arow + 16 * i) * 4;
+    }
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
+    // LDS positions: 32-column blocks stored in the order {0, 2, 1, 3}
+    auto blkpos = [](int c) { return (c & 31) | ((c & 32) << 1) | ((c & 64) >> 1); };
+    float* const ab = smem;                       // [2][32][128]
+    float* const xb = smem + 2 * GB_BKR * 128;    // [2][32][128]
+    float* const xw = xb + xrow * 128 + blkpos(4 * xc4);              // + (buf * 32 + 8 i) * 128
+    float* const aw = ab + arow * 128 + blkpos(4 * ad4);              // V block; U block: blkpos(64 + 4 ad4) = + 32
+    const float* const ap = ab + h * 128 + 32 * wi + r;               // + buf * 4096 + ks * 256 (+ 64)
+    const float* const bp = xb + h * 128 + 32 * wj + r;
+
+    u32x4_t rx[4], rv[2], ru[2];
+    unsigned rm[4] = {0, 0, 0, 0};
+    float rds[2];
+    f32x4 rt[2];
+    f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
+    float acc_ds = 0.f;
+
+    // scalar: resources of slice `row0`.  Rows >= rend are out of range -> the loads return zeros.
+    auto x_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)row0 * L), 0, max(rend - row0, 0) * L * 4, MIL_SRD_FLAGS);
+    };
+    auto g_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(gates + (size_t)row0 * GF_NG), 0, max(rend - row0, 0) * GF_NG * 4,
+                                                 MIL_SRD_FLAGS);
+    };
+    auto d_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(ds + row0), 0, max(rend - row0, 0) * 4, MIL_SRD_FLAGS);
+    };
+    auto m_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(xbits + (size_t)row0 * LW), 0, max(rend - row0, 0) * LW * 4,
+                                                 MIL_SRD_FLAGS);
+    };
+    auto xload = [&](int i, int row0) {
+        rx[i] = __builtin_amdgcn_raw_buffer_load_b128(x_srd(row0), vx[i], 0, 0);
+        if (DROP) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(m_srd(row0), vm[i], 0, 0);
+    };
+    auto aload = [&](int i, int row0) {
+        const __amdgpu_buffer_rsrc_t g = g_srd(row0);
+        rv[i] = __builtin_amdgcn_raw_buffer_load_b128(g, vg[i], 0, 0);
+        ru[i] = __builtin_amdgcn_raw_buffer_load_b128(g, vg[i] + 192 * 4, 0, 0);
+        rds[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d_srd(row0), vd[i], 0, 0));
+    };
+    auto xwrite = [&](int i, int buf) {
+        f32x4 v = __builtin_bit_cast(f32x4, rx[i]);
+        if (DROP) {
+            const unsigned mm = rm[i] >> (4 * (xc4 & 7));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = keep_if(v[e], mm, e);
+        }
+        *reinterpret_cast<f32x4*>(xw + (buf * GB_BKR + 8 * i) * 128) = v;
+    };
+    auto awrite_v = [&](int i, int buf) {           // dPreV = a - (a V) V,  a = ds w U
+        const f32x4 v = __builtin_bit_cast(f32x4, rv[i]);
+        const f32x4 a = (rds[i] * w4) * __builtin_bit_cast(f32x4, ru[i]);
+        const f32x4 t = a * v;
+        rt[i] = t;
+        *reinterpret_cast<f32x4*>(aw + (buf * GB_BKR + 16 * i) * 128) = a - t * v;
+    };
+    auto awrite_u = [&](int i, int buf, bool pub) { // dPreU = t - t U,  t = ds w U V
+        const f32x4 t = rt[i], u = __builtin_bit_cast(f32x4, ru[i]);
+        const f32x4 pu = t - t * u;
+        *reinterpret_cast<f32x4*>(aw + (buf * GB_BKR + 16 * i) * 128 + 32) = pu;
+        if (pub) {                                    // scalar branch: this slice's sums belong to this workgroup
+            const f32x4 v = __builtin_bit_cast(f32x4, rv[i]);
+            acc_bv += (rds[i] * w4) * u - t * v;      // = dPreV again (3 VALU per element, only every NJ-th slice)
+            acc_bu += pu;
+            acc_w += (rds[i] * v) * u;
+            if (ad4 == 0) acc_ds += rds[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // prologue: slice 0 -> LDS buffer 0, slice 1 -> registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xload(i, rbeg);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aload(i, rbeg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xwrite(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { awrite_v(i, 0); awrite_u(i, 0, jt == 0); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xload(i, rbeg + GB_BKR);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aload(i, rbeg + GB_BKR);
+    __syncthreads();
+
+    // one slice: 16 k-steps x 4 MFMAs; between the MFMAs the parts that stage slice sl + 1 and reload slice sl + 2
+    auto slice = [&](int sl, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        const int row2 = rbeg + (sl + 2) * GB_BKR;
+        const bool pub = ((sl + 1) % NJ) == jt;                     // the slice being written now is sl + 1
+        const float* apb = ap + buf * GB_BKR * 128;
+        const float* bpb = bp + buf * GB_BKR * 128;
+        float fa[2][2], fb[2][2];
+        fa[0][0] = apb[0]; fa[0][1] = apb[64]; fb[0][0] = bpb[0]; fb[0][1] = bpb[64];
+#pragma unroll
+        for (int ks = 0; ks < GB_BKR / 2; ++ks) {
+            const int q = ks & 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < GB_BKR / 2) {
+                fa[q ^ 1][0] = apb[(ks + 1) * 256]; fa[q ^ 1][1] = apb[(ks + 1) * 256 + 64];
+                fb[q ^ 1][0] = bpb[(ks + 1) * 256]; fb[q ^ 1][1] = bpb[(ks + 1) * 256 + 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks >= 1 && ks <= 4) xwrite(ks - 1, buf ^ 1);
+            if (ks == 5) awrite_v(0, buf ^ 1);
+            if (ks == 6) awrite_u(0, buf ^ 1, pub);
+            if (ks == 7) awrite_v(1, buf ^ 1);
+            if (ks == 8) awrite_u(1, buf ^ 1, pub);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks >= 1 && ks <= 4) xload(ks - 1, row2);
+            if (ks == 6) aload(0, row2);
+            if (ks == 8) aload(1, row2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int sl = 0;
+    for (; sl + 1 < nloop; sl += 2) {
+        slice(sl, std::integral_constant<int, 0>{});
+        __syncthreads();
+        slice(sl + 1, std::integral_constant<int, 1>{});
+        __syncthreads();
+    }
+    if (sl < nloop) {
+        slice(sl, std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+
+    // partial tile -> part[s][128m + 64wi + row][j0 + 64wj + col]: every wave writes its 64 x 64 tile row-major into its own
+    // 16 KB of its group's (now dead) staging area; the two waves that own the same tile (one per K group) each fold
+    // and store half of its rows with 16-byte stores.
+    {
+        float* tw = smem + wave * (64 * 64);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tw[(32 * a + mfma32_row(i, h)) * 64 + 32 * b + r] = acc[a][b][i];
+        __syncthreads();
+        float* pt = part + ((size_t)s * GF_NG + 128 * m + 64 * wi) * L + j0 + 64 * wj;
+        const int c4 = lane & 15, rr = lane >> 4;
+        const float* t0 = smem_all + wave * (64 * 64);
+        const float* t1 = smem_all + (2 * 2 * GB_BKR * 128) + wave * (64 * 64);
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = 4 * (pass + 8 * grp) + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(t0 + row * 64 + 4 * c4) +
+                            *reinterpret_cast<const f32x4*>(t1 + row * 64 + 4 * c4);
+            *reinterpret_cast<f32x4*>(pt + (size_t)row * L + 4 * c4) = v;
+        }
+    }
+
+    // bias / w / b partials: every (s, jt) workgroup publishes the sums of its share of the slices -> pbias[s][jt][4][192]
+    {
+        float* redf = smem_all;   // [32 row groups][3][64]
+        const int arow_all = arow + 16 * grp;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            redf[(arow_all * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
+            redf[(arow_all * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
+            redf[(arow_all * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
+        }
+        __syncthreads();
+        float* pb = pbias + ((size_t)s * NJ + jt) * 4 * 192;
+        if (threadIdx.x < 192) {
+            const int which = threadIdx.x / 64, d = threadIdx.x % 64;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) v += redf[(g * 3 + which) * 64 + d];
+            pb[which * 192 + 64 * m + d] = v;
+        }
+        if (m == 0) {
+            __syncthreads();
+            redf[threadIdx.x] = acc_ds;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float v = 0.f;
+                for (int g = 0; g < 512; g += 16) v += redf[g];
+                pb[3 * 192] = v;
             }
         }
     }
@@ -1024,11 +1415,33 @@ extern "C" int mil_attn_pool_bwd(const float* x, const float* scores, const floa
     return MIL_OK;
 }
 
+template <bool XB16>
+static void launch_gate_bwd_dw(const void* x, const float* gates, const float* ds, const float* w, float* part, float* pbias,
+                               int R, int L, int kc, int NJ, int S, const uint32_t* xbits, hipStream_t st) {
+    const dim3 grid(S * 3 * NJ);
+    if (split_kg(R, L) == 2) {
+        if (xbits) hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 2, true>), grid, dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+        else hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 2, false>), grid, dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    } else {
+        if (xbits) hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 1, true>), grid, dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+        else hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 1, false>), grid, dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    }
+}
+
+// fp32 x, two K groups per workgroup, offsets within 32 bits: the low-VALU kernel (k_gate_bwd_dw2)
+static inline bool use_dw2(int R, int L) {
+#if defined(GB_NO_DW2)
+    return false;
+#endif
+    return split_kg(R, L) == 2 && (long long)R * L < (1ll << 29);
+}
+static inline size_t gate_bwd_ws_floats(int S, int L) { return (size_t)S * GF_NG * L + (size_t)S * (L / 128) * 4 * 192; }
+
 extern "C" size_t mil_gate_bwd_workspace_floats(int R, int L) {
     if (R <= 0 || L <= 0 || (L % 128) != 0) return 0;
     int kc;
     const int S = split_plan(R, L, &kc);
-    return (size_t)S * GF_NG * L + (size_t)S * 4 * 192;
+    return gate_bwd_ws_floats(S, L);
 }
 
 // The two launches of mil_gate_bwd_params as separate entry points (bench.py times the MFMA kernel alone).
@@ -1039,14 +1452,21 @@ extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const f
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
     const int S = split_plan(R, L, &kc);
-    if (workspace_floats < (size_t)S * GF_NG * L + (size_t)S * 4 * 192) return MIL_ENOSPC;
+    if (workspace_floats < gate_bwd_ws_floats(S, L)) return MIL_ENOSPC;
     const int NJ = L / 128;
-    if (split_kg(R, L) == 2)
-        hipLaunchKernelGGL((k_gate_bwd_dw<false, 2>), dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, (const void*)x, gates, ds,
-                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ, xbits);
-    else
-        hipLaunchKernelGGL((k_gate_bwd_dw<false, 1>), dim3(S * 3 * NJ), dim3(256), 0, (hipStream_t)stream, (const void*)x, gates, ds,
-                           w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ, xbits);
+    if (use_dw2(R, L)) {
+        float* pb = workspace + (size_t)S * GF_NG * L;
+        if (xbits)
+            hipLaunchKernelGGL(k_gate_bwd_dw2<true>, dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, x, gates, ds, w, workspace, pb,
+                               R, L, kc, NJ, xbits);
+        else
+            hipLaunchKernelGGL(k_gate_bwd_dw2<false>, dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, x, gates, ds, w, workspace, pb,
+                               R, L, kc, NJ, xbits);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
+    launch_gate_bwd_dw<false>((const void*)x, gates, ds, w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ, S, xbits,
+                              (hipStream_t)stream);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1057,9 +1477,10 @@ extern "C" int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* 
     if (L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
     const int S = split_plan(R, L, &kc);
-    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    const int nthreads = GF_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
-                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xscale);
+                       workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
+                       accumulate, xscale);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1075,12 +1496,12 @@ extern "C" int mil_gate_bwd_params_head(const float* x, const float* gates, cons
     if (rc != MIL_OK) return rc;
     int kc;
     const int S = split_plan(R, L, &kc);
-    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    const int nthreads = GF_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
     const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
-                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate,
-                       xbits ? xscale : 1.0f, nred, head);
+                       workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
+                       accumulate, xbits ? xscale : 1.0f, nred, head);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1095,11 +1516,12 @@ extern "C" int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, fl
     if (L <= 0 || (L % 128) != 0 || R <= 0 || B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
     int kc;
     const int S = split_plan(R, L, &kc);
-    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
+    const int nthreads = GF_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
     const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
-                       workspace + (size_t)S * GF_NG * L, S, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xscale, nred, head);
+                       workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
+                       accumulate, xscale, nred, head);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1122,21 +1544,16 @@ extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, co
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
     const int S = split_plan(R, L, &kc);
-    const size_t need = (size_t)S * GF_NG * L + (size_t)S * 4 * 192;
+    const size_t need = gate_bwd_ws_floats(S, L);
     if (workspace_floats < need) return MIL_ENOSPC;
     float* part = workspace;
     float* pbias = workspace + (size_t)S * GF_NG * L;
     const int NJ = L / 128;
     hipStream_t st = (hipStream_t)stream;
-    if (split_kg(R, L) == 2)
-        hipLaunchKernelGGL((k_gate_bwd_dw<true, 2>), dim3(S * 3 * NJ), dim3(512), 0, st, (const void*)x, gates, ds, w, part, pbias,
-                           R, L, kc, NJ, xbits);
-    else
-        hipLaunchKernelGGL((k_gate_bwd_dw<true, 1>), dim3(S * 3 * NJ), dim3(256), 0, st, (const void*)x, gates, ds, w, part, pbias,
-                       R, L, kc, NJ, xbits);
+    launch_gate_bwd_dw<true>((const void*)x, gates, ds, w, part, pbias, R, L, kc, NJ, S, xbits, st);
     MIL_CHECK_LAUNCH();
-    const int nthreads = GF_NG * (L / 4) + 3 * 192 + 1;
-    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
+    const int nthreads = GF_NG * (L / 4) + GR_NB * (3 * 192 + 1);
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, S, L, dWv, dbv, dWu,
                        dbu, dw, db, accumulate, xbits ? xscale : 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;

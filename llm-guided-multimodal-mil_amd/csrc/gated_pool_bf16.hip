@@ -800,8 +800,8 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, c
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_gate_bwd_dw_bf16, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
     MIL_CHECK_LAUNCH();
-    const int nthreads = HB_NG * (L / 4) + 3 * 192 + 1;
-    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, L, dWv, dbv, dWu,
+    const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, S, L, dWv, dbv, dWu,
                        dbu, dw, db, accumulate, 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
