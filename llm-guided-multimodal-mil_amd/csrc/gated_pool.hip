@@ -172,6 +172,196 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
     }
 }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define MIL_SRD_FLAGS 0x00020000      /* raw buffer resource word 3 as hipcc's examples build it for gfx950 */
+
+// ================================================================================ K1a gate forward, "VALU diet" form
+// Same tiling, k order and results (bit for bit) as k_gate_fwd; the main loop sheds the vector-ALU instructions that the
+// f32 MFMA cannot hide (see k_gate_bwd_dw2 / tools/mfma_valu_mix.hip):
+//   * LDS-DMA through buffer resources (buffer_load_dwordx4 ... lds): the per-lane source offset is a loop invariant, the
+//     K offset an SGPR, the LDS destination goes to M0 by scalar ALU (no 64-bit pointer adds, no v_readfirstlane);
+//     rows of the last tile beyond R read as zeros by the hardware range check;
+//   * fragment reads are ds_read_b128 with immediate offsets from twelve precomputed per-lane LDS addresses (the buffer
+//     index is a compile-time constant: the slice loop is unrolled by two);
+//   * in train mode the keep-mask word of the next slice comes through a buffer resource as well.
+// Left in the loop per 32-column slice and wave: the mask itself (2 VALU per A element, train mode only).
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+#define GF2_XS_BYTES (GF_TM * 32 * 4)          /* one x buffer  (16 KB) */
+#define GF2_WS_BYTES (GF_NG * 32 * 4)          /* one W buffer  (48 KB) */
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, const float* __restrict__ Wv,
+                                                   const float* __restrict__ bv, const float* __restrict__ Wu,
+                                                   const float* __restrict__ bu, const float* __restrict__ wvec,
+                                                   const float* __restrict__ battn, float* __restrict__ scores,
+                                                   float* __restrict__ gates, int R, int L,
+                                                   const uint32_t* __restrict__ xbits, float xscale) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * 32];      // [2] x buffers, then [2] W buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * GF_TM;
+    const int nslice = L / GF_BK;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+
+    // ---- DMA pieces of this wave: 2 x pieces (8 rows each), 6 W pieces; lane -> (row in piece, physical 16-byte chunk)
+    const int prow = lane >> 3, pch = lane & 7;
+    const int rows_here = min(GF_TM, R - row0);
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)row0 * L), 0, rows_here * L * 4, MIL_SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc((void*)Wv, 0, MIL_GATE_D * L * 4, MIL_SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc((void*)Wu, 0, MIL_GATE_D * L * 4, MIL_SRD_FLAGS);
+    int vsrc[8];                 // per-lane byte offset of the piece's source (slice 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < 2) {
+            const int lr = (2 * wave + i) * 8 + prow;
+            vsrc[i] = (lr * L + 4 * (pch ^ ((lr >> 1) & 7))) * 4;
+        } else {
+            const int wrow = (6 * wave + (i - 2)) * 8 + prow;                 // 0..383: pieces never straddle Wv / Wu
+            vsrc[i] = ((wrow % MIL_GATE_D) * L + 4 * (pch ^ ((wrow >> 1) & 7))) * 4;
+        }
+    }
+    auto dma_piece = [&](int i, int buf, int kbytes) {            // i, buf compile-time after unrolling; kbytes scalar
+        if (i < 2) {
+            const unsigned dst = lds0 + (unsigned)(buf * GF2_XS_BYTES + (2 * wave + i) * 8 * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_x, (lds_void*)(uintptr_t)dst, 16, vsrc[i], kbytes, 0, 0);
+        } else {
+            const int p = 6 * wave + (i - 2);
+            const unsigned dst = lds0 + (unsigned)(2 * GF2_XS_BYTES + buf * GF2_WS_BYTES + p * 8 * 128);
+            if (p < 24) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_void*)(uintptr_t)dst, 16, vsrc[i], kbytes, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_u, (lds_void*)(uintptr_t)dst, 16, vsrc[i], kbytes, 0, 0);
+        }
+    };
+    // ---- fragment addresses (bytes): row (32 wr + r) of the x image / row (96 wc + r) of the W image, swizzled chunk of k-group t
+    const int fx = (r >> 1) & 7;
+    unsigned fa_addr[4], fb_addr[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned ch = 16u * (unsigned)((2 * t + h) ^ fx);
+        fa_addr[t] = lds0 + (unsigned)((32 * wr + r) * 128) + ch;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            fb_addr[b][t] = lds0 + (unsigned)(2 * GF2_XS_BYTES + b * GF2_WS_BYTES + (96 * wc + r) * 128) + ch;
+    }
+    // ---- keep bits of this lane's fragment row (train mode)
+    __amdgpu_buffer_rsrc_t srd_m = srd_x;
+    int vmask = 0;
+    unsigned mnext = 0;
+    if (DROP) {
+        srd_m = __builtin_amdgcn_make_buffer_rsrc((void*)(xbits + (size_t)row0 * nslice), 0, rows_here * nslice * 4, MIL_SRD_FLAGS);
+        vmask = (32 * wr + r) * nslice * 4;
+        mnext = __builtin_amdgcn_raw_buffer_load_b32(srd_m, vmask, 0, 0);
+    }
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][u][i] = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(i, 0, 0);
+    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+
+    auto slice = [&](int s, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        const int s1 = min(s + 1, nslice - 1);
+        const int k1bytes = s1 * GF_BK * 4;
+        unsigned mcur = 0;
+        if (DROP) {
+            mcur = mnext >> (4 * h);
+            mnext = __builtin_amdgcn_raw_buffer_load_b32(srd_m, vmask, s1 * 4, 0);
+        }
+        f32x4 a[2], b[2][3][2];
+        auto frag_piece = [&](int t, int q, int p) {
+            if (p == 0) {
+                a[q] = *(lds_cf4*)(uintptr_t)(fa_addr[t] + (unsigned)(buf * GF2_XS_BYTES));
+            } else {
+                const int c = (p - 1) >> 1, u = (p - 1) & 1;
+                b[q][c][u] = *(lds_cf4*)(uintptr_t)(fb_addr[buf][t] + (unsigned)((u * 192 + 32 * c) * 128));
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < 7; ++p) frag_piece(0, 0, p);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = t & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = 4 * t + j;
+#if defined(GF2_ABL_NODMA)
+                (void)k1bytes;
+#elif defined(GF2_ABL_XONLY)
+                if (g < 2) dma_piece(g, buf ^ 1, k1bytes);
+#elif defined(GF2_ABL_WONLY)
+                if (g >= 2 && g < 8) dma_piece(g, buf ^ 1, k1bytes);
+#else
+                if (g < 8) dma_piece(g, buf ^ 1, k1bytes);     // next slice, one DMA piece per MFMA group
+#endif
+                if (t < 3) {
+                    frag_piece(t + 1, q ^ 1, 2 * j);
+                    if (2 * j + 1 < 7) frag_piece(t + 1, q ^ 1, 2 * j + 1);
+                }
+                const float av = DROP ? keep_if(a[q][j], mcur, 8 * t + j) : a[q][j];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[q][c][u][j], acc[c][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    int s = 0;
+    for (; s + 1 < nslice; s += 2) {
+        slice(s, std::integral_constant<int, 0>{});
+        __syncthreads();
+        slice(s + 1, std::integral_constant<int, 1>{});
+        __syncthreads();
+    }
+    if (s < nslice) {
+        slice(s, std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+
+    float part[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int d = 32 * (3 * wc + c) + r;
+        const float bvd = bv[d], bud = bu[d], wd = wvec[d];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = fast_tanh(DROP ? fmaf(acc[c][0][i], xscale, bvd) : acc[c][0][i] + bvd);
+            const float u = fast_sigmoid(DROP ? fmaf(acc[c][1][i], xscale, bud) : acc[c][1][i] + bud);
+            part[i] += wd * v * u;
+            if (gates != nullptr) {
+                const int gr = row0 + 32 * wr + mfma32_row(i, h);
+                if (gr < R) {
+                    gates[(size_t)gr * GF_NG + d] = v;
+                    gates[(size_t)gr * GF_NG + 192 + d] = u;
+                }
+            }
+        }
+    }
+    float* sred = smem;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = half_allsum(part[i]);
+        if (r == 0) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
+    }
+    __syncthreads();
+    if (tid < GF_TM) {
+        const int gr = row0 + tid;
+        if (gr < R) scores[gr] = sred[tid] + sred[GF_TM + tid] + battn[0];
+    }
+}
+
 // ================================================================================ K1b attention pool forward
 // One workgroup (256 threads) per tile of <= 32 rows of one bag.  Wave w streams rows w, w+4, ...;
 // lane l owns columns 4l + 256q (16-byte loads, 1 KiB per wave instruction).
@@ -872,8 +1062,6 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
 //   * the bias / w / b sums are spread over the NJ column-tile workgroups of a row chunk (slice sl is summed by the
 //     workgroup with jt == sl % NJ, scalar branch) instead of being summed by all of them and published by one.
 // What is left is the arithmetic itself: dPre (20 VALU per (V, U) float4 pair) and, in train mode, the keep mask of x.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-#define MIL_SRD_FLAGS 0x00020000      /* raw buffer, 32-bit data format field as hipcc expects for gfx950 */
 
 template <bool DROP>
 __global__ __launch_bounds__(512) void k_gate_bwd_dw2(const float* __restrict__ x, const float* __restrict__ gates,
@@ -1316,7 +1504,18 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
     const int tail = gates != nullptr ? gate_tail_rows(R, MIL_NUM_CU) : 0;       // the tail path keeps V, U in `gates`
     const int Rm = R - tail;
     const int grid = (Rm + GF_TM - 1) / GF_TM;
-    if (xbits)
+#if defined(GF_NO_FWD2)
+    const bool fwd2 = false;
+#else
+    const bool fwd2 = L <= 4096;                 // 128 rows x L floats must stay inside the 32-bit buffer offsets (and int math)
+#endif
+    if (fwd2 && xbits)
+        hipLaunchKernelGGL(k_gate_fwd2<true>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
+                           xscale);
+    else if (fwd2)
+        hipLaunchKernelGGL(k_gate_fwd2<false>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
+                           1.0f);
+    else if (xbits)
         hipLaunchKernelGGL(k_gate_fwd<true>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
                            xscale);
     else
