@@ -203,9 +203,11 @@ int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, cons
  * arithmetic as the fp32 entry points on rounded inputs (model/dim1/ABMIL.py:47-59); the deviation from
  * the fp32 oracle is reported, the 1e-3 bar applies to the fp32 path.  L % 64 == 0 (gate), L in {512,1024} (pool). */
 int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
+/* gates (fp32 [R, 384], nullable) and/or gates16 (bf16 [R, 384], nullable): the saved {V | U}.  The bf16 form is what
+ * mil_gate_bwd_params_bf16 reads: half the bytes of the largest tensor of the step, written with 16-byte stores. */
 int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu,
                              const float* bu, const float* w, const float* b, float* scores, float* gates,
-                             int R, int L, int D, void* stream);
+                             int R, int L, int D, uint16_t* gates16, void* stream);
 int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
                                float* partials, void* stream);
 /* mil_attn_pool_partial_bf16 with the head-projection by-product of mil_attn_pool_partial_h (hrow [R, C] = x Wf^T on the
@@ -217,7 +219,7 @@ int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, const float* 
 /* Gate parameter gradients on the bf16 MFMA: x and dPre rounded to bf16, fp32 accumulation, fp32 partials and
  * outputs (same contract as mil_gate_bwd_params; L % 256 == 0; workspace mil_gate_bwd_workspace_floats_bf16). */
 size_t mil_gate_bwd_workspace_floats_bf16(int R, int L);
-int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R, int L,
+int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates16, const float* ds, const float* w, int R, int L,
                              int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,
                              float* dbu, float* dw, float* db, int accumulate, void* stream);
 /* mil_gate_bwd_params with x stored as bf16 (widened while staged; fp32 MFMA product: exact on the rounded x). */
@@ -495,7 +497,8 @@ typedef struct mil_image_only_step {
     float* loss_out;                /* [1]: sum over the bags of loss_scale * BCE */
     /* per-step state kept for the backward, caller-allocated */
     float* scores;                  /* [R] */
-    float* gates;                   /* [R, 384] */
+    float* gates;                   /* [R, 384] fp32 (fp32 x; bf16 x with the fp32-MFMA weight gradient) */
+    uint16_t* gates16;              /* [R, 384] bf16 (bf16 x with the bf16-MFMA weight gradient) */
     float* partials;                /* [T, L + 2] */
     float* hrow;                    /* [R, C] (C <= 4) or NULL: the backward then re-reads x */
     float* ds;                      /* [R] */

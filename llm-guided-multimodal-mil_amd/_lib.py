@@ -49,7 +49,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_image_only_step_run": (c_int, [_P, _P]),
     "mil_image_only_step_time": (c_int, [_P, c_uint32, c_int, c_int, _P, _P]),
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
-    "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
+    "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, _P]),
     "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P]),
     "mil_attn_pool_partial_h_bf16": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),
     "mil_attn_pool_bwd_bf16": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
@@ -124,7 +124,7 @@ class ImageOnlyStep(ctypes.Structure):
          ("x_bf16", c_int32), ("loss_scale", c_float), ("loss_kind", c_int32), ("accumulate", c_int32)]
         + [(n, _P) for n in ("Wv", "bv", "Wu", "bu", "w", "b", "Wf", "bf", "Wv16", "Wu16")]
         + [(n, _P) for n in ("dWv", "dbv", "dWu", "dbu", "dw", "db", "dWf", "dbf", "loss_out")]
-        + [(n, _P) for n in ("scores", "gates", "partials", "hrow", "ds", "dw_ws")]
+        + [(n, _P) for n in ("scores", "gates", "gates16", "partials", "hrow", "ds", "dw_ws")]
         + [("dw_ws_floats", c_uint64)]
         + [(n, _P) for n in ("M", "Mdrop", "lse", "logits", "prob", "loss_bag", "dz", "dM", "cdot")]
         + [("train", c_int32), ("bf16_grad_mfma", c_int32), ("xbits", _P), ("mbits", _P), ("seed", c_uint64),

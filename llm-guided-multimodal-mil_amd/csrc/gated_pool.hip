@@ -162,8 +162,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd(const float* __restrict__ x, c
     float* sred = smem;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float v = half_allsum(part[i]);
-        if (r == 0) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
+        const float v = half_sum_lane31(part[i]);
+        if (r == 31) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
     }
     __syncthreads();
     if (tid < GF_TM) {
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
     float* sred = smem;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float v = half_allsum(part[i]);
-        if (r == 0) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
+        const float v = half_sum_lane31(part[i]);
+        if (r == 31) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
     }
     __syncthreads();
     if (tid < GF_TM) {

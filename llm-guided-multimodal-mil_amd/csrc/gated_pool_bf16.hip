@@ -32,6 +32,35 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ src
     }
 }
 
+// Saved gates in bf16 (round 2).  Round 1 kept {V | U} as fp32 [R, 384]: at config 5 that is 201 MB written by the
+// forward (4-byte scattered stores in the epilogue, nothing to overlap with) and 201 MB re-read by every column tile of
+// the weight-gradient kernel - more traffic than the bf16 x itself (268 MB).  The bf16-MFMA weight gradient rounds dPre
+// to bf16 anyway, so V and U are stored rounded to bf16: half the bytes, and written 16 bytes per lane: a wave converts
+// its 32 x 192 tile, transposes it through its own 12 KB of LDS and stores whole 16-byte chunks.
+//   tile_lds: this wave's [32][192] u16 scratch; val(c, u, i) = gate value of d-chunk c, V/U u, accumulator register i
+//   row_base: first global row of the tile; dcol0: first d of the wave (96 wc)
+template <typename F>
+__device__ __forceinline__ void store_gates16_tile(u16* tile_lds, u16* __restrict__ gates16, int row_base, int R, int dcol0,
+                                                   int lane, F val) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                tile_lds[mfma32_row(i, h) * 192 + u * 96 + 32 * c + r] = __builtin_bit_cast(u16, (__bf16)val(c, u, i));
+    // same wave wrote what it reads: LDS operations of a wave complete in order
+#pragma unroll
+    for (int n = 0; n < 12; ++n) {
+        const int k = lane + 64 * n, row = k / 24, ch = k % 24;        // 24 chunks of 8 columns per row
+        const int u = ch / 12, d = dcol0 + 8 * (ch % 12);
+        const u16x8 v = *reinterpret_cast<const u16x8*>(tile_lds + row * 192 + 8 * ch);
+        const int gr = row_base + row;
+        if (gr < R) *reinterpret_cast<u16x8*>(gates16 + (size_t)gr * 384 + u * 192 + d) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- gate forward
 // Same decomposition as k_gate_fwd: 512 threads, 128 rows x 384 gate columns, wave (wr, wc) = 32 rows x 3 d-chunks
 // x {V, U}.  K-slices of 64 bf16 = 128 B per row: byte-for-byte the fp32 kernel's LDS geometry, so the same LDS-DMA
@@ -47,7 +76,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
                                                        const float* __restrict__ bv, const u16* __restrict__ Wu,
                                                        const float* __restrict__ bu, const float* __restrict__ wvec,
                                                        const float* __restrict__ battn, float* __restrict__ scores,
-                                                       float* __restrict__ gates, int R, int L) {
+                                                       float* __restrict__ gates, int R, int L, u16* __restrict__ gates16) {
     __shared__ __attribute__((aligned(16))) u16 smem[2 * (HB_TM + HB_NG) * HB_RS];
     u16* xs = smem;                        // [2][128][64]
     u16* ws = smem + 2 * HB_TM * HB_RS;    // [2][384][64]
@@ -153,13 +182,20 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
     float* sred = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float v = half_allsum(part[i]);
-        if (r == 0) sred[wc * HB_TM + 32 * wr + mfma32_row(i, h)] = v;
+        const float v = half_sum_lane31(part[i]);
+        if (r == 31) sred[wc * HB_TM + 32 * wr + mfma32_row(i, h)] = v;
     }
     __syncthreads();
     if (tid < HB_TM) {
         const int gr = row0 + tid;
         if (gr < R) scores[gr] = sred[tid] + sred[HB_TM + tid] + battn[0];
+    }
+    if (gates16 != nullptr) {
+        __syncthreads();                   // sred is read; the staging area is free again
+        store_gates16_tile(smem + wave * (32 * 192), gates16, row0 + 32 * wr, R, 96 * wc, lane, [&](int c, int u, int i) {
+            const int d = 32 * (3 * wc + c) + r;
+            return u == 0 ? fast_tanh(acc[c][0][i] + bv[d]) : fast_sigmoid(acc[c][1][i] + bu[d]);
+        });
     }
 }
 
@@ -197,14 +233,17 @@ __device__ __forceinline__ void dma16_raw(const void* gptr, unsigned lds_byte_ad
 #define HC_BK 32
 #define HC_XS (HC_TM * HC_BK)        // u16 per x slot  (16 KB)
 #define HC_WS (HB_NG * HC_BK)        // u16 per weight slot (24 KB)
-#define HC_NX 5
+#define HC_NX 4          // x ring: slices s .. s + 3
+#define HC_NW 3          // weight ring: slices s .. s + 2
 
+template <int GMODE>      // saved gates: 0 none, 1 fp32 [R, 384], 2 bf16 [R, 384] (branch-free epilogue per mode)
 __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restrict__ x, const u16* __restrict__ Wv,
                                                             const float* __restrict__ bv, const u16* __restrict__ Wu,
                                                             const float* __restrict__ bu, const float* __restrict__ wvec,
                                                             const float* __restrict__ battn, float* __restrict__ scores,
-                                                            float* __restrict__ gates, int R, int L) {
-    __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + 2 * HC_WS];      // 80 + 48 KB
+                                                            float* __restrict__ gates, int R, int L,
+                                                            u16* __restrict__ gates16) {
+    __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + HC_NW * HC_WS];      // 64 + 72 KB
     u16* xring = smem;
     u16* wring = smem + HC_NX * HC_XS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -245,6 +284,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
                 for (int i = 0; i < 16; ++i) acc[a][c][u][i] = 0.f;
 
     const int nslice = L / HC_BK;
+    // prologue: x slices 0 .. 2 and weight slices 0, 1
 #pragma unroll
     for (int q = 0; q < HC_NX - 1; ++q) {
         const int k0 = min(q, nslice - 1) * HC_BK;
@@ -252,22 +292,37 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
         dma_x(1, q, k0);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dma_w(i, 0, 0);
+    for (int q = 0; q < HC_NW - 1; ++q) {
+        const int k0 = min(q, nslice - 1) * HC_BK;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma_w(i, q, k0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+#if defined(HC_STAMP)
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int fx = (r >> 2) & 3;       // rows 64 wr + 32 q + r and 32 (..) + r: (row >> 2) & 3 == (r >> 2) & 3
     // Per slice: 12 B fragments j = 6 ks + 2 c + u, each feeding two MFMAs (row tiles q = 0, 1).  B fragments rotate
     // through three register slots and are read two ahead of their use; the A pair of k-step 1 is read during
     // k-step 0; the DMA pieces are spread over the fragment steps.  sched_barrier pins the order.
-    int xs = 0;                         // slot of slice s in the x ring; s & 1 in the weight ring
+    // Both streams run TWO slices ahead of their use (round 2; round 1 kept the weights one slice ahead in a two-slot
+    // ring: every slice then had to wait out one full issue-to-landed latency of its weight pieces, ~1.1 us against
+    // 0.85 us of MFMA time per slice - the "weights only: 54 us" of the round-1 ablation was that latency x 64 slices,
+    // not bandwidth).  Issue order inside a slice: the three weight pieces of slice s + 2 FIRST, the two x pieces of slice
+    // s + 3 LAST; the queue retires in order, so one counted s_waitcnt vmcnt(7) at the end of slice s (= all but the x
+    // pieces of s + 2, the weight pieces of s + 2 and the x pieces of s + 3) publishes "weights of s + 1, x of s + 1"
+    // and leaves every younger piece in flight across the barrier.
+    int xs = 0, wsl = 0;                // slots of slice s in the x ring / the weight ring
     for (int s = 0; s < nslice; ++s) {
-        const int kw = min(s + 1, nslice - 1) * HC_BK, kx = min(s + HC_NX - 1, nslice - 1) * HC_BK;
-        const int xnew = xs == 0 ? HC_NX - 1 : xs - 1;          // slot of slice s + 4 = the one slice s - 1 used
-        const int wnew = (s + 1) & 1;
+        const int kw = min(s + HC_NW - 1, nslice - 1) * HC_BK, kx = min(s + HC_NX - 1, nslice - 1) * HC_BK;
+        const int xnew = xs == 0 ? HC_NX - 1 : xs - 1;          // slot of slice s + 3 = the one slice s - 1 used
+        const int wnew = wsl == 0 ? HC_NW - 1 : wsl - 1;        // slot of slice s + 2 = the one slice s - 1 used
         const u16* xa = xring + xs * HC_XS + (64 * wr + r) * HC_BK;
-        const u16* wb = wring + (s & 1) * HC_WS + (96 * wc + r) * HC_BK;
+        const u16* wb = wring + wsl * HC_WS + (96 * wc + r) * HC_BK;
+#if !defined(HC_PHASED_LOOP)
         u16x8 a[2][2], bs[3];
         auto read_a = [&](int ks) {
             const int ch = 8 * ((2 * ks + h) ^ fx);
@@ -297,15 +352,64 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
             acc[1][c][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][1]), bf, acc[1][c][u], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but this slice's two x pieces (slice s + 4) have landed
+#else
+        // Phased k-step (round 2): ALL eight fragments of a k-step are read as one block, then its twelve MFMAs run as one
+        // uninterrupted cluster at raised priority.  With the fragments trickling in one per MFMA pair (round 1) the two
+        // waves of a SIMD stayed in lockstep - both waiting on LDS, then both multiplying: MFMA busy 0.37.  A contiguous
+        // read block and a contiguous 384-cycle cluster let them fall into alternation on their own: the matrix pipe
+        // serialises the two clusters once, and from then on one wave reads while the other multiplies.
+        u16x8 a[2], bq[6];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = 8 * ((2 * ks + h) ^ fx);
+            a[0] = *reinterpret_cast<const u16x8*>(xa + ch);
+            a[1] = *reinterpret_cast<const u16x8*>(xa + 32 * HC_BK + ch);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) bq[j] = *reinterpret_cast<const u16x8*>(wb + ((j & 1) * 192 + 32 * (j >> 1)) * HC_BK + ch);
+#if !defined(HC_ABL_NOW)
+            if (ks == 0) { dma_w(0, wnew, kw); dma_w(1, wnew, kw); dma_w(2, wnew, kw); }
+#endif
+#if !defined(HC_ABL_NOX)
+            if (ks == 1) { dma_x(0, xnew, kx); dma_x(1, xnew, kx); }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[j]);
+#if !defined(HC_ABL_NOMFMA)
+                acc[0][j >> 1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), bf, acc[0][j >> 1][j & 1], 0, 0, 0);
+                acc[1][j >> 1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), bf, acc[1][j >> 1][j & 1], 0, 0, 0);
+#else
+                asm volatile("" ::"v"(bf), "v"(a[0]), "v"(a[1]));
+#endif
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+#if defined(HC_ABL_NOW) && defined(HC_ABL_NOX)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif defined(HC_ABL_NOW)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // ablation: x pieces only (2 per slice): x of s + 1 landed
+#elif defined(HC_ABL_NOX)
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // ablation: weight pieces only (3 per slice)
+#else
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");     // everything issued before the previous slice's x pieces has landed
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         xs = xs == HC_NX - 1 ? 0 : xs + 1;
+        wsl = wsl == HC_NW - 1 ? 0 : wsl + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail pieces must not land on the scratch below
     __builtin_amdgcn_s_barrier();
 
-    float* sred = reinterpret_cast<float*>(smem);            // [2][256]
+#if defined(HC_STAMP)
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float* sred = reinterpret_cast<float*>(smem) + 8 * (32 * 192) / 2;       // [2][256], behind the eight gate tiles
+    u16* tile_lds = smem + wave * (32 * 192);                               // this wave's [32][192] bf16 tile (12 KB)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         float part[16];
@@ -320,7 +424,11 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
                 const float v = fast_tanh(acc[q][c][0][i] + bvd);
                 const float u = fast_sigmoid(acc[q][c][1][i] + bud);
                 part[i] += wd * v * u;
-                if (gates != nullptr) {
+                if (GMODE == 2) {
+                    u16* t = tile_lds + mfma32_row(i, h) * 192 + 32 * c + r;
+                    t[0] = __builtin_bit_cast(u16, (__bf16)v);
+                    t[96] = __builtin_bit_cast(u16, (__bf16)u);
+                } else if (GMODE == 1) {
                     const int gr = row0 + 64 * wr + 32 * q + mfma32_row(i, h);
                     if (gr < R) {
                         gates[(size_t)gr * HB_NG + d] = v;
@@ -329,10 +437,22 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
                 }
             }
         }
+        if (GMODE == 2) {
+            // bf16 gates: the wave's 32 x 192 tile leaves through its own LDS scratch as whole 16-byte chunks (same wave
+            // wrote what it reads: the LDS operations of a wave complete in order)
+            const int row_base = row0 + 64 * wr + 32 * q;
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int k = lane + 64 * n, row = k / 24, ch = k % 24;          // 24 chunks of 8 columns per row
+                const u16x8 vv = *reinterpret_cast<const u16x8*>(tile_lds + row * 192 + 8 * ch);
+                if (row_base + row < R)
+                    *reinterpret_cast<u16x8*>(gates16 + (size_t)(row_base + row) * HB_NG + (ch / 12) * 192 + 96 * wc + 8 * (ch % 12)) = vv;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float v = half_allsum(part[i]);
-            if (r == 0) sred[wc * HC_TM + 64 * wr + 32 * q + mfma32_row(i, h)] = v;
+            const float v = half_sum_lane31(part[i]);
+            if (r == 31) sred[wc * HC_TM + 64 * wr + 32 * q + mfma32_row(i, h)] = v;
         }
     }
     __syncthreads();
@@ -340,6 +460,13 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
         const int gr = row0 + tid;
         if (gr < R) scores[gr] = sred[tid] + sred[HC_TM + tid] + battn[0];
     }
+#if defined(HC_STAMP)
+    if (tid == 0 && GMODE == 2) {      // diagnostic build: (loop cycles, loop 100 MHz ticks, epilogue cycles, start tick) per workgroup
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+        float* dbg = reinterpret_cast<float*>(gates16) + 4 * blockIdx.x;
+        dbg[0] = (float)(st1 - st0); dbg[1] = (float)(sr1 - sr0); dbg[2] = (float)(st2 - st1); dbg[3] = (float)(sr0 & 0xffffff);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- pool stages, bf16 x
@@ -541,7 +668,7 @@ __device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
     return o;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const float* __restrict__ gates,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const u16* __restrict__ gates,
                                                           const float* __restrict__ ds, const float* __restrict__ wvec,
                                                           float* __restrict__ part, float* __restrict__ pbias, int R, int L,
                                                           int KC, int NJ) {
@@ -587,9 +714,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto aload = [&](int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
         const int gc = min(gr, rend - 1);
-        const float* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
-        rv[i] = *reinterpret_cast<const f32x4*>(gp);
-        ru[i] = *reinterpret_cast<const f32x4*>(gp + 192);
+        const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
+        const ushort4 hv = *reinterpret_cast<const ushort4*>(gp), hu = *reinterpret_cast<const ushort4*>(gp + 192);
+        rv[i] = f32x4{bf16_to_f32(hv.x), bf16_to_f32(hv.y), bf16_to_f32(hv.z), bf16_to_f32(hv.w)};
+        ru[i] = f32x4{bf16_to_f32(hu.x), bf16_to_f32(hu.y), bf16_to_f32(hu.z), bf16_to_f32(hu.w)};
         rds[i] = ds[gc];
         rmask[i] = (live && gr < rend) ? 1.f : 0.f;
     };
@@ -717,17 +845,26 @@ extern "C" int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* st
 
 extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu,
                                         const float* bu, const float* w, const float* b, float* scores, float* gates,
-                                        int R, int L, int D, void* stream) {
+                                        int R, int L, int D, uint16_t* gates16, void* stream) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % HB_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
     // 256-row tiles with the three-stage pipeline once they fill the chip; the 128-row kernel for small R
-    if (R >= HC_TM * MIL_NUM_CU)
-        hipLaunchKernelGGL(k_gate_fwd_bf16_deep, dim3((R + HC_TM - 1) / HC_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv,
-                           Wu, bu, w, b, scores, gates, R, L);
+    if (R >= HC_TM * MIL_NUM_CU) {
+        const dim3 grid((R + HC_TM - 1) / HC_TM);
+        if (gates16)
+            hipLaunchKernelGGL(k_gate_fwd_bf16_deep<2>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
+                               gates, R, L, gates16);
+        else if (gates)
+            hipLaunchKernelGGL(k_gate_fwd_bf16_deep<1>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
+                               gates, R, L, gates16);
+        else
+            hipLaunchKernelGGL(k_gate_fwd_bf16_deep<0>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
+                               gates, R, L, gates16);
+    }
     else
         hipLaunchKernelGGL(k_gate_fwd_bf16, dim3((R + HB_TM - 1) / HB_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu,
-                           bu, w, b, scores, gates, R, L);
+                           bu, w, b, scores, gates, R, L, gates16);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -785,7 +922,7 @@ extern "C" size_t mil_gate_bwd_workspace_floats_bf16(int R, int L) {
     return (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
 }
 
-extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R,
+extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates, const float* ds, const float* w, int R,
                                         int L, int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
                                         float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
     if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;

@@ -3,6 +3,18 @@
 // train_ddp.py:99,323-324 (BCELoss), train_ddp.py:115-118 (Adam).  All tiny, latency-bound kernels.
 #include "mil_common.h"
 
+template <int NT>
+__device__ __forceinline__ float block_allsum_nt(float v, float* red) {
+    const int tid = threadIdx.x;
+    v = wave_allsum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) t += red[w];
+    return t;
+}
 __device__ __forceinline__ float block_allsum_256(float v, float* red) {
     const int tid = threadIdx.x;
     v = wave_allsum(v);
@@ -199,7 +211,8 @@ extern "C" int mil_counter_add(int32_t* counter, int v, void* stream) {
 //   if labels: loss_bag[b] = BCE(p_b, y_b) * scale, dz = (p - y) * scale, dM = dz Wf, cdot = M . dM
 // Thread (g, c4): column float4 c4 < L/4, tile group g < 256/(L/4); tile loads are unrolled 8 deep
 // so one workgroup keeps ~8 x 4 KiB in flight (the kernel is latency-bound: B workgroups only).
-__global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict__ partials,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pool_merge_head(const float* __restrict__ partials,
                                                          const int32_t* __restrict__ bag_tile_off, int T, int L,
                                                          const float* __restrict__ Wf, const float* __restrict__ bf,
                                                          int C, const float* __restrict__ y, float scale,
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
                                                          float mscale, float* __restrict__ Mdrop, int loss_kind) {
     // mbits [B][L/32]: keep bits of the head's Dropout(.25) on the bag embedding (aggregator.py:129; train mode).  M stays
     // the un-dropped ABMIL output, Mdrop = M * keep * mscale feeds the head (and dWf); dM = d loss / d M carries the mask.
-    __shared__ float red[4];
+    __shared__ float red[NT / 64];
     __shared__ float scale_lds[1024];
     __shared__ __attribute__((aligned(16))) float m_lds[1024];
     __shared__ __attribute__((aligned(16))) float part_lds[4 * 1024];
@@ -222,28 +235,30 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     const int b = blockIdx.x, tid = threadIdx.x;
     const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
     const float* ml = partials + (size_t)T * L;
-    for (int j = tid; j < L; j += 256)
+    for (int j = tid; j < L; j += NT)
         keep_lds[j] = mbits == nullptr ? 1.0f : (((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f);
     // global max / normaliser over the bag's tiles
     float m = -INFINITY;
-    for (int t = t0 + tid; t < t1; t += 256) m = fmaxf(m, ml[2 * t]);
+    for (int t = t0 + tid; t < t1; t += NT) m = fmaxf(m, ml[2 * t]);
     m = wave_allmax(m);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
     float l = 0.f;
-    for (int t = t0 + tid; t < t1; t += 256) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
-    l = block_allsum_256(l, red);
+    for (int t = t0 + tid; t < t1; t += NT) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
+    l = block_allsum_nt<NT>(l, red);
     const float inv = nt > 0 ? 1.0f / l : 0.f;
 
-    const int L4 = L >> 2, NG = 256 / L4;          // L in {256, 512, 768, 1024} -> NG in {4, 2, 1, 1}
+    const int L4 = L >> 2, NG = NT / L4;          // NT = 256: L in {256, 512, 768, 1024} -> NG in {4, 2, 1, 1}; NT = 1024: 4x
     const int c4 = tid % L4, g = tid / L4;
     const bool worker = g < NG;                    // L = 768 leaves 64 threads without a column group
     f32x4 acc = {0, 0, 0, 0};
     for (int tb = 0; tb < nt; tb += 1024) {
         __syncthreads();
-        for (int k = tid; k < 1024; k += 256) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
+        for (int k = tid; k < 1024; k += NT) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
         __syncthreads();
         const int cnt = worker ? min(1024, nt - tb) : 0;
         int k = g;
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     }
     if (worker) *reinterpret_cast<f32x4*>(part_lds + g * L + 4 * c4) = acc;
     __syncthreads();
-    for (int j = tid; j < L; j += 256) {
+    for (int j = tid; j < L; j += NT) {
         float v = 0.f;
         for (int gg = 0; gg < NG; ++gg) v += part_lds[gg * L + j];
         v *= inv;
@@ -275,8 +290,8 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     float lossacc = 0.f;
     for (int c = 0; c < C; ++c) {
         float v = 0.f;
-        for (int j = tid; j < L; j += 256) v += m_lds[j] * keep_lds[j] * Wf[(size_t)c * L + j];
-        v = block_allsum_256(v, red);
+        for (int j = tid; j < L; j += NT) v += m_lds[j] * keep_lds[j] * Wf[(size_t)c * L + j];
+        v = block_allsum_nt<NT>(v, red);
         if (tid == 0) {
             const float zz = v + bf[c];
             const float pp = 1.0f / (1.0f + expf(-zz));
@@ -320,20 +335,20 @@ __global__ __launch_bounds__(256) void k_pool_merge_head(const float* __restrict
     if (tid == 0) loss_sum[b] = lossacc * scale;      // per-bag loss; summed (fixed order) by k_head_bwd_params
     __syncthreads();
     float dot = 0.f;
-    for (int j = tid; j < L; j += 256) {
+    for (int j = tid; j < L; j += NT) {
         float v = 0.f;
         for (int c = 0; c < C; ++c) v += dzs[c] * Wf[(size_t)c * L + j];
         v *= keep_lds[j];
         dM[(size_t)b * L + j] = v;
         dot += v * m_lds[j];
     }
-    dot = block_allsum_256(dot, red);
+    dot = block_allsum_nt<NT>(dot, red);
     if (tid == 0) cdot[b] = dot;
     if (ds != nullptr) {
         // the score gradient of this bag's rows from the forward's head projections (k_pool_ds_from_h, fused here: every
         // quantity it needs - lse, dz, M . dM - was just formed by this workgroup):  ds_i = A_i (sum_c dz_c h_i[c] - M . dM)
         const float lse_b = m + logf(l);
-        for (int g8 = t0 + (tid >> 5); g8 < t1; g8 += 8) {
+        for (int g8 = t0 + (tid >> 5); g8 < t1; g8 += NT / 32) {
             const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
             if (lr < nrows) {
                 const size_t row = (size_t)(row0 + lr);
@@ -356,9 +371,16 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
     if (ds && (!y || !tile_map || !scores || !hrow)) return MIL_EINVAL;
     if (!(L == 256 || L == 512 || L == 768 || L == 1024) || C <= 0 || C > 32 || B < 0) return MIL_EINVAL;
     if (B == 0) return MIL_OK;
-    hipLaunchKernelGGL(k_pool_merge_head, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
-                       bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop,
-                       loss_kind);
+    // one workgroup per bag; bags of many tiles (>= 48 on average: 1536 rows) get 1024 threads - four times the tile
+    // groups walking the partials and the rows of the ds pass (config 5, 128 tiles per bag: 21 -> see DESIGN.md)
+    if (T >= 48 * B)
+        hipLaunchKernelGGL(k_pool_merge_head<1024>, dim3(B), dim3(1024), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
+                           bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale,
+                           Mdrop, loss_kind);
+    else
+        hipLaunchKernelGGL(k_pool_merge_head<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
+                           bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale,
+                           Mdrop, loss_kind);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -50,6 +50,20 @@ __device__ __forceinline__ float half_allsum(float v) {
     return v;
 }
 
+// Sum over each 32-lane half with DPP adds only (no LDS round trips: __shfl_xor lowers to ds_bpermute_b32, one LDS
+// operation plus its latency per step - the gate epilogues ran 160 of them back to back).  The total of lanes 0-31 is
+// valid in lane 31, that of lanes 32-63 in lane 63; other lanes hold partial sums.
+__device__ __forceinline__ float half_sum_lane31(float v) {
+    // row_shr:n = 0x110 + n (shift right inside a row of 16, zeros shifted in), row_bcast:15 = 0x142 (lane 15 of each
+    // row to the next row; row_mask 0xa = rows 1 and 3 take it)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));
+    return v;
+}
+
 // Sum 16 per-lane values over the 64 lanes of a wave with 17 cross-lane steps instead of 16 x 6: each step halves the
 // number of values a lane carries while it doubles the lanes summed.  Afterwards lane l holds the wave total of value
 // index k(l) = 8 b5 + 4 b4 + 2 b3 + b2 (b_i = bit i of l); wave_reduce16_owner(k) is one lane holding index k.
@@ -91,9 +105,12 @@ __device__ __forceinline__ int wave_reduce16_index(int lane) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// exp2-based forms: v_exp_f32 + v_rcp_f32, abs error ~1e-7 on outputs in [-1, 1].
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// exp2-based forms: v_exp_f32 + v_rcp_f32 (1 ulp), abs error ~1e-7 on outputs in [-1, 1].  The reciprocal is the bare
+// v_rcp_f32: __frcp_rn expands to the full IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup, ~11 VALU
+// instructions per call) - in the gate epilogues (96-192 activations per lane, no MFMA left to hide under) that was
+// two thirds of the instructions: the bf16 gate kernel spent as many cycles in its epilogue as in its main loop.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Row of a 32x32 MFMA accumulator register: C/D layout col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (dtype independent on gfx950).

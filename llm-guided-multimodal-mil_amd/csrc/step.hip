@@ -16,7 +16,7 @@ static int step_check(const mil_image_only_step* a) {
     if (a->x_bf16 && a->train) return MIL_EINVAL;               // in-kernel dropout exists on the fp32 path only
     if (a->train && (!a->xbits || !a->mbits || !a->Mdrop)) return MIL_EINVAL;
     if (a->y) {
-        if (!a->gates || !a->ds || !a->loss_bag || !a->dz || !a->dM || !a->cdot) return MIL_EINVAL;
+        if ((!a->gates && !a->gates16) || !a->ds || !a->loss_bag || !a->dz || !a->dM || !a->cdot) return MIL_EINVAL;
     }
     return MIL_OK;
 }
@@ -43,9 +43,11 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     }
     if (st & MIL_STAGE_GATE_FWD) {
         float* gates = grads ? a->gates : nullptr;
+        const bool g16 = a->x_bf16 && a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16 != nullptr;
         if (a->x_bf16)
-            rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores, gates,
-                                          a->R, a->L, MIL_GATE_D, stream);
+            rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores,
+                                          g16 ? nullptr : gates, a->R, a->L, MIL_GATE_D, (grads && g16) ? a->gates16 : nullptr,
+                                          stream);
         else
             rc = mil_gate_scores_fwd((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R, a->L,
                                      MIL_GATE_D, xbits, xscale, stream);
@@ -87,8 +89,8 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     if (a->x_bf16) {
         // bf16 storage: one entry point per weight-gradient flavour (its launch pair), then the head's parameter gradients
         if (st & (MIL_STAGE_GATE_BWD | MIL_STAGE_REDUCE)) {
-            if (a->bf16_grad_mfma && (a->L % 256) == 0)
-                rc = mil_gate_bwd_params_bf16((const uint16_t*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
+            if (a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16)
+                rc = mil_gate_bwd_params_bf16((const uint16_t*)a->x, a->gates16, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
                                               (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
                                               a->accumulate, stream);
             else

@@ -977,15 +977,20 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
-def gate_scores_fwd_bf16(x16, Wv16, bv, Wu16, bu, w, b, save_gates: bool = True):
+def gate_scores_fwd_bf16(x16, Wv16, bv, Wu16, bu, w, b, save_gates: bool = True, gates_bf16: bool = False):
     x16 = _bf16c(x16, "x")
     R, L = x16.shape
     scores = torch.empty(R, device=x16.device, dtype=torch.float32)
-    gates = torch.empty((R, 2 * GATE_D), device=x16.device, dtype=torch.float32) if save_gates else None
+    """gates_bf16: save {V | U} rounded to bf16 (what gate_bwd_params_bf16 reads) instead of fp32."""
+    gates = gates16 = None
+    if save_gates and gates_bf16:
+        gates16 = torch.empty((R, 2 * GATE_D), device=x16.device, dtype=torch.bfloat16)
+    elif save_gates:
+        gates = torch.empty((R, 2 * GATE_D), device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_gate_scores_fwd_bf16(_p(x16), _p(_bf16c(Wv16, "Wv")), _p(bv), _p(_bf16c(Wu16, "Wu")), _p(bu), _p(w),
-                                             _p(b), _p(scores), _p(gates), R, L, Wv16.shape[0], _stream())
+                                             _p(b), _p(scores), _p(gates), R, L, Wv16.shape[0], _p(gates16), _stream())
     _lib.check(rc, "mil_gate_scores_fwd_bf16")
-    return scores, gates
+    return scores, (gates16 if gates_bf16 else gates)
 
 
 def attn_pool_partial_bf16(x16, scores, layout: BagLayout):
@@ -1065,8 +1070,9 @@ def add_bag_row(x, o, segs):
 
 
 def gate_bwd_params_bf16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None):
-    """Weight gradients on the bf16 MFMA (dPre and x rounded to bf16, fp32 accumulate)."""
+    """Weight gradients on the bf16 MFMA (dPre and x rounded to bf16, fp32 accumulate); gates: bf16 [R, 384]."""
     x16 = _bf16c(x16, "x")
+    gates = _bf16c(gates, "gates")
     R, L = x16.shape
     need = _lib.lib().mil_gate_bwd_workspace_floats_bf16(R, L)
     if workspace is None or workspace.numel() < need:

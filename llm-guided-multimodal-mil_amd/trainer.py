@@ -185,7 +185,12 @@ class ImageOnlyTrainer:
                     _lib.lib().mil_gate_bwd_workspace_floats(R, L)
             else:
                 need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
-            st.update(gates=self._buf("gates", R * 2 * ops.GATE_D), ds=self._buf("ds", R),
+            # bf16-MFMA weight gradient: gates saved as bf16 (MIL_BF16_GATES=0: the fp32-MFMA gradient on fp32 gates, for A/B)
+            if b16 and os.environ.get("MIL_BF16_GATES") == "0":
+                self.bf16_grad_mfma = False
+            g16 = b16 and self.bf16_grad_mfma and L % 256 == 0
+            st.update(gates=None if g16 else self._buf("gates", R * 2 * ops.GATE_D),
+                      gates16=self._buf("gates16", R * 2 * ops.GATE_D, torch.bfloat16) if g16 else None, ds=self._buf("ds", R),
                       hrow=self._buf("hrow", R * C) if C <= 4 else None, dw_ws=self._buf("dw_ws", need),
                       Mdrop=self._buf("Mdrop", B * L), loss_bag=self._buf("loss_bag", B), dz=self._buf("dz", B * C),
                       dM=self._buf("dM", B * L), cdot=self._buf("cdot", B))
@@ -206,7 +211,8 @@ class ImageOnlyTrainer:
         self.last = dict(x=x, layout=layout, scores=st["scores"][:R], M=st["M"][:B * L].view(B, L), lse=st["lse"][:B],
                          logits=st["logits"][:B * C].view(B, C), prob=st["prob"][:B * C].view(B, C))
         if grads:
-            self.last.update(gates=st["gates"][:R * 2 * ops.GATE_D].view(R, 2 * ops.GATE_D), ds=st["ds"][:R],
+            gsaved = st["gates"] if st["gates"] is not None else st["gates16"]
+            self.last.update(gates=gsaved[:R * 2 * ops.GATE_D].view(R, 2 * ops.GATE_D), ds=st["ds"][:R],
                              hrow=None if st["hrow"] is None else st["hrow"][:R * C].view(R, C),
                              dz=st["dz"][:B * C].view(B, C), dM=st["dM"][:B * L].view(B, L), cdot=st["cdot"][:B],
                              loss_bag=st["loss_bag"][:B], Mdrop=st["Mdrop"][:B * L].view(B, L))

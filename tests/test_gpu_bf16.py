@@ -43,7 +43,11 @@ def test_bf16_step_matches_oracle_on_rounded_inputs(lengths, L, grad_mfma):
         if float(grads[k].norm()) > 1e-7:
             # fp32-MFMA gradient: exact on the rounded x.  bf16-MFMA gradient: dPre is rounded to bf16 too
             # (relative 2^-9 per element), only the two weight matrices see it - biases / w / head stay fp32.
-            tol = 6e-3 if (grad_mfma and k.endswith(("attention_V.0.weight", "attention_U.0.weight"))) else 5e-4
+            # With the bf16-MFMA gradient the saved gates V, U are bf16 too (half the bytes of the step's largest tensor), so the
+            # gate biases and w see 2^-9 relative rounding per factor as well; the head and the fp32-MFMA variant stay fp32.
+            gate_param = k.startswith("aggregator.attention")
+            tol = 1.2e-2 if (grad_mfma and L % 256 == 0 and gate_param) else \
+                (6e-3 if (grad_mfma and k.endswith(("attention_V.0.weight", "attention_U.0.weight"))) else 5e-4)
             assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= tol, (k, rel_err(tr.fp.g(k).cpu(), grads[k]))
     # deviation from the UNROUNDED fp32 oracle (reported in DESIGN.md; loose bound here)
     _, logits32, _, _ = orc.batch_loss_and_grads(bags, y, p)
