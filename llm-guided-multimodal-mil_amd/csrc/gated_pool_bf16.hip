@@ -644,7 +644,6 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds_bf16(const u16* __restrict_
 // neither HBM nor prefetch depth: per slice the CU moves 96 KB of transpose reads + 48 KB of staging writes through LDS
 // (~1400 clk at the LDS rates) against 1024 MFMA clk, with the fragment reads of each k-step exposed (no register room
 // to double-buffer 6 fragments next to 128 accumulators at two waves per SIMD).
-#define WB_BKR 32
 #define WB_S 160
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -668,12 +667,22 @@ __device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
     return o;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const u16* __restrict__ gates,
+// Round 2 structure: ONE 256-thread workgroup per CU (252 of them: 21 row chunks x 12 output tiles), i.e. one wave per
+// SIMD with the whole 512-entry register file, and
+//   * 64-row slices (four k-steps of 16 rows) - half the barriers, and half as many post-barrier bubbles in which a lone
+//     wave has no partner to cover the LDS latency of its first fragments;
+//   * fragments double-buffered in registers: the twelve transpose reads of k-step ks + 1 are issued before the eight
+//     MFMAs of k-step ks (round 1 read, waited, multiplied);
+//   * the staging of the next slice (8 x pieces, 4 gate pieces per thread) cut into twelve parts laid between MFMA pairs
+//     (the bf16 MFMA hides VALU and LDS-write issue, unlike the f32 one).
+// Round 1 ran 2 x 256 threads per CU on 32-row slices: 200 us + reduce at config 5.
+#define WB_BKR 64
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const u16* __restrict__ gates,
                                                           const float* __restrict__ ds, const float* __restrict__ wvec,
                                                           float* __restrict__ part, float* __restrict__ pbias, int R, int L,
                                                           int KC, int NJ) {
-    __shared__ __attribute__((aligned(16))) u16 smem[2 * (WB_BKR * WB_S + WB_BKR * 2 * WB_S)];
-    // per stage: A image [32][160] (128 gi used), B image [32][320] (256 j used, two 160-wide panels of 128 j)
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (WB_BKR * WB_S + WB_BKR * 2 * WB_S)];      // 2 x 60 KB
+    // per stage: A image [64][160] (128 gi used), B image [64][320] (256 j used, two 160-wide panels of 128 j)
     constexpr int ASZ = WB_BKR * WB_S, BSZ = WB_BKR * 2 * WB_S;
     u16* ab = smem;
     u16* xb = smem + 2 * ASZ;
@@ -691,14 +700,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rbeg = s * KC, rend = min(R, rbeg + KC);
     const int nslice = (rend - rbeg + WB_BKR - 1) / WB_BKR;
 
-    // staging maps: x: 32 rows x 256 cols bf16 = 1024 16-byte chunks, 4 per thread: row (tid >> 5) + 8i, chunk tid & 31
-    //               gates: rows (tid >> 4) + 16i (i < 2), d = 64m + 4 (tid & 15)
+    // staging maps: x: 64 rows x 256 cols bf16 = 2048 16-byte chunks, 8 per thread: row (tid >> 5) + 8i, chunk tid & 31
+    //               gates: rows (tid >> 4) + 16i (i < 4), d = 64m + 4 (tid & 15)
     const int xrow = tid >> 5, xc = tid & 31;
     const int arow = tid >> 4, ad4 = tid & 15;
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
-    u16x8 rx[4];
-    f32x4 rv[2], ru[2];
-    float rds[2], rmask[2];
+    u16x8 rx[8];
+    ushort4 hv[4], hu[4];
+    float rds[4], rmask[4];
     f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
     float acc_ds = 0.f;
 
@@ -715,23 +724,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int gr = rs + arow + 16 * i;
         const int gc = min(gr, rend - 1);
         const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
-        const ushort4 hv = *reinterpret_cast<const ushort4*>(gp), hu = *reinterpret_cast<const ushort4*>(gp + 192);
-        rv[i] = f32x4{bf16_to_f32(hv.x), bf16_to_f32(hv.y), bf16_to_f32(hv.z), bf16_to_f32(hv.w)};
-        ru[i] = f32x4{bf16_to_f32(hu.x), bf16_to_f32(hu.y), bf16_to_f32(hu.z), bf16_to_f32(hu.w)};
+        hv[i] = *reinterpret_cast<const ushort4*>(gp);
+        hu[i] = *reinterpret_cast<const ushort4*>(gp + 192);
         rds[i] = ds[gc];
         rmask[i] = (live && gr < rend) ? 1.f : 0.f;
     };
     auto awrite = [&](int i, int buf) {
-        const f32x4 v = rv[i], u = ru[i];
+        const f32x4 v = {bf16_to_f32(hv[i].x), bf16_to_f32(hv[i].y), bf16_to_f32(hv[i].z), bf16_to_f32(hv[i].w)};
+        const f32x4 u = {bf16_to_f32(hu[i].x), bf16_to_f32(hu[i].y), bf16_to_f32(hu[i].z), bf16_to_f32(hu[i].w)};
         const float dsv = rds[i] * rmask[i];
-        const f32x4 pv = (dsv * w4) * u * (1.0f - v * v);
-        const f32x4 pu = (dsv * w4) * v * u * (1.0f - u);
+        const f32x4 a = (dsv * w4) * u;
+        const f32x4 t = a * v;
+        const f32x4 pv = a - t * v;               // ds w U (1 - V^2)
+        const f32x4 pu = t - t * u;               // ds w V U (1 - U)
         u16* dst = ab + buf * ASZ + (arow + 16 * i) * WB_S + 4 * ad4;
         *reinterpret_cast<ushort4*>(dst) = pack_bf16x4(pv);
         *reinterpret_cast<ushort4*>(dst + 64) = pack_bf16x4(pu);
         acc_bv += pv;
         acc_bu += pu;
-        acc_w += dsv * v * u;
+        acc_w += (dsv * v) * u;
         if (ad4 == 0) acc_ds += dsv;
     };
 
@@ -745,18 +756,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     if (nslice > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xload(i, rbeg);
+        for (int i = 0; i < 8; ++i) xload(i, rbeg);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) aload(i, rbeg, true);
+        for (int i = 0; i < 4; ++i) aload(i, rbeg, true);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xwrite(i, 0);
+        for (int i = 0; i < 8; ++i) xwrite(i, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) awrite(i, 0);
+        for (int i = 0; i < 4; ++i) awrite(i, 0);
         const int rs1 = rbeg + min(1, nslice - 1) * WB_BKR;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xload(i, rs1);
+        for (int i = 0; i < 8; ++i) xload(i, rs1);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) aload(i, rs1, nslice > 1);
+        for (int i = 0; i < 4; ++i) aload(i, rs1, nslice > 1);
     }
     __syncthreads();
     // fragment column offsets inside an image: wave tile + 16-lane group + 4 p
@@ -768,28 +779,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int rs2 = rbeg + min(sl + 2, nslice - 1) * WB_BKR;
         const u16* ai = ab + buf * ASZ;
         const u16* bi = xb + buf * BSZ + wj * ASZ;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        u16x8 fa[2][2], fb[2][4];                                // [register set][tile]
+        auto frags = [&](int ks, int q) {
             const int row = 16 * ks + 8 * h + tq;
-            u16x8 fa[2], fb[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = tr_frag(ai, row, acol + 32 * a);
+            for (int a = 0; a < 2; ++a) fa[q][a] = tr_frag(ai, row, acol + 32 * a);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) fb[b] = tr_frag(bi, row, bcol + 32 * b);
-            // staging for the next slice rides between the two k-steps
-            if (ks == 0) {
+            for (int b = 0; b < 4; ++b) fb[q][b] = tr_frag(bi, row, bcol + 32 * b);
+        };
+        // twelve staging parts of the next slice, three per k-step
+        auto stage = [&](int p) {
+            if (p < 8) { xwrite(p, buf ^ 1); xload(p, rs2); }
+            else { awrite(p - 8, buf ^ 1); aload(p - 8, rs2, live2); }
+        };
+        frags(0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { xwrite(i, buf ^ 1); xload(i, rs2); }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) { awrite(i, buf ^ 1); aload(i, rs2, live2); }
-            }
+        for (int ks = 0; ks < WB_BKR / 16; ++ks) {
+            const int q = ks & 1;
+            if (ks + 1 < WB_BKR / 16) frags(ks + 1, q ^ 1);      // next k-step's fragments fly under this k-step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
-                                                                        __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[q][a]),
+                                                                        __builtin_bit_cast(bf16x8, fb[q][b]), acc[a][b], 0, 0, 0);
+                    const int g = a * 4 + b;                     // 8 MFMAs per k-step: a staging part behind #1, #3, #5
+                    if (g == 1 || g == 3 || g == 5) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage(3 * ks + (g >> 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
         }
         __syncthreads();
     }
