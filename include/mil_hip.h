@@ -89,6 +89,12 @@ int mil_attn_pool_fwd(const float* x, const float* scores, const int32_t* tile_m
 int mil_attn_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
                           float* partials, const uint32_t* xbits, float xscale, void* stream);
 
+/* Tile map built on the device from device-resident bag lengths (see mil_image_only_step.bag_len_dev): tile_map
+ * [T_cap][4], bag_tile_off [B + 1], rows_out [1] = sum of the lengths.  Tiles past the last real one are {0,0,0,0}:
+ * the pool kernels emit a neutral partial for them.  B <= 1024, T_cap >= sum ceil(len / MIL_POOL_TILE). */
+int mil_build_tile_map(const int32_t* bag_len, int B, int32_t* tile_map, int32_t* bag_tile_off, int32_t* rows_out,
+                       int T_cap, void* stream);
+
 /* Pool partial pass that also emits the head's projection of every patch, hrow[row][c] = x_row . Wf[c] (C <= 4):
  * when ABMIL feeds the linear head directly (model/aggregator.py:199-200), dM = dz Wf, so the backward's
  * x_i . dM equals sum_c dz[bag][c] hrow[i][c] and mil_attn_pool_bwd_from_h yields ds WITHOUT re-reading x
@@ -174,6 +180,10 @@ int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, con
  * reduce (workspace -> outputs). */
 int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
                           int D, float* workspace, size_t workspace_floats, const uint32_t* xbits, void* stream);
+/* mil_gate_bwd_partials sized for R rows (grid, split-K plan, workspace) of which only rows_dev[0] <= R are real. */
+int mil_gate_bwd_partials_rows(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                               int D, float* workspace, size_t workspace_floats, const uint32_t* xbits,
+                               const int32_t* rows_dev, void* stream);
 int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
                         float* dw, float* db, int accumulate, float xscale, void* stream);
 
@@ -475,7 +485,8 @@ int mil_sgd_step(float* param, const float* grad, size_t n, float lr, float weig
 #define MIL_STAGE_GATE_BWD 0x10u
 #define MIL_STAGE_REDUCE   0x20u
 #define MIL_STAGE_ADAM     0x40u
-#define MIL_STAGE_ALL      0x7fu
+#define MIL_STAGE_TILEMAP  0x80u     /* build tile_map / bag_tile_off / rows_dev on the device from bag_len_dev */
+#define MIL_STAGE_ALL      0xffu
 typedef struct mil_image_only_step {
     uint32_t struct_bytes;          /* sizeof(mil_image_only_step): ABI check */
     uint32_t stages;                /* MIL_STAGE_* to run */
@@ -484,7 +495,14 @@ typedef struct mil_image_only_step {
     const float* y;                 /* [B, C] one-hot labels, or NULL */
     const int32_t* tile_map;        /* [T, 4] */
     const int32_t* bag_tile_off;    /* [B + 1] */
-    int32_t R, L, B, C, T;
+    int32_t R, L, B, C, T;          /* with bag_len_dev: R and T are the CAPACITY (bucket) the launches are sized for */
+    /* Ragged batches whose lengths change every step (the authors' regime: one bag of 1 000 - 15 592 patches per GPU,
+     * 10-20 % of the patches dropped at random per epoch, dataset.py:374-381): bag_len_dev [B] int32 holds the true
+     * lengths ON THE DEVICE; MIL_STAGE_TILEMAP rebuilds tile_map [T][4], bag_tile_off [B + 1] (both written, so they must be
+     * writable buffers) and rows_dev [1] from it, and the backward masks rows >= rows_dev[0].  Shapes, grids and
+     * workspaces depend on the bucket (R, T) only: one struct / one captured graph per bucket.  fp32 x only. */
+    const int32_t* bag_len_dev;     /* or NULL: tile_map / bag_tile_off are host-built for exactly R rows */
+    int32_t* rows_dev;
     int32_t x_bf16;
     float loss_scale;               /* 1 / (C * global bags) for MIL_LOSS_BCE, 1 / global bags for MIL_LOSS_CE_ON_SIGMOID */
     int32_t loss_kind;              /* MIL_LOSS_* */

@@ -43,6 +43,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gate_bwd_params_head": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int] + [_P] * 4
                                  + [c_int, c_int, _P, _P, _P, c_float, _P]),
     "mil_gate_bwd_partials": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "mil_gate_bwd_partials_rows": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "mil_build_tile_map": (c_int, [_P, c_int, _P, _P, _P, c_int, _P]),
     "mil_gate_bwd_reduce": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float, _P]),
     "mil_gate_bwd_reduce_head": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float] + [_P] * 4 + [c_int, c_int, _P, _P, _P]),
     "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
@@ -112,7 +114,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
 }
 
 STAGE_DROPBITS, STAGE_GATE_FWD, STAGE_POOL, STAGE_TAIL, STAGE_GATE_BWD, STAGE_REDUCE, STAGE_ADAM = 1, 2, 4, 8, 16, 32, 64
-STAGE_ALL = 0x7f
+STAGE_TILEMAP = 0x80
+STAGE_ALL = 0xff
 
 
 class ImageOnlyStep(ctypes.Structure):
@@ -121,6 +124,7 @@ class ImageOnlyStep(ctypes.Structure):
         [("struct_bytes", c_uint32), ("stages", c_uint32),
          ("x", _P), ("y", _P), ("tile_map", _P), ("bag_tile_off", _P),
          ("R", c_int32), ("L", c_int32), ("B", c_int32), ("C", c_int32), ("T", c_int32),
+         ("bag_len_dev", _P), ("rows_dev", _P),
          ("x_bf16", c_int32), ("loss_scale", c_float), ("loss_kind", c_int32), ("accumulate", c_int32)]
         + [(n, _P) for n in ("Wv", "bv", "Wu", "bu", "w", "b", "Wf", "bf", "Wv16", "Wu16")]
         + [(n, _P) for n in ("dWv", "dbv", "dWu", "dbu", "dw", "db", "dWf", "dbf", "loss_out")]

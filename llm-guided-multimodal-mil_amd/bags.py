@@ -110,3 +110,42 @@ class BagLayout:
                   tile_map=torch.from_numpy(np.ascontiguousarray(tm)).to(device),
                   bag_tile_off=torch.from_numpy(bto).to(device), bag_off=torch.from_numpy(bo_n).to(device))
         return cls._put(key, lay)
+
+
+def bucket_rows(n: int, floor: int = 256) -> int:
+    """Capacity bucket for n rows: the smallest of {2^k, 1.5 * 2^k} (multiples of 256) that holds n - at most a third
+    of a bucket is padding, and bags of 2 000 .. 15 592 patches (dataset.py:383-391) fall into seven buckets."""
+    n = max(int(n), 1)
+    b = floor
+    while True:
+        if b >= n:
+            return b
+        if b + b // 2 >= n and (b + b // 2) % 256 == 0:
+            return b + b // 2
+        b *= 2
+
+
+class DeviceBagLayout:
+    """Bag layout whose lengths live ON THE DEVICE: the step kernels rebuild the tile map from `bag_len_dev` every pass
+    (mil_build_tile_map) and mask the rows beyond the true total, so one set of launch parameters - one captured hipGraph -
+    serves every batch that fits the capacity (R rows, B bags).  The authors' regime is one ragged bag per GPU whose
+    length changes every step (run_train.sh:81; dataset.py:374-381 drops a random 10-20 % of the patches per epoch):
+    host-built maps keyed by the exact lengths (BagLayout) never repeat there."""
+
+    def __init__(self, capacity_rows: int, B: int, device):
+        self.R, self.B = int(capacity_rows), int(B)
+        self.T = self.R // POOL_TILE + self.B                  # every bag may end in a partial tile
+        self.tile_map = torch.zeros((self.T, 4), device=device, dtype=torch.int32)
+        self.bag_tile_off = torch.zeros(self.B + 1, device=device, dtype=torch.int32)
+        self.bag_len_dev = torch.zeros(self.B, device=device, dtype=torch.int32)
+        self.rows_dev = torch.zeros(1, device=device, dtype=torch.int32)
+        self.lengths = None
+
+    def set_lengths(self, lengths):
+        """Upload this step's lengths (a tiny async copy; the tile map itself is rebuilt by the step on the device)."""
+        lengths = [int(v) for v in lengths]
+        if len(lengths) != self.B or sum(lengths) > self.R:
+            raise ValueError(f"{len(lengths)} bags / {sum(lengths)} rows do not fit a layout of {self.B} bags / {self.R} rows")
+        self.lengths = lengths
+        self.bag_len_dev.copy_(torch.tensor(lengths, dtype=torch.int32), non_blocking=True)
+        return self

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
     unsigned mk[MIL_POOL_TILE / 4][NQ];
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const int rr = min(wave + 4 * i, nrows - 1);
+        const int rr = max(min(wave + 4 * i, nrows - 1), 0);      // nrows == 0: a padding tile of a device-built map
         const float* xr = x + (size_t)(row0 + rr) * L + 4 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
     const int sh = 4 * (lane & 7);
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const size_t row = (size_t)(row0 + min(wave + 4 * i, nrows - 1));
+        const size_t row = (size_t)(row0 + max(min(wave + 4 * i, nrows - 1), 0));
         const float* xr = x + row * L + 4 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
@@ -662,8 +662,10 @@ template <bool XB16, int KG, bool DROP>
 __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict__ xv, const float* __restrict__ gates,
                                                      const float* __restrict__ ds, const float* __restrict__ wvec,
                                                      float* __restrict__ part, float* __restrict__ pbias, int R, int L,
-                                                     int KC, int NJ, const uint32_t* __restrict__ xbits) {
+                                                     int KC, int NJ, const uint32_t* __restrict__ xbits,
+                                                     const int32_t* __restrict__ rows_dev) {
     __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * 2 * GB_BKR * 128];
+    if (rows_dev != nullptr) R = min(R, rows_dev[0]);      // bucketed batches: the true row count lives on the device
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
     float* smem = smem_all + grp * (2 * 2 * GB_BKR * 128);      // this K group's stages
     float* ab = smem;                         // [2][32][128] dPre
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256 * KG) void k_gate_bwd_dw(const void* __restrict
     const int j0 = jt * 128;
     // row chunk of the workgroup, then this K group's part of it (whole slices to group 0 first); the slice loop runs
     // nloop times for everybody (common barriers): iterations past a group's own slices multiply dead copies (ds = 0)
-    const int cbeg = s * KC, cend = min(R, cbeg + KC);
+    const int cbeg = min(s * KC, R), cend = min(R, cbeg + KC);
     const int half = KG == 1 ? cend - cbeg : ((cend - cbeg + 2 * GB_BKR - 1) / (2 * GB_BKR)) * GB_BKR;
     const int rbeg = min(cend, cbeg + grp * half), rend = KG == 1 ? cend : min(cend, rbeg + half);
     const int nslice = (rend - rbeg + GB_BKR - 1) / GB_BKR;
@@ -1067,8 +1069,10 @@ template <bool DROP>
 __global__ __launch_bounds__(512) void k_gate_bwd_dw2(const float* __restrict__ x, const float* __restrict__ gates,
                                                       const float* __restrict__ ds, const float* __restrict__ wvec,
                                                       float* __restrict__ part, float* __restrict__ pbias, int R, int L,
-                                                      int KC, int NJ, const uint32_t* __restrict__ xbits) {
+                                                      int KC, int NJ, const uint32_t* __restrict__ xbits,
+                                                      const int32_t* __restrict__ rows_dev) {
     __shared__ __attribute__((aligned(16))) float smem_all[2 * 2 * 2 * GB_BKR * 128];
+    if (rows_dev != nullptr) R = min(R, __builtin_amdgcn_readfirstlane(rows_dev[0]));      // bucketed batches: true row count on the device
     const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     float* smem = smem_all + grp * (2 * 2 * GB_BKR * 128);      // this K group's stages: [2][32][128] dPre, [2][32][128] x
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -1081,7 +1085,7 @@ __global__ __launch_bounds__(512) void k_gate_bwd_dw2(const float* __restrict__ 
     }
     const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
     const int j0 = jt * 128;
-    const int cbeg = s * KC, cend = min(R, cbeg + KC);
+    const int cbeg = min(s * KC, R), cend = min(R, cbeg + KC);
     const int half = ((cend - cbeg + 2 * GB_BKR - 1) / (2 * GB_BKR)) * GB_BKR;
     const int rbeg = min(cend, cbeg + grp * half), rend = min(cend, rbeg + half);
     const int nloop = (min(half, cend - cbeg) + GB_BKR - 1) / GB_BKR;      // common to both groups (shared barriers)
@@ -1556,6 +1560,49 @@ static int launch_pool_partial(const float* x, const float* scores, const int32_
     return MIL_OK;
 }
 
+// Tile map on the device (ragged batches whose lengths change every step): one workgroup scans the B bag lengths and
+// writes tile_map [T_cap][4], bag_tile_off [B + 1] and rows_out [1] = total rows.  Tiles beyond the last real one are
+// padding: {0, 0, 0, 0} (the pool kernels emit a neutral partial for nrows == 0).  T_cap >= sum ceil(len / 32).
+__global__ __launch_bounds__(256) void k_build_tile_map(const int32_t* __restrict__ bag_len, int B, int32_t* __restrict__ tile_map,
+                                                        int32_t* __restrict__ bag_tile_off, int32_t* __restrict__ rows_out,
+                                                        int T_cap) {
+    __shared__ int s_row[1025], s_tile[1025];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int r = 0, t = 0;
+        for (int b = 0; b < B; ++b) {
+            s_row[b] = r;
+            s_tile[b] = t;
+            const int n = max(bag_len[b], 0);
+            r += n;
+            t += (n + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+        }
+        s_row[B] = r;
+        s_tile[B] = min(t, T_cap);
+        rows_out[0] = r;
+    }
+    __syncthreads();
+    for (int b = tid; b <= B; b += 256) bag_tile_off[b] = min(s_tile[b], T_cap);
+    const int T = s_tile[B];
+    for (int b = 0; b < B; ++b) {
+        const int t0 = s_tile[b], t1 = min(s_tile[b + 1], T_cap), r0 = s_row[b], r1 = s_row[b + 1];
+        for (int t = t0 + tid; t < t1; t += 256) {
+            const int row0 = r0 + (t - t0) * MIL_POOL_TILE;
+            reinterpret_cast<int4*>(tile_map)[t] = make_int4(b, row0, min(MIL_POOL_TILE, r1 - row0), 0);
+        }
+    }
+    for (int t = T + tid; t < T_cap; t += 256) reinterpret_cast<int4*>(tile_map)[t] = make_int4(0, 0, 0, 0);
+}
+
+extern "C" int mil_build_tile_map(const int32_t* bag_len, int B, int32_t* tile_map, int32_t* bag_tile_off, int32_t* rows_out,
+                                  int T_cap, void* stream) {
+    if (!bag_len || !tile_map || !bag_tile_off || !rows_out || B <= 0 || B > 1024 || T_cap < 0) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_build_tile_map, dim3(1), dim3(256), 0, (hipStream_t)stream, bag_len, B, tile_map, bag_tile_off, rows_out,
+                       T_cap);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_attn_pool_partial_h(const float* x, const float* scores, const int32_t* tile_map, int T, int L,
                                        float* partials, const float* Wf, int C, float* hrow, const uint32_t* xbits,
                                        float xscale, const uint32_t* mbits, float mscale, void* stream) {
@@ -1616,14 +1663,15 @@ extern "C" int mil_attn_pool_bwd(const float* x, const float* scores, const floa
 
 template <bool XB16>
 static void launch_gate_bwd_dw(const void* x, const float* gates, const float* ds, const float* w, float* part, float* pbias,
-                               int R, int L, int kc, int NJ, int S, const uint32_t* xbits, hipStream_t st) {
+                               int R, int L, int kc, int NJ, int S, const uint32_t* xbits, hipStream_t st,
+                               const int32_t* rows_dev = nullptr) {
     const dim3 grid(S * 3 * NJ);
     if (split_kg(R, L) == 2) {
-        if (xbits) hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 2, true>), grid, dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
-        else hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 2, false>), grid, dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+        if (xbits) hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 2, true>), grid, dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits, rows_dev);
+        else hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 2, false>), grid, dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits, rows_dev);
     } else {
-        if (xbits) hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 1, true>), grid, dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
-        else hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 1, false>), grid, dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+        if (xbits) hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 1, true>), grid, dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits, rows_dev);
+        else hipLaunchKernelGGL((k_gate_bwd_dw<XB16, 1, false>), grid, dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits, rows_dev);
     }
 }
 
@@ -1644,9 +1692,9 @@ extern "C" size_t mil_gate_bwd_workspace_floats(int R, int L) {
 }
 
 // The two launches of mil_gate_bwd_params as separate entry points (bench.py times the MFMA kernel alone).
-extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
-                                     int D, float* workspace, size_t workspace_floats, const uint32_t* xbits,
-                                     void* stream) {
+static int gate_bwd_partials_impl(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                                  int D, float* workspace, size_t workspace_floats, const uint32_t* xbits,
+                                  const int32_t* rows_dev, void* stream) {
     if (!x || !gates || !ds || !w || !workspace) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
@@ -1657,17 +1705,31 @@ extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const f
         float* pb = workspace + (size_t)S * GF_NG * L;
         if (xbits)
             hipLaunchKernelGGL(k_gate_bwd_dw2<true>, dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, x, gates, ds, w, workspace, pb,
-                               R, L, kc, NJ, xbits);
+                               R, L, kc, NJ, xbits, rows_dev);
         else
             hipLaunchKernelGGL(k_gate_bwd_dw2<false>, dim3(S * 3 * NJ), dim3(512), 0, (hipStream_t)stream, x, gates, ds, w, workspace, pb,
-                               R, L, kc, NJ, xbits);
+                               R, L, kc, NJ, xbits, rows_dev);
         MIL_CHECK_LAUNCH();
         return MIL_OK;
     }
     launch_gate_bwd_dw<false>((const void*)x, gates, ds, w, workspace, workspace + (size_t)S * GF_NG * L, R, L, kc, NJ, S, xbits,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, rows_dev);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_gate_bwd_partials(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                                     int D, float* workspace, size_t workspace_floats, const uint32_t* xbits,
+                                     void* stream) {
+    return gate_bwd_partials_impl(x, gates, ds, w, R, L, D, workspace, workspace_floats, xbits, nullptr, stream);
+}
+// rows_dev: device int32 holding the TRUE number of rows (<= R).  R then is the bucket the launch is sized for (grid,
+// split-K plan, workspace); rows beyond the true count contribute nothing.  One launch configuration - one captured
+// graph - serves every batch of the bucket.
+extern "C" int mil_gate_bwd_partials_rows(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
+                                          int D, float* workspace, size_t workspace_floats, const uint32_t* xbits,
+                                          const int32_t* rows_dev, void* stream) {
+    return gate_bwd_partials_impl(x, gates, ds, w, R, L, D, workspace, workspace_floats, xbits, rows_dev, stream);
 }
 
 extern "C" int mil_gate_bwd_reduce(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,

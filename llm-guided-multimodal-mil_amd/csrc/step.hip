@@ -14,6 +14,7 @@ static int step_check(const mil_image_only_step* a) {
     if (!a->scores || !a->partials || !a->M || !a->lse || !a->logits || !a->prob) return MIL_EINVAL;
     if (a->x_bf16 && (!a->Wv16 || !a->Wu16)) return MIL_EINVAL;
     if (a->x_bf16 && a->train) return MIL_EINVAL;               // in-kernel dropout exists on the fp32 path only
+    if (a->bag_len_dev && (a->x_bf16 || !a->rows_dev || a->B > 1024)) return MIL_EINVAL;
     if (a->train && (!a->xbits || !a->mbits || !a->Mdrop)) return MIL_EINVAL;
     if (a->y) {
         if ((!a->gates && !a->gates16) || !a->ds || !a->loss_bag || !a->dz || !a->dM || !a->cdot) return MIL_EINVAL;
@@ -33,6 +34,11 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     const uint32_t* mbits = train ? a->mbits : nullptr;
     const bool use_h = a->hrow != nullptr && grads && a->C <= 4;
 
+    if ((st & MIL_STAGE_TILEMAP) && a->bag_len_dev) {
+        rc = mil_build_tile_map(a->bag_len_dev, a->B, const_cast<int32_t*>(a->tile_map), const_cast<int32_t*>(a->bag_tile_off),
+                                a->rows_dev, a->T, stream);
+        if (rc != MIL_OK) return rc;
+    }
     if ((st & MIL_STAGE_DROPBITS) && train) {
         rc = mil_dropout_keep_bits(a->xbits, a->R, a->L, 0.5f, a->seed, a->offset, a->offset_dev, stream);
         if (rc != MIL_OK) return rc;
@@ -106,8 +112,8 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
         }
     } else {
         if (st & MIL_STAGE_GATE_BWD) {
-            rc = mil_gate_bwd_partials((const float*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
-                                       (size_t)a->dw_ws_floats, xbits, stream);
+            rc = mil_gate_bwd_partials_rows((const float*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
+                                            (size_t)a->dw_ws_floats, xbits, a->bag_len_dev ? a->rows_dev : nullptr, stream);
             if (rc != MIL_OK) return rc;
         }
         if (st & MIL_STAGE_REDUCE) {

@@ -19,7 +19,7 @@ import torch.distributed as dist
 import ctypes
 
 from . import _lib, ops
-from .bags import BagLayout
+from .bags import BagLayout, DeviceBagLayout, bucket_rows
 from .dist_utils import allreduce_flat, broadcast_flat
 
 PARAM_ORDER = [
@@ -161,6 +161,10 @@ class ImageOnlyTrainer:
         pv = lambda t: None if t is None else t.data_ptr()      # noqa: E731
         a.x, a.y, a.tile_map, a.bag_tile_off = pv(x), pv(y), pv(layout.tile_map), pv(layout.bag_tile_off)
         a.R, a.L, a.B, a.C, a.T, a.x_bf16 = R, L, B, C, T, int(b16)
+        if isinstance(layout, DeviceBagLayout):                  # lengths on the device: tile map rebuilt by the step itself
+            if b16:
+                raise _lib.MilHipError("device-side bag lengths are supported on the fp32 path only")
+            a.bag_len_dev, a.rows_dev = pv(layout.bag_len_dev), pv(layout.rows_dev)
         nb = global_bags if global_bags is not None else B * self.world
         a.loss_kind = 1 if self.loss == "ce" else 0
         a.loss_scale = 1.0 / (max(1, nb) * (C if self.loss == "bce" else 1) * self.accum)
@@ -239,7 +243,7 @@ class ImageOnlyTrainer:
         a = self._fill(x, layout, y, global_bags)
         if a.train:
             self.drop_pass += 1
-        self._run(a, _lib.STAGE_DROPBITS | _lib.STAGE_GATE_FWD | _lib.STAGE_POOL | _lib.STAGE_TAIL)
+        self._run(a, _lib.STAGE_TILEMAP | _lib.STAGE_DROPBITS | _lib.STAGE_GATE_FWD | _lib.STAGE_POOL | _lib.STAGE_TAIL)
         return self.last["prob"], self.last["logits"]
 
     def backward(self):
@@ -394,3 +398,52 @@ class ImageOnlyTrainer:
             self._args = g["args"]
             self.reduce_and_step()
         return self.loss_sum, self.last["prob"]
+
+
+class RaggedImageOnlyStepper:
+    """The one-ragged-bag-per-GPU regime on the fused step: every batch is placed in a capacity bucket
+    (bags.bucket_rows: 2 048, 3 072, 4 096, ... rows), the bag lengths go to the device, and the bucket's step - the
+    same launch parameters whatever the lengths - is captured into a hipGraph the second time the bucket is seen and
+    replayed from then on.  A stream of bags with 2 000 .. 15 592 patches touches seven buckets, i.e. seven graphs.
+
+        stepper = RaggedImageOnlyStepper(trainer, B=1)
+        slot = stepper.slot(n_rows)            # static input buffers of the bucket: fill slot.x[:n_rows], slot.y
+        loss, prob = stepper.step(slot, [n_rows])
+    """
+
+    class Slot:
+        def __init__(self, cap, B, L, C, device):
+            self.cap, self.visits, self.graph = cap, 0, None
+            self.x = torch.zeros((cap, L), device=device, dtype=torch.float32)      # rows beyond the batch stay zero / stale: masked
+            self.y = torch.zeros((B, C), device=device, dtype=torch.float32)
+            self.layout = DeviceBagLayout(cap, B, device)
+
+    def __init__(self, trainer: ImageOnlyTrainer, B: int = 1, use_graph: bool = True):
+        self.tr, self.B, self.use_graph = trainer, int(B), bool(use_graph)
+        if self.use_graph and trainer.step_counter is None:
+            raise ValueError("graph replay needs ImageOnlyTrainer(counted=True): step number and dropout stream on the device")
+        self.slots = {}
+        self.replays = self.eager_steps = 0
+
+    def slot(self, n_rows: int) -> "RaggedImageOnlyStepper.Slot":
+        cap = bucket_rows(n_rows)
+        s = self.slots.get(cap)
+        if s is None:
+            L = self.tr.fp.p("fc.1.weight").shape[1]
+            C = self.tr.fp.p("fc.1.weight").shape[0]
+            s = self.slots[cap] = self.Slot(cap, self.B, L, C, self.tr.device)
+        return s
+
+    def step(self, slot: "RaggedImageOnlyStepper.Slot", lengths):
+        tr = self.tr
+        slot.layout.set_lengths(lengths)
+        slot.visits += 1
+        if slot.graph is None and self.use_graph and slot.visits >= 2:
+            tr.capture(slot.x, slot.layout, slot.y)                # warm-up pass + capture (two optimizer-free passes)
+            slot.graph = tr._graph
+        if slot.graph is not None:
+            tr._graph = slot.graph
+            self.replays += 1
+            return tr.replay_step()
+        self.eager_steps += 1
+        return tr.train_step(slot.x, slot.layout, slot.y)
