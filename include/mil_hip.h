@@ -427,6 +427,11 @@ int mil_add_bag_row(const float* x, const float* o, const int32_t* row_bag, int 
                     void* stream);
 int mil_segment_colsum(const float* Y, const int32_t* row_off, int B, int max_rows, int E, float* out,
                        float* workspace, void* stream);
+/* CT feature map -> tokens (sam/transformer.py:86-98; the map is the CT encoder's output [B, C = 512, D = 160, h, w],
+ * model/aggregator.py:139-140, HW = h * w): reduce != 0 (resnetMC3_18): out [B * D, C] = mean over (h, w), permuted;
+ * reduce == 0 (medicalNet): out [B * D * HW, C] = flatten(2).permute(0, 2, 1).  The encoders themselves are out of scope:
+ * the module accepts the precomputed map. */
+int mil_ct_map_tokens(const float* ct, int B, int C, int D, int HW, int reduce, float* out, void* stream);
 /* The sinusoidal table of model/aggregator.py:99-106 built on the device: pe [n, E]. */
 int mil_sinusoid_pe(float* pe, int n, int E, void* stream);
 

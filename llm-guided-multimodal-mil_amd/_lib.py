@@ -99,6 +99,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_add_bag_row": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "mil_segment_colsum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "mil_sinusoid_pe": (c_int, [_P, c_int, c_int, _P]),
+    "mil_ct_map_tokens": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_embed_tokens": (c_int, [_P] * 3 + [c_int] * 3 + [_P, _P]),
     "mil_gather_eot": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),

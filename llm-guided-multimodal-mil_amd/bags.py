@@ -36,6 +36,12 @@ def build_tile_map(lengths: Sequence[int], tile: int = POOL_TILE):
     return tm, bag_tile_off.astype(np.int32), bag_off.astype(np.int32)
 
 
+def _np_offsets(lengths) -> np.ndarray:
+    off = np.zeros(len(lengths) + 1, dtype=np.int32)
+    off[1:] = np.cumsum(lengths)
+    return off
+
+
 @dataclass
 class BagLayout:
     """Device-resident description of how R rows split into B bags."""
@@ -82,6 +88,37 @@ class BagLayout:
     @classmethod
     def uniform(cls, B: int, N: int, device) -> "BagLayout":
         return cls.make([N] * B, device)
+
+    @classmethod
+    def multi_segment(cls, seg_lengths: Sequence[Sequence[int]], device) -> "BagLayout":
+        """Rows laid out as [segment 0 of all bags | segment 1 of all bags | ...]; bag b owns its range of every segment.
+        The 4-segment multi-modal bag of model/aggregator.py:173 (text-from-CT tokens, CT tokens, text-from-pathology
+        tokens, patch tokens) without materialising the per-bag concatenation: the pool kernels only follow the tile map
+        and attention pooling does not depend on the order of a bag's rows."""
+        key = ("mseg", tuple(tuple(int(v) for v in seg) for seg in seg_lengths), str(device))
+        hit = cls._get(key)
+        if hit is not None:
+            return hit
+        segs = [np.asarray(k, dtype=np.int64) for k in key[1]]
+        B = len(segs[0])
+        maps, base = [], 0
+        for seg in segs:
+            tm, bto, bo = build_tile_map(seg)
+            tm = tm.copy()
+            tm[:, 1] += base
+            maps.append((tm, bto))
+            base += int(bo[-1])
+        tiles = []
+        for b in range(B):
+            for tm, bto in maps:
+                tiles.append(tm[bto[b]:bto[b + 1]])
+        tm = np.concatenate(tiles, 0) if tiles else np.zeros((0, 4), np.int32)
+        bto = sum(m[1].astype(np.int64) for m in maps).astype(np.int32)
+        lay = cls(lengths=[int(sum(seg[b] for seg in segs)) for b in range(B)], R=base, B=B, T=int(tm.shape[0]),
+                  tile_map=torch.from_numpy(np.ascontiguousarray(tm)).to(device),
+                  bag_tile_off=torch.from_numpy(bto).to(device),
+                  bag_off=torch.from_numpy(_np_offsets(segs[0])).to(device))
+        return cls._put(key, lay)
 
     @classmethod
     def two_segment(cls, n_lengths: Sequence[int], t_lengths: Sequence[int], device) -> "BagLayout":

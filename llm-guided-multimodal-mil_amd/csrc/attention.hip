@@ -876,6 +876,49 @@ extern "C" int mil_add_pe(const float* x, const float* pe, const int32_t* row_ba
     return MIL_OK;
 }
 
+// CT feature map -> tokens (sam/transformer.py:86-98).  ct [B][C][D][HW] fp32 contiguous (the CT encoder's output
+// [B, 512, 160, h, w], model/aggregator.py:139-140, HW = h * w):
+//   reduce != 0 (resnetMC3_18): tokens[b][d][c] = mean over HW                      -> out [B * D, C]
+//   reduce == 0 (medicalNet):   tokens[b][d * HW + s][c] = ct[b][c][d][s]           -> out [B * D * HW, C]
+// One workgroup per (b, 32-channel tile): the 32 x T sums go through LDS so that the token rows leave as 128-byte runs.
+__global__ __launch_bounds__(256) void k_ct_map_tokens(const float* __restrict__ ct, float* __restrict__ out, int C, int D, int HW,
+                                                       int reduce) {
+    extern __shared__ float tile[];                 // [32][TT + 1]
+    const int T = reduce ? D : D * HW;              // tokens per bag
+    const int inner = reduce ? HW : 1;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TT = 256;                         // tokens per pass
+    const float inv = 1.0f / (float)inner;
+    for (int t0 = 0; t0 < T; t0 += TT) {
+        // wave w sums channels c0 + w, w + 4, ...; lane = token
+        for (int cc = wave; cc < 32 && c0 + cc < C; cc += 4) {
+            const float* src = ct + ((size_t)(b * C + c0 + cc) * T) * inner;
+            for (int t = t0 + lane; t < min(T, t0 + TT); t += 64) {
+                float v = 0.f;
+                const float* q = src + (size_t)t * inner;
+                for (int i = 0; i < inner; ++i) v += q[i];
+                tile[cc * (TT + 1) + (t - t0)] = v * inv;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < 32 * TT; k += 256) {
+            const int t = t0 + k / 32, cc = k % 32;
+            if (t < T && c0 + cc < C) out[((size_t)b * T + t) * C + c0 + cc] = tile[cc * (TT + 1) + (t - t0)];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int mil_ct_map_tokens(const float* ct, int B, int C, int D, int HW, int reduce, float* out, void* stream) {
+    if (!ct || !out || B < 0 || C <= 0 || D <= 0 || HW <= 0) return MIL_EINVAL;
+    if (B == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_ct_map_tokens, dim3((C + 31) / 32, B), dim3(256), 32 * 257 * sizeof(float), (hipStream_t)stream, ct, out, C, D,
+                       HW, reduce);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_sinusoid_pe(float* pe, int n, int E, void* stream) {
     if (!pe || n < 0 || E <= 0 || (E & 1)) return MIL_EINVAL;
     if (n == 0) return MIL_OK;

@@ -35,9 +35,10 @@ class aggregator(nn.Module):
         super().__init__()
         self.args = args
         modality = list(args.modality)
-        if "CT" in modality:
-            raise NotImplementedError("CT encoders (torchvision/MONAI 3-D backbones) are outside the MIL hot path "
-                                      "(SURVEY.md section 2 #14); use modality ['pathology'] or ['CI']")
+        # 'CT' in modality: the CT ENCODERS (torchvision / MONAI 3-D backbones, model/dim3/*) stay outside the hot path, but
+        # their output - the feature map [B, 512, 160, h, w] of aggregator.py:139-140 - is accepted as x_list[0], precomputed
+        # (extractor_CT is the identity here), and everything downstream of it is built: map -> tokens, fc_CI2CT,
+        # TwoWayTransformer_CT / _Both, the 4-segment multi-modal bag (:155-184).
         mk_twoway = lambda: TwoWayTransformer(args=args, depth=2, embedding_dim=EMBED, num_heads=8, mlp_dim=2048)  # noqa: E731
         self.fc_CI2CT = nn.Sequential(nn.Linear(EMBED, EMBED), nn.Tanh())                 # aggregator.py:44
         if "pathology" in modality:
@@ -48,6 +49,8 @@ class aggregator(nn.Module):
             elif args.model_pathology not in ("-", None):
                 raise NotImplementedError(f"model_pathology={args.model_pathology}: only ABMIL is on the built path")
             self.TwoWayTransformer_Pth = mk_twoway()                                      # :58
+        if "CT" in modality:
+            self.TwoWayTransformer_CT = mk_twoway()                                       # :36
         self.fc_CI2Pth = nn.Sequential(nn.Linear(EMBED, EMBED), nn.Tanh())                # :66
         self.fc_CI = nn.Sequential(nn.Linear(EMBED, EMBED), nn.Tanh())                    # :68
         self.TwoWayTransformer_Both = mk_twoway()                                         # :70
@@ -92,6 +95,51 @@ class aggregator(nn.Module):
         self.last_logits = z
         return p
 
+    # ------------------------------------------------------------------ CT branches (aggregator.py:155-184)
+    def _forward_ct(self, x_list, t, lengths):
+        """x_list[0] = the CT encoder's feature map [B, 512, 160, h, w] (precomputed; or tokens [B, D, 512]);
+        with 'pathology' also x_list[1] = [B, N, 768].  Returns (prob, x_CT2CI[, x_Pth2CI]) as :202-205."""
+        B, P, _ = t.shape
+        dev = t.device
+        ct = x_list[0]
+        if ct.dim() == 5:
+            ct_rows, D = ops.ct_map_tokens(ct, _arg(self.args, "model_CT", "resnetMC3_18"))     # sam/transformer.py:86-98
+        else:
+            D = ct.shape[1]
+            ct_rows = ct.reshape(B * D, EMBED).contiguous()
+        tflat = t.reshape(B * P, EMBED)
+        point_ct = self._lin_tanh(self.fc_CI2CT, tflat)                                       # :160 / :179
+        if "pathology" not in self.args.modality:
+            q, k = self.TwoWayTransformer_CT.flat(ct_rows, point_ct, self.pe_rows(D, dev), [D] * B, [P] * B,
+                                                  keys_tail_rows=B * P)                       # :179
+            x0 = ops.append_rows(k, q, tail_reserved=True)                                    # :184
+            layout = BagLayout.two_segment([D] * B, [P] * B, dev)
+            M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0
+            return self._head(M), q.view(B, P, EMBED)                                         # :204-205
+        x = x_list[1]
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        N = x.shape[1]
+        if lengths is None:
+            n_len = [N] * B
+            flat = x.reshape(B * N, x.shape[2])
+        else:
+            n_len = [int(v) for v in lengths]
+            flat = torch.cat([x[b, :n] for b, n in enumerate(n_len)], 0)
+        tw = self.TwoWayTransformer_Both                                                      # :160,168: one module, twice
+        q_ct, k_ct = tw.flat(ct_rows, point_ct, self.pe_rows(D, dev), [D] * B, [P] * B)
+        xi = self._lin_tanh(self.fc_pathology, flat)                                          # :141
+        point_p = self._lin_tanh(self.fc_CI2Pth, tflat)
+        extra = B * (2 * P + D)
+        q_p, k_p = tw.flat(xi, point_p, self.pe_rows(max(n_len), dev), n_len, [P] * B, keys_tail_rows=extra)
+        # multi-modal bag (:173) = [x_CT2CI | x_CI2CT | x_Pth2CI | x_CI2Pth] per patient.  Rows are kept as
+        # [all patch tokens | CT-side text tokens | CT tokens | pathology-side text tokens]: the big patch block stays where
+        # the last LayerNorm wrote it, the small blocks are appended, the tile map says which rows form a bag.
+        x0 = ops.append_rows(k_p, torch.cat([q_ct, k_ct, q_p], 0), tail_reserved=True)
+        layout = BagLayout.multi_segment([n_len, [P] * B, [D] * B, [P] * B], dev)
+        M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0           # :198-199
+        return self._head(M), q_ct.view(B, P, EMBED), q_p.view(B, P, EMBED)                   # :202-203
+
     # ------------------------------------------------------------------ forward (aggregator.py:134-209)
     def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
                 text_features: Optional[torch.Tensor] = None):
@@ -103,6 +151,8 @@ class aggregator(nn.Module):
         # `self.clinic_extractor(x_CI)`; lets a captured hipGraph replay the trainable part only
         t = text_features if text_features is not None else self.clinic_extractor(x_CI)   # :151  [B, P, 512]
         B, P, _ = t.shape
+        if "CT" in modality:
+            return self._forward_ct(x_list, t, lengths)
         if "pathology" in modality:
             x = x_list[0]
             if x.dim() == 2:

@@ -212,9 +212,16 @@ class TwoWayTransformer(nn.Module):
 
     def forward(self, image_embedding, image_pe, point_embedding):
         """Reference signature (sam/transformer.py:58-63): image_embedding [B, N, E], image_pe [B or 1, N, E],
-        point_embedding [B, T, E] -> (queries [B, T, E], keys [B, N, E]).  5-D CT maps are out of scope."""
+        point_embedding [B, T, E] -> (queries [B, T, E], keys [B, N, E]).  A 5-D image_embedding is a CT feature map
+        [B, E, D, h, w] (:78-98): it becomes D tokens (mean over h, w; resnetMC3_18) or D*h*w tokens (medicalNet)."""
+        if getattr(self.args, "alignment_base", "CI") == "CT":
+            raise NotImplementedError("alignment_base='CT' (CT tokens as queries, :78-86) is not on the built path")
+        if image_embedding.dim() == 5:
+            Bc = image_embedding.shape[0]
+            rows, Tn = ops.ct_map_tokens(image_embedding, getattr(self.args, "model_CT", "resnetMC3_18"))
+            image_embedding = rows.view(Bc, Tn, rows.shape[1])
         if image_embedding.dim() != 3:
-            raise NotImplementedError("CT feature maps (5-D image_embedding) are outside the MIL hot path")
+            raise ValueError("image_embedding must be [B, N, E] or a 5-D CT map [B, E, D, h, w]")
         B, N, E = image_embedding.shape
         T = point_embedding.shape[1]
         pe = image_pe.reshape(-1, E)[:N].contiguous()

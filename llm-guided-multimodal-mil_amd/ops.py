@@ -930,6 +930,24 @@ def add_pe(x, pe, row_bag, row_off):
     return _AddPE.apply(x, pe, row_bag, row_off)
 
 
+def ct_map_tokens(ct, model_CT: str = "resnetMC3_18"):
+    """CT feature map [B, C, D, h, w] -> flat token rows [B * T, C] (sam/transformer.py:86-98): T = D tokens by a mean over
+    (h, w) for resnetMC3_18, T = D * h * w by flatten + permute for medicalNet.  The map is an input (the CT encoders are
+    outside the hot path), so no gradient flows into it."""
+    if ct.dim() != 5:
+        raise _lib.MilHipError("ct_map_tokens: expected a 5-D map [B, C, D, h, w]")
+    if ct.requires_grad:
+        raise NotImplementedError("the CT encoder is outside the MIL hot path: pass its output detached")
+    ct = _f32c(ct, "ct")
+    B, C, D, hh, ww = ct.shape
+    reduce = 0 if model_CT == "medicalNet" else 1
+    T = D if reduce else D * hh * ww
+    out = torch.empty((B * T, C), device=ct.device, dtype=torch.float32)
+    rc = _lib.lib().mil_ct_map_tokens(_p(ct), B, C, D, hh * ww, reduce, _p(out), _stream())
+    _lib.check(rc, "mil_ct_map_tokens")
+    return out, T
+
+
 def sinusoid_pe(n: int, E: int, device):
     pe = torch.empty((n, E), device=device, dtype=torch.float32)
     rc = _lib.lib().mil_sinusoid_pe(_p(pe), n, E, _stream())

@@ -129,13 +129,15 @@ def clip_text_params(seed: int, width: int = 512, layers: int = 12, vocab: int =
 
 
 def fused_params(seed: int = 1234, twoway: str = "TwoWayTransformer_Pth", clip_width: int = 512,
-                 clip_layers: int = 12, clip_vocab: int = 49408, E: int = 512, C: int = 2) -> Params:
+                 clip_layers: int = 12, clip_vocab: int = 49408, E: int = 512, C: int = 2, with_ct: bool = False) -> Params:
     """Live parameters of the pathology + clinical-text branch (model/aggregator.py:47,58-66,
     79-81,120-131)."""
     p: Params = {}
     g = _gen(seed + 10)
     _put_linear(p, g, "fc_pathology.0", E, 768)
     _put_linear(p, g, "fc_CI2Pth.0", E, E)
+    if with_ct:
+        _put_linear(p, g, "fc_CI2CT.0", E, E)                     # model/aggregator.py:44
     p.update(twoway_params(seed + 20, twoway, E=E))
     p.update(clip_text_params(seed + 30, width=clip_width, layers=clip_layers, vocab=clip_vocab, embed=E))
     p.update(image_only_params(seed, L=E, C=C))
@@ -146,6 +148,11 @@ def fused_params(seed: int = 1234, twoway: str = "TwoWayTransformer_Pth", clip_w
 def make_bags(seed: int, B: int, N: int, L: int) -> Tensor:
     """Patch-feature bags x ~ N(0,1) fp32 [B, N, L]."""
     return torch.randn((B, N, L), generator=_gen(seed))
+
+
+def make_ct_map(seed: int, B: int, D: int = 160, hw: int = 14, E: int = 512) -> Tensor:
+    """A stand-in for the CT encoder's output (model/aggregator.py:139-140: (160, 512, 512) volume -> [B, 512, 160, h, w])."""
+    return torch.randn((B, E, D, hw, hw), generator=_gen(seed))
 
 
 def make_labels(seed: int, B: int, C: int = 2) -> Tensor:

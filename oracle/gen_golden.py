@@ -174,6 +174,73 @@ def gen_twoway(tw, tag, seed, T, N, store_inputs=True):
     npz(tag, **arrs)
 
 
+def gen_twoway_ctmap(tw, tag, seed, T, D, hw):
+    """The 5-D branch of sam/transformer.py:78-98: a CT feature map [1, 512, D, h, w] (the output of the CT encoder,
+    model/aggregator.py:139-140) becomes D tokens by a mean over (h, w) and a permute; image_pe = pe[:, :D] (:160)."""
+    name = "TwoWayTransformer_CT"
+    p = syn.twoway_params(seed, name)
+    args = SimpleNamespace(alignment_base="CI", model_CT="resnetMC3_18")
+    m = tw.TwoWayTransformer(args=args, depth=2, embedding_dim=512, num_heads=8, mlp_dim=2048).eval()
+    m.load_state_dict(sub(p, name + "."))
+    ct = syn.make_ct_map(seed + 1, 1, D, hw)
+    g = torch.Generator().manual_seed(seed + 2)
+    pt = torch.randn((1, T, 512), generator=g).requires_grad_(True)
+    import oracle.mil_oracle as orc
+    pe = orc.sinusoidal_pe(D, 512).unsqueeze(0)
+    q, k = m(ct, pe, pt)
+    gq = torch.randn(q.shape, generator=g)
+    gk = torch.randn(k.shape, generator=g)
+    ((q * gq).sum() + (k * gk).sum()).backward()
+    arrs = dict(seed=seed, shape=np.array([T, D, hw]), queries=q[0], keys=k[0], dpoint=pt.grad[0])
+    pack_grads(arrs, grads_of(m, "g." + name + "."), full=False)
+    npz(tag, **arrs)
+
+
+def gen_fused_ct_pth(ab, tw, cm, tag, seed, B, N, P, D, hw, clip_layers):
+    """model/aggregator.py:134-209 with modality ['CT', 'pathology'] and a PRECOMPUTED CT map in place of extractor_CT:
+    both modalities go through TwoWayTransformer_Both (:160,168), the multi-modal bag is the 4-segment concat of :173."""
+    name = "TwoWayTransformer_Both"
+    p = syn.fused_params(seed, name, clip_width=512, clip_layers=clip_layers, clip_vocab=49408, with_ct=True)
+    import oracle.mil_oracle as orc
+    mk = lambda i, o: torch.nn.Sequential(torch.nn.Linear(i, o), torch.nn.Tanh())          # noqa: E731
+    fc_path, fc_ci2p, fc_ci2c = mk(768, 512), mk(512, 512), mk(512, 512)
+    fc_path.load_state_dict(sub(p, "fc_pathology."))
+    fc_ci2p.load_state_dict(sub(p, "fc_CI2Pth."))
+    fc_ci2c.load_state_dict(sub(p, "fc_CI2CT."))
+    args = SimpleNamespace(alignment_base="CI", model_CT="resnetMC3_18")
+    twm = tw.TwoWayTransformer(args=args, depth=2, embedding_dim=512, num_heads=8, mlp_dim=2048)
+    twm.load_state_dict(sub(p, name + "."))
+    abmil = ab.ABMIL(None, L=512)
+    abmil.load_state_dict(sub(p, "aggregator."))
+    fc = torch.nn.Sequential(torch.nn.Dropout(0.25), torch.nn.Linear(512, 2))
+    fc.load_state_dict(sub(p, "fc."))
+    clip = build_ref_clip(cm, p, 512, clip_layers, 49408, 8, 512)
+    for m in (fc_path, fc_ci2p, fc_ci2c, twm, abmil, fc):
+        m.eval()
+    x = syn.make_bags(seed + 3, B, N, 768)
+    ids = syn.make_token_ids(seed + 4, B, P)
+    y = syn.make_labels(seed + 5, B)
+    ct = syn.make_ct_map(seed + 6, B, D, hw)
+    probs, logits, q_ct, q_p = [], [], [], []
+    for b in range(B):
+        with torch.no_grad():
+            t = clip.encode_text(ids[b]).unsqueeze(0)
+        a, c_ = twm(ct[b:b + 1], orc.sinusoidal_pe(D, 512).unsqueeze(0), fc_ci2c(t))               # :160
+        e, f = twm(fc_path(x[b:b + 1]), orc.sinusoidal_pe(N, 512).unsqueeze(0), fc_ci2p(t))        # :168
+        x0 = torch.cat([a, c_, e, f], dim=1)                                                      # :173
+        z = fc(abmil(x0))
+        logits.append(z); probs.append(torch.sigmoid(z)); q_ct.append(a[0]); q_p.append(e[0])
+    prob = torch.cat(probs, 0)
+    loss = torch.nn.BCELoss()(prob, y)
+    loss.backward()
+    arrs = dict(seed=seed, cfg=np.array([B, N, P, D, hw, clip_layers]), logits=torch.cat(logits, 0), prob=prob, loss=loss,
+                x_CT2CI=torch.stack(q_ct, 0).detach(), x_Pth2CI=torch.stack(q_p, 0).detach())
+    for mod, pre in ((fc_path, "fc_pathology."), (fc_ci2p, "fc_CI2Pth."), (fc_ci2c, "fc_CI2CT."), (twm, name + "."),
+                     (abmil, "aggregator."), (fc, "fc.")):
+        pack_grads(arrs, grads_of(mod, "g." + pre), full=False)
+    npz(tag, **arrs)
+
+
 def gen_twoway_block(tw, tag, seed, skip, T, N):
     p = {}
     g = torch.Generator().manual_seed(seed)
@@ -306,6 +373,8 @@ def main():
     gen_twoway(tw, "twoway_T1_N64", 71, 1, 64)
     gen_twoway(tw, "twoway_T10_N64", 72, 10, 64)
     gen_twoway(tw, "twoway_T1_N200", 73, 1, 200)
+    gen_twoway_ctmap(tw, "twoway_ctmap_T1", 75, 1, 160, 3)
+    gen_twoway_ctmap(tw, "twoway_ctmap_T10", 76, 10, 160, 2)
     gen_clip(cm, "clip_text_small", 81, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, store_params=False)
     gen_clip(cm, "clip_text_vitb32", 82, width=512, layers=12, vocab=49408, heads=8, embed=512, P=2,
              store_params=False)
@@ -317,10 +386,17 @@ def main():
               clip_vocab=49408, clip_heads=8)
     gen_fused(ab, tw, cm, "fused_vitb32", 93, B=2, N=128, P=1, clip_layers=12, clip_width=512,
               clip_vocab=49408, clip_heads=8)
+    gen_fused_ct_pth(ab, tw, cm, "fused_ct_pth", 95, B=2, N=96, P=1, D=160, hw=2, clip_layers=2)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "coop":        # regenerate only the learnable-context fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == "ct":          # only the CT-map fixtures (round 2)
+        torch.set_num_threads(8)
+        _ab, _tw, _cm = load_reference()
+        gen_twoway_ctmap(_tw, "twoway_ctmap_T1", 75, 1, 160, 3)
+        gen_twoway_ctmap(_tw, "twoway_ctmap_T10", 76, 10, 160, 2)
+        gen_fused_ct_pth(_ab, _tw, _cm, "fused_ct_pth", 95, B=2, N=96, P=1, D=160, hw=2, clip_layers=2)
+    elif len(sys.argv) > 1 and sys.argv[1] == "coop":        # regenerate only the learnable-context fixtures
         torch.set_num_threads(8)
         _ab, _tw, _cm = load_reference()
         gen_coop(_cm, "coop_small", 85, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, n_ctx=8)

@@ -266,6 +266,31 @@ def fused_forward(x768: Tensor, ids: Tensor, p: Params, clip_heads: int = 8,
             "logits": z, "prob": prob}
 
 
+def ct_map_tokens(ct: Tensor, model_CT: str = "resnetMC3_18") -> Tensor:
+    """sam/transformer.py:86-98: a CT feature map [B, 512, D, h, w] becomes tokens [B, D, 512] by a mean over (h, w) and a
+    permute (resnetMC3_18), or [B, D*h*w, 512] by flatten(2).permute (medicalNet)."""
+    if model_CT == "medicalNet":
+        return ct.flatten(2).permute(0, 2, 1)
+    return ct.mean(dim=(3, 4)).permute(0, 2, 1)
+
+
+def fused_forward_ct_pth(ct: Tensor, x768: Tensor, ids: Tensor, p: Params, clip_heads: int = 8) -> Dict[str, Tensor]:
+    """model/aggregator.py:134-209 for one patient with modality ['CT', 'pathology'] and a precomputed CT map
+    ct [512, D, h, w] in place of extractor_CT's output: both modalities through TwoWayTransformer_Both (:160,168), the
+    multi-modal bag is cat([x_CT2CI, x_CI2CT, x_Pth2CI, x_CI2Pth]) (:173)."""
+    tw = "TwoWayTransformer_Both"
+    with torch.no_grad():
+        t = clip_encode_text(ids, p, clip_heads)                                             # :151
+    ctk = ct_map_tokens(ct.unsqueeze(0))[0]                                                   # [D, 512]
+    a, c_ = twoway_transformer(ctk, sinusoidal_pe(ctk.shape[0], 512), linear_tanh(t, p["fc_CI2CT.0.weight"], p["fc_CI2CT.0.bias"]), p, tw)   # :160
+    xi = linear_tanh(x768, p["fc_pathology.0.weight"], p["fc_pathology.0.bias"])             # :141
+    e, f = twoway_transformer(xi, sinusoidal_pe(xi.shape[0], 512), linear_tanh(t, p["fc_CI2Pth.0.weight"], p["fc_CI2Pth.0.bias"]), p, tw)    # :168
+    x0 = torch.cat([a, c_, e, f], dim=0)                                                      # :173
+    M, A, s = abmil_forward(x0, p)
+    z, prob = head_forward(M, p)
+    return {"x_CT2CI": a, "x_Pth2CI": e, "M": M, "logits": z, "prob": prob}
+
+
 def batch_loss_and_grads(bags: List[Tensor], labels: Tensor, p: Params, forward=image_only_forward,
                          wrt: Optional[List[str]] = None, extra: Optional[List[Tensor]] = None):
     """Mean-BCE over a list of independent B=1 bags, and its gradients (torch autograd on

@@ -103,8 +103,10 @@ def test_ci_only_branch_runs():
 
 
 def test_out_of_scope_branches_raise():
-    with pytest.raises(NotImplementedError):
-        get_model(make_args(modality=["CT", "pathology"]))
+    m = get_model(make_args(modality=["CT", "pathology"], clip_layers=1))       # built since round 2 (precomputed CT map)
+    with pytest.raises(NotImplementedError):                                      # ... but the CT encoder itself is not
+        m.to(DEV)([torch.randn(1, 512, 4, 2, 2, device=DEV, requires_grad=True), torch.randn(1, 8, 768, device=DEV)],
+                  syn.make_token_ids(1, 1, 1).to(DEV))
     with pytest.raises(NotImplementedError):
         get_model(make_args(aggregator="TransMIL"))
     with pytest.raises(NotImplementedError):

@@ -212,3 +212,61 @@ def test_learnable_prompts(tag):
     (out * go).sum().backward()
     assert rel_err(out.detach(), g["out"]) <= TOL
     assert rel_err(ctx.grad, g["dctx"]) <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["twoway_ctmap_T1", "twoway_ctmap_T10"])
+def test_twoway_on_a_ct_map(tag):
+    """The 5-D branch of sam/transformer.py:78-98 (CT feature map -> 160 tokens) against the reference's own forward."""
+    g = load_golden(tag)
+    seed = int(g["seed"])
+    T, D, hw = [int(v) for v in g["shape"]]
+    name = "TwoWayTransformer_CT"
+    p = syn.twoway_params(seed, name)
+    ct = syn.make_ct_map(seed + 1, 1, D, hw)
+    gen = torch.Generator().manual_seed(seed + 2)
+    pt = torch.randn((1, T, 512), generator=gen)[0].requires_grad_(True)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+    q, k = orc.twoway_transformer(orc.ct_map_tokens(ct)[0], orc.sinusoidal_pe(D, 512), pt, leaves, name)
+    gq = torch.randn((1, T, 512), generator=gen)[0]
+    gk = torch.randn((1, D, 512), generator=gen)[0]
+    ((q * gq).sum() + (k * gk).sum()).backward()
+    assert rel_err(q, g["queries"]) <= TOL and rel_err(k, g["keys"]) <= TOL
+    assert rel_err(pt.grad, g["dpoint"]) <= 1e-4
+    for n in p:
+        gn = float(g["g." + n + ".norm"])
+        got = leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(leaves[n])
+        if gn == 0.0:
+            assert float(got.abs().max()) <= 1e-12, n
+        else:
+            check_grad("g." + n, got, g, 2e-4)
+
+
+def test_fused_ct_and_pathology():
+    """modality ['CT', 'pathology'] with a precomputed CT map: TwoWayTransformer_Both twice, 4-segment bag (aggregator.py:155-173)."""
+    g = load_golden("fused_ct_pth")
+    seed = int(g["seed"])
+    B, N, P, D, hw, clayers = [int(v) for v in g["cfg"]]
+    p = syn.fused_params(seed, "TwoWayTransformer_Both", clip_layers=clayers, with_ct=True)
+    x = syn.make_bags(seed + 3, B, N, 768)
+    ids = syn.make_token_ids(seed + 4, B, P)
+    y = syn.make_labels(seed + 5, B)
+    ct = syn.make_ct_map(seed + 6, B, D, hw)
+    train = [k for k in p if not k.startswith("clinic_extractor.")]
+    leaves = dict(p)
+    leaves.update({k: p[k].clone().requires_grad_(True) for k in train})
+    outs = [orc.fused_forward_ct_pth(ct[b], x[b], ids[b], leaves) for b in range(B)]
+    prob = torch.cat([o["prob"] for o in outs], 0)
+    logits = torch.cat([o["logits"] for o in outs], 0)
+    loss = orc.bce_loss(prob, y)
+    loss.backward()
+    assert float((logits - g["logits"]).abs().max()) <= 2e-6
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert rel_err(torch.stack([o["x_CT2CI"] for o in outs], 0), g["x_CT2CI"]) <= TOL
+    assert rel_err(torch.stack([o["x_Pth2CI"] for o in outs], 0), g["x_Pth2CI"]) <= TOL
+    for k in train:
+        gn = float(g["g." + k + ".norm"])
+        got = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        if gn == 0.0:
+            assert float(got.abs().max()) <= 1e-12, k
+        else:
+            check_grad("g." + k, got, g, 5e-4)
