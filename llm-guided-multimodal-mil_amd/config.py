@@ -56,6 +56,12 @@ def create_arg_parser(argv=None):
     p.add_argument("--dist_backend", type=str, default="nccl")
     p.add_argument("--world_size", type=int, default=1)
     p.add_argument("--rank", type=int, default=0)
+    # ---- on-disk cohort (reference: --path_data_pathology, config.py; dataset.py:366-393).  A directory of
+    # <patientid>.npy patch-feature bags [n, F] fp32 plus a JSON index {"id": {"label", "kind", "ids"}} in place of the
+    # private Excel sheets; unset = synthetic bags.
+    p.add_argument("--path_data_pathology", type=str, default="", help="directory of <patientid>.npy bags (dataset.py:367)")
+    p.add_argument("--index_json", type=str, default="", help="cohort index; default <path_data_pathology>/index.json")
+    p.add_argument("--augmentation", type=int, default=1, help="train-time patch drop (dataset.py:374-381)")
     # ---- synthetic data (no hospital data offline)
     p.add_argument("--synthetic", default=[1024, 768, 64], type=arg_as_list,
                    help="[patches per bag, patch feature dim, bags in the synthetic cohort]")

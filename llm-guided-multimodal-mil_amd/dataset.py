@@ -28,6 +28,26 @@ class SyntheticBags(Dataset):
         return {"pathology": x, "CI": self.ids[i], "label": self.labels[i], "length": self.lengths[i], "index": i}
 
 
+def load_cohort(args, mode: str, prompts: int):
+    """The dataset the entry points iterate: on-disk `.npy` bags when --path_data_pathology is given (dataset.py:366-393),
+    synthetic bags otherwise.  Returns (dataset, patch feature width)."""
+    import json
+    import os
+    root = getattr(args, "path_data_pathology", "")
+    if root:
+        idx_path = getattr(args, "index_json", "") or os.path.join(root, "index.json")
+        with open(idx_path) as f:
+            index = json.load(f)
+        ds = NpyBagDataset(root, index, mode=mode, augmentation=bool(getattr(args, "augmentation", 1)),
+                           num_classes=args.num_classes, seed=args.seed)
+        import numpy as np
+        first = np.load(os.path.join(root, ds.keys[0] + ".npy"), mmap_mode="r")       # header only: feature width
+        return ds, int(first.shape[1])
+    n_patch, feat, n_bags = [int(v) for v in args.synthetic]
+    seed = args.seed + (0 if mode == "train" else 1)
+    return SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, seed, args.ragged), feat
+
+
 def collate_bags(items):
     """Zero-pad to the longest bag of the batch (dataset.py:386-391 pads to a fixed length when batch > 1) and
     return the true lengths alongside."""

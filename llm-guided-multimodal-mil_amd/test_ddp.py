@@ -14,7 +14,7 @@ if __package__ in (None, ""):
     __package__ = "mil_amd"
 
 from .config import create_arg_parser  # noqa: E402
-from .dataset import SyntheticBags, collate_bags  # noqa: E402
+from .dataset import collate_bags, load_cohort  # noqa: E402
 from .train_ddp import build_model  # noqa: E402
 
 
@@ -23,16 +23,15 @@ def test(args):
         raise NotImplementedError("the MIL hot path runs on MI355X only: no GPU is visible")
     dev = torch.device("cuda", int(args.gpu.split(",")[0]))
     torch.cuda.set_device(dev)
+    prompts = 10 if args.CI_prompt_version == "devided" else 1
+    if args.learnablePrompt:
+        prompts = len(args.clinical_features) + 1
+    data, args.patch_dim = load_cohort(args, "test", prompts)
     model = build_model(args).to(dev)
     if args.test_pth:
         ck = torch.load(os.path.join(args.test_pth, "checkpoint_best.pth.tar"), map_location=dev, weights_only=True)
         model.load_state_dict(ck["state_dict"])                       # strict, as test_ddp.py:99
     model.eval()
-    n_patch, feat, n_bags = [int(v) for v in args.synthetic]
-    prompts = 10 if args.CI_prompt_version == "devided" else 1
-    if args.learnablePrompt:
-        prompts = len(args.clinical_features) + 1
-    data = SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, args.seed + 1, args.ragged)
     preds, labels, times = [], [], []
     with torch.no_grad():
         for i in range(len(data)):                                     # batch_size = 1 (test_ddp.py:73)

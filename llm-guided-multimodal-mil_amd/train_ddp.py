@@ -25,7 +25,7 @@ if __package__ in (None, ""):
 
 from .bags import BagLayout  # noqa: E402
 from .config import create_arg_parser  # noqa: E402
-from .dataset import SyntheticBags, collate_bags  # noqa: E402
+from .dataset import collate_bags, load_cohort  # noqa: E402
 from .dist_utils import broadcast_flat, env_world, init_process_group, shard_indices  # noqa: E402
 from .utils import AverageMeter, ProgressMeter, calculate_accuracy, save_checkpoint, scheduled_lr  # noqa: E402
 
@@ -33,7 +33,8 @@ from .utils import AverageMeter, ProgressMeter, calculate_accuracy, save_checkpo
 def build_model(args):
     if args.variant == "image_only":
         from .model.utils_clip import get_model
-        args.patch_dim = int(args.synthetic[1])
+        if not getattr(args, "patch_dim", 0):
+            args.patch_dim = int(args.synthetic[1])
     else:
         from .model.utils import get_model
     return get_model(args)
@@ -54,11 +55,10 @@ def main_worker(local_rank: int, nprocs: int, args):
         import builtins
         builtins.print = lambda *a, **k: None                                            # train_ddp.py:45-48
     torch.manual_seed(args.seed)
-    n_patch, feat, n_bags = [int(v) for v in args.synthetic]
     prompts = 10 if args.CI_prompt_version == "devided" else 1
     if args.learnablePrompt:
         prompts = len(args.clinical_features) + 1                                        # dim1/CLIP.py:19
-    data = SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, args.seed, args.ragged)
+    data, args.patch_dim = load_cohort(args, "train", prompts)                           # train_ddp.py:188-196
     per_gpu = max(1, args.batch_size // world)                                           # train_ddp.py:75
     model = build_model(args).to(dev)
     lr0 = 1e-3 if args.num_classes > 2 else 1e-5                                         # train_ddp.py:110-113
@@ -71,7 +71,14 @@ def main_worker(local_rank: int, nprocs: int, args):
         params = {k.replace("extractor_pathology.", "aggregator."): v for k, v in sd.items()}
         # a true model.train() step: dropout on the patches and in front of the head, masks drawn in-kernel (Philox)
         tr = ImageOnlyTrainer(params, dev, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world,
-                              train_mode=not getattr(args, "no_dropout", False), seed=args.seed)
+                              train_mode=not getattr(args, "no_dropout", False), seed=args.seed,
+                              counted=bool(getattr(args, "hip_graph", 0)))
+        stepper = None
+        if getattr(args, "hip_graph", 0):
+            # ragged bags whose lengths change every step (one bag per GPU upstream): lengths on the device, one captured
+            # graph per capacity bucket (trainer.RaggedImageOnlyStepper)
+            from .trainer import RaggedImageOnlyStepper
+            stepper = RaggedImageOnlyStepper(tr, B=per_gpu)
         if args.resume:
             ck = torch.load(args.resume, map_location=dev, weights_only=True)
             tr.load_model_state_dict(ck["state_dict"])
@@ -129,8 +136,17 @@ def main_worker(local_rank: int, nprocs: int, args):
             y = batch["label"].to(dev, non_blocking=True)
             if fused:
                 tr.lr = lr
-                flat = torch.cat([x[b, :n] for b, n in enumerate(batch["lengths"])], 0)
-                loss, prob = tr.train_step(flat, BagLayout.make(batch["lengths"], dev), y)
+                if stepper is not None and len(batch["lengths"]) == per_gpu:
+                    slot = stepper.slot(sum(batch["lengths"]))
+                    r0 = 0
+                    for b, n in enumerate(batch["lengths"]):                              # the bucket's static input buffers
+                        slot.x[r0:r0 + n].copy_(x[b, :n], non_blocking=True)
+                        r0 += n
+                    slot.y.copy_(y, non_blocking=True)
+                    loss, prob = stepper.step(slot, batch["lengths"])
+                else:
+                    flat = torch.cat([x[b, :n] for b, n in enumerate(batch["lengths"])], 0)
+                    loss, prob = tr.train_step(flat, BagLayout.make(batch["lengths"], dev), y)
             else:
                 for g in optimizer.param_groups:
                     g["lr"] = lr
