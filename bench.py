@@ -352,13 +352,12 @@ def config3_fusion(dev, steps=30, warmup=4):
         dl = max(dl, float((z[b] - o["logits"][0]).abs().max()))
         top1 = top1 and bool(torch.equal(prob[b].cpu().argmax(-1), o["prob"][0].argmax(-1)))
     opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7, counted=True)
-    crit = torch.nn.BCELoss()
     with torch.no_grad():
         tfeat = model.clinic_extractor(ids)         # frozen tower: cached per note in training (dim1/CLIP.py cache_text)
 
     def gstep():
-        p_, _ = model([x], ids, text_features=tfeat)
-        loss = crit(p_, y)
+        model([x], ids, text_features=tfeat, labels=y)      # criterion(prob, y) of train_ddp.py:323-324 inside the module:
+        loss = model.last_loss                              # pool + head + BCE run as one fused node
         loss.backward()
         opt.step()
         return loss

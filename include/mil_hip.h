@@ -207,6 +207,13 @@ int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, float* dWv, f
 int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv,
                        const float* Wu, int R, int L, int D, float* dx, const uint32_t* xbits, float xscale,
                        void* stream);
+/* The same with the pool's own input gradient formed in the epilogue instead of read from dx:
+ * dx[row] = a_row dM[row_bag[row]] + dPreV Wv + dPreU Wu, a_row = exp(scores[row] - lse[bag]) (ABMIL.py:57-59: the
+ * d/dx of M = sum_i a_i x_i at fixed weights; the part through the scores is the gate term).  dx is WRITTEN, never read:
+ * no pool-backward pass over [R, L].  row_bag int32 [R] = the bag of every row; dM [B, L]. */
+int mil_gate_bwd_input_pool(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu, int R,
+                            int L, int D, float* dx, const uint32_t* xbits, float xscale, const float* scores,
+                            const float* lse, const int32_t* row_bag, const float* dM, void* stream);
 
 /* ---- K1, bf16-storage variant (BASELINE config 5: N=4096, D=1024) -------------------------------
  * x and the gate weights are stored as bf16 (uint16_t bit patterns); all accumulation is fp32.  Same
@@ -415,6 +422,20 @@ int mil_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
  * for frozen parameters (the CLIP tower under learnable prompts): no parameter sums, workspace may be NULL. */
 int mil_layernorm_bwd_res(const float* x, const float* gamma, const float* dy, const float* stats, const float* dres,
                           int rows, int E, float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+
+/* LayerNorm(x + o[row_bag[row]]) with the per-bag row o [B, E] added on the way in (one text token per bag: the
+ * image->token attention of sam/transformer.py:303-309 degenerates to this add followed by norm4) - the sum is never
+ * stored.  The backward recomputes xhat from x + o and returns dx, d_o [B, E] (= the per-bag column sums of dx, folded in
+ * fixed order), dgamma, dbeta in two launches.  Precondition (checked by the caller, who knows the bag lengths): every bag
+ * has at least mil_layernorm_bagrow_rows_per_block(rows) rows, so that a workgroup's row range meets at most two bags.
+ * workspace: mil_layernorm_bwd_blocks(rows) * 4 * E floats.  row_off int32 [B + 1], row_bag int32 [rows]. */
+int mil_layernorm_bagrow_fwd(const float* x, const float* o, const int32_t* row_bag, const float* gamma, const float* beta,
+                             int rows, int E, float eps, float* y, float* stats, void* stream);
+int mil_layernorm_bagrow_bwd(const float* x, const float* o, const int32_t* row_bag, const int32_t* row_off, int B,
+                             const float* gamma, const float* dy, const float* stats, int rows, int E, float* dx, float* d_o,
+                             float* dgamma, float* dbeta, float* workspace, void* stream);
+int mil_layernorm_bagrow_rows_per_block(int rows);
+
 /* out[row] = x[row] + pe[row - row_off[row_bag[row]]]: keys + key_pe (sam/transformer.py:292,304) with the
  * table rows indexed by the position inside the bag (aggregator.py:190 passes pe[:, :N]). */
 int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,

@@ -48,6 +48,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gate_bwd_reduce": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float, _P]),
     "mil_gate_bwd_reduce_head": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float] + [_P] * 4 + [c_int, c_int, _P, _P, _P]),
     "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
+    "mil_gate_bwd_input_pool": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "mil_image_only_step_run": (c_int, [_P, _P]),
     "mil_image_only_step_time": (c_int, [_P, c_uint32, c_int, c_int, _P, _P]),
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
@@ -95,6 +96,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_layernorm_bwd_blocks": (c_int, [c_int]),
     "mil_layernorm_bwd": (c_int, [_P] * 4 + [c_int, c_int] + [_P] * 4 + [_P]),
     "mil_layernorm_bwd_res": (c_int, [_P] * 5 + [c_int, c_int] + [_P] * 4 + [_P]),
+    "mil_layernorm_bagrow_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_float, _P, _P, _P]),
+    "mil_layernorm_bagrow_bwd": (c_int, [_P] * 4 + [c_int] + [_P] * 3 + [c_int, c_int] + [_P] * 5 + [_P]),
+    "mil_layernorm_bagrow_rows_per_block": (c_int, [c_int]),
     "mil_add_pe": (c_int, [_P] * 4 + [c_int, c_int, _P, _P]),
     "mil_add_bag_row": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "mil_segment_colsum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),

@@ -3,7 +3,7 @@ attention-pool kernels iterate over (include/mil_hip.h, "tile map")."""
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import ClassVar, List, Sequence
+from typing import ClassVar, List, Optional, Sequence
 
 from collections import OrderedDict
 
@@ -52,6 +52,17 @@ class BagLayout:
     tile_map: torch.Tensor       # int32 [T, 4]
     bag_tile_off: torch.Tensor   # int32 [B+1]
     bag_off: torch.Tensor        # int32 [B+1]
+    _row_bag: Optional[torch.Tensor] = None
+
+    def row_bag(self) -> torch.Tensor:
+        """int32 [R]: the bag of every row (built from the tile map on first use; mil_gate_bwd_input_pool reads it)."""
+        if self._row_bag is None:
+            tm = self.tile_map.cpu().numpy()
+            rb = np.zeros(self.R, dtype=np.int32)
+            for bag, row0, nrows, _ in tm:
+                rb[row0:row0 + nrows] = bag
+            self._row_bag = torch.from_numpy(rb).to(self.tile_map.device)
+        return self._row_bag
 
     _cache: ClassVar["OrderedDict[tuple, BagLayout]"] = OrderedDict()
     CACHE_ENTRIES: ClassVar[int] = 256

@@ -481,13 +481,22 @@ __global__ void k_attn_pool_bwd_reduce(const float* __restrict__ pdq, const int3
 template <int NE>     // E = 64 * NE
 __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int rows, float eps,
-                                                       float* __restrict__ y, float* __restrict__ stats) {
+                                                       float* __restrict__ y, float* __restrict__ stats,
+                                                       const float* __restrict__ o, const int32_t* __restrict__ row_bag) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), E = 64 * NE;
     if (row >= rows) return;
     float v[NE];
     float s = 0.f;
+    if (o != nullptr) {
+        // LayerNorm(x + o[bag of row]): the per-bag row of the one-token image->token attention (k_add_bag_row) added on
+        // the way in - the sum is never written to memory
+        const float* orow = o + (size_t)row_bag[row] * E;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { v[e] = x[(size_t)row * E + lane + 64 * e]; s += v[e]; }
+        for (int e = 0; e < NE; ++e) { v[e] = x[(size_t)row * E + lane + 64 * e] + orow[lane + 64 * e]; s += v[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { v[e] = x[(size_t)row * E + lane + 64 * e]; s += v[e]; }
+    }
     const float mean = wave_allsum(s) / E;
     float ss = 0.f;
 #pragma unroll
@@ -573,6 +582,121 @@ __global__ __launch_bounds__(1024) void k_layernorm_param_fold(const float* __re
 #pragma unroll
         for (int i = 0; i < 16; ++i) v += red[i][lane];
         if (c < E) dgamma[c] = v; else dbeta[c - E] = v;
+    }
+}
+
+// Backward of LayerNorm(x + o[bag of row]) (k_layernorm_fwd with o): dx as k_layernorm_bwd with xhat recomputed from
+// x + o, and - since d(x + o) reaches o as the sum over the bag's rows - the per-bag column sums of dx in the same pass
+// (replaces k_segment_colsum's second trip over [rows, E]).  A workgroup's row range may cross ONE bag boundary (the host
+// guarantees every bag has at least rows_per_blk rows): sums go to slot 2 for the bag of the block's first row, slot 3
+// for the next bag.  part [nblk][4][E] = {dgamma, dbeta, do(first bag), do(second bag)}; folded in fixed order by
+// k_layernorm_bagrow_fold (no atomics).
+template <int NE>
+__global__ __launch_bounds__(256) void k_layernorm_bagrow_bwd(const float* __restrict__ x, const float* __restrict__ o,
+                                                              const int32_t* __restrict__ row_bag,
+                                                              const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                              const float* __restrict__ stats, int rows, int rows_per_blk,
+                                                              float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[4][4][64 * NE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, E = 64 * NE;
+    float dg[NE], db[NE], d0[NE], d1[NE], gm[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { dg[e] = 0.f; db[e] = 0.f; d0[e] = 0.f; d1[e] = 0.f; gm[e] = gamma[lane + 64 * e]; }
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+    const int fb = r0 < rows ? row_bag[r0] : 0;
+    for (int row = r0 + w; row < r1; row += 4) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const int bag = row_bag[row];
+        const float* orow = o + (size_t)bag * E;
+        float xh[NE], g[NE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int c = lane + 64 * e;
+            const float d = dy[(size_t)row * E + c];
+            xh[e] = (x[(size_t)row * E + c] + orow[c] - mean) * rstd;
+            g[e] = d * gm[e];
+            s1 += g[e];
+            s2 += g[e] * xh[e];
+            dg[e] += d * xh[e];
+            db[e] += d;
+        }
+        s1 = wave_allsum(s1) / E;
+        s2 = wave_allsum(s2) / E;
+        if (bag == fb) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float v = rstd * (g[e] - s1 - xh[e] * s2);
+                dx[(size_t)row * E + lane + 64 * e] = v;
+                d0[e] += v;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float v = rstd * (g[e] - s1 - xh[e] * s2);
+                dx[(size_t)row * E + lane + 64 * e] = v;
+                d1[e] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        red[w][0][lane + 64 * e] = dg[e];
+        red[w][1][lane + 64 * e] = db[e];
+        red[w][2][lane + 64 * e] = d0[e];
+        red[w][3][lane + 64 * e] = d1[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 4 * E; c += 256) {
+        const int which = c / E, cc = c % E;
+        part[((size_t)blockIdx.x * 4 + which) * E + cc] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+    }
+}
+
+// Fold of k_layernorm_bagrow_bwd's partials, one launch: workgroups [0, 2E/64) sum dgamma / dbeta over all blocks (as
+// k_layernorm_param_fold), workgroups behind them take (bag, 64 columns): the blocks whose row range meets the bag's rows,
+// slot 2 where the bag is the block's first bag, slot 3 where it is the second.
+__global__ __launch_bounds__(1024) void k_layernorm_bagrow_fold(const float* __restrict__ part, int nb, int E, int rows_per_blk,
+                                                               const int32_t* __restrict__ row_off,
+                                                               const int32_t* __restrict__ row_bag, int B,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ d_o) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int nA = (2 * E + 63) / 64;
+    const size_t st = (size_t)4 * E;
+    float v = 0.f;
+    if ((int)blockIdx.x < nA) {
+        const int c = blockIdx.x * 64 + lane;              // column of the [2 E] row: < E -> dgamma, else dbeta
+        if (c < 2 * E)
+            for (int b = g; b < nb; b += 16) v += part[(size_t)b * st + c];
+        red[g][lane] = v;
+        __syncthreads();
+        if (g == 0 && c < 2 * E) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i][lane];
+            if (c < E) dgamma[c] = t; else dbeta[c - E] = t;
+        }
+        return;
+    }
+    const int q = blockIdx.x - nA, ncb = E / 64;
+    const int bag = q / ncb, c = (q % ncb) * 64 + lane;
+    const int lo = row_off[bag], hi = row_off[bag + 1];
+    if (hi > lo) {
+        const int b0 = lo / rows_per_blk, b1 = (hi - 1) / rows_per_blk;
+        for (int b = b0 + g; b <= b1; b += 16) {
+            const int slot = row_bag[b * rows_per_blk] == bag ? 2 : 3;
+            v += part[(size_t)b * st + (size_t)slot * E + c];
+        }
+    }
+    red[g][lane] = v;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][lane];
+        d_o[(size_t)bag * E + c] = t;
     }
 }
 
@@ -790,21 +914,65 @@ extern "C" int mil_attn_pool_bwd_mh(const float* q, const float* k, const float*
     return MIL_OK;
 }
 
-extern "C" int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps,
-                                 float* y, float* stats, void* stream) {
+static int layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
+                              float* stats, const float* o, const int32_t* row_bag, void* stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || E <= 0 || (E % 64) != 0 || E > 512) return MIL_EINVAL;
     if (rows == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((rows + 3) / 4), blk(256);
     switch (E / 64) {
-        case 1: hipLaunchKernelGGL(k_layernorm_fwd<1>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
-        case 2: hipLaunchKernelGGL(k_layernorm_fwd<2>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
-        case 4: hipLaunchKernelGGL(k_layernorm_fwd<4>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
-        case 8: hipLaunchKernelGGL(k_layernorm_fwd<8>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats); break;
+        case 1: hipLaunchKernelGGL(k_layernorm_fwd<1>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
+        case 2: hipLaunchKernelGGL(k_layernorm_fwd<2>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
+        case 4: hipLaunchKernelGGL(k_layernorm_fwd<4>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
+        case 8: hipLaunchKernelGGL(k_layernorm_fwd<8>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
         default: return MIL_EINVAL;
     }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps,
+                                 float* y, float* stats, void* stream) {
+    return layernorm_fwd_impl(x, gamma, beta, rows, E, eps, y, stats, nullptr, nullptr, stream);
+}
+
+extern "C" int mil_layernorm_bagrow_fwd(const float* x, const float* o, const int32_t* row_bag, const float* gamma,
+                                        const float* beta, int rows, int E, float eps, float* y, float* stats,
+                                        void* stream) {
+    if (!o || !row_bag) return MIL_EINVAL;
+    return layernorm_fwd_impl(x, gamma, beta, rows, E, eps, y, stats, o, row_bag, stream);
+}
+
+extern "C" int mil_layernorm_bagrow_bwd(const float* x, const float* o, const int32_t* row_bag, const int32_t* row_off,
+                                        int B, const float* gamma, const float* dy, const float* stats, int rows, int E,
+                                        float* dx, float* d_o, float* dgamma, float* dbeta, float* workspace,
+                                        void* stream) {
+    if (!x || !o || !row_bag || !row_off || !gamma || !dy || !stats || !dx || !d_o || !dgamma || !dbeta || !workspace)
+        return MIL_EINVAL;
+    if (rows <= 0 || B <= 0 || (E % 64) != 0 || E > 512) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb0 = mil_layernorm_bwd_blocks(rows);
+    const int rpb = (rows + nb0 - 1) / nb0;
+    const int nb = (rows + rpb - 1) / rpb;                 // every block owns at least one row
+    const dim3 grid(nb), blk(256);
+    switch (E / 64) {
+        case 1: hipLaunchKernelGGL(k_layernorm_bagrow_bwd<1>, grid, blk, 0, st, x, o, row_bag, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 2: hipLaunchKernelGGL(k_layernorm_bagrow_bwd<2>, grid, blk, 0, st, x, o, row_bag, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 4: hipLaunchKernelGGL(k_layernorm_bagrow_bwd<4>, grid, blk, 0, st, x, o, row_bag, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        case 8: hipLaunchKernelGGL(k_layernorm_bagrow_bwd<8>, grid, blk, 0, st, x, o, row_bag, gamma, dy, stats, rows, rpb, dx, workspace); break;
+        default: return MIL_EINVAL;
+    }
+    MIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_layernorm_bagrow_fold, dim3((2 * E + 63) / 64 + B * (E / 64)), dim3(1024), 0, st, workspace, nb, E, rpb,
+                       row_off, row_bag, B, dgamma, dbeta, d_o);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_layernorm_bagrow_rows_per_block(int rows) {
+    if (rows <= 0) return 1;
+    const int nb0 = mil_layernorm_bwd_blocks(rows);
+    return (rows + nb0 - 1) / nb0;
 }
 
 extern "C" int mil_layernorm_bwd_blocks(int rows) {

@@ -1829,10 +1829,15 @@ extern "C" int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, co
 // ([128][36], ds_read_b128 fragments: lane (r, h) takes k = 8t + 4h + jj), the weights k-major ([32][128]); registers
 // carry the slice after next and the staging is issued in pieces between MFMA groups.  A slice of 32 k's is 16 gate units:
 // local k 0..15 = dPreV_d, 16..31 = dPreU_d (d = 16 kk + k), built from (V, U, ds, w) when the slice is written to LDS.
+// Pool term: with (scores, lse, row_bag, dM) given the kernel does not read dx at all - the attention pool's own input
+// gradient, a_row dM[bag(row)] with a_row = exp(score_row - lse[bag]) (ABMIL.py:57-59), is formed in the epilogue from the
+// [B, L] table dM and dx is written once (no pool-backward pass over [R, L], no read-modify-write here).
 __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ gates, const float* __restrict__ ds,
                                                      const float* __restrict__ wvec, const float* __restrict__ Wv,
                                                      const float* __restrict__ Wu, float* __restrict__ dx, int R, int L,
-                                                     const uint32_t* __restrict__ xbits, float xscale) {
+                                                     const uint32_t* __restrict__ xbits, float xscale,
+                                                     const float* __restrict__ scores, const float* __restrict__ lse,
+                                                     const int32_t* __restrict__ row_bag, const float* __restrict__ dM) {
     constexpr int ASZ = 128 * GX_KS, BSZ = 32 * 128;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
     float* as = smem;
@@ -1945,8 +1950,27 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
             float* o = dx + j0 + 64 * wj + 32 * b + r;
             const int rbase = row0 + 64 * wi + 32 * a;
             float cv[16];
+            if (dM != nullptr) {
+                const int col = j0 + 64 * wj + 32 * b + r;
+                int bg[16];
+                float ar[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) cv[i] = o[(size_t)min(rbase + mfma32_row(i, h), R - 1) * L];
+                for (int i = 0; i < 16; ++i) {
+                    const int gr = min(rbase + mfma32_row(i, h), R - 1);
+                    bg[i] = row_bag[gr];
+                    ar[i] = scores[gr];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    cv[i] = dM[(size_t)bg[i] * L + col];
+                    ar[i] = expf(ar[i] - lse[bg[i]]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cv[i] *= ar[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cv[i] = o[(size_t)min(rbase + mfma32_row(i, h), R - 1) * L];
+            }
             if (xbits != nullptr) {
                 // this launch is the last writer of dx: the backward of the patch dropout (ABMIL.py:49) is applied here,
                 // dx = keep ? (pool term + gate term) / (1 - p) : 0
@@ -1974,7 +1998,9 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
 __global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restrict__ gates, const float* __restrict__ ds,
                                                           const float* __restrict__ wvec, const float* __restrict__ Wv,
                                                           const float* __restrict__ Wu, float* __restrict__ dx, int L,
-                                                          const uint32_t* __restrict__ xbits, float xscale) {
+                                                          const uint32_t* __restrict__ xbits, float xscale,
+                                                          const float* __restrict__ scores, const float* __restrict__ lse,
+                                                          const int32_t* __restrict__ row_bag, const float* __restrict__ dM) {
     __shared__ float pv[MIL_GATE_D], pu[MIL_GATE_D];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float dsr = ds[row];
@@ -1992,7 +2018,13 @@ __global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restric
             acc += pv[d] * *reinterpret_cast<const f32x4*>(Wv + (size_t)d * L + j) +
                    pu[d] * *reinterpret_cast<const f32x4*>(Wu + (size_t)d * L + j);
         f32x4* o = reinterpret_cast<f32x4*>(dx + (size_t)row * L + j);
-        f32x4 v = *o + acc;
+        f32x4 v;
+        if (dM != nullptr) {
+            const int bg = row_bag[row];
+            v = expf(scores[row] - lse[bg]) * *reinterpret_cast<const f32x4*>(dM + (size_t)bg * L + j) + acc;
+        } else {
+            v = *o + acc;
+        }
         if (xbits != nullptr) {
             const unsigned m = xbits[(size_t)row * (L >> 5) + (j >> 5)] >> (j & 31);
 #pragma unroll
@@ -2002,8 +2034,9 @@ __global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restric
     }
 }
 
-extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu,
-                                  int R, int L, int D, float* dx, const uint32_t* xbits, float xscale, void* stream) {
+static int gate_bwd_input_impl(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu,
+                               int R, int L, int D, float* dx, const uint32_t* xbits, float xscale, const float* scores,
+                               const float* lse, const int32_t* row_bag, const float* dM, void* stream) {
     if (!gates || !ds || !w || !Wv || !Wu || !dx) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 128) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
@@ -2012,12 +2045,27 @@ extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const flo
     const int tail = per_round > 0 ? gate_tail_rows(R, per_round) : 0;
     const int Rm = R - tail;
     const int grid = ((Rm + 127) / 128) * (L / 128);
-    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, st, gates, ds, w, Wv, Wu, dx, Rm, L, xbits, xscale);
+    hipLaunchKernelGGL(k_gate_bwd_dx, dim3(grid), dim3(256), 0, st, gates, ds, w, Wv, Wu, dx, Rm, L, xbits, xscale, scores, lse,
+                       row_bag, dM);
     MIL_CHECK_LAUNCH();
     if (tail > 0) {
         hipLaunchKernelGGL(k_gate_bwd_dx_tail, dim3(tail), dim3(128), 0, st, gates + (size_t)Rm * GF_NG, ds + Rm, w, Wv, Wu,
-                           dx + (size_t)Rm * L, L, xbits ? xbits + (size_t)Rm * (L >> 5) : nullptr, xscale);
+                           dx + (size_t)Rm * L, L, xbits ? xbits + (size_t)Rm * (L >> 5) : nullptr, xscale,
+                           scores ? scores + Rm : nullptr, lse, row_bag ? row_bag + Rm : nullptr, dM);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
+}
+
+extern "C" int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu,
+                                  int R, int L, int D, float* dx, const uint32_t* xbits, float xscale, void* stream) {
+    return gate_bwd_input_impl(gates, ds, w, Wv, Wu, R, L, D, dx, xbits, xscale, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mil_gate_bwd_input_pool(const float* gates, const float* ds, const float* w, const float* Wv,
+                                       const float* Wu, int R, int L, int D, float* dx, const uint32_t* xbits, float xscale,
+                                       const float* scores, const float* lse, const int32_t* row_bag, const float* dM,
+                                       void* stream) {
+    if (!scores || !lse || !row_bag || !dM) return MIL_EINVAL;
+    return gate_bwd_input_impl(gates, ds, w, Wv, Wu, R, L, D, dx, xbits, xscale, scores, lse, row_bag, dM, stream);
 }

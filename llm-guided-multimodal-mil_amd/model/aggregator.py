@@ -70,6 +70,9 @@ class aggregator(nn.Module):
         self.fc = nn.Sequential(nn.Dropout(0.25), nn.Linear(EMBED, args.num_classes))     # :128-131
         self._pe: Optional[torch.Tensor] = None
         self.last_logits: Optional[torch.Tensor] = None
+        self.last_loss: Optional[torch.Tensor] = None
+        self._labels: Optional[torch.Tensor] = None
+        self._loss_scale: Optional[float] = None
 
     # ------------------------------------------------------------------ positional table (aggregator.py:99-106)
     def pe_rows(self, n: int, device) -> torch.Tensor:
@@ -95,6 +98,28 @@ class aggregator(nn.Module):
         self.last_logits = z
         return p
 
+    def _pool_head(self, x0, layout):
+        """Multi-modal bag rows -> prob.  With labels handed to forward() (the training loop's `criterion(prob, y)` of
+        train_ddp.py:323-324 moved inside) and an ABMIL aggregator, pool + Dropout(.25) + fc + sigmoid + BCE / CE run as one
+        fused node (ops.gated_pool_head_loss) and the loss is left in `self.last_loss`; otherwise op by op."""
+        y = self._labels
+        C = self.args.num_classes
+        if y is not None and hasattr(getattr(self, "aggregator", None), "flat_head_loss") and \
+                self.aggregator.can_fuse_head(x0, C):
+            ce = C > 2                                     # train_ddp.py:95-98: CrossEntropyLoss on the sigmoid outputs
+            scale = self._loss_scale if self._loss_scale is not None else 1.0 / (layout.B * (1 if ce else C))
+            loss, p, z = self.aggregator.flat_head_loss(x0, layout, self.fc[1].weight, self.fc[1].bias, y, scale,
+                                                        1 if ce else 0, head_train=self.training)
+            self.last_logits, self.last_loss = z, loss
+            return p
+        M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0
+        p = self._head(M)
+        if y is not None:
+            crit = torch.nn.CrossEntropyLoss() if C > 2 else torch.nn.BCELoss()
+            self.last_loss = crit(p, y) * (1.0 if self._loss_scale is None else
+                                           self._loss_scale * layout.B * (1 if C > 2 else C))
+        return p
+
     # ------------------------------------------------------------------ CT branches (aggregator.py:155-184)
     def _forward_ct(self, x_list, t, lengths):
         """x_list[0] = the CT encoder's feature map [B, 512, 160, h, w] (precomputed; or tokens [B, D, 512]);
@@ -114,8 +139,7 @@ class aggregator(nn.Module):
                                                   keys_tail_rows=B * P)                       # :179
             x0 = ops.append_rows(k, q, tail_reserved=True)                                    # :184
             layout = BagLayout.two_segment([D] * B, [P] * B, dev)
-            M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0
-            return self._head(M), q.view(B, P, EMBED)                                         # :204-205
+            return self._pool_head(x0, layout), q.view(B, P, EMBED)                           # :204-205
         x = x_list[1]
         if x.dim() == 2:
             x = x.unsqueeze(0)
@@ -137,15 +161,19 @@ class aggregator(nn.Module):
         # the last LayerNorm wrote it, the small blocks are appended, the tile map says which rows form a bag.
         x0 = ops.append_rows(k_p, torch.cat([q_ct, k_ct, q_p], 0), tail_reserved=True)
         layout = BagLayout.multi_segment([n_len, [P] * B, [D] * B, [P] * B], dev)
-        M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0           # :198-199
-        return self._head(M), q_ct.view(B, P, EMBED), q_p.view(B, P, EMBED)                   # :202-203
+        return self._pool_head(x0, layout), q_ct.view(B, P, EMBED), q_p.view(B, P, EMBED)     # :198-200,202-203
 
     # ------------------------------------------------------------------ forward (aggregator.py:134-209)
     def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
-                text_features: Optional[torch.Tensor] = None):
+                text_features: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                loss_scale: Optional[float] = None):
         """x_list = [x_pathology [B, N, 768]] (or [] for CI only); x_CI int64 [B, P, ctx] token ids.
         `lengths` (optional) gives the true patch count of each zero-padded bag (dataset.py:386-391 pads to a
         fixed length when batch > 1); padded rows are then dropped instead of being attended to."""
+        # labels [B, C] float one-hot (optional, an extension of the reference signature): the criterion of
+        # train_ddp.py:323-324 evaluated inside, result in `self.last_loss` (mean loss unless loss_scale is given);
+        # the return tuple is unchanged
+        self._labels, self._loss_scale, self.last_loss = labels, loss_scale, None
         modality = self.args.modality
         # text_features [B, P, 512] (optional): embeddings of the frozen text tower computed earlier by
         # `self.clinic_extractor(x_CI)`; lets a captured hipGraph replay the trainable part only
@@ -174,10 +202,8 @@ class aggregator(nn.Module):
             # attention pooling does not depend on the order of a bag's rows.
             x0 = ops.append_rows(k, q, tail_reserved=True)     # k comes from the last block's norm4 with keys_tail_rows
             layout = BagLayout.two_segment(n_len, [P] * B, x0.device)
-            M = self.aggregator.flat(x0, layout) if hasattr(self, "aggregator") else x0   # :198-199
-            return self._head(M), q.view(B, P, EMBED)                                     # :200,207
+            return self._pool_head(x0, layout), q.view(B, P, EMBED)                       # :198-200,207
         if "CI" in modality:
             x0 = self._lin_tanh(self.fc_CI, t.reshape(B * P, EMBED))                      # :195
-            M = self.aggregator.flat(x0, BagLayout.uniform(B, P, x0.device)) if hasattr(self, "aggregator") else x0
-            return self._head(M)                                                          # :209
+            return self._pool_head(x0, BagLayout.uniform(B, P, x0.device))                # :198-200,209
         raise NotImplementedError(f"modality {modality}")

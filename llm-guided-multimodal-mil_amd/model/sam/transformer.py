@@ -155,7 +155,7 @@ class TwoWayAttentionBlock(nn.Module):
             a = self.cross_attn_image_to_token
             _zero_grad_params(a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias)
             o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
-            keys = self.norm4(ops.add_bag_row(keys, o, s_it), keys_tail_rows)
+            keys = ops.layer_norm_bag_row(keys, o, s_it, self.norm4.weight, self.norm4.bias, self.norm4.eps, keys_tail_rows)
         elif multi:
             keys = self.norm4(self.cross_attn_image_to_token.multi_token_rows(k, q, queries, s_it, residual=keys), keys_tail_rows)
         else:

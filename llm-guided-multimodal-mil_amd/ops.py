@@ -335,6 +335,82 @@ def gated_attention_pool(x, Wv, bv, Wu, bu, w, b, layout: BagLayout, xbits=None)
     return _GatedAttentionPool.apply(x, Wv, bv, Wu, bu, w, b, layout, xbits)
 
 
+def gate_bwd_input_pool(gates, ds, w, Wv, Wu, dx, scores, lse, row_bag, dM, xbits=None, xscale: float = 1.0):
+    """dx = a_row dM[bag(row)] + dPre [Wv; Wu] written in ONE pass (mil_gate_bwd_input_pool): the attention pool's own input
+    gradient is formed in the epilogue of the gate's input-gradient product, dx is never read."""
+    R, L = dx.shape
+    rc = _lib.lib().mil_gate_bwd_input_pool(_p(gates), _p(ds), _p(_f32c(w, "w")), _p(_f32c(Wv, "Wv")), _p(_f32c(Wu, "Wu")),
+                                            R, L, GATE_D, _p(dx), _p(xbits), float(xscale), _p(scores), _p(lse), _p(row_bag),
+                                            _p(dM), _stream())
+    _lib.check(rc, "mil_gate_bwd_input_pool")
+    return dx
+
+
+class _GatedPoolHeadLoss(torch.autograd.Function):
+    """ABMIL pool -> Dropout(.25) -> fc -> sigmoid -> BCELoss(mean) (or CE on the sigmoid outputs) as ONE autograd node
+    (ABMIL.py:47-59 + aggregator.py:128-131,200 + train_ddp.py:95-99,323-324), on the fused per-bag tail of the image-only
+    step: gate forward, pool partial pass with the head-projection by-product, one tail launch (merge, head, loss, dz, dM,
+    ds) and the head's parameter gradients - 4 launches where the op-by-op route takes 17; the backward is the gate's
+    weight-gradient product, its reduce, and ONE pass writing dx (pool term + gate term).
+    Returns (loss [scalar], prob [B, C], logits [B, C], M [B, L]); only the loss is differentiable, and it must be the
+    root of the backward pass (its incoming gradient is taken to be 1; scale through `scale`)."""
+
+    _checked_unit_grad = False
+
+    @staticmethod
+    def forward(ctx, x, Wv, bv, Wu, bu, w, b, Wf, bf, y, layout: BagLayout, scale: float, loss_kind: int, xbits, mbits):
+        x = _f32c(x, "x")
+        L = x.shape[1]
+        xs = X_DROP_SCALE if xbits is not None else 1.0
+        ms = M_DROP_SCALE if mbits is not None else 1.0
+        need_grad = any(ctx.needs_input_grad[:9])
+        scores, gates = gate_scores_fwd(x, Wv, bv, Wu, bu, w.reshape(-1), b, save_gates=need_grad, xbits=xbits, xscale=xs)
+        partials, hrow = attn_pool_partial_h(x, scores, layout, Wf, xbits, xs, mbits, ms)
+        t = pool_merge_head(partials, layout, L, Wf, bf, _f32c(y, "y"), scale, scores, hrow, mbits, ms, loss_kind)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        dWf = (grad_slot(Wf) if need_grad else None)
+        dbf = (grad_slot(bf) if need_grad else None)
+        dWf = dWf if dWf is not None else torch.empty_like(Wf)
+        dbf = dbf if dbf is not None else torch.empty_like(bf)
+        head_bwd_params(t["dz"], t.get("Mdrop", t["M"]), dWf, dbf, t["loss_bag"], loss)
+        ctx.layout, ctx.xbits, ctx.xs = layout, xbits, xs
+        ctx.params = (Wv, bv, Wu, bu, w, b)
+        ctx.save_for_backward(x, Wv, Wu, w, gates if gates is not None else torch.empty(0, device=x.device), scores,
+                              t["lse"], t["ds"], t["dM"], dWf, dbf)
+        for o in (t["prob"], t["logits"], t["M"]):
+            ctx.mark_non_differentiable(o)
+        return loss.reshape(()), t["prob"], t["logits"], t["M"]
+
+    @staticmethod
+    def backward(ctx, dloss, _dp, _dz, _dM):
+        x, Wv, Wu, w, gates, scores, lse, ds, dM, dWf, dbf = ctx.saved_tensors
+        if not _GatedPoolHeadLoss._checked_unit_grad and not torch.cuda.is_current_stream_capturing():
+            _GatedPoolHeadLoss._checked_unit_grad = True
+            if abs(float(dloss) - 1.0) > 1e-6:
+                raise _lib.MilHipError("fused pool+head+loss: the loss must be the root of backward() (incoming gradient 1); "
+                                       "fold any factor into `scale`")
+        pW = ctx.params
+        outs = []
+        for prm in pW:
+            slot = grad_slot(prm)
+            outs.append(slot if slot is not None else torch.empty(prm.shape, device=x.device, dtype=torch.float32))
+        dWv, dbv, dWu, dbu, dw, db = outs
+        wflat = w.reshape(-1)
+        xbits, xs = ctx.xbits, ctx.xs
+        gate_bwd_params(x, gates, ds, wflat, dWv, dbv, dWu, dbu, dw, db, xbits=xbits, xscale=xs)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gate_bwd_input_pool(gates, ds, wflat, Wv, Wu, dx, scores, lse, ctx.layout.row_bag(), dM, xbits=xbits, xscale=xs)
+        return dx, dWv, dbv, dWu, dbu, dw, db, dWf, dbf, None, None, None, None, None, None
+
+
+def gated_pool_head_loss(x, Wv, bv, Wu, bu, w, b, Wf, bf, y, layout: BagLayout, scale: float, loss_kind: int = 0,
+                         xbits=None, mbits=None):
+    """(loss, prob, logits, M) of the fused ABMIL + head + loss node (see _GatedPoolHeadLoss)."""
+    return _GatedPoolHeadLoss.apply(x, Wv, bv, Wu, bu, w, b, Wf, bf, y, layout, float(scale), int(loss_kind), xbits, mbits)
+
+
 class _HeadSigmoid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, M, Wf, bf):
@@ -872,6 +948,52 @@ class _LayerNormRes(torch.autograd.Function):
 def layer_norm_res(x, gamma, beta, eps: float = 1e-5):
     """(LayerNorm(x), x) for a 2-D x - use the returned x for the residual add that skips the norm."""
     return _LayerNormRes.apply(x, gamma, beta, eps)
+
+
+class _LayerNormBagRow(torch.autograd.Function):
+    """LayerNorm(x + o[bag of row]) as one node (mil_layernorm_bagrow_fwd/_bwd): the sum is never materialised, and the
+    backward returns dx, the per-bag sums d_o, dgamma and dbeta from one pass + one fold launch."""
+
+    @staticmethod
+    def forward(ctx, x, o, gamma, beta, eps: float, segs, tail_rows: int):
+        x, o = _f32c(x, "x"), _f32c(o, "o")
+        rows, E = x.shape
+        y = torch.empty((rows + tail_rows, E), device=x.device, dtype=torch.float32)[:rows] if tail_rows else torch.empty_like(x)
+        stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_layernorm_bagrow_fwd(_p(x), _p(o), _p(segs.q_bag), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
+                                                 rows, E, eps, _p(y), _p(stats), _stream())
+        _lib.check(rc, "mil_layernorm_bagrow_fwd")
+        ctx.segs = segs
+        ctx.save_for_backward(x, o, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, o, gamma, stats = ctx.saved_tensors
+        segs = ctx.segs
+        dy = _f32c(dy, "dy")
+        rows, E = x.shape
+        dx = torch.empty_like(x)
+        do = torch.empty_like(o)
+        dg = torch.empty(E, device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        ws = torch.empty(_lib.lib().mil_layernorm_bwd_blocks(rows) * 4 * E, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_layernorm_bagrow_bwd(_p(x), _p(o), _p(segs.q_bag), _p(segs.q_off), segs.B, _p(gamma), _p(dy),
+                                                 _p(stats), rows, E, _p(dx), _p(do), _p(dg), _p(db), _p(ws), _stream())
+        _lib.check(rc, "mil_layernorm_bagrow_bwd")
+        return dx, do, dg, db, None, None, None
+
+
+def layer_norm_bag_row(x, o, segs, gamma, beta, eps: float = 1e-5, tail_rows: int = 0):
+    """LayerNorm(x + o[bag of row]) for x [rows, E], o [B, E]; segs: AttnSegs whose QUERY side are the rows of x.  Fused
+    when every bag is at least one backward workgroup's row range long (see mil_layernorm_bagrow_bwd) and the norm is
+    trainable; otherwise add_bag_row followed by layer_norm."""
+    rows = x.shape[0]
+    ok = (x.dim() == 2 and rows > 64 and gamma.requires_grad == beta.requires_grad and
+          min(segs.q_lengths, default=0) >= _lib.lib().mil_layernorm_bagrow_rows_per_block(rows))
+    if not ok:
+        return layer_norm(add_bag_row(x, o, segs), gamma, beta, eps, tail_rows)
+    return _LayerNormBagRow.apply(x, o, gamma, beta, eps, segs, tail_rows)
 
 
 def layer_norm(x, gamma, beta, eps: float = 1e-5, tail_rows: int = 0):

@@ -162,3 +162,41 @@ def test_ten_prompts_ragged_batch_absorbed_path_matches_the_general_path(monkeyp
         for b, n in enumerate(ns):
             p1, _ = model([x[b:b + 1, :n].to(DEV)], ids[b:b + 1])
             assert float((p_abs[b] - p1[0]).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("num_classes,ns", [(2, [40, 100, 1]), (3, [64, 64])])
+def test_fused_pool_head_loss_node_matches_the_op_by_op_tail(num_classes, ns):
+    """forward(labels=y): pool + head + loss as one autograd node (ops.gated_pool_head_loss) against the same module run op by
+    op with the criterion outside (train_ddp.py:95-99,323-324) - loss, outputs and every parameter gradient."""
+    torch.manual_seed(5)
+    model = get_model(make_args(clip_layers=1, num_classes=num_classes)).to(DEV).eval()
+    B, N = len(ns), max(ns)
+    x = torch.zeros(B, N, 768)
+    gen = torch.Generator().manual_seed(4)
+    for b, n in enumerate(ns):
+        x[b, :n] = torch.randn(n, 768, generator=gen)
+    x = x.to(DEV)
+    ids = syn.make_token_ids(8, B, 1).to(DEV)
+    y = torch.zeros(B, num_classes, device=DEV)
+    y[torch.arange(B), torch.arange(B) % num_classes] = 1.0
+    crit = torch.nn.CrossEntropyLoss() if num_classes > 2 else torch.nn.BCELoss()
+    prob, _ = model([x], ids, lengths=ns)
+    loss_ref = crit(prob, y)
+    loss_ref.backward()
+    ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    z_ref = model.last_logits.detach().clone()
+    model.zero_grad(set_to_none=True)
+    prob2, _ = model([x], ids, lengths=ns, labels=y)
+    assert model.last_loss is not None and model.last_loss.requires_grad
+    model.last_loss.backward()
+    assert abs(float(model.last_loss) - float(loss_ref)) <= 1e-6 * max(1.0, abs(float(loss_ref)))
+    assert float((prob2 - prob.detach()).abs().max()) <= 1e-6
+    assert float((model.last_logits - z_ref).abs().max()) <= 1e-5
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref)
+    for k in ref:
+        if k.endswith("k_proj.bias") or float(ref[k].norm()) < 1e-7:
+            # mathematically-zero gradients (softmax is invariant to a constant on every score): rounding noise on both sides
+            assert float(got[k].abs().max()) < 5e-5, k
+        else:
+            assert rel_err(got[k], ref[k]) <= 2e-4, (k, rel_err(got[k], ref[k]))

@@ -19,6 +19,7 @@ ap.add_argument("--coop", action="store_true", help="learnable prompts (upstream
                 "per bag, ctx trained through the frozen text tower every step; SGD lr 1e-3 as train_ddp.py:104-109")
 ap.add_argument("--clip_gemm_pieces", type=int, default=0, help="2 / 3: split-bf16 products for the frozen text tower's GEMMs")
 ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam / SGD instead of the flat one-launch optimizers")
+ap.add_argument("--op_tail", action="store_true", help="criterion outside the module (op-by-op pool/head/loss tail) instead of forward(labels=y)")
 ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -46,9 +47,15 @@ else:
     opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-5, weight_decay=1e-7, counted=a.graph)
 crit = torch.nn.BCELoss()
 
+def fwd_loss(**kw):
+    if a.op_tail:
+        prob, _ = model([x], ids, **kw)
+        return crit(prob, y)
+    model([x], ids, labels=y, **kw)          # pool + head + BCE as one fused node; the loss is left in model.last_loss
+    return model.last_loss
+
 def step():
-    prob, _ = model([x], ids)
-    loss = crit(prob, y)
+    loss = fwd_loss()
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
@@ -60,8 +67,7 @@ if a.graph:
         with torch.no_grad():
             tfeat = model.clinic_extractor(ids)      # frozen tower: outside the graph (cached per note in training)
     def gstep():
-        prob, _ = model([x], ids, text_features=tfeat)
-        loss = crit(prob, y)
+        loss = fwd_loss(text_features=tfeat)
         loss.backward()
         opt.step()
         return loss
