@@ -75,6 +75,19 @@ int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const 
                         const float* bu, const float* w, const float* b, float* scores,
                         float* gates, int R, int L, int D, const uint32_t* xbits, float xscale, void* stream);
 
+/* Train-mode forward that DRAWS the dropout keep bits instead of reading them: the x words (Dropout(0.5), ABMIL.py:49) are
+ * written to xbits_out [R, L/32] for the later consumers (pool, weight gradient) and - when mbits_out is given - the
+ * head's words (Dropout(0.25), aggregator.py:129; [B, L/32]) as well, exactly the words
+ * mil_dropout_keep_bits(xbits_out, R, L, 0.5, seed, offset, offset_dev) and
+ * mil_dropout_keep_bits(mbits_out, B, L, 0.25, mseed, offset, offset_dev) produce.  Where the shape allows (L <= 1024,
+ * L % 128 == 0, every row on the 128-row kernel) the forward kernel draws them itself, each workgroup its own rows'
+ * words: no generator launch; otherwise the generator runs first.  L % 64 == 0. */
+int mil_gate_scores_fwd_draw(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                             const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
+                             uint32_t* xbits_out, float xscale, uint32_t* mbits_out, int B, uint64_t seed, uint64_t mseed,
+                             uint64_t offset, const int32_t* offset_dev, void* stream);
+
+
 /* ---- K1b: attention pool ----------------------------------------------------------------
  * A = softmax over the rows of each bag of s; M[b] = sum_i A_i x_i; lse[b] = logsumexp(s).
  * Replaces ABMIL.forward lines 56-59.  Split-N: one workgroup per tile writes an online-

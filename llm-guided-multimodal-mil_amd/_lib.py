@@ -24,6 +24,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_dropout_apply_bits": (c_int, [_P, _P, c_int, c_int, c_float, _P]),
     "mil_counter_add": (c_int, [_P, c_int, _P]),
     "mil_gate_scores_fwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, c_float, _P]),
+    "mil_gate_scores_fwd_draw": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, c_float, _P, c_int, c_uint64, c_uint64, c_uint64, _P, _P]),
     "mil_attn_pool_fwd": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
     "mil_attn_pool_partial": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_float, _P]),
     "mil_attn_pool_partial_h": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_int, _P, _P, c_float, _P, c_float, _P]),

@@ -19,26 +19,7 @@
 //   p_drop = 0.25: word w = ~(out[2 (w & 1)] & out[2 (w & 1) + 1]) of block (w >> 1)          (dropped iff 2 bits set)
 //   otherwise    : element e kept iff out[e & 3] of block (e >> 2) >= p_drop * 2^32            (32 random bits / element)
 #include "mil_common.h"
-
-#define PHILOX_M0 0xD2511F53u
-#define PHILOX_M1 0xCD9E8D57u
-#define PHILOX_W0 0x9E3779B9u
-#define PHILOX_W1 0xBB67AE85u
-
-struct philox4 { uint32_t v[4]; };
-
-__device__ __forceinline__ philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
-        const uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += PHILOX_W0;
-        k1 += PHILOX_W1;
-    }
-    return philox4{{c0, c1, c2, c3}};
-}
+#include "philox.h"
 
 // mode 0: p = 0.5, mode 1: p = 0.25, mode 2: generic threshold.  One thread per 128-bit Philox block.
 __global__ __launch_bounds__(256) void k_dropout_keep_bits(uint32_t* __restrict__ bits, size_t nwords, int mode,

@@ -6,6 +6,7 @@
 //     dense fp32 contractions: v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s roof).
 //   * scores -> softmax over the bag -> A.x (and ds in the backward) stream x once: HBM-bound.
 #include "mil_common.h"
+#include "philox.h"
 #include <type_traits>
 
 // ================================================================================ K1a gate forward
@@ -189,14 +190,28 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 #define GF2_XS_BYTES (GF_TM * 32 * 4)          /* one x buffer  (16 KB) */
 #define GF2_WS_BYTES (GF_NG * 32 * 4)          /* one W buffer  (48 KB) */
 
-template <bool DROP>
+// GEN (train mode, L <= 1024): the workgroup DRAWS the keep words of its 128 rows itself - the same Philox blocks
+// k_dropout_keep_bits would produce (philox.h) - keeps them in LDS for its own A fragments and writes them to xbits for
+// the later consumers (pool, weight gradient); workgroup 0 also draws the head's [B, L/32] words.  One launch less per
+// step, and the mask words of the loop come from LDS instead of a buffer load.
+struct GateFwdGen {
+    uint32_t* xbits_out;        // [R, L/32]
+    uint32_t* mbits_out;        // [B, L/32] or NULL
+    int B;
+    uint32_t seed_lo, seed_hi, mseed_lo, mseed_hi;
+    uint64_t offset;
+    const int32_t* offset_dev;
+};
+
+template <bool DROP, bool GEN>
 __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, const float* __restrict__ Wv,
                                                    const float* __restrict__ bv, const float* __restrict__ Wu,
                                                    const float* __restrict__ bu, const float* __restrict__ wvec,
                                                    const float* __restrict__ battn, float* __restrict__ scores,
                                                    float* __restrict__ gates, int R, int L,
-                                                   const uint32_t* __restrict__ xbits, float xscale) {
+                                                   const uint32_t* __restrict__ xbits, float xscale, GateFwdGen gen) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * 32];      // [2] x buffers, then [2] W buffers
+    __shared__ __attribute__((aligned(16))) uint32_t mlds[GEN ? GF_TM * 32 : 4];       // keep words [128][nslice <= 32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -249,10 +264,30 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
     __amdgpu_buffer_rsrc_t srd_m = srd_x;
     int vmask = 0;
     unsigned mnext = 0;
-    if (DROP) {
+    if (DROP && !GEN) {
         srd_m = __builtin_amdgcn_make_buffer_rsrc((void*)(xbits + (size_t)row0 * nslice), 0, rows_here * nslice * 4, MIL_SRD_FLAGS);
         vmask = (32 * wr + r) * nslice * 4;
         mnext = __builtin_amdgcn_raw_buffer_load_b32(srd_m, vmask, 0, 0);
+    }
+    if (GEN) {
+        uint64_t off = gen.offset;
+        if (gen.offset_dev != nullptr) off += (uint64_t)(uint32_t)gen.offset_dev[0];
+        const size_t blk0 = (size_t)row0 * nslice / 4;                  // 128 nslice words per workgroup: a multiple of 4
+        const int nblk = rows_here * nslice / 4;                        // nslice % 4 == 0 (host)
+        for (int q = tid; q < nblk; q += 512) {
+            const uint4 wds = philox_keep_words_half(blk0 + q, off, gen.seed_lo, gen.seed_hi);
+            *reinterpret_cast<uint4*>(gen.xbits_out + 4 * (blk0 + q)) = wds;
+            *reinterpret_cast<uint4*>(mlds + 4 * q) = wds;
+        }
+        if (blockIdx.x == 0 && gen.mbits_out != nullptr) {
+            const int nw = gen.B * (L >> 5);                            // even (L % 64 == 0)
+            for (int q = tid; 2 * q < nw; q += 512) {
+                const uint2 wds = philox_keep_words_quarter((uint64_t)q, off, gen.mseed_lo, gen.mseed_hi);
+                gen.mbits_out[2 * q] = wds.x;
+                gen.mbits_out[2 * q + 1] = wds.y;
+            }
+        }
+        vmask = (32 * wr + r) * nslice;                                 // word index into mlds
     }
 
     f32x16 acc[3][2];
@@ -266,6 +301,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_piece(i, 0, 0);
     __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    if (GEN) mnext = mlds[vmask];
 
     auto slice = [&](int s, auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
@@ -274,7 +310,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
         unsigned mcur = 0;
         if (DROP) {
             mcur = mnext >> (4 * h);
-            mnext = __builtin_amdgcn_raw_buffer_load_b32(srd_m, vmask, s1 * 4, 0);
+            if (GEN) mnext = mlds[vmask + s1];
+            else mnext = __builtin_amdgcn_raw_buffer_load_b32(srd_m, vmask, s1 * 4, 0);
         }
         f32x4 a[2], b[2][3][2];
         auto frag_piece = [&](int t, int q, int p) {
@@ -1494,31 +1531,54 @@ static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv,
     return MIL_OK;
 }
 
-extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
-                                   const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
-                                   const uint32_t* xbits, float xscale, void* stream) {
+static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
+                                const uint32_t* xbits, float xscale, const GateFwdGen* gen, void* stream) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if ((R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4) {
-        // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
-        return launch_gate_fwd_r32(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xscale, st);
-    }
-    const int tail = gates != nullptr ? gate_tail_rows(R, MIL_NUM_CU) : 0;       // the tail path keeps V, U in `gates`
-    const int Rm = R - tail;
-    const int grid = (Rm + GF_TM - 1) / GF_TM;
+    const bool r32 = (R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4;
+    const int tail = (!r32 && gates != nullptr) ? gate_tail_rows(R, MIL_NUM_CU) : 0;   // the tail path keeps V, U in `gates`
 #if defined(GF_NO_FWD2)
     const bool fwd2 = false;
 #else
     const bool fwd2 = L <= 4096;                 // 128 rows x L floats must stay inside the 32-bit buffer offsets (and int math)
 #endif
+    if (gen != nullptr) {
+        // the forward kernel can draw the keep bits itself when every row goes through k_gate_fwd2 and a workgroup's
+        // [128][L/32] words fit its LDS slot; otherwise the stand-alone generator runs first
+        const bool in_kernel = !r32 && tail == 0 && fwd2 && L <= 1024 && (L % 128) == 0;
+        if (in_kernel) {
+            const int grid = (R + GF_TM - 1) / GF_TM;
+            hipLaunchKernelGGL((k_gate_fwd2<true, true>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, R, L,
+                               gen->xbits_out, xscale, *gen);
+            MIL_CHECK_LAUNCH();
+            return MIL_OK;
+        }
+        int rc = mil_dropout_keep_bits(gen->xbits_out, R, L, 0.5f, ((uint64_t)gen->seed_hi << 32) | gen->seed_lo, gen->offset,
+                                       gen->offset_dev, stream);
+        if (rc != MIL_OK) return rc;
+        if (gen->mbits_out != nullptr) {
+            rc = mil_dropout_keep_bits(gen->mbits_out, gen->B, L, 0.25f, ((uint64_t)gen->mseed_hi << 32) | gen->mseed_lo,
+                                       gen->offset, gen->offset_dev, stream);
+            if (rc != MIL_OK) return rc;
+        }
+        xbits = gen->xbits_out;
+    }
+    if (r32) {
+        // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
+        return launch_gate_fwd_r32(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xscale, st);
+    }
+    const int Rm = R - tail;
+    const int grid = (Rm + GF_TM - 1) / GF_TM;
+    const GateFwdGen nogen{};
     if (fwd2 && xbits)
-        hipLaunchKernelGGL(k_gate_fwd2<true>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
-                           xscale);
+        hipLaunchKernelGGL((k_gate_fwd2<true, false>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
+                           xbits, xscale, nogen);
     else if (fwd2)
-        hipLaunchKernelGGL(k_gate_fwd2<false>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
-                           1.0f);
+        hipLaunchKernelGGL((k_gate_fwd2<false, false>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
+                           xbits, 1.0f, nogen);
     else if (xbits)
         hipLaunchKernelGGL(k_gate_fwd<true>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
                            xscale);
@@ -1543,6 +1603,30 @@ extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float*
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
+}
+
+extern "C" int mil_gate_scores_fwd(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                   const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
+                                   const uint32_t* xbits, float xscale, void* stream) {
+    return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, D, xbits, xscale, nullptr, stream);
+}
+
+extern "C" int mil_gate_scores_fwd_draw(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                        const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
+                                        uint32_t* xbits_out, float xscale, uint32_t* mbits_out, int B, uint64_t seed,
+                                        uint64_t mseed, uint64_t offset, const int32_t* offset_dev, void* stream) {
+    if (!xbits_out || (L % 64) != 0 || (mbits_out && B <= 0)) return MIL_EINVAL;
+    GateFwdGen g{};
+    g.xbits_out = xbits_out;
+    g.mbits_out = mbits_out;
+    g.B = B;
+    g.seed_lo = (uint32_t)seed;
+    g.seed_hi = (uint32_t)(seed >> 32);
+    g.mseed_lo = (uint32_t)mseed;
+    g.mseed_hi = (uint32_t)(mseed >> 32);
+    g.offset = offset;
+    g.offset_dev = offset_dev;
+    return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, D, nullptr, xscale, &g, stream);
 }
 
 static int launch_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,

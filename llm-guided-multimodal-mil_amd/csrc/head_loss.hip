@@ -226,30 +226,92 @@ __global__ __launch_bounds__(NT) void k_pool_merge_head(const float* __restrict_
                                                          float mscale, float* __restrict__ Mdrop, int loss_kind) {
     // mbits [B][L/32]: keep bits of the head's Dropout(.25) on the bag embedding (aggregator.py:129; train mode).  M stays
     // the un-dropped ABMIL output, Mdrop = M * keep * mscale feeds the head (and dWf); dM = d loss / d M carries the mask.
-    __shared__ float red[NT / 64];
+    // Latency-bound (one workgroup per bag, a chain of reductions): every load that does not depend on the chain - keep
+    // words, the tile statistics, the head rows of the thread's columns, the rows of the ds pass - is issued before the
+    // first barrier, and the C head dot products share one block reduction.
+    constexpr int NW = NT / 64;
+    constexpr int JP = 1024 / NT;                 // columns per thread (L <= 1024)
+    constexpr int DSP = 4;                        // ds passes whose operands are loaded up front (NT / 32 tiles per pass)
+    __shared__ float red[NW][4];
     __shared__ float scale_lds[1024];
     __shared__ __attribute__((aligned(16))) float m_lds[1024];
     __shared__ __attribute__((aligned(16))) float part_lds[4 * 1024];
     __shared__ float keep_lds[1024];
     __shared__ float dzs[32];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float ps[32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
     const float* ml = partials + (size_t)T * L;
-    for (int j = tid; j < L; j += NT)
-        keep_lds[j] = mbits == nullptr ? 1.0f : (((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f);
-    // global max / normaliser over the bag's tiles
-    float m = -INFINITY;
-    for (int t = t0 + tid; t < t1; t += NT) m = fmaxf(m, ml[2 * t]);
-    m = wave_allmax(m);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = red[0];
+    const bool fastC = C <= 4;
+    // ---- loads that do not depend on the merge
+    float mt = -INFINITY, lt = 0.f;
+    if (tid < nt) { mt = ml[2 * (t0 + tid)]; lt = ml[2 * (t0 + tid) + 1]; }
+    float keepv[JP], wf[JP][4];
 #pragma unroll
-    for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
-    float l = 0.f;
-    for (int t = t0 + tid; t < t1; t += NT) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
-    l = block_allsum_nt<NT>(l, red);
+    for (int q = 0; q < JP; ++q) {
+        const int j = tid + q * NT;
+        keepv[q] = 1.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wf[q][c] = 0.f;
+        if (j < L) {
+            if (mbits != nullptr) keepv[q] = ((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f;
+            if (fastC)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < C) wf[q][c] = Wf[(size_t)c * L + j];
+        }
+    }
+    int ds_row[DSP];
+    float ds_sc[DSP], ds_h[DSP][4];
+#pragma unroll
+    for (int k = 0; k < DSP; ++k) {
+        ds_row[k] = -1;
+        ds_sc[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ds_h[k][c] = 0.f;
+    }
+    if (ds != nullptr && y != nullptr && fastC) {
+#pragma unroll
+        for (int k = 0; k < DSP; ++k) {
+            const int g8 = t0 + (tid >> 5) + k * (NT / 32);
+            if (g8 < t1) {
+                const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+                if (lr < nrows) ds_row[k] = row0 + lr;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DSP; ++k)
+            if (ds_row[k] >= 0) {
+                ds_sc[k] = scores[ds_row[k]];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < C) ds_h[k][c] = hrow[(size_t)ds_row[k] * C + c];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < JP; ++q)
+        if (tid + q * NT < L) keep_lds[tid + q * NT] = keepv[q];
+    // ---- global max / normaliser over the bag's tiles
+    float m = mt;
+    for (int t = t0 + tid + NT; t < t1; t += NT) m = fmaxf(m, ml[2 * t]);
+    m = wave_allmax(m);
+    if (lane == 0) red[wv][0] = m;
+    __syncthreads();
+    m = red[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w][0]);
+    const float sc0 = tid < nt ? expf(mt - m) : 0.f;
+    float l = lt * sc0;
+    for (int t = t0 + tid + NT; t < t1; t += NT) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
+    l = wave_allsum(l);
+    __syncthreads();                               // red[.][0] of the max has been read by everyone
+    if (lane == 0) red[wv][0] = l;
+    scale_lds[tid] = sc0;                          // first chunk of tile weights: this thread's tile
+    for (int k = tid + NT; k < 1024; k += NT) scale_lds[k] = (k < nt) ? expf(ml[2 * (t0 + k)] - m) : 0.f;
+    __syncthreads();
+    l = red[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) l += red[w][0];
     const float inv = nt > 0 ? 1.0f / l : 0.f;
 
     const int L4 = L >> 2, NG = NT / L4;          // NT = 256: L in {256, 512, 768, 1024} -> NG in {4, 2, 1, 1}; NT = 1024: 4x
@@ -257,9 +319,11 @@ __global__ __launch_bounds__(NT) void k_pool_merge_head(const float* __restrict_
     const bool worker = g < NG;                    // L = 768 leaves 64 threads without a column group
     f32x4 acc = {0, 0, 0, 0};
     for (int tb = 0; tb < nt; tb += 1024) {
-        __syncthreads();
-        for (int k = tid; k < 1024; k += NT) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
-        __syncthreads();
+        if (tb > 0) {
+            __syncthreads();
+            for (int k = tid; k < 1024; k += NT) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
+            __syncthreads();
+        }
         const int cnt = worker ? min(1024, nt - tb) : 0;
         int k = g;
         for (; k + 7 * NG < cnt; k += 8 * NG) {
@@ -275,32 +339,68 @@ __global__ __launch_bounds__(NT) void k_pool_merge_head(const float* __restrict_
     }
     if (worker) *reinterpret_cast<f32x4*>(part_lds + g * L + 4 * c4) = acc;
     __syncthreads();
-    for (int j = tid; j < L; j += NT) {
-        float v = 0.f;
-        for (int gg = 0; gg < NG; ++gg) v += part_lds[gg * L + j];
-        v *= inv;
-        m_lds[j] = v;
-        M[(size_t)b * L + j] = v;
-        if (Mdrop != nullptr) Mdrop[(size_t)b * L + j] = v * keep_lds[j];
-    }
-    if (tid == 0) lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
-    __syncthreads();
-    // head
-    __shared__ float ps[32];
-    float lossacc = 0.f;
-    for (int c = 0; c < C; ++c) {
-        float v = 0.f;
-        for (int j = tid; j < L; j += NT) v += m_lds[j] * keep_lds[j] * Wf[(size_t)c * L + j];
-        v = block_allsum_nt<NT>(v, red);
-        if (tid == 0) {
-            const float zz = v + bf[c];
-            const float pp = 1.0f / (1.0f + expf(-zz));
-            z[b * C + c] = zz;
-            p[b * C + c] = pp;
-            ps[c] = pp;
+    float mv[JP];
+    float hd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < JP; ++q) {
+        const int j = tid + q * NT;
+        mv[q] = 0.f;
+        if (j < L) {
+            float v = 0.f;
+            for (int gg = 0; gg < NG; ++gg) v += part_lds[gg * L + j];
+            v *= inv;
+            mv[q] = v;
+            m_lds[j] = v;
+            M[(size_t)b * L + j] = v;
+            if (Mdrop != nullptr) Mdrop[(size_t)b * L + j] = v * keepv[q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hd[c] += v * keepv[q] * wf[q][c];
         }
     }
-    if (y != nullptr && tid == 0) {
+    if (tid == 0) lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
+    // ---- head: the C dot products through one block reduction (C <= 4), else one at a time
+    if (fastC) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hd[c] = wave_allsum(hd[c]);
+        __syncthreads();                           // red[.][0] of the normaliser has been read by everyone
+        if (lane == 0)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[wv][c] = hd[c];
+        __syncthreads();
+        if (tid < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[w][tid];
+            const float zz = v + bf[tid];
+            const float pp = 1.0f / (1.0f + expf(-zz));
+            z[b * C + tid] = zz;
+            p[b * C + tid] = pp;
+            ps[tid] = pp;
+        }
+    } else {
+        __syncthreads();
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            for (int j = tid; j < L; j += NT) v += m_lds[j] * keep_lds[j] * Wf[(size_t)c * L + j];
+            v = wave_allsum(v);
+            __syncthreads();
+            if (lane == 0) red[wv][0] = v;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (int w = 0; w < NW; ++w) t += red[w][0];
+                const float zz = t + bf[c];
+                const float pp = 1.0f / (1.0f + expf(-zz));
+                z[b * C + c] = zz;
+                p[b * C + c] = pp;
+                ps[c] = pp;
+            }
+        }
+    }
+    if (y == nullptr) return;
+    __syncthreads();
+    if (tid == 0) {
+        float lossacc = 0.f;
         if (loss_kind == 0) {
             // BCELoss on the sigmoid outputs vs one-hot float labels (train_ddp.py:98,323-324); log clamped at -100
             for (int c = 0; c < C; ++c) {
@@ -330,25 +430,59 @@ __global__ __launch_bounds__(NT) void k_pool_merge_head(const float* __restrict_
                 dzs[c] = d;
             }
         }
+        loss_sum[b] = lossacc * scale;              // per-bag loss; summed (fixed order) by k_head_bwd_params
     }
-    if (y == nullptr) return;
-    if (tid == 0) loss_sum[b] = lossacc * scale;      // per-bag loss; summed (fixed order) by k_head_bwd_params
     __syncthreads();
     float dot = 0.f;
-    for (int j = tid; j < L; j += NT) {
-        float v = 0.f;
-        for (int c = 0; c < C; ++c) v += dzs[c] * Wf[(size_t)c * L + j];
-        v *= keep_lds[j];
-        dM[(size_t)b * L + j] = v;
-        dot += v * m_lds[j];
+    if (fastC) {
+        float dzr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dzr[c] = c < C ? dzs[c] : 0.f;
+#pragma unroll
+        for (int q = 0; q < JP; ++q) {
+            const int j = tid + q * NT;
+            if (j < L) {
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v += dzr[c] * wf[q][c];
+                v *= keepv[q];
+                dM[(size_t)b * L + j] = v;
+                dot += v * mv[q];
+            }
+        }
+    } else {
+        for (int j = tid; j < L; j += NT) {
+            float v = 0.f;
+            for (int c = 0; c < C; ++c) v += dzs[c] * Wf[(size_t)c * L + j];
+            v *= keep_lds[j];
+            dM[(size_t)b * L + j] = v;
+            dot += v * m_lds[j];
+        }
     }
-    dot = block_allsum_nt<NT>(dot, red);
+    dot = wave_allsum(dot);
+    if (lane == 0) red[wv][1] = dot;               // column 1: column 0 may still be read by a slow wave of the head stage
+    __syncthreads();
+    dot = red[0][1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) dot += red[w][1];
     if (tid == 0) cdot[b] = dot;
     if (ds != nullptr) {
         // the score gradient of this bag's rows from the forward's head projections (k_pool_ds_from_h, fused here: every
         // quantity it needs - lse, dz, M . dM - was just formed by this workgroup):  ds_i = A_i (sum_c dz_c h_i[c] - M . dM)
         const float lse_b = m + logf(l);
-        for (int g8 = t0 + (tid >> 5); g8 < t1; g8 += NT / 32) {
+        int k0 = 0;
+        if (fastC) {
+#pragma unroll
+            for (int k = 0; k < DSP; ++k)
+                if (ds_row[k] >= 0) {
+                    float gd = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gd += dzs[c < C ? c : 0] * (c < C ? ds_h[k][c] : 0.f);
+                    ds[ds_row[k]] = expf(ds_sc[k] - lse_b) * (gd - dot);
+                }
+            k0 = DSP;
+        }
+        for (int g8 = t0 + (tid >> 5) + k0 * (NT / 32); g8 < t1; g8 += NT / 32) {
             const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
             if (lr < nrows) {
                 const size_t row = (size_t)(row0 + lr);

@@ -39,7 +39,9 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                                 a->rows_dev, a->T, stream);
         if (rc != MIL_OK) return rc;
     }
-    if ((st & MIL_STAGE_DROPBITS) && train) {
+    // keep bits drawn by the forward kernel itself (no generator launches) when both stages run in this call
+    const bool draw_in_fwd = (st & MIL_STAGE_DROPBITS) && (st & MIL_STAGE_GATE_FWD) && train && !a->x_bf16;
+    if ((st & MIL_STAGE_DROPBITS) && train && !draw_in_fwd) {
         rc = mil_dropout_keep_bits(a->xbits, a->R, a->L, 0.5f, a->seed, a->offset, a->offset_dev, stream);
         if (rc != MIL_OK) return rc;
         // a second key for the head's mask: same stream position, different Philox key
@@ -54,6 +56,10 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
             rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores,
                                           g16 ? nullptr : gates, a->R, a->L, MIL_GATE_D, (grads && g16) ? a->gates16 : nullptr,
                                           stream);
+        else if (draw_in_fwd)
+            rc = mil_gate_scores_fwd_draw((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R,
+                                          a->L, MIL_GATE_D, a->xbits, xscale, a->mbits, a->B, a->seed,
+                                          a->seed ^ 0x9E3779B97F4A7C15ull, a->offset, a->offset_dev, stream);
         else
             rc = mil_gate_scores_fwd((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R, a->L,
                                      MIL_GATE_D, xbits, xscale, stream);

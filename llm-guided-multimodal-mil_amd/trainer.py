@@ -337,11 +337,12 @@ class ImageOnlyTrainer:
         """HIP-event duration (ms) of each launch group of the step, issued from C (mil_image_only_step_time)."""
         a = self._fill(x, layout, y, None)
         self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)          # state every stage reads exists
-        groups = [("gate_fwd", _lib.STAGE_GATE_FWD), ("pool_partial", _lib.STAGE_POOL),
+        # train mode: the forward launch draws the keep bits itself when the shape allows (mil_gate_scores_fwd_draw), so
+        # the two stages are timed together, as the step runs them
+        fwd = _lib.STAGE_GATE_FWD | (_lib.STAGE_DROPBITS if a.train else 0)
+        groups = [("gate_fwd", fwd), ("pool_partial", _lib.STAGE_POOL),
                   ("merge_head_loss_ds", _lib.STAGE_TAIL), ("gate_bwd_dw", _lib.STAGE_GATE_BWD),
                   ("gate_bwd_reduce_and_head_params", _lib.STAGE_REDUCE)]
-        if a.train:
-            groups.insert(0, ("dropout_bits", _lib.STAGE_DROPBITS))
         if a.x_bf16:        # the bf16 weight gradient's launch pair is one entry point: time it as a whole
             groups = [g for g in groups if g[0] not in ("gate_bwd_dw", "gate_bwd_reduce_and_head_params")]
             groups.append(("gate_bwd_dw", _lib.STAGE_GATE_BWD | _lib.STAGE_REDUCE))

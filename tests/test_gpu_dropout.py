@@ -46,10 +46,13 @@ def _masked_oracle(bags, y, p, xbits, mbits, L):
     return loss.detach(), logits.detach(), prob.detach(), {k: (gi if gi is not None else torch.zeros_like(p[k])) for k, gi in zip(names, g)}
 
 
-@pytest.mark.parametrize("lengths,L", [([300, 77, 1, 129], 512), ([130, 64], 768), ([20000, 12808], 512)])
+@pytest.mark.parametrize("lengths,L", [([300, 77, 1, 129], 512), ([130, 64], 768), ([20000, 12808], 512),
+                                       ([16384, 16000, 384], 512), ([20000, 4576], 1024)])
 def test_train_mode_step_matches_oracle_on_the_same_masks(lengths, L):
     """[20000, 12808] = 256 x 128 + 40 rows: the 128-row MFMA kernel with the mask on its A fragments plus the 32-row
-    kernel on the 40 rows beyond whole rounds; the short cases run the 32-row kernel only."""
+    kernel on the 40 rows beyond whole rounds (keep bits from the stand-alone generator); the short cases run the 32-row
+    kernel only; 32 768 and 24 576 rows = whole rounds of 128-row tiles: the forward kernel draws the keep bits itself
+    (mil_gate_scores_fwd_draw) - the same words, checked against the numpy Philox."""
     p = syn.image_only_params(31, L=L)
     bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(400 + i)) for i, n in enumerate(lengths)]
     y = syn.make_labels(32, len(lengths))
@@ -63,6 +66,7 @@ def test_train_mode_step_matches_oracle_on_the_same_masks(lengths, L):
     frac = float(torch.from_numpy(P.unpack_bits(_u32(xbits), L)).mean())
     assert 0.48 < frac < 0.52
     assert np.array_equal(_u32(xbits), P.keep_bits(sum(lengths), L, 0.5, 99, 1))          # first pass: stream position 1
+    assert np.array_equal(_u32(mbits), P.keep_bits(len(lengths), L, 0.25, 99 ^ 0x9E3779B97F4A7C15, 1))
     loss, logits, rprob, grads = _masked_oracle(bags, y, p, xbits, mbits, L)
     assert float((z.cpu() - logits).abs().max()) <= 2e-5                                   # bar: 1e-3
     assert torch.equal(prob.cpu().argmax(-1), rprob.argmax(-1))
