@@ -533,6 +533,18 @@ def run_rank(args):
                                     "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
             line["kernels_ms"] = {k: round(v, 4) for k, v in kb.items()}
             line["kernels_tflops"] = {k: round(flops[k] / (kb[k] * 1e-3) / 1e12, 2) for k in flops}
+            if args.train_mode and args.dtype == "f32" and world == 1:
+                # the same launches without dropout (model.eval() arithmetic): the keep-bit selects of train mode are work
+                # the 4 R L D flop count does not contain, so the MFMA fraction of the bare products is reported beside it
+                from mil_amd.trainer import ImageOnlyTrainer
+                tr_e = ImageOnlyTrainer(params, dev, train_mode=False)
+                kbe = tr_e.time_pieces(x, lay, y, 20)
+                line["roofline_eval_mode"] = {
+                    "bound": "mfma", "kernel": line["roofline"]["kernel"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "achieved": round(flops[dom] / (kbe[dom] * 1e-3) / 1e12, 2),
+                    "frac": round(flops[dom] / (kbe[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "ms_per_launch": round(kbe[dom], 4), "kernels_ms": {k: round(v, 4) for k, v in kbe.items()}}
+                del tr_e
             if world == 1 and args.dtype == "f32":
                 line["roofline_pool"] = pool_roofline(dev)
         if world == 1 and not args.no_configs and args.dtype == "f32":
