@@ -40,7 +40,7 @@ extern "C" {
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
 
 /* Library/ABI version, for the host mirror's load-time check. */
-int mil_abi_version(void);   /* 2 */
+int mil_abi_version(void);   /* 3 */
 
 /* ---- dropout keep bits (train mode) -------------------------------------------------------
  * model.train() upstream drops the bag rows with p = 0.5 BEFORE the gate and pools the dropped rows
@@ -237,21 +237,27 @@ int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
  * mil_gate_bwd_params_bf16 reads: half the bytes of the largest tensor of the step, written with 16-byte stores. */
 int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu,
                              const float* bu, const float* w, const float* b, float* scores, float* gates,
-                             int R, int L, int D, uint16_t* gates16, void* stream);
+                             int R, int L, int D, uint16_t* gates16, const uint32_t* xbits, float xscale, void* stream);
+/* Train mode (xbits / xscale, mbits / mscale: the keep-bit tensors of mil_dropout_keep_bits, nullable / 1): as in the fp32
+ * entry points the kernels read x through the mask - no dropped copy of the bf16 bag either.  With xbits the forward runs
+ * on the 128-row kernel for every R. */
 int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
-                               float* partials, void* stream);
+                               float* partials, const uint32_t* xbits, float xscale, void* stream);
 /* mil_attn_pool_partial_bf16 with the head-projection by-product of mil_attn_pool_partial_h (hrow [R, C] = x Wf^T on the
  * stored bf16 values, C <= 4): the backward then takes mil_attn_pool_bwd_from_h and never re-reads x. */
 int mil_attn_pool_partial_h_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
-                                 float* partials, const float* Wf, int C, float* hrow, void* stream);
+                                 float* partials, const float* Wf, int C, float* hrow, const uint32_t* xbits, float xscale,
+                                 const uint32_t* mbits, float mscale, void* stream);
 int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, const float* lse, const float* dM,
-                           const float* cdot, const int32_t* tile_map, int T, int L, float* ds, void* stream);
+                           const float* cdot, const int32_t* tile_map, int T, int L, float* ds, const uint32_t* xbits,
+                           float xscale, void* stream);
 /* Gate parameter gradients on the bf16 MFMA: x and dPre rounded to bf16, fp32 accumulation, fp32 partials and
  * outputs (same contract as mil_gate_bwd_params; L % 256 == 0; workspace mil_gate_bwd_workspace_floats_bf16). */
 size_t mil_gate_bwd_workspace_floats_bf16(int R, int L);
 int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates16, const float* ds, const float* w, int R, int L,
                              int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,
-                             float* dbu, float* dw, float* db, int accumulate, void* stream);
+                             float* dbu, float* dw, float* db, int accumulate, const uint32_t* xbits, float xscale,
+                             void* stream);
 /* mil_gate_bwd_params with x stored as bf16 (widened while staged; fp32 MFMA product: exact on the rounded x). */
 int mil_gate_bwd_params_x16(const uint16_t* x, const float* gates, const float* ds, const float* w, int R, int L,
                             int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu,

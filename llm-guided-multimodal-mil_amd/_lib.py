@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mil_hip.h")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/mil_hip.h one to one
@@ -53,12 +53,12 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_image_only_step_run": (c_int, [_P, _P]),
     "mil_image_only_step_time": (c_int, [_P, c_uint32, c_int, c_int, _P, _P]),
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
-    "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, _P]),
-    "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P]),
-    "mil_attn_pool_partial_h_bf16": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),
-    "mil_attn_pool_bwd_bf16": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
+    "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
+    "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_float, _P]),
+    "mil_attn_pool_partial_h_bf16": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_float, _P, c_float, _P]),
+    "mil_attn_pool_bwd_bf16": (c_int, [_P] * 6 + [c_int, c_int, _P, _P, c_float, _P]),
     "mil_gate_bwd_workspace_floats_bf16": (c_size_t, [c_int, c_int]),
-    "mil_gate_bwd_params_bf16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P]),
+    "mil_gate_bwd_params_bf16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P, c_float, _P]),
     "mil_gate_bwd_params_x16": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, c_size_t] + [_P] * 6 + [c_int, _P, c_float, _P]),
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,

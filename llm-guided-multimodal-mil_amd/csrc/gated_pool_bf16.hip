@@ -16,6 +16,20 @@ typedef unsigned short u16;
 
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
 
+// Train mode (ABMIL.py:49): zero the dropped elements of 8 consecutive bf16 values; bits8 = their 8 keep bits (bit e =
+// element e).  Per dword (two values): y = bits b0 -> bit 0, b1 -> bit 16; y * 0xffff = the 16-bit lane masks.
+__device__ __forceinline__ u16x8 keep_bf16x8(const u16x8 v, unsigned bits8) {
+    typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+    u32x4k d = __builtin_bit_cast(u32x4k, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned m2 = (bits8 >> (2 * e)) & 3u;
+        const unsigned y = (m2 | (m2 << 15)) & 0x00010001u;
+        d[e] &= (y << 16) - y;
+    }
+    return __builtin_bit_cast(u16x8, d);
+}
+
 // ---------------------------------------------------------------------------------------------------- cast
 __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ src, u16* __restrict__ dst, size_t n) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -76,7 +90,11 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
                                                        const float* __restrict__ bv, const u16* __restrict__ Wu,
                                                        const float* __restrict__ bu, const float* __restrict__ wvec,
                                                        const float* __restrict__ battn, float* __restrict__ scores,
-                                                       float* __restrict__ gates, int R, int L, u16* __restrict__ gates16) {
+                                                       float* __restrict__ gates, int R, int L, u16* __restrict__ gates16,
+                                                       const uint32_t* __restrict__ xbits, float xscale) {
+    // xbits (train mode, ABMIL.py:49): keep bits of the patch dropout [R][L/32]; a 64-wide K slice is two words per row,
+    // loaded one slice ahead; the A fragment (8 k-values of the lane's row) is masked after its LDS read, the 1/(1-p)
+    // multiplies the finished pre-activation
     __shared__ __attribute__((aligned(16))) u16 smem[2 * (HB_TM + HB_NG) * HB_RS];
     u16* xs = smem;                        // [2][128][64]
     u16* ws = smem + 2 * HB_TM * HB_RS;    // [2][384][64]
@@ -114,6 +132,10 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
             for (int i = 0; i < 16; ++i) acc[c][u][i] = 0.f;
 
     const int nslice = L / HB_BK;
+    const bool drop = xbits != nullptr;
+    const uint32_t* mrow = drop ? xbits + (size_t)min(row0 + 32 * wr + r, R - 1) * (L >> 5) : nullptr;
+    uint2 mnext = make_uint2(0u, 0u);
+    if (drop) mnext = *reinterpret_cast<const uint2*>(mrow);
     // (starting each workgroup's K loop at a different slice, to de-correlate the L2 requests for the shared gate
     //  weights, measured no gain: 107.4 vs 106.2 us fp32, 172 vs 171 us bf16 - the slices stay in natural order)
 #pragma unroll
@@ -123,6 +145,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
     for (int s = 0; s < nslice; ++s) {
         const int buf = s & 1;
         const int k1 = min(s + 1, nslice - 1) * HB_BK;
+        const uint2 mcur = mnext;
+        if (drop) mnext = *reinterpret_cast<const uint2*>(mrow + 2 * min(s + 1, nslice - 1));
         const u16* xa = xs + (buf * HB_TM + 32 * wr + r) * HB_RS;
         const u16* wb = ws + (buf * HB_NG + 32 * 3 * wc + r) * HB_RS;
         u16x8 a[2], b[2][3][2];
@@ -137,6 +161,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
         };
 #pragma unroll
         for (int p = 0; p < 7; ++p) frag_piece(0, 0, p);
+        if (drop) a[0] = keep_bf16x8(a[0], mcur.x >> (8 * h));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int q = ks & 1;
@@ -153,6 +178,11 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
                     acc[c][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q]),
                                                                         __builtin_bit_cast(bf16x8, b[q][c][u]), acc[c][u],
                                                                         0, 0, 0);
+            if (drop && ks < 3) {
+                // keep bits of k-step ks + 1 (k = 16 (ks + 1) + 8 h .. + 7 of the slice) on the fragment just read
+                const unsigned wd_ = (ks + 1) < 2 ? mcur.x : mcur.y;
+                a[q ^ 1] = keep_bf16x8(a[q ^ 1], wd_ >> (16 * ((ks + 1) & 1) + 8 * h));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -167,8 +197,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
         const float bvd = bv[d], bud = bu[d], wd = wvec[d];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float v = fast_tanh(acc[c][0][i] + bvd);
-            const float u = fast_sigmoid(acc[c][1][i] + bud);
+            const float v = fast_tanh(fmaf(acc[c][0][i], xscale, bvd));
+            const float u = fast_sigmoid(fmaf(acc[c][1][i], xscale, bud));
             part[i] += wd * v * u;
             if (gates != nullptr) {
                 const int gr = row0 + 32 * wr + mfma32_row(i, h);
@@ -194,7 +224,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16(const u16* __restrict__ x
         __syncthreads();                   // sred is read; the staging area is free again
         store_gates16_tile(smem + wave * (32 * 192), gates16, row0 + 32 * wr, R, 96 * wc, lane, [&](int c, int u, int i) {
             const int d = 32 * (3 * wc + c) + r;
-            return u == 0 ? fast_tanh(acc[c][0][i] + bv[d]) : fast_sigmoid(acc[c][1][i] + bu[d]);
+            return u == 0 ? fast_tanh(fmaf(acc[c][0][i], xscale, bv[d])) : fast_sigmoid(fmaf(acc[c][1][i], xscale, bu[d]));
         });
     }
 }
@@ -475,7 +505,12 @@ template <int NQ>
 __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict__ x, const float* __restrict__ scores,
                                                            const int32_t* __restrict__ tile_map,
                                                            float* __restrict__ partials, int L,
-                                                           const float* __restrict__ Wf, int C, float* __restrict__ hrow) {
+                                                           const float* __restrict__ Wf, int C, float* __restrict__ hrow,
+                                                           const uint32_t* __restrict__ xbits, float xscale,
+                                                           const uint32_t* __restrict__ mbits, float mscale) {
+    // train mode: xbits [R][L/32] keep bits of the patch dropout - the DROPPED x is what gets pooled (ABMIL.py:49,59):
+    // dropped elements are zeroed right after the load, the 1/(1-p) goes into the tile weights; mbits [B][L/32] = the
+    // head's Dropout(.25) folded into the head rows of the by-product (as k_pool_partial)
     __shared__ float p_lds[MIL_POOL_TILE];
     __shared__ float ml_lds[2];
     __shared__ __attribute__((aligned(16))) float red[3 * NQ * 512];
@@ -503,27 +538,41 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         const u16* xr = x + (size_t)(row0 + rr) * L + 8 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const u16x8*>(xr + 512 * q);
+        if (xbits != nullptr) {
+            const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v[i][q] = keep_bf16x8(v[i][q], mr[16 * q] >> (8 * (lane & 3)));
+        }
     }
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const float p = p_lds[wave + 4 * i];
+        const float p = p_lds[wave + 4 * i] * xscale;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[q][e] += p * bf16_to_f32(v[i][q][e]);
     }
+    const int bag_ = tile_map[4 * t];
+    auto head_row = [&](int c, float (*wf)[8]) {          // Wf[c] (x keep_M x mscale x xscale) of this lane's columns
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wf[q][e] = w0[e] * xscale; wf[q][4 + e] = w1[e] * xscale; }
+            if (mbits != nullptr) {
+                const unsigned mm = mbits[(size_t)bag_ * (L >> 5) + 16 * q + (lane >> 2)] >> (8 * (lane & 3));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[q][e] = ((mm >> e) & 1u) ? wf[q][e] * mscale : 0.f;
+            }
+        }
+    };
     if (Wf != nullptr && C == 2) {
         float d16[16];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             float wf[NQ][8];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { wf[q][e] = w0[e]; wf[q][4 + e] = w1[e]; }
-            }
+            head_row(c, wf);
 #pragma unroll
             for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
                 float d = 0.f;
@@ -542,13 +591,7 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         const int nrows_ = nrows;
         for (int c = 0; c < C; ++c) {
             float wf[NQ][8];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { wf[q][e] = w0[e]; wf[q][4 + e] = w1[e]; }
-            }
+            head_row(c, wf);
 #pragma unroll
             for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
                 float d = 0.f;
@@ -593,7 +636,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds_bf16(const u16* __restrict_
                                                           const float* __restrict__ lse, const float* __restrict__ dM,
                                                           const float* __restrict__ cdot,
                                                           const int32_t* __restrict__ tile_map, float* __restrict__ ds,
-                                                          int L) {
+                                                          int L, const uint32_t* __restrict__ xbits, float xscale) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int bag = tile_map[4 * t], row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
@@ -611,6 +654,11 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds_bf16(const u16* __restrict_
         const u16* xr = x + row * L + 8 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const u16x8*>(xr + 512 * q);
+        if (xbits != nullptr) {
+            const uint32_t* mr = xbits + row * (L >> 5) + (lane >> 2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v[i][q] = keep_bf16x8(v[i][q], mr[16 * q] >> (8 * (lane & 3)));
+        }
         sc[i] = scores[row];
     }
 #pragma unroll
@@ -622,7 +670,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds_bf16(const u16* __restrict_
 #pragma unroll
             for (int e = 0; e < 8; ++e) dot += bf16_to_f32(v[i][q][e]) * g[q][e];
         dot = wave_allsum(dot);
-        if (rr < nrows && lane == 0) ds[row0 + rr] = expf(sc[i] - lse_b) * (dot - c_b);
+        if (rr < nrows && lane == 0) ds[row0 + rr] = expf(sc[i] - lse_b) * (dot * xscale - c_b);
     }
 }
 
@@ -680,7 +728,9 @@ __device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const u16* __restrict__ gates,
                                                           const float* __restrict__ ds, const float* __restrict__ wvec,
                                                           float* __restrict__ part, float* __restrict__ pbias, int R, int L,
-                                                          int KC, int NJ) {
+                                                          int KC, int NJ, const uint32_t* __restrict__ xbits) {
+    // xbits (train mode): keep bits of the patch dropout; x enters the product keep-masked, the 1 / (1 - p) is applied by
+    // the reduce (wscale)
     __shared__ __attribute__((aligned(16))) u16 smem[2 * (WB_BKR * WB_S + WB_BKR * 2 * WB_S)];      // 2 x 60 KB
     // per stage: A image [64][160] (128 gi used), B image [64][320] (256 j used, two 160-wide panels of 128 j)
     constexpr int ASZ = WB_BKR * WB_S, BSZ = WB_BKR * 2 * WB_S;
@@ -711,14 +761,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
     float acc_ds = 0.f;
 
+    unsigned rxm[8];
     auto xload = [&](int i, int rs) {
         const int gr = min(rs + xrow + 8 * i, rend - 1);
         rx[i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
+        if (xbits != nullptr) rxm[i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
     };
     auto xwrite = [&](int i, int buf) {
         // columns 0..127 -> panel 0, 128..255 -> panel 1 (each panel is its own 160-stride image)
         u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
-        *reinterpret_cast<u16x8*>(dst) = rx[i];
+        *reinterpret_cast<u16x8*>(dst) = xbits != nullptr ? keep_bf16x8(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
     };
     auto aload = [&](int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
@@ -866,12 +918,14 @@ extern "C" int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* st
 
 extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu,
                                         const float* bu, const float* w, const float* b, float* scores, float* gates,
-                                        int R, int L, int D, uint16_t* gates16, void* stream) {
+                                        int R, int L, int D, uint16_t* gates16, const uint32_t* xbits, float xscale,
+                                        void* stream) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % HB_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
-    // 256-row tiles with the three-stage pipeline once they fill the chip; the 128-row kernel for small R
-    if (R >= HC_TM * MIL_NUM_CU) {
+    // 256-row tiles with the three-stage pipeline once they fill the chip; the 128-row kernel for small R - and in train
+    // mode (keep bits on the A fragments: the deep kernel's hand-counted DMA waits leave no room for the mask loads)
+    if (R >= HC_TM * MIL_NUM_CU && xbits == nullptr) {
         const dim3 grid((R + HC_TM - 1) / HC_TM);
         if (gates16)
             hipLaunchKernelGGL(k_gate_fwd_bf16_deep<2>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
@@ -885,43 +939,45 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
     }
     else
         hipLaunchKernelGGL(k_gate_fwd_bf16, dim3((R + HB_TM - 1) / HB_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu,
-                           bu, w, b, scores, gates, R, L, gates16);
+                           bu, w, b, scores, gates, R, L, gates16, xbits, xbits ? xscale : 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
-                                          float* partials, void* stream) {
+                                          float* partials, const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !scores || !tile_map || !partials) return MIL_EINVAL;
     if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr);
-    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr);
+    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr, xbits, xbits ? xscale : 1.0f, (const uint32_t*)nullptr, 1.0f);
+    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr, xbits, xbits ? xscale : 1.0f, (const uint32_t*)nullptr, 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_attn_pool_partial_h_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
-                                            float* partials, const float* Wf, int C, float* hrow, void* stream) {
+                                            float* partials, const float* Wf, int C, float* hrow, const uint32_t* xbits,
+                                            float xscale, const uint32_t* mbits, float mscale, void* stream) {
     if (!x || !scores || !tile_map || !partials || !Wf || !hrow) return MIL_EINVAL;
     if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0 || C <= 0 || C > 4) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow);
-    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow);
+    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xbits ? xscale : 1.0f, mbits, mbits ? mscale : 1.0f);
+    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xbits ? xscale : 1.0f, mbits, mbits ? mscale : 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_attn_pool_bwd_bf16(const uint16_t* x, const float* scores, const float* lse, const float* dM,
-                                      const float* cdot, const int32_t* tile_map, int T, int L, float* ds, void* stream) {
+                                      const float* cdot, const int32_t* tile_map, int T, int L, float* ds,
+                                      const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !scores || !lse || !dM || !cdot || !tile_map || !ds) return MIL_EINVAL;
     if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (L == 512) hipLaunchKernelGGL(k_pool_bwd_ds_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, L);
-    else hipLaunchKernelGGL(k_pool_bwd_ds_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, L);
+    if (L == 512) hipLaunchKernelGGL(k_pool_bwd_ds_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, L, xbits, xbits ? xscale : 1.0f);
+    else hipLaunchKernelGGL(k_pool_bwd_ds_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, lse, dM, cdot, tile_map, ds, L, xbits, xbits ? xscale : 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -945,7 +1001,8 @@ extern "C" size_t mil_gate_bwd_workspace_floats_bf16(int R, int L) {
 
 extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates, const float* ds, const float* w, int R,
                                         int L, int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
-                                        float* dWu, float* dbu, float* dw, float* db, int accumulate, void* stream) {
+                                        float* dWu, float* dbu, float* dw, float* db, int accumulate,
+                                        const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 256) != 0 || R <= 0) return MIL_EINVAL;
     int kc;
@@ -956,11 +1013,11 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates
     float* pbias = workspace + (size_t)S * HB_NG * L;
     const int NJ = L / 256;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gate_bwd_dw_bf16, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
+    hipLaunchKernelGGL(k_gate_bwd_dw_bf16, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
     MIL_CHECK_LAUNCH();
     const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, S, L, dWv, dbv, dWu,
-                       dbu, dw, db, accumulate, 1.0f);
+                       dbu, dw, db, accumulate, xbits ? xscale : 1.0f);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -13,7 +13,6 @@ static int step_check(const mil_image_only_step* a) {
     if (!a->Wv || !a->bv || !a->Wu || !a->bu || !a->w || !a->b || !a->Wf || !a->bf) return MIL_EINVAL;
     if (!a->scores || !a->partials || !a->M || !a->lse || !a->logits || !a->prob) return MIL_EINVAL;
     if (a->x_bf16 && (!a->Wv16 || !a->Wu16)) return MIL_EINVAL;
-    if (a->x_bf16 && a->train) return MIL_EINVAL;               // in-kernel dropout exists on the fp32 path only
     if (a->bag_len_dev && (a->x_bf16 || !a->rows_dev || a->B > 1024)) return MIL_EINVAL;
     if (a->train && (!a->xbits || !a->mbits || !a->Mdrop)) return MIL_EINVAL;
     if (a->y) {
@@ -55,7 +54,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
         if (a->x_bf16)
             rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores,
                                           g16 ? nullptr : gates, a->R, a->L, MIL_GATE_D, (grads && g16) ? a->gates16 : nullptr,
-                                          stream);
+                                          xbits, xscale, stream);
         else if (draw_in_fwd)
             rc = mil_gate_scores_fwd_draw((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R,
                                           a->L, MIL_GATE_D, a->xbits, xscale, a->mbits, a->B, a->seed,
@@ -68,9 +67,9 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     if (st & MIL_STAGE_POOL) {
         if (a->x_bf16) {
             rc = use_h ? mil_attn_pool_partial_h_bf16((const uint16_t*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials,
-                                                      a->Wf, a->C, a->hrow, stream)
+                                                      a->Wf, a->C, a->hrow, xbits, xscale, mbits, mscale, stream)
                        : mil_attn_pool_partial_bf16((const uint16_t*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials,
-                                                    stream);
+                                                    xbits, xscale, stream);
         } else {
             rc = use_h ? mil_attn_pool_partial_h((const float*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials, a->Wf,
                                                  a->C, a->hrow, xbits, xscale, mbits, mscale, stream)
@@ -88,7 +87,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
         if (rc != MIL_OK) return rc;
         if (grads && !use_h) {          // no head projections: the score gradient takes a second pass over x
             rc = a->x_bf16 ? mil_attn_pool_bwd_bf16((const uint16_t*)a->x, a->scores, a->lse, a->dM, a->cdot, a->tile_map, a->T,
-                                                    a->L, a->ds, stream)
+                                                    a->L, a->ds, xbits, xscale, stream)
                            : mil_attn_pool_bwd((const float*)a->x, a->scores, a->lse, a->dM, a->cdot, a->tile_map, a->T, a->L,
                                                a->ds, nullptr, xbits, xscale, stream);
             if (rc != MIL_OK) return rc;
@@ -104,11 +103,11 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
             if (a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16)
                 rc = mil_gate_bwd_params_bf16((const uint16_t*)a->x, a->gates16, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
                                               (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
-                                              a->accumulate, stream);
+                                              a->accumulate, xbits, xscale, stream);
             else
                 rc = mil_gate_bwd_params_x16((const uint16_t*)a->x, a->gates, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
                                              (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
-                                             a->accumulate, nullptr, 1.0f, stream);
+                                             a->accumulate, xbits, xscale, stream);
             if (rc != MIL_OK) return rc;
         }
         if (st & MIL_STAGE_REDUCE) {

@@ -1117,7 +1117,8 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
-def gate_scores_fwd_bf16(x16, Wv16, bv, Wu16, bu, w, b, save_gates: bool = True, gates_bf16: bool = False):
+def gate_scores_fwd_bf16(x16, Wv16, bv, Wu16, bu, w, b, save_gates: bool = True, gates_bf16: bool = False, xbits=None,
+                         xscale: float = 1.0):
     x16 = _bf16c(x16, "x")
     R, L = x16.shape
     scores = torch.empty(R, device=x16.device, dtype=torch.float32)
@@ -1128,21 +1129,24 @@ def gate_scores_fwd_bf16(x16, Wv16, bv, Wu16, bu, w, b, save_gates: bool = True,
     elif save_gates:
         gates = torch.empty((R, 2 * GATE_D), device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_gate_scores_fwd_bf16(_p(x16), _p(_bf16c(Wv16, "Wv")), _p(bv), _p(_bf16c(Wu16, "Wu")), _p(bu), _p(w),
-                                             _p(b), _p(scores), _p(gates), R, L, Wv16.shape[0], _p(gates16), _stream())
+                                             _p(b), _p(scores), _p(gates), R, L, Wv16.shape[0], _p(gates16), _p(xbits),
+                                             float(xscale), _stream())
     _lib.check(rc, "mil_gate_scores_fwd_bf16")
     return scores, (gates16 if gates_bf16 else gates)
 
 
-def attn_pool_partial_bf16(x16, scores, layout: BagLayout):
+def attn_pool_partial_bf16(x16, scores, layout: BagLayout, xbits=None, xscale: float = 1.0):
     x16 = _bf16c(x16, "x")
     R, L = x16.shape
     partials = torch.empty(layout.T * (L + 2), device=x16.device, dtype=torch.float32)
-    rc = _lib.lib().mil_attn_pool_partial_bf16(_p(x16), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials), _stream())
+    rc = _lib.lib().mil_attn_pool_partial_bf16(_p(x16), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials), _p(xbits),
+                                               float(xscale), _stream())
     _lib.check(rc, "mil_attn_pool_partial_bf16")
     return partials
 
 
-def attn_pool_partial_h_bf16(x16, scores, layout: BagLayout, Wf):
+def attn_pool_partial_h_bf16(x16, scores, layout: BagLayout, Wf, xbits=None, xscale: float = 1.0, mbits=None,
+                             mscale: float = 1.0):
     """bf16 tile partials plus hrow [R, C] = x Wf^T (mil_attn_pool_partial_h_bf16)."""
     x16 = _bf16c(x16, "x")
     R, L = x16.shape
@@ -1150,22 +1154,24 @@ def attn_pool_partial_h_bf16(x16, scores, layout: BagLayout, Wf):
     partials = torch.empty(layout.T * (L + 2), device=x16.device, dtype=torch.float32)
     hrow = torch.empty((R, C), device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_attn_pool_partial_h_bf16(_p(x16), _p(scores), _p(layout.tile_map), layout.T, L, _p(partials),
-                                                 _p(_f32c(Wf, "Wf")), C, _p(hrow), _stream())
+                                                 _p(_f32c(Wf, "Wf")), C, _p(hrow), _p(xbits), float(xscale), _p(mbits),
+                                                 float(mscale), _stream())
     _lib.check(rc, "mil_attn_pool_partial_h_bf16")
     return partials, hrow
 
 
-def attn_pool_bwd_bf16(x16, scores, lse, dM, cdot, layout: BagLayout):
+def attn_pool_bwd_bf16(x16, scores, lse, dM, cdot, layout: BagLayout, xbits=None, xscale: float = 1.0):
     x16 = _bf16c(x16, "x")
     R, L = x16.shape
     ds = torch.empty(R, device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_attn_pool_bwd_bf16(_p(x16), _p(scores), _p(lse), _p(dM), _p(cdot), _p(layout.tile_map), layout.T, L,
-                                           _p(ds), _stream())
+                                           _p(ds), _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_attn_pool_bwd_bf16")
     return ds
 
 
-def gate_bwd_params_x16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None):
+def gate_bwd_params_x16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None, xbits=None,
+                        xscale: float = 1.0):
     x16 = _bf16c(x16, "x")
     R, L = x16.shape
     need = _lib.lib().mil_gate_bwd_workspace_floats(R, L)
@@ -1173,7 +1179,7 @@ def gate_bwd_params_x16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulat
         workspace = torch.empty(need, device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_gate_bwd_params_x16(_p(x16), _p(gates), _p(ds), _p(w), R, L, GATE_D, _p(workspace),
                                             workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
-                                            1 if accumulate else 0, None, 1.0, _stream())
+                                            1 if accumulate else 0, _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_gate_bwd_params_x16")
     return workspace
 
@@ -1209,7 +1215,8 @@ def add_bag_row(x, o, segs):
     return _AddBagRow.apply(x, o, segs)
 
 
-def gate_bwd_params_bf16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None):
+def gate_bwd_params_bf16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumulate: bool = False, workspace=None, xbits=None,
+                         xscale: float = 1.0):
     """Weight gradients on the bf16 MFMA (dPre and x rounded to bf16, fp32 accumulate); gates: bf16 [R, 384]."""
     x16 = _bf16c(x16, "x")
     gates = _bf16c(gates, "gates")
@@ -1219,7 +1226,7 @@ def gate_bwd_params_bf16(x16, gates, ds, w, dWv, dbv, dWu, dbu, dw, db, accumula
         workspace = torch.empty(need, device=x16.device, dtype=torch.float32)
     rc = _lib.lib().mil_gate_bwd_params_bf16(_p(x16), _p(gates), _p(ds), _p(w), R, L, GATE_D, _p(workspace),
                                              workspace.numel(), _p(dWv), _p(dbv), _p(dWu), _p(dbu), _p(dw), _p(db),
-                                             1 if accumulate else 0, _stream())
+                                             1 if accumulate else 0, _p(xbits), float(xscale), _stream())
     _lib.check(rc, "mil_gate_bwd_params_bf16")
     return workspace
 

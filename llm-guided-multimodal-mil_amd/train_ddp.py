@@ -106,6 +106,12 @@ def main_worker(local_rank: int, nprocs: int, args):
             optimizer = torch.optim.Adam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7)
         if flat_opt and world > 1:
             broadcast_flat(optimizer.flat, src=0)                                        # DDP's initial broadcast
+        # criterion inside the module (aggregator.forward(labels=...): pool + head + loss as one fused node) whenever the
+        # module is called directly - DDP's unused-parameter search needs the loss to hang off forward's outputs
+        fuse_loss = generator is model and args.variant != "image_only"
+
+        def loss_of(out_prob, y_):
+            return model.last_loss if (fuse_loss and model.last_loss is not None) else criterion(out_prob, y_)
         graphed = None
         if getattr(args, "hip_graph", 0):
             # replay the step body from a hipGraph once a batch shape repeats (graph_step.py); optimizer and the
@@ -160,22 +166,22 @@ def main_worker(local_rank: int, nprocs: int, args):
                         loss, prob = graphed.run(key, (x, y), body)
                     elif args.learnablePrompt:
                         def body(x_, ids_, y_):
-                            prob_ = generator([x_], ids_, lengths)[0]
-                            return criterion(prob_, y_), prob_
+                            prob_ = generator([x_], ids_, lengths, labels=y_ if fuse_loss else None)[0]
+                            return loss_of(prob_, y_), prob_
                         loss, prob = graphed.run(key, (x, batch["CI"].to(dev), y), body)
                     else:
                         tfeat = model.clinic_extractor(batch["CI"].to(dev))      # frozen tower (no_grad): outside the graph
                         def body(x_, t_, y_):
-                            prob_ = generator([x_], None, lengths, text_features=t_)[0]
-                            return criterion(prob_, y_), prob_
+                            prob_ = generator([x_], None, lengths, text_features=t_, labels=y_ if fuse_loss else None)[0]
+                            return loss_of(prob_, y_), prob_
                         loss, prob = graphed.run(key, (x, tfeat, y), body)
                     optimizer.step()
                 else:
                     if args.variant == "image_only":
                         _, prob = generator([x], lengths)
                     else:
-                        prob, _ = generator([x], batch["CI"].to(dev), lengths)
-                    loss = criterion(prob, y)                                            # loss_point 'Last'
+                        prob, _ = generator([x], batch["CI"].to(dev), lengths, labels=y if fuse_loss else None)
+                    loss = loss_of(prob, y) if args.variant != "image_only" else criterion(prob, y)   # loss_point 'Last'
                     optimizer.zero_grad()
                     loss.backward()
                     optimizer.step()

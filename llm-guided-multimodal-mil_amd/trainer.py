@@ -151,7 +151,7 @@ class ImageOnlyTrainer:
         C = fp.p("fc.1.weight").shape[0]
         if fp.p("fc.1.weight").shape[1] != L:
             raise _lib.MilHipError("ImageOnlyTrainer: the head's input width must equal the patch width L")
-        train = self.train_mode and y is not None and not b16
+        train = self.train_mode and y is not None
         key = (x.data_ptr(), R, L, b16, id(layout), None if y is None else y.data_ptr(), global_bags, train)
         if self._args is not None and key == self._args_key:
             return self._args

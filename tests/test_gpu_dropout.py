@@ -126,3 +126,41 @@ def test_autograd_route_with_keep_bits_incl_input_gradient():
     for k in ("aggregator.attention_V.0.weight", "aggregator.attention_U.0.weight", "aggregator.attention_weights.weight",
               "aggregator.attention_V.0.bias", "aggregator.attention_U.0.bias"):
         assert rel_err(d[k].grad.cpu(), leaves[k].grad) <= 2e-4, k
+
+
+@pytest.mark.parametrize("grad_mfma", [False, True])
+@pytest.mark.parametrize("lengths,L", [([300, 77, 129], 512), ([1000, 24], 1024)])
+def test_bf16_train_mode_step_matches_oracle_on_the_same_masks(lengths, L, grad_mfma):
+    """bf16 storage (BASELINE config 5's arithmetic) in model.train() mode: the bf16 kernels read x through the same keep-bit
+    tensors - forward A fragments, pool pass, weight-gradient staging.  Oracle: fp32 on the bf16-rounded x and gate weights
+    with exactly the masks the step drew."""
+    p = syn.image_only_params(41, L=L)
+    bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(500 + i)) for i, n in enumerate(lengths)]
+    y = syn.make_labels(42, len(lengths))
+    tr = ImageOnlyTrainer(p, DEV, lr=1e-3, train_mode=True, seed=7, bf16_grad_mfma=grad_mfma)
+    x16 = torch.cat(bags, 0).to(DEV).to(torch.bfloat16)
+    lay = BagLayout.make(lengths, DEV)
+    prob, z = tr.forward(x16, lay, y.to(DEV))
+    tr.backward()
+    torch.cuda.synchronize()
+    xbits, mbits = tr.last["xbits"], tr.last["mbits"]
+    assert np.array_equal(_u32(xbits), P.keep_bits(sum(lengths), L, 0.5, 7, 1))
+    pr = dict(p)
+    for k in ("aggregator.attention_V.0.weight", "aggregator.attention_U.0.weight"):
+        pr[k] = p[k].to(torch.bfloat16).float()
+    rb = [b.to(torch.bfloat16).float() for b in bags]
+    loss, logits, rprob, grads = _masked_oracle(rb, y, pr, xbits, mbits, L)
+    assert float((z.cpu() - logits).abs().max()) <= 5e-5
+    assert torch.equal(prob.cpu().argmax(-1), rprob.argmax(-1))
+    assert abs(float(tr.loss_sum.item()) - float(loss)) <= 1e-5
+    for k in grads:
+        if float(grads[k].norm()) > 1e-7:
+            gate_param = k.startswith("aggregator.attention")
+            tol = 1.2e-2 if (grad_mfma and L % 256 == 0 and gate_param) else \
+                (6e-3 if (grad_mfma and k.endswith(("attention_V.0.weight", "attention_U.0.weight"))) else 5e-4)
+            assert rel_err(tr.fp.g(k).cpu(), grads[k]) <= tol, (k, rel_err(tr.fp.g(k).cpu(), grads[k]))
+    # three training steps run and keep every parameter finite
+    for _ in range(3):
+        tr.train_step(x16, lay, y.to(DEV))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(tr.fp.flat).all())
