@@ -907,6 +907,196 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+#if defined(WB_ROLESPLIT)
+// EXPERIMENT, not built into the product (tools/build_variants.sh "-DWB_ROLESPLIT ..." + tools/kbench_dw16.py): producer /
+// consumer wave roles, see DESIGN.md (bf16 section).  Waves 0-3: transposed fragment reads + MFMA only; waves 4-7: staging
+// of x and dPre with RS_SETS register sets (loads RS_SETS slices ahead).  Measured at config 5 against the kernel above
+// (175-198 us in that harness): 203-205 us with one or two sets alike; no LDS writes / no staging at all 90 us (the
+// consumer loop alone), no global loads in the loop 108 us, no x staging 141 us, no gate staging 133 us - the producers'
+// global loads are what the time goes into, independent of how far ahead they are issued.  Partial tiles come out
+// intermittently wrong in a few workgroups (bias sums always right): the LDS hand-over between the roles has a race that
+// was not found - one more reason this stays an experiment.
+__global__ __launch_bounds__(512) void k_gate_bwd_dw_bf16_rs(const u16* __restrict__ x, const u16* __restrict__ gates,
+                                                             const float* __restrict__ ds, const float* __restrict__ wvec,
+                                                             float* __restrict__ part, float* __restrict__ pbias, int R, int L,
+                                                             int KC, int NJ) {
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (WB_BKR * WB_S + WB_BKR * 2 * WB_S)];
+    constexpr int ASZ = WB_BKR * WB_S, BSZ = WB_BKR * 2 * WB_S;
+    u16* ab = smem;
+    u16* xb = smem + 2 * ASZ;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
+    const int j0 = jt * 256;
+    const int rbeg = s * KC, rend = min(R, rbeg + KC);
+    const int nslice = (rend - rbeg + WB_BKR - 1) / WB_BKR;
+    if (wave >= 4) {
+        const int tid = threadIdx.x - 256;
+        const int xrow = tid >> 5, xc = tid & 31;
+        const int arow = tid >> 4, ad4 = tid & 15;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
+        // RS_SETS register sets: slice q lives in set q % RS_SETS from its loads (issued RS_SETS slices ahead) until it is
+        // written to its LDS stage.  (At most 20 x RS_SETS loads in flight per wave: the vmcnt counter has 6 bits.)
+#if !defined(RS_SETS)
+#define RS_SETS 2
+#endif
+        u16x8 rx[RS_SETS][8];
+        ushort4 hv[RS_SETS][4], hu[RS_SETS][4];
+        float rds[RS_SETS][4], rmask[RS_SETS][4];
+        f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
+        float acc_ds = 0.f;
+        auto load_slice = [&](auto set_c, int q) {               // slice q of the chunk (x rows clamped, dPre rows masked)
+            constexpr int z = decltype(set_c)::value;
+            const int rs = rbeg + q * WB_BKR;
+            const int rsx = rbeg + min(q, max(nslice - 1, 0)) * WB_BKR;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gr = min(rsx + xrow + 8 * i, rend - 1);
+                rx[z][i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gr = rs + arow + 16 * i;
+                const int gc = min(gr, rend - 1);
+                const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
+                hv[z][i] = *reinterpret_cast<const ushort4*>(gp);
+                hu[z][i] = *reinterpret_cast<const ushort4*>(gp + 192);
+                rds[z][i] = ds[gc];
+                rmask[z][i] = gr < rend ? 1.f : 0.f;
+            }
+        };
+        auto write_slice = [&](auto set_c, int buf) {
+            constexpr int z = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
+                *reinterpret_cast<u16x8*>(dst) = rx[z][i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = {bf16_to_f32(hv[z][i].x), bf16_to_f32(hv[z][i].y), bf16_to_f32(hv[z][i].z), bf16_to_f32(hv[z][i].w)};
+                const f32x4 u = {bf16_to_f32(hu[z][i].x), bf16_to_f32(hu[z][i].y), bf16_to_f32(hu[z][i].z), bf16_to_f32(hu[z][i].w)};
+                const float dsv = rds[z][i] * rmask[z][i];
+                const f32x4 a = (dsv * w4) * u;
+                const f32x4 tt = a * v;
+                const f32x4 pv = a - tt * v;
+                const f32x4 pu = tt - tt * u;
+                u16* dst = ab + buf * ASZ + (arow + 16 * i) * WB_S + 4 * ad4;
+                *reinterpret_cast<ushort4*>(dst) = pack_bf16x4(pv);
+                *reinterpret_cast<ushort4*>(dst + 64) = pack_bf16x4(pu);
+                acc_bv += pv;
+                acc_bu += pu;
+                acc_w += (dsv * v) * u;
+                if (ad4 == 0) acc_ds += dsv;
+            }
+        };
+        using Z0 = std::integral_constant<int, 0>;
+        using Z1 = std::integral_constant<int, 1>;
+        load_slice(Z0{}, 0);
+        load_slice(Z1{}, 1);
+        write_slice(Z0{}, 0);
+        load_slice(Z0{}, 2);
+        __syncthreads();
+        // iteration sl (the consumers multiply slice sl): slice sl + 1 goes from its set to the other stage, the set takes
+        // slice sl + 3
+        auto step = [&](int sl, auto set_c) {
+            write_slice(set_c, (sl + 1) & 1);
+            load_slice(set_c, sl + 3);
+            __syncthreads();
+        };
+        {
+            int sl = 0;
+            for (; sl + 1 < nslice; sl += 2) {
+                step(sl, Z1{});
+                step(sl + 1, Z0{});
+            }
+            if (sl < nslice) step(sl, Z1{});
+        }
+        if (jt == 0) {
+            float* redf = reinterpret_cast<float*>(smem);
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                redf[(arow * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
+                redf[(arow * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
+                redf[(arow * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
+            }
+            redf[16 * 3 * 64 + tid] = acc_ds;
+            __syncthreads();
+            if (tid < 192) {
+                const int which = tid / 64, d = tid % 64;
+                float v = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) v += redf[(g * 3 + which) * 64 + d];
+                pbias[((size_t)s * 4 + which) * 192 + 64 * m + d] = v;
+            }
+            if (m == 0 && tid == 0) {
+                float v = 0.f;
+                for (int g = 0; g < 256; g += 16) v += redf[16 * 3 * 64 + g];
+                pbias[((size_t)s * 4 + 3) * 192] = v;
+            }
+        }
+        return;
+    }
+    const int wi = wave >> 1, wj = wave & 1;
+    const int h = lane >> 5;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int acol = 64 * wi + 16 * tg + 4 * tp;
+    const int bcol = 16 * tg + 4 * tp;
+    __syncthreads();
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int buf = sl & 1;
+        const u16* ai = ab + buf * ASZ;
+        const u16* bi = xb + buf * BSZ + wj * ASZ;
+        u16x8 fa[2][2], fb[2][4];
+        auto frags = [&](int ks, int q) {
+            const int row = 16 * ks + 8 * h + tq;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[q][a] = tr_frag(ai, row, acol + 32 * a);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[q][b] = tr_frag(bi, row, bcol + 32 * b);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < WB_BKR / 16; ++ks) {
+            const int q = ks & 1;
+            if (ks + 1 < WB_BKR / 16) frags(ks + 1, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[q][a]),
+                                                                        __builtin_bit_cast(bf16x8, fb[q][b]), acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int r = lane & 31;
+    float* pt = part + ((size_t)s * HB_NG + 128 * m + 64 * wi) * L + j0 + 128 * wj + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
+    if (jt == 0) {
+        __syncthreads();
+        __syncthreads();
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------- host entry points
 extern "C" int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
     if (!src || !dst) return MIL_EINVAL;
@@ -1013,6 +1203,11 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates
     float* pbias = workspace + (size_t)S * HB_NG * L;
     const int NJ = L / 256;
     hipStream_t st = (hipStream_t)stream;
+#if defined(WB_ROLESPLIT)
+    if (xbits == nullptr)
+        hipLaunchKernelGGL(k_gate_bwd_dw_bf16_rs, dim3(S * 3 * NJ), dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
+    else
+#endif
     hipLaunchKernelGGL(k_gate_bwd_dw_bf16, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
     MIL_CHECK_LAUNCH();
     const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);

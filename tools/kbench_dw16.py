@@ -18,7 +18,7 @@ B, N, L = 32, 4096, 1024
 R = B * N
 torch.manual_seed(0)
 x16 = ops.cast_bf16(torch.randn((R, L), device=dev))
-gates = torch.rand((R, 384), device=dev)
+gates = torch.rand((R, 384), device=dev).to(torch.bfloat16)
 ds = torch.randn((R,), device=dev) * 1e-3
 w = torch.randn((192,), device=dev)
 outs = [torch.empty((192, L), device=dev), torch.empty(192, device=dev), torch.empty((192, L), device=dev), torch.empty(192, device=dev),
