@@ -279,6 +279,15 @@ size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
              int accumulate, float* workspace, size_t workspace_floats, void* stream);
+
+/* Tall NT products C[M, N] = act(A[M, K] W[N, K]^T + bias), act in {0 none, 1 tanh, 2 ReLU}, on the low-VALU LDS-DMA
+ * pipeline of the gate forward kernel (256 x 256 tiles, csrc/linear_nt2.hip): what mil_gemm dispatches nn.Linear layers on
+ * tall activations to when the tiles fill whole rounds of the chip (fc_pathology, model/aggregator.py:47,141-149).
+ * N % 256 == 0, K % 32 == 0, K >= 64, lda / ldw multiples of 4, A and W 16-byte aligned (mil_gemm_nt2_ok). */
+int mil_gemm_nt2_ok(int lda, int ldw, int M, int N, int K);
+int mil_gemm_nt2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                 const float* bias, int act, void* stream);
+
 /* nn.Linear on 65 .. ~1000 rows (T text tokens x bags on the token side of sam/transformer.py:413-416 / common.py:21-26,
  * the few-hundred-row text tower of a one-bag learnable-prompt step, clip/model.py:171-178): one launch per product, the
  * workgroup of a 32 x 32 / 64 x 64 output tile contracts all of K (csrc/mid_linear.hip), no workspace.

@@ -63,6 +63,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
+    "mil_gemm_nt2_ok": (c_int, [c_int] * 5),
+    "mil_gemm_nt2": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "mil_split_bf16": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "mil_gemm_split": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int,
                                c_int, _P]),

@@ -503,6 +503,17 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
     if (b_mode == 1 && (N < 4 || (N & 3))) return MIL_EINVAL;
     if (a_mode == 1 && b_mode == 0) return MIL_EINVAL;             // TT form is never needed
     hipStream_t st = (hipStream_t)stream;
+#if !defined(LG_NO_NT2)
+    if (a_mode == 0 && b_mode == 0 && residual == nullptr && !accumulate && aux_mode == AUX_NONE && act <= ACT_RELU &&
+        ldc >= N && mil_gemm_nt2_ok(lda, ldb, M, N, K) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) {
+        // tall NT product whose 256 x 256 tiles fill whole rounds of the chip (fc_pathology: 32 768 x 512 = 256 tiles): the
+        // low-VALU LDS-DMA kernel (linear_nt2.hip)
+        const long tiles = (long)((M + 255) / 256) * (N / 256);
+        const long rounds = (tiles + MIL_NUM_CU - 1) / MIL_NUM_CU;
+        if (tiles >= (3 * MIL_NUM_CU) / 4 && 8 * tiles >= 7 * rounds * MIL_NUM_CU)
+            return mil_gemm_nt2(A, lda, B, ldb, C, ldc, M, N, K, bias, act, stream);
+    }
+#endif
 #if !defined(LG_NO_TILE64)
     if (a_mode == 0) {
         // Tall products take 64 x 128 tiles (gemm64.h: three workgroups per CU = 768 slots) as soon as those fill half

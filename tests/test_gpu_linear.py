@@ -230,3 +230,24 @@ def test_64_row_tiles_for_partial_rounds(M, N, K, b_mode, extras):
     else:
         out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K)
     assert rel_err(out.cpu(), ref.float()) <= 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,act", [(32768, 512, 768, "tanh"), (49152 + 77, 256, 512, "none"), (65536, 512, 64, "relu")])
+def test_tall_nt_product_on_the_low_valu_kernel(M, N, K, act):
+    """mil_gemm_nt2 (256 x 256 tiles, LDS-DMA, csrc/linear_nt2.hip) directly and through mil_gemm's dispatch (fc_pathology's
+    shape is the first case) against torch in float64; a ragged last row tile in the second case."""
+    from mil_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).to("cuda")
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to("cuda")
+    b = torch.randn(N, generator=g).to("cuda")
+    C = torch.empty(M, N, device="cuda")
+    rc = _lib.lib().mil_gemm_nt2(ops._p(A), K, ops._p(W), K, ops._p(C), N, M, N, K, ops._p(b), ops.ACT[act], ops._stream())
+    assert rc == 0
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)]).to("cuda")
+    ref = A[rows].double() @ W.double().T + b.double()
+    ref = torch.tanh(ref) if act == "tanh" else (torch.relu(ref) if act == "relu" else ref)
+    assert float((C[rows].double() - ref).abs().max()) <= 2e-5
+    via = ops.gemm(A, 0, W, 0, M, N, K, bias=b, act=ops.ACT[act])
+    assert float((via[rows].double() - ref).abs().max()) <= 2e-5
+    assert bool(torch.isfinite(C).all())
