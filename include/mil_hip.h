@@ -363,6 +363,22 @@ int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int l
                          const float* W, int ldw, float* dx, int lddx, float* dW, int lddw, float* db, int M, int N,
                          int K, void* stream);
 
+/* The weight / bias gradients of up to MIL_SMALL_DW_MAX few-rows layers in ONE launch: dW_l = (dy_l (.) act'(y_l))^T x_l,
+ * db_l = its column sums (the dW half of mil_linear_small_bwd, for every queued layer at once).  The backward chain of the
+ * token side then only carries the dx launches; the host queues one descriptor per layer and calls this at the end of the
+ * backward pass.  Descriptors are passed by value (kernel arguments). */
+#define MIL_SMALL_DW_MAX 32
+typedef struct mil_small_dw_desc {
+    const float* dy;      /* [M, N] incoming gradient */
+    const float* yv;      /* [M, N] saved output (act 1 tanh, 2 ReLU, 4 sigmoid) or pre-activation (3 QuickGELU); NULL for act 0 */
+    const float* x;       /* [M, K] layer input */
+    float* dW;            /* [N, K] or NULL */
+    float* db;            /* [N] or NULL */
+    int32_t lddy, ldyv, ldx, lddw, act, M, N, K;
+} mil_small_dw_desc;
+int mil_linear_small_dw_grouped(const mil_small_dw_desc* descs, int n, void* stream);
+
+
 /* ---- K2: attention cores, LayerNorm, positional encoding ---------------------------------------
  * softmax(q k^T / sqrt(C)) v per head and per bag, AFTER the q/k/v projections and BEFORE out_proj of
  * model/sam/transformer.py:428-450 (and clip/model.py:171-184 with causal = 1).  q [Tq, H*C], k, v [Tk, H*C]

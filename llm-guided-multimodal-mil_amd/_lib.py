@@ -79,6 +79,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_linear_small_fwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "mil_linear_small_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P,
                                      c_int, c_int, c_int, _P]),
+    "mil_linear_small_dw_grouped": (c_int, [_P, c_int, _P]),
     "mil_attn_rows_fwd": (c_int, [_P] * 6 + [c_int] * 4 + [_P, _P, _P]),
     "mil_attn_rows_bwd": (c_int, [_P] * 9 + [c_int] * 4 + [_P] * 4 + [_P]),
     "mil_attn_pool_fwd_mh": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
@@ -124,6 +125,16 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
 STAGE_DROPBITS, STAGE_GATE_FWD, STAGE_POOL, STAGE_TAIL, STAGE_GATE_BWD, STAGE_REDUCE, STAGE_ADAM = 1, 2, 4, 8, 16, 32, 64
 STAGE_TILEMAP = 0x80
 STAGE_ALL = 0xff
+
+
+class SmallDwDesc(ctypes.Structure):
+    """Mirror of mil_small_dw_desc (include/mil_hip.h); layout checked against the header by tests/test_abi.py."""
+    _fields_ = [("dy", c_void_p), ("yv", c_void_p), ("x", c_void_p), ("dW", c_void_p), ("db", c_void_p),
+                ("lddy", c_int32), ("ldyv", c_int32), ("ldx", c_int32), ("lddw", c_int32), ("act", c_int32),
+                ("M", c_int32), ("N", c_int32), ("K", c_int32)]
+
+
+SMALL_DW_MAX = 32
 
 
 class ImageOnlyStep(ctypes.Structure):

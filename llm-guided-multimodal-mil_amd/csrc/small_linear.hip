@@ -187,6 +187,65 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
     sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, nullptr, SL_NONE, nullptr, 0, dx, lddx);
 }
 
+// Weight / bias gradients of up to MIL_SMALL_DW_MAX few-rows layers in ONE launch (grid.y = layer): the dW role of
+// k_small_bwd, taken out of the layer-by-layer backward chain.  In the backward pass of the token side every layer's dx is
+// needed before the previous layer can start, its dW only by the optimizer: the chain launches dx alone (half the time of
+// the combined launch) and the host queues (dy, y, x, dW, db) of every layer; this kernel forms all of them at the end of
+// the pass.  Descriptors travel as kernel arguments (no device-side table to build or upload).
+struct SmallDwBatch { mil_small_dw_desc d[MIL_SMALL_DW_MAX]; };
+
+__global__ __launch_bounds__(512) void k_small_dw_grouped(const SmallDwBatch batch) {
+    const mil_small_dw_desc& d = batch.d[blockIdx.y];
+    const int M = d.M, N = d.N, K = d.K, act = d.act;
+    const int nKt = (K + 127) / 128;
+    const int nW = ((N + 63) / 64) * nKt;
+    if ((int)blockIdx.x >= nW) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int kt = blockIdx.x % nKt, nt = blockIdx.x / nKt;
+    const int wn = wave >> 2, wk = wave & 3;
+    const int n = 64 * nt + 32 * wn + r, k = 128 * kt + 32 * wk + r;
+    const int nc = min(n, N - 1), kc = min(k, K - 1);
+    const float* __restrict__ dy = d.dy;
+    const float* __restrict__ yv = d.yv;
+    const float* __restrict__ x = d.x;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    const int steps = (M + 1) >> 1;
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+        float fa[16], fb[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int m = 2 * (s0 + u) + h;
+            const int mm = min(m, M - 1);
+            float g = dy[(size_t)mm * d.lddy + nc];
+            if (act != SL_NONE) g = sl_dact(g, yv[(size_t)mm * d.ldyv + nc], act);
+            fa[u] = m < M ? g : 0.f;
+            fb[u] = m < M ? x[(size_t)mm * d.ldx + kc] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            bsum += fa[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
+        }
+    }
+    if (d.dW != nullptr && k < K) {
+        const int nbase = 64 * nt + 32 * wn;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int nn = nbase + mfma32_row(i, h);
+            if (nn < N) d.dW[(size_t)nn * d.lddw + k] = acc[i];
+        }
+    }
+    if (d.db != nullptr && kt == 0 && wk == 0) {
+        const float tot = bsum + __shfl_xor(bsum, 32);
+        if (h == 0 && n < N) d.db[n] = tot;
+    }
+}
+
 static inline bool sl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int mil_linear_small_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias, int act,
@@ -229,6 +288,25 @@ extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or
     else
         hipLaunchKernelGGL((k_small_bwd<SL_WAVES>), grid, dim3(64 * SL_WAVES), 0, st, dy, lddy, y_or_pre, ldyv, act, x, ldx, W,
                            ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_linear_small_dw_grouped(const mil_small_dw_desc* descs, int n, void* stream) {
+    if (n < 0 || n > MIL_SMALL_DW_MAX || (n > 0 && !descs)) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    SmallDwBatch batch;
+    int maxW = 0;
+    for (int i = 0; i < n; ++i) {
+        const mil_small_dw_desc& d = descs[i];
+        if (!d.dy || !d.x || (!d.dW && !d.db) || d.M <= 0 || d.M > MIL_SMALL_ROWS || d.N <= 0 || d.K <= 0 || d.act < 0 || d.act > 4)
+            return MIL_EINVAL;
+        if (d.act != SL_NONE && !d.yv) return MIL_EINVAL;
+        batch.d[i] = d;
+        const int nW = ((d.N + 63) / 64) * ((d.K + 127) / 128);
+        if (nW > maxW) maxW = nW;
+    }
+    hipLaunchKernelGGL(k_small_dw_grouped, dim3(maxW, n), dim3(512), 0, (hipStream_t)stream, batch);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, deferred, sidestream
 from .bags import BagLayout
 
 GATE_D = 192
@@ -649,8 +649,30 @@ class _LinearAct(torch.autograd.Function):
         if ctx.small:
             if dy.data_ptr() % 16:
                 dy = dy.clone()
-            dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                          ctx.has_b and ctx.needs_input_grad[2], W_slot, b_slot)
+            want_dW, want_db = ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
+            if (deferred.enabled() and ctx.needs_input_grad[0] and want_dW and W_slot is not None and
+                    (not want_db or b_slot is not None) and x.shape[1] % 4 == 0):
+                # the previous layer's backward waits for dx only: dx now, the weight / bias gradient with every other
+                # queued layer's in one grouped launch at the end of the pass (deferred.py), straight into the flat buffer.
+                # The queue holds aliases of its own: autograd adopts a returned gradient without a copy only while
+                # nothing else references that tensor object (see grad_slot)
+                dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False)
+                deferred.queue_dw(dy, y, x, W_slot.detach(), (b_slot.detach() if want_db else None), ctx.act)
+                return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None)
+            if (sidestream.enabled() and ctx.needs_input_grad[0] and want_dW and W_slot is not None and
+                    (not want_db or b_slot is not None)):
+                # the next layer's backward waits for dx only: dx on this stream, the weight / bias gradient (written
+                # straight into the flat gradient buffer) beside the chain on the side stream (sidestream.py)
+                dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False)
+                # the side kernel writes through aliases of its own: autograd adopts a returned gradient without a copy only
+                # while nothing else references that tensor object (see grad_slot)
+                W_side, b_side = W_slot.detach(), (b_slot.detach() if want_db else None)
+                act = ctx.act
+                sidestream.run_in_backward(
+                    lambda: linear_small_bwd(dy, y, act, x, W, False, True, want_db, W_side, b_side),
+                    (dy, y, x, W, W_side, b_side))
+                return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None)
+            dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], want_dW, want_db, W_slot, b_slot)
             return dx, dW, db, None, (dy if ctx.has_res else None)
         if ctx.act == ACT["quickgelu"]:
             dpre = torch.empty_like(dy)

@@ -52,19 +52,22 @@ def test_tile_map_ragged():
         assert (tm[bto[b]:bto[b + 1], 0] == b).all()
 
 
-def test_step_struct_layout_matches_the_header(tmp_path):
-    """The ctypes mirror of `mil_image_only_step` against the C compiler's view of include/mil_hip.h."""
+@pytest.mark.parametrize("cname,pyname", [("mil_image_only_step", "ImageOnlyStep"), ("mil_small_dw_desc", "SmallDwDesc")])
+def test_struct_layouts_match_the_header(tmp_path, cname, pyname):
+    """The ctypes mirrors of the C structs (the one-call step, the grouped weight-gradient descriptor) against the C compiler's
+    view of include/mil_hip.h."""
     import ctypes
     import subprocess
-    from mil_amd._lib import ImageOnlyStep, HEADER_PATH
-    fields = [f[0] for f in ImageOnlyStep._fields_]
+    from mil_amd import _lib
+    st = getattr(_lib, pyname)
+    fields = [f[0] for f in st._fields_]
     src = tmp_path / "layout.c"
-    prints = "\n".join(f'    printf("{f} %zu\\n", offsetof(mil_image_only_step, {f}));' for f in fields)
-    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER_PATH}"\nint main(void) {{\n'
-                   f'    printf("sizeof %zu\\n", sizeof(mil_image_only_step));\n{prints}\n    return 0;\n}}\n')
+    prints = "\n".join(f'    printf("{f} %zu\\n", offsetof({cname}, {f}));' for f in fields)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{_lib.HEADER_PATH}"\nint main(void) {{\n'
+                   f'    printf("sizeof %zu\\n", sizeof({cname}));\n{prints}\n    return 0;\n}}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    assert int(out["sizeof"]) == ctypes.sizeof(ImageOnlyStep)
+    assert int(out["sizeof"]) == ctypes.sizeof(st)
     for f in fields:
-        assert int(out[f]) == getattr(ImageOnlyStep, f).offset, f
+        assert int(out[f]) == getattr(st, f).offset, f
