@@ -668,8 +668,18 @@ __global__ __launch_bounds__(1024) void k_layernorm_bagrow_fold(const float* __r
     float v = 0.f;
     if ((int)blockIdx.x < nA) {
         const int c = blockIdx.x * 64 + lane;              // column of the [2 E] row: < E -> dgamma, else dbeta
-        if (c < 2 * E)
-            for (int b = g; b < nb; b += 16) v += part[(size_t)b * st + c];
+        if (c < 2 * E) {
+            float v1 = 0.f, v2 = 0.f, v3 = 0.f;       // four loads in flight per wave (the sums are latency-bound)
+            int b = g;
+            for (; b + 48 < nb; b += 64) {
+                v += part[(size_t)b * st + c];
+                v1 += part[(size_t)(b + 16) * st + c];
+                v2 += part[(size_t)(b + 32) * st + c];
+                v3 += part[(size_t)(b + 48) * st + c];
+            }
+            for (; b < nb; b += 16) v += part[(size_t)b * st + c];
+            v = (v + v1) + (v2 + v3);
+        }
         red[g][lane] = v;
         __syncthreads();
         if (g == 0 && c < 2 * E) {

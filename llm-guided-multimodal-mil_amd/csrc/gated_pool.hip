@@ -2026,6 +2026,19 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
         }
         __syncthreads();
     }
+    // pool term: a_row and the bag of each of the tile's 128 rows, once per workgroup (the staging area is free: the loop's
+    // last barrier has passed)
+    float* s_arow = smem;
+    int* s_bag = reinterpret_cast<int*>(smem + 128);
+    if (dM != nullptr) {
+        if (tid < 128) {
+            const int gr = min(row0 + tid, R - 1);
+            const int bg = row_bag[gr];
+            s_bag[tid] = bg;
+            s_arow[tid] = expf(scores[gr] - lse[bg]);
+        }
+        __syncthreads();
+    }
     // dx += tile: the 16 old values of a tile column are loaded as one batch before the adds
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -2036,21 +2049,11 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
             float cv[16];
             if (dM != nullptr) {
                 const int col = j0 + 64 * wj + 32 * b + r;
-                int bg[16];
-                float ar[16];
+                const int lr0 = 64 * wi + 32 * a;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int gr = min(rbase + mfma32_row(i, h), R - 1);
-                    bg[i] = row_bag[gr];
-                    ar[i] = scores[gr];
-                }
+                for (int i = 0; i < 16; ++i) cv[i] = dM[(size_t)s_bag[lr0 + mfma32_row(i, h)] * L + col];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    cv[i] = dM[(size_t)bg[i] * L + col];
-                    ar[i] = expf(ar[i] - lse[bg[i]]);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) cv[i] *= ar[i];
+                for (int i = 0; i < 16; ++i) cv[i] *= s_arow[lr0 + mfma32_row(i, h)];
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) cv[i] = o[(size_t)min(rbase + mfma32_row(i, h), R - 1) * L];

@@ -913,24 +913,30 @@ class _LayerNorm(torch.autograd.Function):
                                           _p(stats), _stream())
         _lib.check(rc, "mil_layernorm_fwd")
         ctx.save_for_backward(x, gamma, stats)
+        ctx.beta_param = beta               # only to look up its flat-gradient slot in backward
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, stats = ctx.saved_tensors
-        dx, dg, db = _layer_norm_bwd(x, gamma, stats, dy, None, ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dg, db = _layer_norm_bwd(x, gamma, stats, dy, None, ctx.needs_input_grad[1] or ctx.needs_input_grad[2],
+                                     ctx.beta_param)
         return dx, dg, db, None, None
 
 
-def _layer_norm_bwd(x, gamma, stats, dy, dres, want_params: bool):
+def _layer_norm_bwd(x, gamma, stats, dy, dres, want_params: bool, beta=None):
     """dx (+ dres), dgamma, dbeta of a LayerNorm; frozen parameters skip their sums (and the two column-sum launches)."""
     rows, E = x.shape
     dy = _f32c(dy, "dy")
     dx = torch.empty_like(x)
     dg = db = ws = None
     if want_params:
-        dg = torch.empty(E, device=x.device, dtype=torch.float32)
-        db = torch.empty_like(dg)
+        dg = grad_slot(gamma)
+        if dg is None:
+            dg = torch.empty(E, device=x.device, dtype=torch.float32)
+        db = grad_slot(beta) if beta is not None else None
+        if db is None:
+            db = torch.empty(E, device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.lib().mil_layernorm_bwd_blocks(rows) * 2 * E, device=x.device, dtype=torch.float32)
     rc = _lib.lib().mil_layernorm_bwd_res(_p(x), _p(gamma), _p(dy), _p(stats), _p(dres), rows, E, _p(dx), _p(dg), _p(db),
                                           _p(ws), _stream())
@@ -986,6 +992,7 @@ class _LayerNormBagRow(torch.autograd.Function):
                                                  rows, E, eps, _p(y), _p(stats), _stream())
         _lib.check(rc, "mil_layernorm_bagrow_fwd")
         ctx.segs = segs
+        ctx.beta_param = beta
         ctx.save_for_backward(x, o, gamma, stats)
         return y
 
@@ -997,8 +1004,12 @@ class _LayerNormBagRow(torch.autograd.Function):
         rows, E = x.shape
         dx = torch.empty_like(x)
         do = torch.empty_like(o)
-        dg = torch.empty(E, device=x.device, dtype=torch.float32)
-        db = torch.empty_like(dg)
+        dg = grad_slot(gamma)
+        if dg is None:
+            dg = torch.empty(E, device=x.device, dtype=torch.float32)
+        db = grad_slot(ctx.beta_param)
+        if db is None:
+            db = torch.empty(E, device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.lib().mil_layernorm_bwd_blocks(rows) * 4 * E, device=x.device, dtype=torch.float32)
         rc = _lib.lib().mil_layernorm_bagrow_bwd(_p(x), _p(o), _p(segs.q_bag), _p(segs.q_off), segs.B, _p(gamma), _p(dy),
                                                  _p(stats), rows, E, _p(dx), _p(do), _p(dg), _p(db), _p(ws), _stream())
@@ -1302,7 +1313,11 @@ class _AbsorbQuery(torch.autograd.Function):
         E = Wk.shape[1]
         dQp = _f32c(dQp, "dQp")
         dqp = torch.empty_like(qp) if ctx.needs_input_grad[0] else None
-        dWk = torch.empty_like(Wk) if ctx.needs_input_grad[1] else None
+        dWk = None
+        if ctx.needs_input_grad[1]:
+            dWk = grad_slot(Wk)                       # straight into optim.FlatAdam's flat gradient buffer when there is one
+            if dWk is None:
+                dWk = torch.empty_like(Wk)
         rc = _lib.lib().mil_absorb_query_bwd(_p(qp), _p(Wk), _p(dQp), B, ctx.H, I // ctx.H, E, _p(dqp), _p(dWk), _stream())
         _lib.check(rc, "mil_absorb_query_bwd")
         return dqp, dWk, None
@@ -1364,6 +1379,7 @@ class _ValueProj(torch.autograd.Function):
         rc = _lib.lib().mil_value_proj(_p(pooled), _p(Wv), _p(_f32c(bv, "bv")), B, H, I // H, E, _p(o), _stream())
         _lib.check(rc, "mil_value_proj")
         ctx.save_for_backward(pooled, Wv)
+        ctx.bv_param = bv                   # only to look up its flat-gradient slot in backward
         return o
 
     @staticmethod
@@ -1375,10 +1391,12 @@ class _ValueProj(torch.autograd.Function):
         dpooled = torch.empty_like(pooled)
         rc = _lib.lib().mil_absorb_query(_p(do), _p(Wv), B, H, I // H, E, _p(dpooled), _stream())
         _lib.check(rc, "mil_absorb_query")
-        dWv = torch.empty_like(Wv)
+        dWv = grad_slot(Wv)
+        if dWv is None:
+            dWv = torch.empty_like(Wv)
         rc = _lib.lib().mil_absorb_query_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, None, _p(dWv), _stream())
         _lib.check(rc, "mil_absorb_query_bwd")
-        return dpooled, dWv, colsum(do)
+        return dpooled, dWv, colsum(do, out=grad_slot(ctx.bv_param))
 
 
 def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
