@@ -284,6 +284,13 @@ int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b
  * pipeline of the gate forward kernel (256 x 256 tiles, csrc/linear_nt2.hip): what mil_gemm dispatches nn.Linear layers on
  * tall activations to when the tiles fill whole rounds of the chip (fc_pathology, model/aggregator.py:47,141-149).
  * N % 256 == 0, K % 32 == 0, K >= 64, lda / ldw multiples of 4, A and W 16-byte aligned (mil_gemm_nt2_ok). */
+/* The matching weight-gradient product (TN, split over the rows): partial [S][N][K] = sum over a row chunk of
+ * (dY (.) act'(Y))^T X and cs_partial [S][N] = the column sums of the same operand, S = mil_gemm_tn2_splits(rows, N, K);
+ * what mil_linear_bwd_params dispatches to for tall activations with whole 128 x 128 output tiles (mil_gemm_tn2_ok). */
+int mil_gemm_tn2_ok(int lddy, int ldy, int ldx, int rows, int N, int K);
+int mil_gemm_tn2_splits(int rows, int N, int K);
+int mil_gemm_tn2(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows, int N, int K,
+                 float* partial, float* cs_partial, void* stream);
 int mil_gemm_nt2_ok(int lda, int ldw, int M, int N, int K);
 int mil_gemm_nt2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                  const float* bias, int act, void* stream);

@@ -64,6 +64,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
     "mil_gemm_nt2_ok": (c_int, [c_int] * 5),
+    "mil_gemm_tn2_ok": (c_int, [c_int] * 6),
+    "mil_gemm_tn2_splits": (c_int, [c_int] * 3),
+    "mil_gemm_tn2": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "mil_gemm_nt2": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "mil_split_bf16": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "mil_gemm_split": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int,

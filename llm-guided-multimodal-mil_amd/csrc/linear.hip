@@ -606,6 +606,8 @@ extern "C" size_t mil_linear_bwd_params_workspace_floats(int rows, int n_out, in
     int kc;
     int S = splitk_plan(n_out, k_in, rows, 1, &kc);
     if (S < 1) S = 1;
+    const int S2 = mil_gemm_tn2_splits(rows, n_out, k_in);         // the low-VALU kernel's own row split (linear_nt2.hip)
+    if (S2 > S) S = S2;
     return (size_t)S * n_out * k_in + (size_t)S * n_out;
 }
 
@@ -618,6 +620,22 @@ extern "C" int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, 
     if (act != ACT_NONE && Y == nullptr) return MIL_EINVAL;
     if (workspace_floats < mil_linear_bwd_params_workspace_floats(rows, n_out, k_in)) return MIL_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
+#if !defined(LG_NO_TN2)
+    if (mil_gemm_tn2_ok(lddy, Y ? ldy : lddy, ldx, rows, n_out, k_in) &&
+        ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0) {
+        // tall activation, whole 128 x 128 output tiles: the low-VALU split-rows kernel (linear_nt2.hip), same partial layout
+        const int S2 = mil_gemm_tn2_splits(rows, n_out, k_in);
+        float* cs2 = db != nullptr ? workspace + (size_t)S2 * n_out * k_in : nullptr;
+        int rc = mil_gemm_tn2(dY, lddy, act != ACT_NONE ? Y : nullptr, ldy, act, X, ldx, rows, n_out, k_in, workspace, cs2, stream);
+        if (rc != MIL_OK) return rc;
+        const size_t n2 = (size_t)n_out * k_in;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, workspace, S2, dW, lddw, n_out,
+                           k_in, (const float*)nullptr, 0, (const float*)nullptr, 0, accumulate, (float*)nullptr, 0, 0,
+                           (const float*)cs2, db, accumulate);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
+#endif
     int kchunk;
     int S = splitk_plan(n_out, k_in, rows, 1, &kchunk);
     if (S < 1) { S = 1; kchunk = rows; }

@@ -167,3 +167,238 @@ extern "C" int mil_gemm_nt2(const float* A, int lda, const float* W, int ldw, fl
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
+
+// ================================================================================ tall TN products (weight gradients)
+// dW[n][k] = sum_rows G[row][n] X[row][k],  G = dY (.) act'(Y),  plus db[n] = sum_rows G[row][n]: the parameter half of a
+// Linear layer's backward on a tall activation (fc_pathology: 32 768 rows, 512 x 768 outputs), split over the rows.
+// The low-VALU form of k_gate_bwd_dw2 (gated_pool.hip) with both operands staged alike: 512 threads = two K groups x four
+// waves x (2 x 2) MFMA tiles on a 128 (n) x 128 (k) output tile; global operands through buffer resources whose base
+// advances by scalar ALU (rows beyond the chunk read as zeros: no clamps, no masks), LDS images [32 rows][128] with their
+// 32-column blocks in the order {0, 2, 1, 3} so that one ds_read2st64_b32 fetches both operand values of a k-step, staging
+// pieces and reloads pinned between the MFMAs, the two groups' tiles folded through LDS before the 16-byte partial stores.
+// partial [S][N][K] and colsum partial [S][N] are folded by k_splitk_reduce (linear.hip).
+#define TN2_BKR 32
+typedef unsigned int tn2_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int ACT>
+__global__ __launch_bounds__(512) void k_gemm_tn2(const float* __restrict__ dY, int lddy, const float* __restrict__ Y, int ldy,
+                                                  const float* __restrict__ X, int ldx, float* __restrict__ part,
+                                                  float* __restrict__ cs_part, int rows, int N, int K, int KC, int NJ, int NM) {
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * 2 * 2 * TN2_BKR * 128];
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    float* smem = smem_all + grp * (2 * 2 * TN2_BKR * 128);     // this K group's stages: [2][32][128] G, [2][32][128] X
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int jt = bid % NJ, m = (bid / NJ) % NM, s = bid / (NM * NJ);
+    const int j0 = jt * 128, n0 = m * 128;
+    const int cbeg = min(s * KC, rows), cend = min(rows, cbeg + KC);
+    const int half = ((cend - cbeg + 2 * TN2_BKR - 1) / (2 * TN2_BKR)) * TN2_BKR;
+    const int rbeg = min(cend, cbeg + grp * half), rend = min(cend, rbeg + half);
+    const int nloop = (min(half, cend - cbeg) + TN2_BKR - 1) / TN2_BKR;      // common to both groups (shared barriers)
+
+    // per-lane byte offsets inside a slice (loop invariants): rows xrow + 8 i (i < 4), 16-byte chunk xc4 of the 128-column tile
+    const int xrow = tid >> 5, xc4 = tid & 31;
+    int vx[4], vg[4], vy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        vx[i] = ((xrow + 8 * i) * ldx + j0 + 4 * xc4) * 4;
+        vg[i] = ((xrow + 8 * i) * lddy + n0 + 4 * xc4) * 4;
+        vy[i] = ((xrow + 8 * i) * ldy + n0 + 4 * xc4) * 4;
+    }
+    auto blkpos = [](int c) { return (c & 31) | ((c & 32) << 1) | ((c & 64) >> 1); };
+    float* const ab = smem;                       // [2][32][128]
+    float* const xb = smem + 2 * TN2_BKR * 128;   // [2][32][128]
+    float* const xw = xb + xrow * 128 + blkpos(4 * xc4);              // + (buf * 32 + 8 i) * 128
+    float* const aw = ab + xrow * 128 + blkpos(4 * xc4);
+    const float* const ap = ab + h * 128 + 32 * wi + r;               // + buf * 4096 + ks * 256 (+ 64)
+    const float* const bp = xb + h * 128 + 32 * wj + r;
+
+    tn2_u32x4 rx[4], rg[4], ry[4];
+    f32x4 acc_b = {0, 0, 0, 0};
+    const bool pub = jt == 0;                     // this workgroup's G sums are the chunk's bias partials (scalar)
+
+    auto x_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(X + (size_t)row0 * ldx), 0, max(rend - row0, 0) * ldx * 4, NT2_SRD_FLAGS);
+    };
+    auto g_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(dY + (size_t)row0 * lddy), 0, max(rend - row0, 0) * lddy * 4, NT2_SRD_FLAGS);
+    };
+    auto y_srd = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(Y + (size_t)row0 * ldy), 0, max(rend - row0, 0) * ldy * 4, NT2_SRD_FLAGS);
+    };
+    auto xload = [&](int i, int row0) { rx[i] = __builtin_amdgcn_raw_buffer_load_b128(x_srd(row0), vx[i], 0, 0); };
+    auto aload = [&](int i, int row0) {
+        rg[i] = __builtin_amdgcn_raw_buffer_load_b128(g_srd(row0), vg[i], 0, 0);
+        if (ACT != NT2_ACT_NONE) ry[i] = __builtin_amdgcn_raw_buffer_load_b128(y_srd(row0), vy[i], 0, 0);
+    };
+    auto xwrite = [&](int i, int buf) {
+        *reinterpret_cast<f32x4*>(xw + (buf * TN2_BKR + 8 * i) * 128) = __builtin_bit_cast(f32x4, rx[i]);
+    };
+    auto awrite = [&](int i, int buf) {
+        f32x4 g = __builtin_bit_cast(f32x4, rg[i]);
+        if (ACT == NT2_ACT_TANH) {
+            const f32x4 y = __builtin_bit_cast(f32x4, ry[i]);
+            g = g - (g * y) * y;                      // dY (1 - Y^2)
+        } else if (ACT == NT2_ACT_RELU) {
+            const f32x4 y = __builtin_bit_cast(f32x4, ry[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(aw + (buf * TN2_BKR + 8 * i) * 128) = g;
+        if (pub) acc_b += g;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // prologue: slice 0 -> LDS buffer 0, slice 1 -> registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xload(i, rbeg); aload(i, rbeg); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xwrite(i, 0); awrite(i, 0); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xload(i, rbeg + TN2_BKR); aload(i, rbeg + TN2_BKR); }
+    __syncthreads();
+
+    // one slice: 16 k-steps x 4 MFMAs; between the MFMAs the parts that stage slice sl + 1 and reload slice sl + 2
+    auto slice = [&](int sl, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        const int row2 = rbeg + (sl + 2) * TN2_BKR;
+        const float* apb = ap + buf * TN2_BKR * 128;
+        const float* bpb = bp + buf * TN2_BKR * 128;
+        float fa[2][2], fb[2][2];
+        fa[0][0] = apb[0]; fa[0][1] = apb[64]; fb[0][0] = bpb[0]; fb[0][1] = bpb[64];
+#pragma unroll
+        for (int ks = 0; ks < TN2_BKR / 2; ++ks) {
+            const int q = ks & 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < TN2_BKR / 2) {
+                fa[q ^ 1][0] = apb[(ks + 1) * 256]; fa[q ^ 1][1] = apb[(ks + 1) * 256 + 64];
+                fb[q ^ 1][0] = bpb[(ks + 1) * 256]; fb[q ^ 1][1] = bpb[(ks + 1) * 256 + 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks >= 1 && ks <= 4) xwrite(ks - 1, buf ^ 1);
+            if (ks >= 5 && ks <= 8) awrite(ks - 5, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks >= 1 && ks <= 4) xload(ks - 1, row2);
+            if (ks >= 5 && ks <= 8) aload(ks - 5, row2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int sl = 0;
+    for (; sl + 1 < nloop; sl += 2) {
+        slice(sl, std::integral_constant<int, 0>{});
+        __syncthreads();
+        slice(sl + 1, std::integral_constant<int, 1>{});
+        __syncthreads();
+    }
+    if (sl < nloop) {
+        slice(sl, std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+
+    // partial tile -> part[s][n0 + 64 wi + row][j0 + 64 wj + col]: every wave writes its 64 x 64 tile row-major into its own
+    // 16 KB of its group's (now dead) staging area; the two waves that own the same tile (one per K group) each fold and
+    // store half of its rows with 16-byte stores
+    {
+        float* tw = smem + wave * (64 * 64);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tw[(32 * a + mfma32_row(i, h)) * 64 + 32 * b + r] = acc[a][b][i];
+        __syncthreads();
+        float* pt = part + ((size_t)s * N + n0 + 64 * wi) * K + j0 + 64 * wj;
+        const int c4 = lane & 15, rr = lane >> 4;
+        const float* t0 = smem_all + wave * (64 * 64);
+        const float* t1 = smem_all + (2 * 2 * TN2_BKR * 128) + wave * (64 * 64);
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = 4 * (pass + 8 * grp) + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(t0 + row * 64 + 4 * c4) +
+                            *reinterpret_cast<const f32x4*>(t1 + row * 64 + 4 * c4);
+            *reinterpret_cast<f32x4*>(pt + (size_t)row * K + 4 * c4) = v;
+        }
+    }
+    // bias partial of this chunk: cs_part[s][n0 .. n0 + 127] (workgroups with jt == 0)
+    if (pub && cs_part != nullptr) {
+        float* redf = smem_all;                    // [16 row groups][128]
+        const int rowg = xrow + 8 * grp;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) redf[rowg * 128 + 4 * xc4 + e] = acc_b[e];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += redf[g * 128 + threadIdx.x];
+            cs_part[(size_t)s * N + n0 + threadIdx.x] = v;
+        }
+    }
+}
+
+static inline int tn2_plan(int rows, int N, int K, int* KC_out) {
+    const int tiles = (N / 128) * (K / 128);
+    if (tiles <= 0 || rows <= 0) { *KC_out = 2 * TN2_BKR; return 0; }   // not a shape of this kernel
+    int smax = MIL_NUM_CU / tiles;                 // one 512-thread workgroup per CU
+    if (smax < 1) smax = 1;
+    int kc = ((rows + smax - 1) / smax + 2 * TN2_BKR - 1) / (2 * TN2_BKR) * (2 * TN2_BKR);
+    if (kc < 2 * TN2_BKR) kc = 2 * TN2_BKR;
+    *KC_out = kc;
+    return (rows + kc - 1) / kc;
+}
+
+// 1 when mil_linear_bwd_params should take this kernel: whole 128-tiles, a row chunk deep enough for the two K groups, offsets
+// inside 31 bits, and at least 3/4 of the chip busy.
+extern "C" int mil_gemm_tn2_ok(int lddy, int ldy, int ldx, int rows, int N, int K) {
+    if (rows < 4096 || N <= 0 || K <= 0 || (N % 128) != 0 || (K % 128) != 0 || (lddy & 3) || (ldy & 3) || (ldx & 3)) return 0;
+    int kc;
+    const int S = tn2_plan(rows, N, K, &kc);
+    if ((long long)kc * (lddy > ldx ? lddy : ldx) * 4 >= 0x7fff0000ll || (long long)kc * ldy * 4 >= 0x7fff0000ll) return 0;
+    if ((long)S * (N / 128) * (K / 128) * 4 < 3 * MIL_NUM_CU || kc < 512) return 0;
+    return 1;
+}
+extern "C" int mil_gemm_tn2_splits(int rows, int N, int K) {
+    if (rows <= 0 || N < 128 || K < 128 || (N % 128) != 0 || (K % 128) != 0) return 0;
+    int kc;
+    return tn2_plan(rows, N, K, &kc);
+}
+
+extern "C" int mil_gemm_tn2(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows,
+                            int N, int K, float* partial, float* cs_partial, void* stream) {
+    if (!dY || !X || !partial || !mil_gemm_tn2_ok(lddy, ldy, ldx, rows, N, K)) return MIL_EINVAL;
+    if (act != NT2_ACT_NONE && act != NT2_ACT_TANH && act != NT2_ACT_RELU) return MIL_EINVAL;
+    if (act != NT2_ACT_NONE && !Y) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) return MIL_EINVAL;
+    int kc;
+    const int S = tn2_plan(rows, N, K, &kc);
+    const int NM = N / 128, NJ = K / 128;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(S * NM * NJ);
+    switch (act) {
+        case NT2_ACT_TANH: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_TANH>, grid, dim3(512), 0, st, dY, lddy, Y, ldy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM); break;
+        case NT2_ACT_RELU: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_RELU>, grid, dim3(512), 0, st, dY, lddy, Y, ldy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM); break;
+        default: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_NONE>, grid, dim3(512), 0, st, dY, lddy, Y ? Y : dY, Y ? ldy : lddy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM); break;
+    }
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

@@ -251,3 +251,23 @@ def test_tall_nt_product_on_the_low_valu_kernel(M, N, K, act):
     via = ops.gemm(A, 0, W, 0, M, N, K, bias=b, act=ops.ACT[act])
     assert float((via[rows].double() - ref).abs().max()) <= 2e-5
     assert bool(torch.isfinite(C).all())
+
+
+@pytest.mark.parametrize("rows,N,K,act", [(32768, 512, 768, "tanh"), (40000 + 13, 256, 256, "none"), (32768, 512, 512, "relu")])
+def test_weight_gradient_of_a_tall_activation_on_the_low_valu_kernel(rows, N, K, act):
+    """ops.linear_bwd_params at fc_pathology's size (and two more): dispatched to k_gemm_tn2 (csrc/linear_nt2.hip), checked
+    against float64 - dW = (dY (.) act'(Y))^T X and db = the column sums."""
+    g = torch.Generator().manual_seed(5)
+    dy = (torch.randn(rows, N, generator=g) * 1e-2).to("cuda")
+    x = torch.randn(rows, K, generator=g).to("cuda")
+    pre = torch.randn(rows, N, generator=g).to("cuda")
+    y = torch.tanh(pre) if act == "tanh" else (torch.relu(pre) if act == "relu" else None)
+    dW, db = ops.linear_bwd_params(dy, y, ops.ACT[act], x)
+    G = dy.double()
+    if act == "tanh":
+        G = G * (1 - y.double() ** 2)
+    elif act == "relu":
+        G = G * (y > 0).double()
+    refW, refb = G.T @ x.double(), G.sum(0)
+    assert rel_err(dW.double(), refW) <= 2e-5
+    assert rel_err(db.double(), refb) <= 2e-5
