@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 
 // ---------------------------------------------------------------------------------------------------- pool stages, bf16 x
 // Lane l owns the 8 columns 8l + 512q of a row (16-byte loads); NQ = L / 512.
-template <int NQ>
+template <int NQ, bool DROP>     // DROP: train mode (keep-bit tensors); the eval instantiation carries none of it
 __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict__ x, const float* __restrict__ scores,
                                                            const int32_t* __restrict__ tile_map,
                                                            float* __restrict__ partials, int L,
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         const u16* xr = x + (size_t)(row0 + rr) * L + 8 * lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const u16x8*>(xr + 512 * q);
-        if (xbits != nullptr) {
+        if (DROP && xbits != nullptr) {
             const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 2);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) v[i][q] = keep_bf16x8(v[i][q], mr[16 * q] >> (8 * (lane & 3)));
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
     }
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const float p = p_lds[wave + 4 * i] * xscale;
+        const float p = DROP ? p_lds[wave + 4 * i] * xscale : p_lds[wave + 4 * i];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane);
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wf + (size_t)c * L + 512 * q + 8 * lane + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { wf[q][e] = w0[e] * xscale; wf[q][4 + e] = w1[e] * xscale; }
-            if (mbits != nullptr) {
+            for (int e = 0; e < 4; ++e) { wf[q][e] = DROP ? w0[e] * xscale : w0[e]; wf[q][4 + e] = DROP ? w1[e] * xscale : w1[e]; }
+            if (DROP && mbits != nullptr) {
                 const unsigned mm = mbits[(size_t)bag_ * (L >> 5) + 16 * q + (lane >> 2)] >> (8 * (lane & 3));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) wf[q][e] = ((mm >> e) & 1u) ? wf[q][e] * mscale : 0.f;
@@ -725,6 +725,7 @@ __device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
 //     (the bf16 MFMA hides VALU and LDS-write issue, unlike the f32 one).
 // Round 1 ran 2 x 256 threads per CU on 32-row slices: 200 us + reduce at config 5.
 #define WB_BKR 64
+template <bool DROP>      // DROP: train mode, x read through the keep bits (templated: the eval kernel is the one tuned above)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const u16* __restrict__ gates,
                                                           const float* __restrict__ ds, const float* __restrict__ wvec,
                                                           float* __restrict__ part, float* __restrict__ pbias, int R, int L,
@@ -761,16 +762,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
     float acc_ds = 0.f;
 
-    unsigned rxm[8];
+    unsigned rxm[DROP ? 8 : 1];
     auto xload = [&](int i, int rs) {
         const int gr = min(rs + xrow + 8 * i, rend - 1);
         rx[i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
-        if (xbits != nullptr) rxm[i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
+        if (DROP) rxm[i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
     };
     auto xwrite = [&](int i, int buf) {
         // columns 0..127 -> panel 0, 128..255 -> panel 1 (each panel is its own 160-stride image)
         u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
-        *reinterpret_cast<u16x8*>(dst) = xbits != nullptr ? keep_bf16x8(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
+        *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
     };
     auto aload = [&](int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
@@ -1134,14 +1135,29 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
     return MIL_OK;
 }
 
+// eval / train instantiations: the eval kernels carry no trace of the keep-bit handling (templated, not branched: the
+// branched form cost the eval-mode pool pass 16 us at config 5)
+static void launch_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
+                                     float* partials, const float* Wf, int C, float* hrow, const uint32_t* xbits, float xscale,
+                                     const uint32_t* mbits, float mscale, hipStream_t st) {
+    const bool drop = xbits != nullptr || mbits != nullptr;
+    const float xs = xbits ? xscale : 1.0f, ms = mbits ? mscale : 1.0f;
+    if (L == 512) {
+        if (drop) hipLaunchKernelGGL((k_pool_partial_bf16<1, true>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xs, mbits, ms);
+        else hipLaunchKernelGGL((k_pool_partial_bf16<1, false>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, 1.0f, mbits, 1.0f);
+    } else {
+        if (drop) hipLaunchKernelGGL((k_pool_partial_bf16<2, true>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xs, mbits, ms);
+        else hipLaunchKernelGGL((k_pool_partial_bf16<2, false>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, 1.0f, mbits, 1.0f);
+    }
+}
+
 extern "C" int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
                                           float* partials, const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !scores || !tile_map || !partials) return MIL_EINVAL;
     if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr, xbits, xbits ? xscale : 1.0f, (const uint32_t*)nullptr, 1.0f);
-    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, (const float*)nullptr, 0, (float*)nullptr, xbits, xbits ? xscale : 1.0f, (const uint32_t*)nullptr, 1.0f);
+    launch_pool_partial_bf16(x, scores, tile_map, T, L, partials, nullptr, 0, nullptr, xbits, xscale, nullptr, 1.0f, st);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1153,8 +1169,7 @@ extern "C" int mil_attn_pool_partial_h_bf16(const uint16_t* x, const float* scor
     if (L <= 0 || (L % 512) != 0 || L > 1024 || T < 0 || C <= 0 || C > 4) return MIL_EINVAL;
     if (T == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (L == 512) hipLaunchKernelGGL(k_pool_partial_bf16<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xbits ? xscale : 1.0f, mbits, mbits ? mscale : 1.0f);
-    else hipLaunchKernelGGL(k_pool_partial_bf16<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xbits ? xscale : 1.0f, mbits, mbits ? mscale : 1.0f);
+    launch_pool_partial_bf16(x, scores, tile_map, T, L, partials, Wf, C, hrow, xbits, xscale, mbits, mscale, st);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1208,7 +1223,10 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates
         hipLaunchKernelGGL(k_gate_bwd_dw_bf16_rs, dim3(S * 3 * NJ), dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
     else
 #endif
-    hipLaunchKernelGGL(k_gate_bwd_dw_bf16, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    if (xbits != nullptr)
+        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<true>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    else
+        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<false>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
     MIL_CHECK_LAUNCH();
     const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, S, L, dWv, dbv, dWu,
