@@ -49,7 +49,8 @@ def queue_dw(dy, yv, x, dW, db, act: int) -> None:
     """Queue dW = (dy (.) act'(yv))^T x, db = its column sums; the tensors are held until the flush.  Call from inside a
     backward pass only (the flush is an end-of-backward callback of the autograd engine)."""
     global _armed
-    _queue.append((dy, yv if act != 0 else None, x, dW, db, act))
     if not _armed:
+        _queue.clear()                # leftovers of a backward pass that raised before its callback ran
         _armed = True
         torch.autograd.Variable._execution_engine.queue_callback(flush)
+    _queue.append((dy, yv if act != 0 else None, x, dW, db, act))

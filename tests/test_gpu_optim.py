@@ -130,3 +130,35 @@ def test_flat_adam_large_buffer_path():
             o.step()
     for (k, a), b in zip(ref.named_parameters(), ours.parameters()):
         assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(a.detach().abs().max())), k
+
+
+def test_deferred_grouped_weight_gradients_equal_the_per_layer_ones(monkeypatch):
+    """deferred.py: with FlatAdam's gradient slots the few-rows layers launch dx alone and one grouped launch forms every
+    dW / db at the end of the backward pass - same numbers as the per-layer launches (MIL_DEFER_DW=0), bit for bit."""
+    import torch.nn as nn
+    from mil_amd import ops
+    from mil_amd.optim import FlatAdam
+
+    def run(defer):
+        monkeypatch.setenv("MIL_DEFER_DW", "1" if defer else "0")
+        torch.manual_seed(0)
+        layers = [nn.Linear(512, 512), nn.Linear(512, 2048), nn.Linear(2048, 512), nn.Linear(512, 256)]
+        layers = [l.to("cuda") for l in layers]
+        acts = ["tanh", "relu", "none", "none"]
+        opt = FlatAdam([p for l in layers for p in l.parameters()], lr=1e-3)
+        x = torch.randn(32, 512, generator=torch.Generator().manual_seed(1)).to("cuda").requires_grad_(True)
+        h = x
+        for l, a in zip(layers, acts):
+            h = ops.linear_act(h, l.weight, l.bias, a)
+        opt.zero_grad()
+        (h * h).sum().backward()
+        torch.cuda.synchronize()
+        grads = [p.grad.clone() for l in layers for p in l.parameters()] + [x.grad.clone()]
+        in_slot = all(p.grad.data_ptr() == p._mil_grad.data_ptr() for l in layers for p in l.parameters())
+        return grads, in_slot
+
+    g1, slot1 = run(True)
+    g0, slot0 = run(False)
+    assert slot1 and slot0
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
