@@ -424,21 +424,12 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
     const int t = blockIdx.x;
     const int row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
 
-    if (wave == 0) {
-        const float s = lane < nrows ? scores[row0 + lane] : -INFINITY;
-        const float m = wave_allmax(s);
-        const float p = lane < nrows ? expf(s - m) : 0.f;
-        const float l = wave_allsum(p);
-        if (lane < MIL_POOL_TILE) p_lds[lane] = p;
-        if (lane == 0) { ml_lds[0] = m; ml_lds[1] = l; }
-    }
-    __syncthreads();
-
     f32x4 acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0, 0, 0, 0};
     // Rows past the tile end are clamped to its last row and carry weight 0 (p_lds is 0 there): the
-    // loop is branch-free, so all 8 x NQ 16-byte loads of a wave are in flight together.
+    // loop is branch-free, so all 8 x NQ 16-byte loads of a wave are in flight together - and they are issued BEFORE the
+    // tile's softmax weights are formed (below), whose score load + two wave reductions then run under the x stream.
     f32x4 v[MIL_POOL_TILE / 4][NQ];
     unsigned mk[MIL_POOL_TILE / 4][NQ];
 #pragma unroll
@@ -453,6 +444,15 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
             for (int q = 0; q < NQ; ++q) mk[i][q] = mr[8 * q];
         }
     }
+    if (wave == 0) {
+        const float s = lane < nrows ? scores[row0 + lane] : -INFINITY;
+        const float m = wave_allmax(s);
+        const float p = lane < nrows ? expf(s - m) : 0.f;
+        const float l = wave_allsum(p);
+        if (lane < MIL_POOL_TILE) p_lds[lane] = p;
+        if (lane == 0) { ml_lds[0] = m; ml_lds[1] = l; }
+    }
+    __syncthreads();
     if (xbits != nullptr) {
         const int sh = 4 * (lane & 7);
 #pragma unroll
