@@ -546,6 +546,9 @@ def run_rank(args):
                                     "traffic": _pmc_traffic("cfg2_" + dom) if (B, N, L) == (32, 1024, 512) else None,
                                     "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
             line["kernels_ms"] = {k: round(v, 4) for k, v in kb.items()}
+            line["kernels_ms_note"] = ("each launch group timed stand-alone through mil_image_only_step_time; in the step itself "
+                                       "the keep bits are drawn by gate_fwd, and at world size 1 Adam is applied inside the "
+                                       "reduce launch (no separate adam launch)")
             line["kernels_tflops"] = {k: round(flops[k] / (kb[k] * 1e-3) / 1e12, 2) for k in flops}
             if args.train_mode and args.dtype == "f32" and world == 1:
                 # the same launches without dropout (model.eval() arithmetic): the keep-bit selects of train mode are work

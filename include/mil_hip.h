@@ -214,6 +214,17 @@ int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, float* dWv, f
                              float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
                              float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out, void* stream);
 
+/* mil_gate_bwd_reduce_head with torch.optim.Adam (train_ddp.py:115-118) applied by the very threads that produce the final
+ * gradients - valid when nothing sits between gradient and update (world size 1).  dWv .. dbf must lie inside
+ * grad_flat [n_param]; param_flat / exp_avg / exp_avg_sq are indexed alike; step >= 1.  One launch less per step. */
+int mil_gate_bwd_reduce_head_adam(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                                  float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
+                                  float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                                  float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
+                                  float* exp_avg_sq, int step, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, float grad_scale, void* stream);
+
+
 /* Input gradient through the gate (needed when the bag is itself a computed tensor, i.e.
  * the fused text+image path): dx += dPreV Wv + dPreU Wu. */
 /* With xbits this launch, the last writer of dx, also applies the backward of the patch dropout: dx = keep ? dx * xscale : 0. */

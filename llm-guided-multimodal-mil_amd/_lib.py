@@ -48,6 +48,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_build_tile_map": (c_int, [_P, c_int, _P, _P, _P, c_int, _P]),
     "mil_gate_bwd_reduce": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float, _P]),
     "mil_gate_bwd_reduce_head": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float] + [_P] * 4 + [c_int, c_int, _P, _P, _P]),
+    "mil_gate_bwd_reduce_head_adam": (c_int, [_P, c_int, c_int] + [_P] * 6 + [c_int, c_float] + [_P] * 4 + [c_int, c_int, _P, _P]
+                                      + [_P, _P, c_size_t, _P, _P, c_int] + [c_float] * 6 + [_P]),
     "mil_gate_bwd_input": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
     "mil_gate_bwd_input_pool": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "mil_image_only_step_run": (c_int, [_P, _P]),

@@ -19,7 +19,8 @@ struct HeadBwdArgs {
     int B, L, C;
     int accumulate;             // != 0: add to dWf / dbf / loss_out (gradient accumulation over micro-batches)
 };
-static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& a, int blk, float (*red)[64]) {
+static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& a, int blk, float (*red)[64],
+                                                             const AdamFuse& ad) {
     const int nlb = (a.L + 63) / 64;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     if (blk < a.C * nlb) {
@@ -31,15 +32,19 @@ static __device__ __forceinline__ void head_bwd_params_block(const HeadBwdArgs& 
         __syncthreads();
         if (g == 0 && j < a.L) {
             float* o = a.dWf + (size_t)c * a.L + j;
-            const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-            *o = a.accumulate ? *o + t : t;
+            float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            if (a.accumulate) t += *o;
+            *o = t;
+            adam_fused(ad, o, t);
         }
     } else {
         if ((int)threadIdx.x < a.C) {
             const int c = threadIdx.x;
             float v = 0.f;
             for (int b = 0; b < a.B; ++b) v += a.dz[b * a.C + c];
-            a.dbf[c] = a.accumulate ? a.dbf[c] + v : v;
+            if (a.accumulate) v += a.dbf[c];
+            a.dbf[c] = v;
+            adam_fused(ad, a.dbf + c, v);
         }
         if (a.loss_bag != nullptr && g == 1) {
             float v = 0.f;
@@ -61,10 +66,10 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
                                                                 float* __restrict__ dWu, float* __restrict__ dbu,
                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate,
                                                                 float wscale, int head_first = 1 << 30,
-                                                                HeadBwdArgs head = HeadBwdArgs{}) {
+                                                                HeadBwdArgs head = HeadBwdArgs{}, AdamFuse ad = AdamFuse{}) {
     if ((int)blockIdx.x >= head_first) {          // appended workgroups: the head's parameter gradients (uniform branch)
         __shared__ float hred[4][64];
-        head_bwd_params_block(head, blockIdx.x - head_first, hred);
+        head_bwd_params_block(head, blockIdx.x - head_first, hred, ad);
         return;
     }
     const int L4 = L / 4;
@@ -89,6 +94,7 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
         float* dst = (ii < 64 ? dWv + (size_t)(64 * m + ii) * L : dWu + (size_t)(64 * m + ii - 64) * L) + 4 * c4;
         if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
+        adam_fused4(ad, dst, v);
     } else if (idx < nW + GR_NB * (3 * 192 + 1)) {
         // bias / w / b: GR_NB lanes per output, each sums every GR_NB-th slab (loads in flight), then a fixed-order
         // shuffle fold.  (One thread per output walked the S * NJ slabs of the low-VALU kernel serially: 9.5 us.)
@@ -102,5 +108,6 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
         float* dst = which == 0 ? dbv + d : which == 1 ? dbu + d : which == 2 ? dw + d : db;
         if (accumulate) v += *dst;
         *dst = v;
+        adam_fused(ad, dst, v);
     }
 }

@@ -1871,6 +1871,44 @@ extern "C" int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, fl
     return MIL_OK;
 }
 
+// mil_gate_bwd_reduce_head with Adam applied by the threads that produce the final gradients (world size 1: nothing sits
+// between the gradient and the update): param_flat / exp_avg / exp_avg_sq are indexed like grad_flat, in which dWv .. dbf all
+// lie; `step` >= 1 is the update's number (bias corrections on the host).  Saves the Adam launch of the image-only step.
+extern "C" int mil_gate_bwd_reduce_head_adam(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu,
+                                             float* dbu, float* dw, float* db, int accumulate, float xscale, const float* dz,
+                                             const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag,
+                                             float* loss_out, float* param_flat, const float* grad_flat, size_t n_param,
+                                             float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2,
+                                             float eps, float weight_decay, float grad_scale, void* stream) {
+    if (!workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
+    if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || step < 1) return MIL_EINVAL;
+    if (L <= 0 || (L % 128) != 0 || R <= 0 || B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
+    // every gradient this launch produces must lie inside the flat buffer (16-byte aligned where it is stored as float4)
+    const float* outs[8] = {dWv, dbv, dWu, dbu, dw, db, dWf, dbf};
+    const size_t lens[8] = {(size_t)192 * L, 192, (size_t)192 * L, 192, 192, 1, (size_t)C * L, (size_t)C};
+    for (int i = 0; i < 8; ++i)
+        if (outs[i] < grad_flat || outs[i] + lens[i] > grad_flat + n_param) return MIL_EINVAL;
+    if (((dWv - grad_flat) | (dWu - grad_flat)) & 3) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param_flat) | reinterpret_cast<uintptr_t>(grad_flat) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return MIL_EINVAL;
+    int kc;
+    const int S = split_plan(R, L, &kc);
+    const int nthreads = GF_NG * (L / 4) + GR_NB * (3 * 192 + 1);
+    const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
+    const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    // the same single-precision quotient k_adam forms (lr / (float)bc1): the two routes stay bit-identical
+    const AdamFuse ad{param_flat, grad_flat, exp_avg, exp_avg_sq, lr / (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
+                      (float)sqrt(bc2)};
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
+                       workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
+                       accumulate, xscale, nred, head, ad);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_gate_bwd_params(const float* x, const float* gates, const float* ds, const float* w, int R, int L,
                                    int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
                                    float* dWu, float* dbu, float* dw, float* db, int accumulate, const uint32_t* xbits,

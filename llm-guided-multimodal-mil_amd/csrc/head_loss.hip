@@ -133,16 +133,6 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
 // torch.optim.Adam, weight decay folded into the gradient (L2), bias-corrected.  Four elements per thread; the
 // bias corrections come from the host (step known there) or, for a step that is replayed from a hipGraph, from
 // a device-side counter (step_dev holds the number of steps ALREADY taken).
-__device__ __forceinline__ float adam_one(float& pi, float gi, float& mi, float& vi, float lr_bc1, float b1, float b2,
-                                          float eps, float wd, float gscale, float bc2_sqrt) {
-    const float g = gi * gscale + wd * pi;
-    mi = b1 * mi + (1.0f - b1) * g;
-    vi = b2 * vi + (1.0f - b2) * g * g;
-    // torch: denom = sqrt(v)/sqrt(bc2) + eps; param -= (lr / bc1) * m / denom
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi = pi - lr_bc1 * (mi / denom);
-    return pi;
-}
 
 template <int AD_U>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,

@@ -112,6 +112,56 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// torch.optim.Adam on one element (L2 weight decay folded into the gradient, bias-corrected, eps outside the sqrt);
+// train_ddp.py:115-118.  lr_bc1 = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).
+__device__ __forceinline__ float adam_one(float& pi, float gi, float& mi, float& vi, float lr_bc1, float b1, float b2,
+                                          float eps, float wd, float gscale, float bc2_sqrt) {
+    // every product / sum pinned (no compiler-chosen FMA contraction): the stand-alone Adam kernel and the reduce kernel
+    // that applies Adam on the spot (AdamFuse) must produce the same bits
+    const float g = __fmaf_rn(wd, pi, __fmul_rn(gi, gscale));
+    mi = __fmaf_rn(b1, mi, __fmul_rn(1.0f - b1, g));
+    vi = __fmaf_rn(b2, vi, __fmul_rn(__fmul_rn(1.0f - b2, g), g));
+    // torch: denom = sqrt(v)/sqrt(bc2) + eps; param -= (lr / bc1) * m / denom
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+    pi = __fsub_rn(pi, __fmul_rn(lr_bc1, __fdiv_rn(mi, denom)));
+    return pi;
+}
+
+// Adam applied by the kernel that PRODUCES the final gradient (the split-K reduce of the image-only step at world size 1: no
+// all-reduce between gradient and update): the thread that stores gradient element i of the flat buffer updates parameter i
+// and its moments on the spot - one launch less per step.  param == NULL: off.
+struct AdamFuse {
+    float* param;             // flat parameters
+    const float* grad_base;   // flat gradients: index = (address the gradient is stored at) - grad_base
+    float* m;
+    float* v;
+    float lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt;
+};
+__device__ __forceinline__ void adam_fused(const AdamFuse& ad, const float* gptr, float g) {
+    if (ad.param == nullptr) return;
+    const size_t i = (size_t)(gptr - ad.grad_base);
+    float p = ad.param[i], m = ad.m[i], v = ad.v[i];
+    adam_one(p, g, m, v, ad.lr_bc1, ad.b1, ad.b2, ad.eps, ad.wd, ad.gscale, ad.bc2_sqrt);
+    ad.param[i] = p;
+    ad.m[i] = m;
+    ad.v[i] = v;
+}
+__device__ __forceinline__ void adam_fused4(const AdamFuse& ad, const float* gptr, f32x4 g) {
+    if (ad.param == nullptr) return;
+    const size_t i = (size_t)(gptr - ad.grad_base);
+    f32x4 p = *reinterpret_cast<const f32x4*>(ad.param + i), m = *reinterpret_cast<const f32x4*>(ad.m + i),
+          v = *reinterpret_cast<const f32x4*>(ad.v + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float pe = p[e], me = m[e], ve = v[e];
+        adam_one(pe, g[e], me, ve, ad.lr_bc1, ad.b1, ad.b2, ad.eps, ad.wd, ad.gscale, ad.bc2_sqrt);
+        p[e] = pe; m[e] = me; v[e] = ve;
+    }
+    *reinterpret_cast<f32x4*>(ad.param + i) = p;
+    *reinterpret_cast<f32x4*>(ad.m + i) = m;
+    *reinterpret_cast<f32x4*>(ad.v + i) = v;
+}
+
 // Row of a 32x32 MFMA accumulator register: C/D layout col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (dtype independent on gfx950).
 __device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }

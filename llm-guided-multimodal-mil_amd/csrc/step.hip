@@ -32,6 +32,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     const uint32_t* xbits = train ? a->xbits : nullptr;
     const uint32_t* mbits = train ? a->mbits : nullptr;
     const bool use_h = a->hrow != nullptr && grads && a->C <= 4;
+    bool adam_in_reduce = false;
 
     if ((st & MIL_STAGE_TILEMAP) && a->bag_len_dev) {
         rc = mil_build_tile_map(a->bag_len_dev, a->B, const_cast<int32_t*>(a->tile_map), const_cast<int32_t*>(a->bag_tile_off),
@@ -122,12 +123,23 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
             if (rc != MIL_OK) return rc;
         }
         if (st & MIL_STAGE_REDUCE) {
-            rc = mil_gate_bwd_reduce_head(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db, a->accumulate,
-                                          xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag, a->loss_out, stream);
+            // reduce and Adam in ONE launch when both stages run in this call with a host-side step number (world size 1,
+            // no all-reduce in between): the threads that store the final gradients update their parameters on the spot
+            adam_in_reduce = (st & MIL_STAGE_ADAM) && !a->adam_step_dev && a->param_flat && a->grad_flat && a->exp_avg &&
+                             a->exp_avg_sq && a->adam_step >= 1;
+            if (adam_in_reduce)
+                rc = mil_gate_bwd_reduce_head_adam(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
+                                                   a->accumulate, xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag,
+                                                   a->loss_out, a->param_flat, a->grad_flat, (size_t)a->n_param, a->exp_avg,
+                                                   a->exp_avg_sq, a->adam_step, a->lr, a->beta1, a->beta2, a->eps,
+                                                   a->weight_decay, a->grad_scale, stream);
+            else
+                rc = mil_gate_bwd_reduce_head(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db, a->accumulate,
+                                              xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag, a->loss_out, stream);
             if (rc != MIL_OK) return rc;
         }
     }
-    if (st & MIL_STAGE_ADAM) {
+    if ((st & MIL_STAGE_ADAM) && !adam_in_reduce) {
         if (!a->param_flat || !a->grad_flat || !a->exp_avg || !a->exp_avg_sq) return MIL_EINVAL;
         if (a->adam_step_dev)
             rc = mil_adam_step_counted(a->param_flat, a->grad_flat, a->exp_avg, a->exp_avg_sq, (size_t)a->n_param,
