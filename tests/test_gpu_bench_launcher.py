@@ -39,19 +39,22 @@ def test_one_rank_through_rccl_reports_the_collective():
     assert line["rccl"]["allreduce_us"] > 0
 
 
-def test_two_ranks_rehearsal_equals_the_single_process_step(tmp_path):
+@pytest.mark.parametrize("W", [2, 4])
+def test_ranks_rehearsal_equals_the_single_process_step(tmp_path, W):
+    """W ranks started by bench.py itself, all on GPU 0 over gloo (rehearsal; 4 ranks stay inside the box's limit of 6
+    processes on the card): the all-reduced gradient and loss equal ONE process on the union of the ranks' bags."""
     dump = str(tmp_path / "g.pt")
-    line = bench("--gpus", "2", *SMALL, "--train-mode", "0", "--dump", dump, env={"MIL_BENCH_REHEARSAL": "1"})
-    assert line["n_gpus"] == 2 and line["config"]["global_bags"] == 8
-    assert line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"          # rehearsal: both ranks on GPU 0
+    line = bench("--gpus", str(W), *SMALL, "--train-mode", "0", "--dump", dump, env={"MIL_BENCH_REHEARSAL": "1"})
+    assert line["n_gpus"] == W and line["config"]["global_bags"] == 4 * W
+    assert line["rccl"]["world_size"] == W and line["rccl"]["backend"] == "gloo"          # rehearsal: every rank on GPU 0
     got = torch.load(dump, weights_only=True)
-    # the same 8 bags (rank r draws make_bags(4321 + r) / make_labels(99 + r)) in ONE process
+    # the same bags (rank r draws make_bags(4321 + r) / make_labels(99 + r)) in ONE process
     dev = torch.device("cuda")
     B, N, L = 4, 128, 512
-    x = torch.cat([syn.make_bags(4321 + r, B, N, L).reshape(B * N, L) for r in range(2)], 0).to(dev)
-    y = torch.cat([syn.make_labels(99 + r, B, 2) for r in range(2)], 0).to(dev)
+    x = torch.cat([syn.make_bags(4321 + r, B, N, L).reshape(B * N, L) for r in range(W)], 0).to(dev)
+    y = torch.cat([syn.make_labels(99 + r, B, 2) for r in range(W)], 0).to(dev)
     tr = ImageOnlyTrainer(syn.image_only_params(1234, L=L), dev)
-    tr.forward(x, BagLayout.uniform(2 * B, N, dev), y)
+    tr.forward(x, BagLayout.uniform(W * B, N, dev), y)
     tr.backward()
     assert abs(float(tr.loss_sum.item()) - got["loss"]) <= 1e-6
     assert rel_err(got["grad"], tr.fp.grad.cpu()) <= 1e-5
