@@ -192,17 +192,22 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
 // needed before the previous layer can start, its dW only by the optimizer: the chain launches dx alone (half the time of
 // the combined launch) and the host queues (dy, y, x, dW, db) of every layer; this kernel forms all of them at the end of
 // the pass.  Descriptors travel as kernel arguments (no device-side table to build or upload).
-struct SmallDwBatch { mil_small_dw_desc d[MIL_SMALL_DW_MAX]; };
+struct SmallDwBatch {
+    mil_small_dw_desc d[MIL_SMALL_DW_MAX];
+    int first[MIL_SMALL_DW_MAX + 1];          // first workgroup of every layer (prefix sums of the tile counts): no idle workgroups
+    int n;
+};
 
 __global__ __launch_bounds__(512) void k_small_dw_grouped(const SmallDwBatch batch) {
-    const mil_small_dw_desc& d = batch.d[blockIdx.y];
+    int layer = 0;
+    while (layer + 1 < batch.n && (int)blockIdx.x >= batch.first[layer + 1]) ++layer;      // <= 31 scalar steps
+    const mil_small_dw_desc& d = batch.d[layer];
+    const int wg = (int)blockIdx.x - batch.first[layer];
     const int M = d.M, N = d.N, K = d.K, act = d.act;
     const int nKt = (K + 127) / 128;
-    const int nW = ((N + 63) / 64) * nKt;
-    if ((int)blockIdx.x >= nW) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int kt = blockIdx.x % nKt, nt = blockIdx.x / nKt;
+    const int kt = wg % nKt, nt = wg / nKt;
     const int wn = wave >> 2, wk = wave & 3;
     const int n = 64 * nt + 32 * wn + r, k = 128 * kt + 32 * wk + r;
     const int nc = min(n, N - 1), kc = min(k, K - 1);
@@ -296,17 +301,19 @@ extern "C" int mil_linear_small_dw_grouped(const mil_small_dw_desc* descs, int n
     if (n < 0 || n > MIL_SMALL_DW_MAX || (n > 0 && !descs)) return MIL_EINVAL;
     if (n == 0) return MIL_OK;
     SmallDwBatch batch;
-    int maxW = 0;
+    int total = 0;
+    batch.n = n;
     for (int i = 0; i < n; ++i) {
         const mil_small_dw_desc& d = descs[i];
         if (!d.dy || !d.x || (!d.dW && !d.db) || d.M <= 0 || d.M > MIL_SMALL_ROWS || d.N <= 0 || d.K <= 0 || d.act < 0 || d.act > 4)
             return MIL_EINVAL;
         if (d.act != SL_NONE && !d.yv) return MIL_EINVAL;
         batch.d[i] = d;
-        const int nW = ((d.N + 63) / 64) * ((d.K + 127) / 128);
-        if (nW > maxW) maxW = nW;
+        batch.first[i] = total;
+        total += ((d.N + 63) / 64) * ((d.K + 127) / 128);
     }
-    hipLaunchKernelGGL(k_small_dw_grouped, dim3(maxW, n), dim3(512), 0, (hipStream_t)stream, batch);
+    batch.first[n] = total;
+    hipLaunchKernelGGL(k_small_dw_grouped, dim3(total), dim3(512), 0, (hipStream_t)stream, batch);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
