@@ -93,3 +93,41 @@ def test_config3_fusion_32x1024x768_two_bags_against_oracle_and_properties():
     for n_, q in model.named_parameters():
         if q.requires_grad and q.grad is not None:
             assert bool(torch.isfinite(q.grad).all()), n_
+
+
+def test_config4_batch_of_256_bags_on_one_gpu():
+    """BASELINE config 4's global batch (256 bags x 1024 x 512 = what 8 GPUs see together) through ONE process: 262 144
+    rows - four rounds of the 128-row MFMA tiles, 84 row chunks of the weight gradient - against the oracle on 2 bags, plus
+    independence of the bags and one finite training step in train mode."""
+    dev = torch.device("cuda")
+    B, N, L = 256, 1024, 512
+    p = syn.image_only_params(1234, L=L)
+    x = torch.cat([syn.make_bags(4321 + r, 32, N, L) for r in range(8)], 0)          # the 8 ranks' bags of bench.py --gpus 8
+    y = torch.cat([syn.make_labels(99 + r, 32, 2) for r in range(8)], 0).to(dev)
+    xd = x.reshape(B * N, L).to(dev)
+    lay = BagLayout.uniform(B, N, dev)
+    tr = ImageOnlyTrainer(p, dev, train_mode=False)
+    prob, z = tr.forward(xd, lay, y)
+    tr.backward()
+    g_all = tr.fp.grad.clone()
+    z, prob = z.cpu(), prob.cpu()
+    for b in (0, 255):
+        o = orc.image_only_forward(x[b], p)
+        assert float((z[b] - o["logits"][0]).abs().max()) <= 2e-5
+        assert torch.equal(prob[b].argmax(-1), o["prob"][0].argmax(-1))
+    # the same gradient as the sum over the 8 ranks' 32-bag steps (what the all-reduce adds up), each normalised by 256 bags
+    acc = torch.zeros_like(g_all)
+    for r in range(8):
+        t = ImageOnlyTrainer(p, dev, world_size=8, train_mode=False)
+        t.force_collectives = False
+        xs = xd[r * 32 * N:(r + 1) * 32 * N]
+        t.forward(xs, BagLayout.uniform(32, N, dev), y[r * 32:(r + 1) * 32], global_bags=256)
+        t.backward()
+        acc += t.fp.grad
+    from conftest import rel_err
+    assert rel_err(acc, g_all) <= 2e-5
+    # train mode at this size: one step, finite parameters
+    tt = ImageOnlyTrainer(p, dev, train_mode=True)
+    tt.train_step(xd, lay, y)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(tt.fp.flat).all())
