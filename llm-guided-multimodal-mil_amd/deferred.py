@@ -8,7 +8,6 @@ callback of the autograd engine then forms every queued dW / db in a single laun
 layer).  The gradients are written straight into optim.FlatAdam's flat buffer (ops.grad_slot), which is why this is only
 used when such a slot exists: no autograd accumulation kernel may read the tensor before the grouped launch has run.
 MIL_DEFER_DW=0 turns it off."""
-import ctypes
 import os
 from typing import List
 
