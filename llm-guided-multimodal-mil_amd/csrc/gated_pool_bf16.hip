@@ -266,14 +266,21 @@ __device__ __forceinline__ void dma16_raw(const void* gptr, unsigned lds_byte_ad
 #define HC_NX 4          // x ring: slices s .. s + 3
 #define HC_NW 3          // weight ring: slices s .. s + 2
 
-template <int GMODE>      // saved gates: 0 none, 1 fp32 [R, 384], 2 bf16 [R, 384] (branch-free epilogue per mode)
+// DROP (train mode, ABMIL.py:49): the keep words of the patch dropout ride the same LDS-DMA stream as x - one 1 KiB piece
+// = the 4 words (4 K slices) of 64 rows, issued by waves 0-3 every fourth slice, TWO four-slice groups ahead into a
+// three-group ring (12 KB) - so no ordinary load enters the kernel's hand-counted vmcnt accounting (the piece is the
+// oldest operation of its slice: that slice's wait becomes vmcnt(8), and by the next slice's vmcnt(7) it has landed);
+// the A fragments are masked after their LDS read (keep_bf16x8), the 1 / (1 - p) multiplies the finished pre-activation.
+template <int GMODE, bool DROP>      // saved gates: 0 none, 1 fp32 [R, 384], 2 bf16 [R, 384] (branch-free epilogue per mode)
 __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restrict__ x, const u16* __restrict__ Wv,
                                                             const float* __restrict__ bv, const u16* __restrict__ Wu,
                                                             const float* __restrict__ bu, const float* __restrict__ wvec,
                                                             const float* __restrict__ battn, float* __restrict__ scores,
                                                             float* __restrict__ gates, int R, int L,
-                                                            u16* __restrict__ gates16) {
+                                                            u16* __restrict__ gates16, const uint32_t* __restrict__ xbits,
+                                                            float xscale) {
     __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + HC_NW * HC_WS];      // 64 + 72 KB
+    __shared__ __attribute__((aligned(16))) uint32_t mring[DROP ? 3 * HC_TM * 4 : 4];    // keep words [3 groups][256 rows][4 slices]
     u16* xring = smem;
     u16* wring = smem + HC_NX * HC_XS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -302,6 +309,14 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
     }
     auto dma_x = [&](int i, int slot, int k0) { dma16_raw(xsrc[i] + k0, xdst[i] + 2u * (unsigned)(slot * HC_XS)); };
     auto dma_w = [&](int i, int slot, int k0) { dma16_raw(wsrc[i] + k0, wdst[i] + 2u * (unsigned)(slot * HC_WS)); };
+    // keep words: wave w < 4 moves rows 64 w .. 64 w + 63 (lane = row), the 4 words of slice group `grp`, into ring slot grp % 3
+    const int ngrp = (L / HC_BK) / 4;                                 // L % 128 == 0 (host)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);         // scalar copy: branch conditions and LDS bases of the keep words
+    const uint32_t* msrc = DROP ? xbits + (size_t)min(row0 + 64 * (wave_u & 3) + lane, R - 1) * (L >> 5) : nullptr;
+    const unsigned mdst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(hb_lds_void*)mring + (unsigned)(64 * (wave_u & 3) * 16));
+    auto dma_m = [&](int grp) {
+        dma16_raw(msrc + 4 * min(grp, ngrp - 1), __builtin_amdgcn_readfirstlane(mdst + (unsigned)((grp % 3) * HC_TM * 16)));
+    };
 
     f32x16 acc[2][3][2];
 #pragma unroll
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 #pragma unroll
         for (int i = 0; i < 3; ++i) dma_w(i, q, k0);
     }
+    if (DROP && wave_u < 4) { dma_m(0); dma_m(1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -352,12 +368,24 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
         const int wnew = wsl == 0 ? HC_NW - 1 : wsl - 1;        // slot of slice s + 2 = the one slice s - 1 used
         const u16* xa = xring + xs * HC_XS + (64 * wr + r) * HC_BK;
         const u16* wb = wring + wsl * HC_WS + (96 * wc + r) * HC_BK;
+        const bool mask_slice = DROP && wave_u < 4 && (s & 3) == 0;         // scalar
+        if (mask_slice) dma_m((s >> 2) + 2);                                  // first operation of the slice
+        unsigned mw[2] = {0u, 0u};
+        if (DROP) {
+            const uint32_t* mp = mring + ((s >> 2) % 3) * (HC_TM * 4) + (64 * wr + r) * 4 + (s & 3);
+            mw[0] = mp[0];
+            mw[1] = mp[32 * 4];
+        }
 #if !defined(HC_PHASED_LOOP)
         u16x8 a[2][2], bs[3];
         auto read_a = [&](int ks) {
             const int ch = 8 * ((2 * ks + h) ^ fx);
             a[ks][0] = *reinterpret_cast<const u16x8*>(xa + ch);
             a[ks][1] = *reinterpret_cast<const u16x8*>(xa + 32 * HC_BK + ch);
+            if (DROP) {
+                a[ks][0] = keep_bf16x8(a[ks][0], mw[0] >> (16 * ks + 8 * h));
+                a[ks][1] = keep_bf16x8(a[ks][1], mw[1] >> (16 * ks + 8 * h));
+            }
         };
         auto read_b = [&](int j) {
             const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
@@ -425,7 +453,10 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 #elif defined(HC_ABL_NOX)
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // ablation: weight pieces only (3 per slice)
 #else
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");     // everything issued before the previous slice's x pieces has landed
+        // everything issued before the previous slice's x pieces has landed (a slice that opened with a keep-word piece has
+        // one more operation behind them)
+        if (mask_slice) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 #endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -451,8 +482,8 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
             const float bvd = bv[d], bud = bu[d], wd = wvec[d];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = fast_tanh(acc[q][c][0][i] + bvd);
-                const float u = fast_sigmoid(acc[q][c][1][i] + bud);
+                const float v = fast_tanh(DROP ? fmaf(acc[q][c][0][i], xscale, bvd) : acc[q][c][0][i] + bvd);
+                const float u = fast_sigmoid(DROP ? fmaf(acc[q][c][1][i], xscale, bud) : acc[q][c][1][i] + bud);
                 part[i] += wd * v * u;
                 if (GMODE == 2) {
                     u16* t = tile_lds + mfma32_row(i, h) * 192 + 32 * c + r;
@@ -1114,19 +1145,18 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % HB_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
-    // 256-row tiles with the three-stage pipeline once they fill the chip; the 128-row kernel for small R - and in train
-    // mode (keep bits on the A fragments: the deep kernel's hand-counted DMA waits leave no room for the mask loads)
-    if (R >= HC_TM * MIL_NUM_CU && xbits == nullptr) {
+    // 256-row tiles with the three-stage pipeline once they fill the chip (train mode too: the keep words ride the kernel's
+    // own LDS-DMA stream); the 128-row kernel for small R
+    if (R >= HC_TM * MIL_NUM_CU && (xbits == nullptr || (L % 128) == 0)) {
         const dim3 grid((R + HC_TM - 1) / HC_TM);
-        if (gates16)
-            hipLaunchKernelGGL(k_gate_fwd_bf16_deep<2>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
-                               gates, R, L, gates16);
-        else if (gates)
-            hipLaunchKernelGGL(k_gate_fwd_bf16_deep<1>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
-                               gates, R, L, gates16);
-        else
-            hipLaunchKernelGGL(k_gate_fwd_bf16_deep<0>, grid, dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu, bu, w, b, scores,
-                               gates, R, L, gates16);
+        const hipStream_t st_ = (hipStream_t)stream;
+#define HC_LAUNCH(G, D) hipLaunchKernelGGL((k_gate_fwd_bf16_deep<G, D>), grid, dim3(512), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, gates16, xbits, xbits ? xscale : 1.0f)
+        if (xbits) {
+            if (gates16) HC_LAUNCH(2, true); else if (gates) HC_LAUNCH(1, true); else HC_LAUNCH(0, true);
+        } else {
+            if (gates16) HC_LAUNCH(2, false); else if (gates) HC_LAUNCH(1, false); else HC_LAUNCH(0, false);
+        }
+#undef HC_LAUNCH
     }
     else
         hipLaunchKernelGGL(k_gate_fwd_bf16, dim3((R + HB_TM - 1) / HB_TM), dim3(512), 0, (hipStream_t)stream, x, Wv, bv, Wu,

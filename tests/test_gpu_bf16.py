@@ -77,3 +77,28 @@ def test_deep_pipeline_kernel_matches_the_128_row_kernel():
         s_ref, g_ref = ops.gate_scores_fwd_bf16(x16[lo:hi].contiguous(), *args, save_gates=True)
         assert torch.equal(s_all[lo:hi], s_ref)
         assert torch.equal(g_all[lo:hi], g_ref)
+
+
+def test_deep_pipeline_kernel_with_keep_bits_matches_the_128_row_kernel():
+    """Train mode at config-5 size: the deep kernel takes the dropout keep words through its own LDS-DMA stream (a three-group
+    ring); scores and gates must equal the 128-row kernel's (run on slices with the matching slices of the bit tensor), bit
+    for bit, including a ragged last tile."""
+    from mil_amd import ops, synthetic as syn
+    L, R = 1024, 65536 + 72
+    p = {k: v.to(DEV) for k, v in syn.image_only_params(11, L=L).items()}
+    x16 = ops.cast_bf16(torch.randn((R, L), generator=torch.Generator().manual_seed(3)).to(DEV))
+    bits = ops.dropout_keep_bits(R, L, 0.5, seed=77, offset=3, device=torch.device(DEV))
+    args = (ops.cast_bf16(p["aggregator.attention_V.0.weight"]), p["aggregator.attention_V.0.bias"],
+            ops.cast_bf16(p["aggregator.attention_U.0.weight"]), p["aggregator.attention_U.0.bias"],
+            p["aggregator.attention_weights.weight"].reshape(-1), p["aggregator.attention_weights.bias"])
+    s_all, g_all = ops.gate_scores_fwd_bf16(x16, *args, save_gates=True, xbits=bits, xscale=2.0)
+    s_eval, _ = ops.gate_scores_fwd_bf16(x16, *args, save_gates=False)
+    assert not torch.equal(s_all, s_eval)                         # the mask does something
+    for lo, hi in ((0, 4096), (30000, 34000), (R - 1000, R)):
+        s_ref, g_ref = ops.gate_scores_fwd_bf16(x16[lo:hi].contiguous(), *args, save_gates=True,
+                                                xbits=bits[lo:hi].contiguous(), xscale=2.0)
+        assert torch.equal(s_all[lo:hi], s_ref)
+        assert torch.equal(g_all[lo:hi], g_ref)
+    s16, g16 = ops.gate_scores_fwd_bf16(x16, *args, save_gates=True, gates_bf16=True, xbits=bits, xscale=2.0)
+    assert torch.equal(s16, s_all)
+    assert torch.equal(g16, g_all.to(torch.bfloat16))
