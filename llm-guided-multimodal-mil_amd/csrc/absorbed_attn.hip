@@ -201,13 +201,41 @@ __global__ void k_apool_merge(const float* __restrict__ pacc, const float* __res
     const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
     const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
     float m = -INFINITY;
-    for (int g = g0; g < g1; ++g) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
+    {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {                 // eight loads in flight per pass: the merge is pure latency
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pml[((size_t)(g + u) * AP_H + h) * 2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, t[u]);
+        }
+        for (; g < g1; ++g) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
+    }
     float l = 0.f;
     f32x4 acc = {0, 0, 0, 0};
-    for (int g = g0; g < g1; ++g) {
-        const float sc = __expf(pml[((size_t)g * AP_H + h) * 2] - m);
-        l += sc * pml[((size_t)g * AP_H + h) * 2 + 1];
-        acc += sc * *reinterpret_cast<const f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 4 * j4);
+    {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            float2 ml[8];
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ml[u] = *reinterpret_cast<const float2*>(pml + ((size_t)(g + u) * AP_H + h) * 2);
+                t[u] = *reinterpret_cast<const f32x4*>(pacc + ((size_t)(g + u) * AP_H + h) * E + 4 * j4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float sc = __expf(ml[u].x - m);
+                l += sc * ml[u].y;
+                acc += sc * t[u];
+            }
+        }
+        for (; g < g1; ++g) {
+            const float sc = __expf(pml[((size_t)g * AP_H + h) * 2] - m);
+            l += sc * pml[((size_t)g * AP_H + h) * 2 + 1];
+            acc += sc * *reinterpret_cast<const f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 4 * j4);
+        }
     }
     const float inv = g1 > g0 ? 1.0f / l : 0.f;
     *reinterpret_cast<f32x4*>(pooled + ((size_t)b * AP_H + h) * E + 4 * j4) = acc * inv;
@@ -348,8 +376,16 @@ __global__ void k_apool_bwd_merge(const float* __restrict__ pdq, const int32_t* 
                                   float* __restrict__ dQp) {
     const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
     f32x4 acc = {0, 0, 0, 0};
-    for (int g = bag_tile_off[b]; g < bag_tile_off[b + 1]; ++g)
-        acc += *reinterpret_cast<const f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 4 * j4);
+    const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {                     // eight tile loads in flight (the merge is pure latency)
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(pdq + ((size_t)(g + u) * AP_H + h) * E + 4 * j4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; g < g1; ++g) acc += *reinterpret_cast<const f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 4 * j4);
     *reinterpret_cast<f32x4*>(dQp + ((size_t)b * AP_H + h) * E + 4 * j4) = acc;
 }
 
