@@ -2120,42 +2120,70 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
 
 // The same tile quantisation for dx (two 128 x 128 workgroups per CU): the rows beyond whole rounds, one workgroup
 // per row, thread = four columns, d looped (W is L2-resident).
-__global__ __launch_bounds__(128) void k_gate_bwd_dx_tail(const float* __restrict__ gates, const float* __restrict__ ds,
+// One 16 x 16 output tile per workgroup (rows = tail rows, columns of L), the 8 waves split the 384 gate units, operands
+// straight from global memory (16x16x4 MFMA, all loads of a wave issued before its first MFMA), partial tiles folded
+// through LDS: every workgroup reads 24 KB of the weights.  (One workgroup per ROW streamed all 768 KB of Wv, Wu through a
+// single CU: 21-23 us for 32 rows.)
+__global__ __launch_bounds__(512) void k_gate_bwd_dx_tail(const float* __restrict__ gates, const float* __restrict__ ds,
                                                           const float* __restrict__ wvec, const float* __restrict__ Wv,
-                                                          const float* __restrict__ Wu, float* __restrict__ dx, int L,
+                                                          const float* __restrict__ Wu, float* __restrict__ dx, int L, int rows,
                                                           const uint32_t* __restrict__ xbits, float xscale,
                                                           const float* __restrict__ scores, const float* __restrict__ lse,
                                                           const int32_t* __restrict__ row_bag, const float* __restrict__ dM) {
-    __shared__ float pv[MIL_GATE_D], pu[MIL_GATE_D];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const float dsr = ds[row];
-    for (int d = tid; d < MIL_GATE_D; d += 128) {
-        const float v = gates[(size_t)row * GF_NG + d], u = gates[(size_t)row * GF_NG + 192 + d];
-        const float dsw = dsr * wvec[d];
-        pv[d] = dsw * u * (1.0f - v * v);
-        pu[d] = dsw * v * u * (1.0f - u);
-    }
-    __syncthreads();
-    for (int j = 4 * tid; j < L; j += 512) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int d = 0; d < MIL_GATE_D; ++d)
-            acc += pv[d] * *reinterpret_cast<const f32x4*>(Wv + (size_t)d * L + j) +
-                   pu[d] * *reinterpret_cast<const f32x4*>(Wu + (size_t)d * L + j);
-        f32x4* o = reinterpret_cast<f32x4*>(dx + (size_t)row * L + j);
-        f32x4 v;
-        if (dM != nullptr) {
-            const int bg = row_bag[row];
-            v = expf(scores[row] - lse[bg]) * *reinterpret_cast<const f32x4*>(dM + (size_t)bg * L + j) + acc;
-        } else {
-            v = *o + acc;
-        }
-        if (xbits != nullptr) {
-            const unsigned m = xbits[(size_t)row * (L >> 5) + (j >> 5)] >> (j & 31);
+    __shared__ float red[8][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int mrow = min(m0 + r, rows - 1);
+    const int jc = j0 + r;                                   // L % 16 == 0: always a valid column
+    const float dsr = ds[mrow];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // wave w: gate units [24 w, 24 w + 24) of V and of U = 12 k-chunks of 4 units; A = dPre[row][unit], B = W[unit][column]
+    f32x4 fa[12];
+    float fb[12][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((m >> e) & 1u) ? v[e] * xscale : 0.f;
+    for (int u = 0; u < 12; ++u) {
+        const int isu = u >= 6;
+        const int d = 24 * wave + 4 * (u % 6);                    // first gate unit of the chunk (chunks 0-5: V half, 6-11: U half)
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(gates + (size_t)mrow * GF_NG + d);
+        const f32x4 u4 = *reinterpret_cast<const f32x4*>(gates + (size_t)mrow * GF_NG + 192 + d);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + d);
+        const f32x4 dsw = dsr * w4;
+        fa[u] = isu ? dsw * v4 * u4 * (1.0f - u4) : dsw * u4 * (1.0f - v4 * v4);
+        const float* Wp = (isu ? Wu : Wv) + (size_t)d * L + jc;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) fb[u][jj] = Wp[(size_t)jj * L];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 16x16x4: lane (r, kq) supplies A[m = r][k = kq] and B[k = kq][n = r]; the chunk's 4 units are its 4 k values, so the
+    // A value of lane kq is component kq of the chunk's dPre vector and the B value is row kq of the chunk's weight rows
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+        const float av = kq == 0 ? fa[u][0] : kq == 1 ? fa[u][1] : kq == 2 ? fa[u][2] : fa[u][3];
+        const float bv_ = kq == 0 ? fb[u][0] : kq == 1 ? fb[u][1] : kq == 2 ? fb[u][2] : fb[u][3];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv_, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (tid < 256) {
+        const int i = tid >> 6, l = tid & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w][i][l];
+        const int row = m0 + 4 * (l >> 4) + i, col = j0 + (l & 15);
+        if (row < rows) {
+            float* o = dx + (size_t)row * L + col;
+            float t;
+            if (dM != nullptr) {
+                const int bg = row_bag[row];
+                t = expf(scores[row] - lse[bg]) * dM[(size_t)bg * L + col] + v;
+            } else {
+                t = *o + v;
+            }
+            if (xbits != nullptr) t = ((xbits[(size_t)row * (L >> 5) + (col >> 5)] >> (col & 31)) & 1u) ? t * xscale : 0.f;
+            *o = t;
         }
-        *o = v;
     }
 }
 
@@ -2174,8 +2202,8 @@ static int gate_bwd_input_impl(const float* gates, const float* ds, const float*
                        row_bag, dM);
     MIL_CHECK_LAUNCH();
     if (tail > 0) {
-        hipLaunchKernelGGL(k_gate_bwd_dx_tail, dim3(tail), dim3(128), 0, st, gates + (size_t)Rm * GF_NG, ds + Rm, w, Wv, Wu,
-                           dx + (size_t)Rm * L, L, xbits ? xbits + (size_t)Rm * (L >> 5) : nullptr, xscale,
+        hipLaunchKernelGGL(k_gate_bwd_dx_tail, dim3(L / 16, (tail + 15) / 16), dim3(512), 0, st, gates + (size_t)Rm * GF_NG, ds + Rm, w,
+                           Wv, Wu, dx + (size_t)Rm * L, L, tail, xbits ? xbits + (size_t)Rm * (L >> 5) : nullptr, xscale,
                            scores ? scores + Rm : nullptr, lse, row_bag ? row_bag + Rm : nullptr, dM);
         MIL_CHECK_LAUNCH();
     }
