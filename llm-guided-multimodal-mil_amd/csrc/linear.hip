@@ -359,7 +359,19 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     if (idx >= (size_t)M * N) return;
     const int row = (int)(idx / N), j = (int)(idx % N);
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += partial[((size_t)s * M + row) * N + j];
+    {
+        const float* src = partial + (size_t)row * N + j;
+        const size_t stride = (size_t)M * N;
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {                      // eight partials in flight per thread
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(s + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; s < S; ++s) v += src[(size_t)s * stride];
+    }
     if (bias != nullptr) v += bias[j];
     v = epilogue_aux(v, aux, ldaux, aux_mode, row, j);
     if (act == ACT_TANH) v = tanhf(v);
