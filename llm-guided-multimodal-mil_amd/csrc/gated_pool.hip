@@ -411,7 +411,10 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
 // 4 (l & 7).. of word 8q + (l >> 3) of its row; the survivors' scale rides on the softmax weight.  mbits / mscale: the
 // head's Dropout(.25) on the bag embedding (aggregator.py:129) folds into the head rows used for the by-product
 // h[row][c] = x_row . (Wf[c] * keepM[bag] * mscale), so that x_i . dM = sum_c dz_c h[i][c] still holds in the backward.
-template <int NQ>
+// NT: x is larger than the Infinity Cache, so the pass is a pure HBM stream: nontemporal loads (tools/cu_load_bw.hip: a
+// streaming read of 512 MB runs at 7.2 TB/s with the hint, 6.5 TB/s without).  Off when x fits the cache and the
+// weight-gradient pass re-reads it from there.
+template <int NQ, bool NT>
 __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ x, const float* __restrict__ scores,
                                                       const int32_t* __restrict__ tile_map, float* __restrict__ partials,
                                                       int L, const float* __restrict__ Wf, int C,
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
         const int rr = max(min(wave + 4 * i, nrows - 1), 0);      // nrows == 0: a padding tile of a device-built map
         const float* xr = x + (size_t)(row0 + rr) * L + 4 * lane;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+        for (int q = 0; q < NQ; ++q)
+            v[i][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 256 * q)) : *reinterpret_cast<const f32x4*>(xr + 256 * q);
         if (xbits != nullptr) {
             const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 3);
 #pragma unroll
@@ -612,6 +616,7 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int bag = tile_map[4 * t], row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
+    constexpr bool NT = false;
     if (xbits == nullptr) xscale = 1.0f;
     f32x4 g[NQ];
 #pragma unroll
@@ -627,7 +632,8 @@ __global__ __launch_bounds__(256) void k_pool_bwd_ds(const float* __restrict__ x
         const size_t row = (size_t)(row0 + max(min(wave + 4 * i, nrows - 1), 0));
         const float* xr = x + row * L + 4 * lane;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+        for (int q = 0; q < NQ; ++q)
+            v[i][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 256 * q)) : *reinterpret_cast<const f32x4*>(xr + 256 * q);
         if (xbits != nullptr) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) mk[i][q] = xbits[row * (L >> 5) + 8 * q + (lane >> 3)] >> sh;
@@ -1634,12 +1640,17 @@ static int launch_pool_partial(const float* x, const float* scores, const int32_
                                const uint32_t* xbits = nullptr, float xscale = 1.0f, const uint32_t* mbits = nullptr,
                                float mscale = 1.0f) {
     if (T <= 0) return MIL_OK;
+    const bool nt = (size_t)T * MIL_POOL_TILE * L * sizeof(float) > MIL_STREAM_BYTES;
+#define POOL_LAUNCH(NQ_) do { \
+        if (nt) hipLaunchKernelGGL((k_pool_partial<NQ_, true>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); \
+        else hipLaunchKernelGGL((k_pool_partial<NQ_, false>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); } while (0)
     switch (L / 256) {
-        case 1: hipLaunchKernelGGL(k_pool_partial<1>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
-        case 2: hipLaunchKernelGGL(k_pool_partial<2>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
-        case 3: hipLaunchKernelGGL(k_pool_partial<3>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
-        default: hipLaunchKernelGGL(k_pool_partial<4>, dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xscale, mbits, mscale); break;
+        case 1: POOL_LAUNCH(1); break;
+        case 2: POOL_LAUNCH(2); break;
+        case 3: POOL_LAUNCH(3); break;
+        default: POOL_LAUNCH(4); break;
     }
+#undef POOL_LAUNCH
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 
 // ---------------------------------------------------------------------------------------------------- pool stages, bf16 x
 // Lane l owns the 8 columns 8l + 512q of a row (16-byte loads); NQ = L / 512.
-template <int NQ, bool DROP>     // DROP: train mode (keep-bit tensors); the eval instantiation carries none of it
+template <int NQ, bool DROP, bool NT>     // DROP: train mode (keep-bit tensors); the eval instantiation carries none of it.  NT: as k_pool_partial
 __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict__ x, const float* __restrict__ scores,
                                                            const int32_t* __restrict__ tile_map,
                                                            float* __restrict__ partials, int L,
@@ -568,7 +568,8 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         const int rr = min(wave + 4 * i, nrows - 1);
         const u16* xr = x + (size_t)(row0 + rr) * L + 8 * lane;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = *reinterpret_cast<const u16x8*>(xr + 512 * q);
+        for (int q = 0; q < NQ; ++q)
+            v[i][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(xr + 512 * q)) : *reinterpret_cast<const u16x8*>(xr + 512 * q);
         if (DROP && xbits != nullptr) {
             const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 2);
 #pragma unroll
@@ -1172,13 +1173,16 @@ static void launch_pool_partial_bf16(const uint16_t* x, const float* scores, con
                                      const uint32_t* mbits, float mscale, hipStream_t st) {
     const bool drop = xbits != nullptr || mbits != nullptr;
     const float xs = xbits ? xscale : 1.0f, ms = mbits ? mscale : 1.0f;
+    const bool nt = (size_t)T * MIL_POOL_TILE * L * sizeof(uint16_t) > MIL_STREAM_BYTES;
+#define POOL16(NQ_, D_, N_) hipLaunchKernelGGL((k_pool_partial_bf16<NQ_, D_, N_>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, (D_) ? xs : 1.0f, mbits, (D_) ? ms : 1.0f)
     if (L == 512) {
-        if (drop) hipLaunchKernelGGL((k_pool_partial_bf16<1, true>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xs, mbits, ms);
-        else hipLaunchKernelGGL((k_pool_partial_bf16<1, false>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, 1.0f, mbits, 1.0f);
+        if (drop) { if (nt) POOL16(1, true, true); else POOL16(1, true, false); }
+        else { if (nt) POOL16(1, false, true); else POOL16(1, false, false); }
     } else {
-        if (drop) hipLaunchKernelGGL((k_pool_partial_bf16<2, true>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, xs, mbits, ms);
-        else hipLaunchKernelGGL((k_pool_partial_bf16<2, false>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, 1.0f, mbits, 1.0f);
+        if (drop) { if (nt) POOL16(2, true, true); else POOL16(2, true, false); }
+        else { if (nt) POOL16(2, false, true); else POOL16(2, false, false); }
     }
+#undef POOL16
 }
 
 extern "C" int mil_attn_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,

@@ -26,6 +26,10 @@ static inline int mil_num_cu() {
 }
 #define MIL_NUM_CU (mil_num_cu())
 
+// An operand larger than this is streamed from HBM whatever the access order (the Infinity Cache holds 256 MB, and a
+// linear sweep over more than that leaves nothing useful behind): its loads carry the nontemporal hint.
+#define MIL_STREAM_BYTES ((size_t)192 << 20)
+
 #define MIL_CHECK_LAUNCH()                               \
     do {                                                 \
         hipError_t e_ = hipGetLastError();               \

@@ -131,3 +131,23 @@ def test_config4_batch_of_256_bags_on_one_gpu():
     tt.train_step(xd, lay, y)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(tt.fp.flat).all())
+
+
+def test_pool_stage_64x4096x512_streaming_loads_equal_the_cached_path_and_float64():
+    """The north_star pool point (512 MiB of x: beyond the Infinity Cache) takes the nontemporal-load instantiation of
+    k_pool_partial; the same bags in an 8-bag batch (64 MiB) take the plain one.  Both must give the same bits, and bag 5
+    must match a float64 softmax-weighted sum (ABMIL.py:56-59)."""
+    from mil_amd import ops
+    dev = torch.device("cuda")
+    B, N, L = 64, 4096, 512
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(B * N, L, device=dev, generator=g)
+    s = torch.randn(B * N, device=dev, generator=g) * 3.0
+    M, lse = ops.attn_pool_fwd(x, s, BagLayout.uniform(B, N, dev))
+    M8, lse8 = ops.attn_pool_fwd(x[:8 * N].contiguous(), s[:8 * N].contiguous(), BagLayout.uniform(8, N, dev))
+    assert torch.equal(M[:8], M8) and torch.equal(lse[:8], lse8)
+    b = 5
+    a = torch.softmax(s[b * N:(b + 1) * N].double(), 0)
+    ref = (a[:, None] * x[b * N:(b + 1) * N].double()).sum(0)
+    assert float((M[b].double() - ref).abs().max()) <= 2e-6
+    assert abs(float(lse[b]) - float(torch.logsumexp(s[b * N:(b + 1) * N].double(), 0))) <= 1e-5
