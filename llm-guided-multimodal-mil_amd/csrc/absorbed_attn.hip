@@ -99,97 +99,127 @@ __global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------- absorbed pool, forward
-// One workgroup (256 threads) per 64-key tile: tile_map[g] = {bag, key0, nkeys}.  Wave w walks rows w, w+4, ...
-// Lane l holds columns 4l + 256q (q < 2) of a row.  Per-wave running online-softmax state for the H heads; the four
-// waves are merged through LDS; partial per tile: acc [H][E], then (m, l) [H][2].
-__global__ __launch_bounds__(256) void k_apool_partial(const float* __restrict__ keys, const float* __restrict__ pe,
+// One workgroup (256 threads) per 64-key tile: tile_map[g] = {bag, key0, nkeys}.  Wave w owns rows w, w+4, ... (16 rows);
+// lane l holds columns 4l + 256q (q < 2) of a row.  Partial per tile: acc [H][E] = sum_n exp(s_h[n] - m_h) keys_n, then
+// (m_h, l_h) [H][2] with m_h the TILE maximum.
+// Two phases (round 2; the one-pass online softmax it replaces re-scaled 8 x 512 accumulators per key row and evaluated
+// the eight exponentials of a row on all 64 lanes: ~260 VALU instructions per row, 33 us per site at 32 x 1024 keys
+// against 7 us of memory time):
+//   1. every load of the wave's 16 rows is issued up front (32 + 32 16-byte loads in flight per lane) and the rows STAY
+//      in registers; the eight head scores of a row (8 FMAs per lane and head, one 10-step transposing wave reduction)
+//      go to LDS;
+//   2. thread (row, head) pairs form the tile maxima, the 64 x 8 probabilities (one exponential each) and their sums
+//      through LDS; then each wave accumulates its 16 register-resident rows with plain FMAs - no re-scaling - and the
+//      four waves' accumulators (same reference maximum) are summed through LDS.
+__global__ __launch_bounds__(256, 2) void k_apool_partial(const float* __restrict__ keys, const float* __restrict__ pe,
                                                        const float* __restrict__ Qp, const int32_t* __restrict__ k_off,
                                                        const int32_t* __restrict__ tile_map, float scale,
                                                        float* __restrict__ pacc, float* __restrict__ pml) {
-    constexpr int E = 512, NQ = 2;
+    constexpr int E = 512, NQ = 2, RW = AP_TILE / 4;
     __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
-    __shared__ float mls[4][AP_H][2];
+    __shared__ __attribute__((aligned(16))) float s_lds[AP_TILE][AP_H];      // scores, then probabilities
+    __shared__ float mh_lds[4][AP_H], lh_lds[4][AP_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
     const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
     const int pos0 = key0 - k_off[b];
-    f32x4 qv[AP_H][NQ], acc[AP_H][NQ];
-    float m[AP_H], l[AP_H];
+    f32x4 kv[RW][NQ];
 #pragma unroll
-    for (int h = 0; h < AP_H; ++h) {
+    for (int i = 0; i < RW; ++i) {
+        const int rr = max(min(wave + 4 * i, nkeys - 1), 0);              // rows past the tile end: clamped, weight 0 below
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            qv[h][q] = scale * *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
-            acc[h][q] = f32x4{0, 0, 0, 0};
-        }
-        m[h] = -INFINITY;
-        l[h] = 0.f;
+        for (int q = 0; q < NQ; ++q) kv[i][q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
     }
-    for (int rr = wave; rr < nkeys; rr += 4) {
-        f32x4 kv[NQ], kin[NQ];
+    {
+        f32x4 qv[AP_H][NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            kv[q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
-            kin[q] = kv[q] + *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
-        }
-        float d8[AP_H];
-#pragma unroll
-        for (int h = 0; h < AP_H; ++h) {
-            float d = 0.f;
+        for (int h = 0; h < AP_H; ++h)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                d += kin[q][0] * qv[h][q][0] + kin[q][1] * qv[h][q][1] + kin[q][2] * qv[h][q][2] + kin[q][3] * qv[h][q][3];
-            d8[h] = d;
+                qv[h][q] = scale * *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+        // the positional rows (a 2 MB table, L2-resident) in batches of four, so that the keys (128 registers), the
+        // queries (64) and one batch (32) leave room for two workgroups per CU
+#pragma unroll
+        for (int i0 = 0; i0 < RW; i0 += 4) {
+            f32x4 pv[4][NQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = max(min(wave + 4 * (i0 + u), nkeys - 1), 0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pv[u][q] = *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                float d8[AP_H];
+#pragma unroll
+                for (int h = 0; h < AP_H; ++h) {
+                    f32x4 t = (kv[i][0] + pv[u][0]) * qv[h][0];
+                    t += (kv[i][1] + pv[u][1]) * qv[h][1];
+                    d8[h] = (t[0] + t[1]) + (t[2] + t[3]);
+                }
+                const float tot = wave_reduce8(d8, lane);          // lane 8k holds the score of head k
+                if ((lane & 7) == 0) s_lds[wave + 4 * i][lane >> 3] = wave + 4 * i < nkeys ? tot : -INFINITY;
+            }
         }
-        const float tot = wave_reduce8(d8, lane);              // the eight head scores of this key in 10 cross-lane steps
-#pragma unroll
-        for (int h = 0; h < AP_H; ++h) {
-            const float s = wave_reduce8_get(tot, h);
-            const float mn = fmaxf(m[h], s);
-            const float alpha = __expf(m[h] - mn), p = __expf(s - mn);
-            l[h] = l[h] * alpha + p;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[h][q] = acc[h][q] * alpha + p * kv[q];
-            m[h] = mn;
-        }
-    }
-    // merge the four waves (a wave with no rows carries m = -inf, l = 0, acc = 0)
-    if (lane == 0) {
-#pragma unroll
-        for (int h = 0; h < AP_H; ++h) { mls[wave][h][0] = m[h]; mls[wave][h][1] = l[h]; }
     }
     __syncthreads();
-    float mt[AP_H], sc[AP_H];
+    // thread (row r0 = tid >> 3 and r0 + 32, head h = tid & 7): tile maximum, probabilities, their sum
+    const int h_ = tid & 7, r0 = tid >> 3;
+    const float s0 = s_lds[r0][h_], s1 = s_lds[32 + r0][h_];
+    float m = fmaxf(s0, s1);
+    m = fmaxf(m, dpp_mov<0x128>(m));          // lanes with the same head: xor 8, 16, 32 without the LDS crossbar
+    m = swap16_max(m, m);
+    m = swap32_max(m, m);
+    if (lane < AP_H) mh_lds[wave][lane] = m;
+    __syncthreads();
+    const float mt = fmaxf(fmaxf(mh_lds[0][h_], mh_lds[1][h_]), fmaxf(mh_lds[2][h_], mh_lds[3][h_]));
+    const float p0 = s0 == -INFINITY ? 0.f : __expf(s0 - mt), p1 = s1 == -INFINITY ? 0.f : __expf(s1 - mt);
+    s_lds[r0][h_] = p0;
+    s_lds[32 + r0][h_] = p1;
+    float l = p0 + p1;
+    l += dpp_mov<0x128>(l);
+    l = swap16_add(l, l);
+    l = swap32_add(l, l);
+    if (lane < AP_H) lh_lds[wave][lane] = l;
+    __syncthreads();
+    f32x4 acc[AP_H][NQ];
 #pragma unroll
-    for (int h = 0; h < AP_H; ++h) {
-        mt[h] = fmaxf(fmaxf(mls[0][h][0], mls[1][h][0]), fmaxf(mls[2][h][0], mls[3][h][0]));
-        sc[h] = m[h] == -INFINITY ? 0.f : __expf(m[h] - mt[h]);
+    for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[h][q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(&s_lds[wave + 4 * i][0]);      // wave-uniform: LDS broadcast
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(&s_lds[wave + 4 * i][4]);
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            const float p = h < 4 ? pa[h & 3] : pb[h & 3];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[h][q] += p * kv[i][q];
+        }
     }
     if (wave > 0) {
 #pragma unroll
         for (int h = 0; h < AP_H; ++h)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                *reinterpret_cast<f32x4*>(red + ((wave - 1) * AP_H + h) * E + 256 * q + 4 * lane) = sc[h] * acc[h][q];
+                *reinterpret_cast<f32x4*>(red + ((wave - 1) * AP_H + h) * E + 256 * q + 4 * lane) = acc[h][q];
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int h = 0; h < AP_H; ++h) {
+        for (int h = 0; h < AP_H; ++h)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                f32x4 v = sc[h] * acc[h][q];
+                f32x4 v = acc[h][q];
 #pragma unroll
                 for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * AP_H + h) * E + 256 * q + 4 * lane);
                 *reinterpret_cast<f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v;
             }
-            if (lane == 0) {
-                float lt = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) lt += mls[w][h][0] == -INFINITY ? 0.f : mls[w][h][1] * __expf(mls[w][h][0] - mt[h]);
-                pml[((size_t)g * AP_H + h) * 2] = mt[h];
-                pml[((size_t)g * AP_H + h) * 2 + 1] = lt;
-            }
+        if (lane < AP_H) {                                        // lane = head (h_ == lane in wave 0)
+            pml[((size_t)g * AP_H + lane) * 2] = mt;
+            pml[((size_t)g * AP_H + lane) * 2 + 1] = (lh_lds[0][lane] + lh_lds[1][lane]) + (lh_lds[2][lane] + lh_lds[3][lane]);
         }
     }
 }

@@ -68,35 +68,69 @@ __device__ __forceinline__ float half_sum_lane31(float v) {
     return v;
 }
 
-// Sum 16 per-lane values over the 64 lanes of a wave with 17 cross-lane steps instead of 16 x 6: each step halves the
-// number of values a lane carries while it doubles the lanes summed.  Afterwards lane l holds the wave total of value
+// Cross-lane primitives of the transposing reductions below, none of which touches the LDS crossbar (ds_bpermute, what
+// __shfl_xor compiles to, costs an LDS issue slot per step; k_apool_partial spent a third of its time in them):
+//   swap32_add(x, y): lanes 0-31 get x[l] + x[l + 32], lanes 32-63 get y[l - 32] + y[l]      (v_permlane32_swap, gfx950)
+//   swap16_add(x, y): even 16-lane rows get x[l] + x[l + 16], odd rows y[l - 16] + y[l]     (v_permlane16_swap, gfx950)
+//   dpp_mov<ctrl>: row_ror:8 (0x128) = xor 8, row_half_mirror (0x141), quad_perm [1,0,3,2] (0xB1) / [2,3,0,1] (0x4E)
+// The swaps go through inline asm: with the builtins (__builtin_amdgcn_permlane32_swap) this compiler adds the first
+// result to itself (v_add v, v6, v6 after v_permlane32_swap v6, v2; checked on the box with tools/variants probes).
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+__device__ __forceinline__ float swap32_max(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float swap16_max(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return fmaxf(x, y);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// value of lane l ^ 4: row_shl:4 into the lanes with bit 2 clear (banks 0, 2), row_shr:4 into the others
+__device__ __forceinline__ float dpp_xor4(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x114, 0xf, 0xa, false);
+    return __builtin_bit_cast(float, t);
+}
+
+// Sum 16 per-lane values over the 64 lanes of a wave: each step halves the number of values a lane carries while it
+// doubles the lanes summed.  Afterwards lane l holds the wave total of value
 // index k(l) = 8 b5 + 4 b4 + 2 b3 + b2 (b_i = bit i of l); wave_reduce16_owner(k) is one lane holding index k.
 __device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
     float w8[8], w4[4], w2[2];
-    const bool s5 = lane & 32, s4 = lane & 16, s3 = lane & 8, s2 = lane & 4;
+    const bool s3 = lane & 8, s2 = lane & 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w8[j] = (s5 ? v[j + 8] : v[j]) + __shfl_xor(s5 ? v[j] : v[j + 8], 32);
+    for (int j = 0; j < 8; ++j) w8[j] = swap32_add(v[j], v[j + 8]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = (s4 ? w8[j + 4] : w8[j]) + __shfl_xor(s4 ? w8[j] : w8[j + 4], 16);
+    for (int j = 0; j < 4; ++j) w4[j] = swap16_add(w8[j], w8[j + 4]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w2[j] = (s3 ? w4[j + 2] : w4[j]) + __shfl_xor(s3 ? w4[j] : w4[j + 2], 8);
-    float r = (s2 ? w2[1] : w2[0]) + __shfl_xor(s2 ? w2[0] : w2[1], 4);
-    r += __shfl_xor(r, 2);
-    r += __shfl_xor(r, 1);
+    for (int j = 0; j < 2; ++j) w2[j] = (s3 ? w4[j + 2] : w4[j]) + dpp_mov<0x128>(s3 ? w4[j] : w4[j + 2]);
+    float r = (s2 ? w2[1] : w2[0]) + dpp_xor4(s2 ? w2[0] : w2[1]);
+    r += dpp_mov<0x4E>(r);
+    r += dpp_mov<0xB1>(r);
     return r;
 }
-// Eight values: 10 cross-lane steps instead of 8 x 6; lane l ends with the total of index 4 b5 + 2 b4 + b3.
+// Eight values; lane l ends with the total of index 4 b5 + 2 b4 + b3.
 __device__ __forceinline__ float wave_reduce8(const float (&v)[8], int lane) {
     float w4[4], w2[2];
-    const bool s5 = lane & 32, s4 = lane & 16, s3 = lane & 8;
+    const bool s3 = lane & 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = (s5 ? v[j + 4] : v[j]) + __shfl_xor(s5 ? v[j] : v[j + 4], 32);
+    for (int j = 0; j < 4; ++j) w4[j] = swap32_add(v[j], v[j + 4]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w2[j] = (s4 ? w4[j + 2] : w4[j]) + __shfl_xor(s4 ? w4[j] : w4[j + 2], 16);
-    float r = (s3 ? w2[1] : w2[0]) + __shfl_xor(s3 ? w2[0] : w2[1], 8);
-    r += __shfl_xor(r, 4);
-    r += __shfl_xor(r, 2);
-    r += __shfl_xor(r, 1);
+    for (int j = 0; j < 2; ++j) w2[j] = swap16_add(w4[j], w4[j + 2]);
+    float r = (s3 ? w2[1] : w2[0]) + dpp_mov<0x128>(s3 ? w2[0] : w2[1]);
+    r += dpp_mov<0x141>(r);          // 8-lane group: i <-> 7 - i, then the two quad permutations complete the sum
+    r += dpp_mov<0xB1>(r);
+    r += dpp_mov<0x4E>(r);
     return r;
 }
 // the total of index k (0..7) of wave_reduce8, made wave-uniform (k is a compile-time constant after unrolling)

@@ -147,7 +147,6 @@ class TwoWayAttentionBlock(nn.Module):
             k = keys_pe_fn(keys)
             queries = self.norm2(self.cross_attn_token_to_image.flat(q, k, keys, s_ti, "pool", residual=queries))
         queries = self.norm3(self.mlp(queries, residual=queries))               # :298-300
-        q = queries + query_pe                                                  # :303-307
         if s_it.Tk_max == 1 and min(s_it.k_lengths, default=1) == 1:
             # One text token per bag: the softmax over a single key is exactly 1, every patch receives the same
             # out_proj(v_proj(token)) and q_proj / k_proj get exactly zero gradient (as upstream).  Skips two
@@ -156,7 +155,9 @@ class TwoWayAttentionBlock(nn.Module):
             _zero_grad_params(a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias)
             o = ops.linear_act(ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias), a.out_proj.weight, a.out_proj.bias)
             keys = ops.layer_norm_bag_row(keys, o, s_it, self.norm4.weight, self.norm4.bias, self.norm4.eps, keys_tail_rows)
-        elif multi:
+            return queries, keys                                                # (queries + query_pe of :303 has no reader here)
+        q = queries + query_pe                                                  # :303-307
+        if multi:
             keys = self.norm4(self.cross_attn_image_to_token.multi_token_rows(k, q, queries, s_it, residual=keys), keys_tail_rows)
         else:
             if k is None:

@@ -379,6 +379,7 @@ class _GatedPoolHeadLoss(torch.autograd.Function):
                               t["lse"], t["ds"], t["dM"], dWf, dbf)
         for o in (t["prob"], t["logits"], t["M"]):
             ctx.mark_non_differentiable(o)
+        ctx.set_materialize_grads(False)        # no zero tensors for the three non-differentiable outputs
         return loss.reshape(()), t["prob"], t["logits"], t["M"]
 
     @staticmethod
