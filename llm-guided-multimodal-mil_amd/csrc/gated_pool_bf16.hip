@@ -7,6 +7,8 @@
 //   k_pool_*_bf16     the HBM-bound pool stages read half the bytes
 //   k_gate_bwd_dw_x16 weight gradient with x read as bf16 and widened in staging (fp32 MFMA; a bf16-MFMA
 //                     version of the transposed product is the next step)
+#include <stdlib.h>
+
 #include "mil_common.h"
 #include "gate_reduce.h"
 
@@ -528,6 +530,185 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
         dbg[0] = (float)(st1 - st0); dbg[1] = (float)(sr1 - sr0); dbg[2] = (float)(st2 - st1); dbg[3] = (float)(sr0 & 0xffffff);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------- gate forward, fat waves
+// Eval-mode form of the deep pipeline with ONE wave per SIMD: the same 256 rows x 384 gate columns per workgroup, the same
+// LDS rings and LDS-DMA pieces, but four waves of 128 rows x 192 columns = 24 accumulator tiles (384 registers) each.
+// Why: per 32-k slice the eight-wave kernel reads 16 operand fragments per wave (2 A + 6 B per k-step, every fragment feeding
+// 2 or 6 MFMAs) = 128 KB of LDS reads + 40 KB of DMA writes per CU against 1536 MFMA clocks - 87 % of what the LDS can move
+// (128 B/clk), i.e. the kernel is LDS-bound before it is MFMA-bound.  A 4 x 6 wave tile needs 10 fragments per 24 MFMAs:
+// 80 + 40 KB per slice = 61 %.
+// 384 accumulator registers do not fit the 256 AGPRs, and left to itself hipcc shuttles tiles between the register files
+// around every MFMA (round 1: 240 us).  Here the MFMAs are inline asm whose accumulator operand is constrained per tile -
+// 16 tiles "+a" (AGPR), 8 tiles "+v" (VGPR) - so every tile has ONE home for the whole loop (checked in the ISA: no
+// v_accvgpr_* in the loop).  The hazard recogniser cannot see inside the asm: explicit s_nop after the zero-fill and
+// before the epilogue reads the accumulators.  Same k order per output as the eight-wave kernel: bit-identical results.
+// MEASURED (tools/kbench_fat.py, config 5, same box, one process each): 124 us against 110 us for the eight-wave kernel
+// without saved gates, 152 against 136 with them - the register trick works (main loop: 48 MFMAs, 20 ds_read_b128, 10 DMA
+// pieces, nothing else), but a lone in-order wave per SIMD exposes what a second wave used to cover: after every slice
+// barrier the first fragments of the new slice (6 reads, ~250 clk of 1536) and any lateness of a DMA piece stall the
+// matrix pipe outright.  Reading the next slice's first fragments BEFORE the barrier needs its pieces landed one slice
+// earlier, i.e. one more slot in both rings (176 KB > the 160 KB of LDS at 256 rows).  So it stays an opt-in experiment
+// (MIL_BF16_FAT=1) and the record of how to give hipcc more than 256 accumulator registers.
+#define FAT_IN_V(q, c) ((q) == 3 || ((q) == 2 && (c) == 2))
+#define FAT_MFMA(ACC, A, B, INV)                                                                             \
+    do {                                                                                                     \
+        if (INV) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B));       \
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B));           \
+    } while (0)
+
+template <int GMODE>      // saved gates: 0 none, 2 bf16 [R, 384]
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gate_fwd_bf16_fat(
+    const u16* __restrict__ x, const u16* __restrict__ Wv, const float* __restrict__ bv, const u16* __restrict__ Wu,
+    const float* __restrict__ bu, const float* __restrict__ wvec, const float* __restrict__ battn, float* __restrict__ scores,
+    int R, int L, u16* __restrict__ gates16) {
+    __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + HC_NW * HC_WS];      // 64 + 72 KB
+    u16* xring = smem;
+    u16* wring = smem + HC_NX * HC_XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * HC_TM;
+    // DMA pieces of 16 rows x 64 B: x 16 per slice (wave takes w + 4 i, i < 4), weights 24 (w + 4 i, i < 6)
+    const int prow = lane >> 2, pch = lane & 3;
+    const u16* xsrc[4];
+    const u16* wsrc[6];
+    unsigned xdst[4], wdst[6];
+    const unsigned lds0 = (unsigned)(uintptr_t)(hb_lds_void*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = wave + 4 * i, lr = 16 * p + prow;
+        const int gr = min(row0 + lr, R - 1);
+        xsrc[i] = x + (size_t)gr * L + 8 * (pch ^ ((lr >> 2) & 3));
+        xdst[i] = __builtin_amdgcn_readfirstlane(lds0 + 2u * (unsigned)(16 * p * HC_BK));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int p = wave + 4 * i, wrow = 16 * p + prow;
+        wsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 8 * (pch ^ ((wrow >> 2) & 3));
+        wdst[i] = __builtin_amdgcn_readfirstlane(lds0 + 2u * (unsigned)(HC_NX * HC_XS + 16 * p * HC_BK));
+    }
+    auto dma_x = [&](int i, int slot, int k0) { dma16_raw(xsrc[i] + k0, xdst[i] + 2u * (unsigned)(slot * HC_XS)); };
+    auto dma_w = [&](int i, int slot, int k0) { dma16_raw(wsrc[i] + k0, wdst[i] + 2u * (unsigned)(slot * HC_WS)); };
+
+    f32x16 acc[4][3][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[q][c][u][i] = 0.f;
+
+    const int nslice = L / HC_BK;
+#pragma unroll
+    for (int qq = 0; qq < HC_NX - 1; ++qq) {
+        const int k0 = min(qq, nslice - 1) * HC_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_x(i, qq, k0);
+    }
+#pragma unroll
+    for (int qq = 0; qq < HC_NW - 1; ++qq) {
+        const int k0 = min(qq, nslice - 1) * HC_BK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dma_w(i, qq, k0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int fx = (r >> 2) & 3;
+    int xs = 0, wsl = 0;
+    for (int s = 0; s < nslice; ++s) {
+        const int kw = min(s + HC_NW - 1, nslice - 1) * HC_BK, kx = min(s + HC_NX - 1, nslice - 1) * HC_BK;
+        const int xnew = xs == 0 ? HC_NX - 1 : xs - 1;
+        const int wnew = wsl == 0 ? HC_NW - 1 : wsl - 1;
+        const u16* xa = xring + xs * HC_XS + (128 * wr + r) * HC_BK;
+        const u16* wb = wring + wsl * HC_WS + (96 * wc + r) * HC_BK;
+        u16x8 a[2][4], bs[3];
+        auto read_a = [&](int ks) {
+            const int ch = 8 * ((2 * ks + h) ^ fx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[ks][q] = *reinterpret_cast<const u16x8*>(xa + 32 * q * HC_BK + ch);
+        };
+        auto read_b = [&](int j) {
+            const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
+            const int ch = 8 * ((2 * ks + h) ^ fx);
+            bs[j % 3] = *reinterpret_cast<const u16x8*>(wb + (u * 192 + 32 * c) * HC_BK + ch);
+        };
+        read_a(0);
+        read_b(0);
+        read_b(1);
+        // 12 B fragments per slice, each feeding the 4 row tiles; weight pieces of slice s + 2 first, x pieces of s + 3 last
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            if (j + 2 < 12) read_b(j + 2);
+            if (j == 2) read_a(1);
+            if (j < 6) dma_w(j, wnew, kw);
+            if (j >= 7 && j < 11) dma_x(j - 7, xnew, kx);
+            const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) FAT_MFMA(acc[q][c][u], a[ks][q], bs[j % 3], FAT_IN_V(q, c));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // in order: x(s+1) [slice s-2] | W(s+1) 6, x(s+2) 4 [slice s-1] | W(s+2) 6, x(s+3) 4 [this slice]: all but the last
+        // 14 operations have landed = the weights and x of slice s + 1
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        xs = xs == HC_NX - 1 ? 0 : xs + 1;
+        wsl = wsl == HC_NW - 1 ? 0 : wsl + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // tail pieces landed; last MFMAs retired
+    __builtin_amdgcn_s_barrier();
+
+    float* sred = reinterpret_cast<float*>(smem) + 8 * (32 * 192) / 2;       // [2][256], behind the gate tiles
+    u16* tile_lds = smem + wave * (32 * 192);                               // this wave's [32][192] bf16 tile (12 KB)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float part[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int d = 32 * (3 * wc + c) + r;
+            const float bvd = bv[d], bud = bu[d], wd = wvec[d];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = fast_tanh(acc[q][c][0][i] + bvd);
+                const float u = fast_sigmoid(acc[q][c][1][i] + bud);
+                part[i] += wd * v * u;
+                if (GMODE == 2) {
+                    u16* t = tile_lds + mfma32_row(i, h) * 192 + 32 * c + r;
+                    t[0] = __builtin_bit_cast(u16, (__bf16)v);
+                    t[96] = __builtin_bit_cast(u16, (__bf16)u);
+                }
+            }
+        }
+        if (GMODE == 2) {
+            const int row_base = row0 + 128 * wr + 32 * q;
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int k = lane + 64 * n, row = k / 24, ch = k % 24;
+                const u16x8 vv = *reinterpret_cast<const u16x8*>(tile_lds + row * 192 + 8 * ch);
+                if (row_base + row < R)
+                    *reinterpret_cast<u16x8*>(gates16 + (size_t)(row_base + row) * HB_NG + (ch / 12) * 192 + 96 * wc + 8 * (ch % 12)) = vv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = half_sum_lane31(part[i]);
+            if (r == 31) sred[wc * HC_TM + 128 * wr + 32 * q + mfma32_row(i, h)] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int gr = row0 + tid;
+        if (gr < R) scores[gr] = sred[tid] + sred[HC_TM + tid] + battn[0];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- pool stages, bf16 x
@@ -1152,6 +1333,13 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
         const dim3 grid((R + HC_TM - 1) / HC_TM);
         const hipStream_t st_ = (hipStream_t)stream;
 #define HC_LAUNCH(G, D) hipLaunchKernelGGL((k_gate_fwd_bf16_deep<G, D>), grid, dim3(512), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, gates16, xbits, xbits ? xscale : 1.0f)
+        // EXPERIMENT (MIL_BF16_FAT=1; tools/kbench_fat.py): bit-identical to the eight-wave kernel and 12 % SLOWER at config 5
+        // (124 vs 110 us without saved gates) - see the comment above k_gate_fwd_bf16_fat
+        static const bool fat = []() { const char* e = getenv("MIL_BF16_FAT"); return e != nullptr && e[0] == '1'; }();
+        if (fat && !xbits && (gates16 || !gates)) {       // eval mode, bf16 (or no) saved gates: one wave per SIMD, 24 tiles each
+            if (gates16) hipLaunchKernelGGL((k_gate_fwd_bf16_fat<2>), grid, dim3(256), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, R, L, gates16);
+            else hipLaunchKernelGGL((k_gate_fwd_bf16_fat<0>), grid, dim3(256), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, R, L, gates16);
+        } else
         if (xbits) {
             if (gates16) HC_LAUNCH(2, true); else if (gates) HC_LAUNCH(1, true); else HC_LAUNCH(0, true);
         } else {
