@@ -18,7 +18,8 @@ def short(name):
 
 
 def stats(w, top=40):
-    f = glob.glob(os.path.join(SRC, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
+    # gpurun merges a run's files into gpurun_out/ beside those of earlier runs: take the newest
+    f = sorted(glob.glob(os.path.join(SRC, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if not f:
         return
     rows = list(csv.DictReader(open(f[0])))
@@ -32,7 +33,7 @@ def stats(w, top=40):
 
 
 def pmc(sub):
-    f = glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True)
+    f = sorted(glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f[0])):
