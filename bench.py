@@ -547,7 +547,9 @@ def run_rank(args):
                                     "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
             line["kernels_ms"] = {k: round(v, 4) for k, v in kb.items()}
             line["kernels_ms_note"] = ("each launch group timed stand-alone through mil_image_only_step_time; in the step itself "
-                                       "the keep bits are drawn by gate_fwd, and at world size 1 Adam is applied inside the "
+                                       "the keep bits are drawn by gate_fwd, the pool partial pass runs in gate_fwd's epilogue "
+                                       "(gate_fwd_with_pool_fused is that one launch; gate_fwd and pool_partial are the two "
+                                       "stand-alone launches it replaces), and at world size 1 Adam is applied inside the "
                                        "reduce launch (no separate adam launch)")
             line["kernels_tflops"] = {k: round(flops[k] / (kb[k] * 1e-3) / 1e12, 2) for k in flops}
             if args.train_mode and args.dtype == "f32" and world == 1:

@@ -575,6 +575,11 @@ int mil_sgd_step(float* param, const float* grad, size_t n, float lr, float weig
 #define MIL_STAGE_ADAM     0x40u
 #define MIL_STAGE_TILEMAP  0x80u     /* build tile_map / bag_tile_off / rows_dev on the device from bag_len_dev */
 #define MIL_STAGE_ALL      0xffu
+/* Hint, not a stage (outside MIL_STAGE_ALL): the caller asserts that tile_map is the plain single-segment map of bags whose
+ * lengths are all multiples of 32 - every tile full, tile t = rows 32 t .. 32 t + 31.  With GATE_FWD and POOL in the same
+ * call (fp32 x, C == 2, hrow given) the pool partial pass then runs in the epilogue of the gate-forward launch instead of
+ * as a launch of its own (same partials / hrow; ABMIL.py:52-59 in one kernel).  Never set it for multi-segment maps. */
+#define MIL_STAGE_POOL_FUSED 0x100u
 typedef struct mil_image_only_step {
     uint32_t struct_bytes;          /* sizeof(mil_image_only_step): ABI check */
     uint32_t stages;                /* MIL_STAGE_* to run */

@@ -130,6 +130,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
 STAGE_DROPBITS, STAGE_GATE_FWD, STAGE_POOL, STAGE_TAIL, STAGE_GATE_BWD, STAGE_REDUCE, STAGE_ADAM = 1, 2, 4, 8, 16, 32, 64
 STAGE_TILEMAP = 0x80
 STAGE_ALL = 0xff
+STAGE_POOL_FUSED = 0x100      # hint: all tiles full and aligned (include/mil_hip.h) - pool partial pass inside the forward launch
 
 
 class SmallDwDesc(ctypes.Structure):

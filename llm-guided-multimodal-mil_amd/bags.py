@@ -53,6 +53,7 @@ class BagLayout:
     bag_tile_off: torch.Tensor   # int32 [B+1]
     bag_off: torch.Tensor        # int32 [B+1]
     _row_bag: Optional[torch.Tensor] = None
+    aligned32: bool = False      # single segment, every bag length a multiple of 32: tile t = rows 32 t .. 32 t + 31
 
     def row_bag(self) -> torch.Tensor:
         """int32 [R]: the bag of every row (built from the tile map on first use; mil_gate_bwd_input_pool reads it)."""
@@ -93,7 +94,7 @@ class BagLayout:
         tm, bto, bo = build_tile_map(lengths)
         lay = cls(lengths=list(key[0]), R=int(bo[-1]), B=len(key[0]), T=int(tm.shape[0]),
                   tile_map=torch.from_numpy(tm).to(device), bag_tile_off=torch.from_numpy(bto).to(device),
-                  bag_off=torch.from_numpy(bo).to(device))
+                  bag_off=torch.from_numpy(bo).to(device), aligned32=all(v % 32 == 0 for v in key[0]))
         return cls._put(key, lay)
 
     @classmethod

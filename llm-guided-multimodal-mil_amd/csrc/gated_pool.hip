@@ -203,13 +203,31 @@ struct GateFwdGen {
     const int32_t* offset_dev;
 };
 
-template <bool DROP, bool GEN>
+// PQ > 0 (= L / 256): the attention-pool PARTIAL PASS of the workgroup's four 32-row tiles runs in the epilogue, once the
+// 128 scores are final - k_pool_partial's arithmetic, operation for operation (tile weights by the same wave reductions,
+// virtual wave v = rows v, v + 4, ..., the four virtual waves of a tile folded in the same order, the head-projection
+// by-product through the same 16-value reduction), so partials / hrow equal the stand-alone kernel's.  The rows come back
+// from L2 / Infinity Cache (the DMA stream of the main loop read them moments ago): one launch and one cold start less
+// per step - the stand-alone pass costs 14 us at 32 x 1024 x 512 although its bytes take 7.  Only for batches whose
+// tiles are all full and aligned (T * 32 == R, i.e. tile t = rows 32 t ..), which the host checks.
+struct GateFwdPool {
+    const int32_t* tile_map;    // [T][4] = {bag, row0, nrows, 0}
+    float* partials;            // [T][L] then [T][2]
+    int T;
+    const float* Wf;            // [2][L] head rows (C == 2)
+    float* hrow;                // [R][2]
+    const uint32_t* mbits;      // [B][L/32] keep words of the head's dropout (train mode without GEN), else NULL
+    float mscale;
+};
+
+template <bool DROP, bool GEN, int PQ>
 __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, const float* __restrict__ Wv,
                                                    const float* __restrict__ bv, const float* __restrict__ Wu,
                                                    const float* __restrict__ bu, const float* __restrict__ wvec,
                                                    const float* __restrict__ battn, float* __restrict__ scores,
                                                    float* __restrict__ gates, int R, int L,
-                                                   const uint32_t* __restrict__ xbits, float xscale, GateFwdGen gen) {
+                                                   const uint32_t* __restrict__ xbits, float xscale, GateFwdGen gen,
+                                                   GateFwdPool pool) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (GF_TM + GF_NG) * 32];      // [2] x buffers, then [2] W buffers
     __shared__ __attribute__((aligned(16))) uint32_t mlds[GEN ? GF_TM * 32 : 4];       // keep words [128][nslice <= 32]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -269,8 +287,9 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
         vmask = (32 * wr + r) * nslice * 4;
         mnext = __builtin_amdgcn_raw_buffer_load_b32(srd_m, vmask, 0, 0);
     }
+    uint64_t off = 0;
     if (GEN) {
-        uint64_t off = gen.offset;
+        off = gen.offset;
         if (gen.offset_dev != nullptr) off += (uint64_t)(uint32_t)gen.offset_dev[0];
         const size_t blk0 = (size_t)row0 * nslice / 4;                  // 128 nslice words per workgroup: a multiple of 4
         const int nblk = rows_here * nslice / 4;                        // nslice % 4 == 0 (host)
@@ -365,6 +384,23 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
         __syncthreads();
     }
 
+    // fused pool pass: the x rows of this wave's tile are requested NOW (they depend on nothing the epilogue computes), so
+    // that their trip from L2 / Infinity Cache runs under the activation epilogue
+    constexpr int PNQ = PQ > 0 ? PQ : 1;
+    f32x4 pv[PQ > 0 ? 2 : 1][PQ > 0 ? MIL_POOL_TILE / 4 : 1][PNQ];
+    if (PQ > 0) {
+        const int trow0 = row0 + 32 * wr;
+        if (trow0 < R) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                    const float* xr = x + (size_t)(trow0 + 2 * wc + j + 4 * i) * L + 4 * lane;
+#pragma unroll
+                    for (int q = 0; q < PNQ; ++q) pv[j][i][q] = *reinterpret_cast<const f32x4*>(xr + 256 * q);
+                }
+        }
+    }
     float part[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) part[i] = 0.f;
@@ -393,9 +429,123 @@ __global__ __launch_bounds__(512) void k_gate_fwd2(const float* __restrict__ x, 
         if (r == 31) sred[wc * GF_TM + 32 * wr + mfma32_row(i, h)] = v;
     }
     __syncthreads();
+    float* sc_lds = smem + 2 * GF_TM;                  // [128] final scores (fused pool pass)
     if (tid < GF_TM) {
         const int gr = row0 + tid;
-        if (gr < R) scores[gr] = sred[tid] + sred[GF_TM + tid] + battn[0];
+        const float sc = sred[tid] + sred[GF_TM + tid] + battn[0];
+        if (gr < R) scores[gr] = sc;
+        if (PQ > 0) sc_lds[tid] = gr < R ? sc : -INFINITY;
+    }
+    if (PQ > 0) {
+        constexpr int NQ = PQ > 0 ? PQ : 1;
+        float* pred = smem + 1024;                     // [4 tiles][2 virtual waves][NQ][256]
+        __syncthreads();
+        const int trow0 = row0 + 32 * wr;              // this wave's tile: rows trow0 .. trow0 + 31 (wave-uniform)
+        const bool live = trow0 < R;                   // R % 32 == 0 (host): a tile is whole or absent
+        const int t = trow0 >> 5;
+        // tile weights, as wave 0 of k_pool_partial forms them
+        const float s_ = lane < 32 ? sc_lds[32 * wr + lane] : -INFINITY;
+        const float m_ = wave_allmax(s_);
+        const float p_ = lane < 32 ? expf(s_ - m_) : 0.f;
+        const float l_ = wave_allsum(p_);
+        const float xs = DROP ? xscale : 1.0f;
+        f32x4 pacc[2][NQ];
+        if (live) {
+            auto& v = pv;
+            const int sh = 4 * (lane & 7);
+            if (DROP) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                        const int rr = 2 * wc + j + 4 * i;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const unsigned wd = GEN ? mlds[(32 * wr + rr) * nslice + 8 * q + (lane >> 3)]
+                                                    : xbits[(size_t)(trow0 + rr) * (L >> 5) + 8 * q + (lane >> 3)];
+                            const unsigned mm = wd >> sh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[j][i][q][e] = keep_if(v[j][i][q][e], mm, e);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pacc[j][q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                    const int rr = 2 * wc + j + 4 * i;
+                    const float pw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_), rr)) * xs;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) pacc[j][q] += pw * v[j][i][q];
+                }
+            }
+            // head rows as this tile's bag sees them (k_pool_partial's head_row), then the by-product h[row][c]
+            const int bag_ = pool.tile_map[4 * t];
+            f32x4 wf[2][NQ];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    f32x4 w = *reinterpret_cast<const f32x4*>(pool.Wf + (size_t)c * L + 256 * q + 4 * lane) * xs;
+                    if (DROP) {
+                        const int widx = bag_ * (L >> 5) + 8 * q + (lane >> 3);
+                        unsigned wd;
+                        if (GEN) {      // the word workgroup 0 writes to mbits_out in this same launch: drawn again here
+                            const uint2 pr = philox_keep_words_quarter((uint64_t)(widx >> 1), off, gen.mseed_lo, gen.mseed_hi);
+                            wd = (widx & 1) ? pr.y : pr.x;
+                        } else {
+                            wd = pool.mbits[widx];
+                        }
+                        const unsigned mm = wd >> sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = keep_if(w[e], mm, e) * pool.mscale;
+                    }
+                    wf[c][q] = w;
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float d16[16];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            d += v[j][i][q][0] * wf[c][q][0] + v[j][i][q][1] * wf[c][q][1] + v[j][i][q][2] * wf[c][q][2] + v[j][i][q][3] * wf[c][q][3];
+                        d16[2 * i + c] = d;
+                    }
+                const float tot = wave_reduce16(d16, lane);
+                const int k = wave_reduce16_index(lane), rr = 2 * wc + j + 4 * (k >> 1);
+                if ((lane & 3) == 0) pool.hrow[(size_t)(trow0 + rr) * 2 + (k & 1)] = tot;
+            }
+            if (wc == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        *reinterpret_cast<f32x4*>(pred + ((wr * 2 + j) * NQ + q) * 256 + 4 * lane) = pacc[j][q];
+            }
+        }
+        __syncthreads();
+        if (live && wc == 0) {
+            float* out = pool.partials + (size_t)t * L;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 vv = pacc[0][q];
+                vv += pacc[1][q];
+                vv += *reinterpret_cast<const f32x4*>(pred + ((wr * 2 + 0) * NQ + q) * 256 + 4 * lane);
+                vv += *reinterpret_cast<const f32x4*>(pred + ((wr * 2 + 1) * NQ + q) * 256 + 4 * lane);
+                *reinterpret_cast<f32x4*>(out + 256 * q + 4 * lane) = vv;
+            }
+            if (lane == 0) {
+                float* ml = pool.partials + (size_t)pool.T * L + 2 * t;
+                ml[0] = m_;
+                ml[1] = l_;
+            }
+        }
     }
 }
 
@@ -1539,7 +1689,8 @@ static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv,
 
 static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                 const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
-                                const uint32_t* xbits, float xscale, const GateFwdGen* gen, void* stream) {
+                                const uint32_t* xbits, float xscale, const GateFwdGen* gen, void* stream,
+                                const GateFwdPool* pool = nullptr, int* fused = nullptr) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
@@ -1551,14 +1702,26 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
 #else
     const bool fwd2 = L <= 4096;                 // 128 rows x L floats must stay inside the 32-bit buffer offsets (and int math)
 #endif
+    if (fused != nullptr) *fused = 0;
+    const GateFwdPool nopool{};
+    // the pool partial pass rides in the forward's epilogue when every row goes through k_gate_fwd2 and every tile of the
+    // map is a full, aligned 32-row tile (T * 32 == R: tile t = rows 32 t ..)
+    const bool pool_in = pool != nullptr && fused != nullptr && !r32 && tail == 0 && fwd2 && L == 512 && (R % 32) == 0 &&
+                         pool->T * MIL_POOL_TILE == R && pool->tile_map && pool->partials && pool->Wf && pool->hrow;
     if (gen != nullptr) {
         // the forward kernel can draw the keep bits itself when every row goes through k_gate_fwd2 and a workgroup's
         // [128][L/32] words fit its LDS slot; otherwise the stand-alone generator runs first
         const bool in_kernel = !r32 && tail == 0 && fwd2 && L <= 1024 && (L % 128) == 0;
         if (in_kernel) {
             const int grid = (R + GF_TM - 1) / GF_TM;
-            hipLaunchKernelGGL((k_gate_fwd2<true, true>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, R, L,
-                               gen->xbits_out, xscale, *gen);
+            if (pool_in && gen->mbits_out != nullptr) {
+                hipLaunchKernelGGL((k_gate_fwd2<true, true, 2>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates,
+                                   R, L, gen->xbits_out, xscale, *gen, *pool);
+                *fused = 1;
+            } else {
+                hipLaunchKernelGGL((k_gate_fwd2<true, true, 0>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates,
+                                   R, L, gen->xbits_out, xscale, *gen, nopool);
+            }
             MIL_CHECK_LAUNCH();
             return MIL_OK;
         }
@@ -1579,12 +1742,20 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
     const int Rm = R - tail;
     const int grid = (Rm + GF_TM - 1) / GF_TM;
     const GateFwdGen nogen{};
-    if (fwd2 && xbits)
-        hipLaunchKernelGGL((k_gate_fwd2<true, false>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
-                           xbits, xscale, nogen);
+    if (pool_in && xbits && pool->mbits) {
+        hipLaunchKernelGGL((k_gate_fwd2<true, false, 2>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
+                           xbits, xscale, nogen, *pool);
+        *fused = 1;
+    } else if (pool_in && !xbits && !pool->mbits) {
+        hipLaunchKernelGGL((k_gate_fwd2<false, false, 2>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
+                           xbits, 1.0f, nogen, *pool);
+        *fused = 1;
+    } else if (fwd2 && xbits)
+        hipLaunchKernelGGL((k_gate_fwd2<true, false, 0>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
+                           xbits, xscale, nogen, nopool);
     else if (fwd2)
-        hipLaunchKernelGGL((k_gate_fwd2<false, false>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
-                           xbits, 1.0f, nogen);
+        hipLaunchKernelGGL((k_gate_fwd2<false, false, 0>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L,
+                           xbits, 1.0f, nogen, nopool);
     else if (xbits)
         hipLaunchKernelGGL(k_gate_fwd<true>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
                            xscale);
@@ -1633,6 +1804,39 @@ extern "C" int mil_gate_scores_fwd_draw(const float* x, const float* Wv, const f
     g.offset = offset;
     g.offset_dev = offset_dev;
     return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, D, nullptr, xscale, &g, stream);
+}
+
+// Internal (step.hip): gate forward with the pool partial pass in its epilogue when the batch allows it; *fused says
+// whether partials / hrow were produced (otherwise the caller runs the stand-alone pool pass).  seed / mseed / offset as
+// mil_gate_scores_fwd_draw when draw != 0 (train mode, keep bits drawn by the kernel), else xbits / mbits are inputs.
+int gate_fwd_with_pool(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* w,
+                       const float* b, float* scores, float* gates, int R, int L, int draw, uint32_t* xbits, float xscale,
+                       uint32_t* mbits, float mscale, int B, uint64_t seed, uint64_t mseed, uint64_t offset,
+                       const int32_t* offset_dev, const int32_t* tile_map, int T, float* partials, const float* Wf, float* hrow,
+                       int* fused, void* stream) {
+    GateFwdPool pl{};
+    pl.tile_map = tile_map;
+    pl.partials = partials;
+    pl.T = T;
+    pl.Wf = Wf;
+    pl.hrow = hrow;
+    pl.mbits = draw ? nullptr : mbits;
+    pl.mscale = mscale;
+    if (draw) {
+        if (!xbits || !mbits || (L % 64) != 0 || B <= 0) return MIL_EINVAL;
+        GateFwdGen g{};
+        g.xbits_out = xbits;
+        g.mbits_out = mbits;
+        g.B = B;
+        g.seed_lo = (uint32_t)seed;
+        g.seed_hi = (uint32_t)(seed >> 32);
+        g.mseed_lo = (uint32_t)mseed;
+        g.mseed_hi = (uint32_t)(mseed >> 32);
+        g.offset = offset;
+        g.offset_dev = offset_dev;
+        return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, MIL_GATE_D, nullptr, xscale, &g, stream, &pl, fused);
+    }
+    return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, MIL_GATE_D, xbits, xscale, nullptr, stream, &pl, fused);
 }
 
 static int launch_pool_partial(const float* x, const float* scores, const int32_t* tile_map, int T, int L,

@@ -4,7 +4,16 @@
 // through the Python interpreter and ATen's dispatcher (dozens of implicit launches).  Here the step is a fixed
 // sequence of eight launches issued from C on the caller's stream; nothing is allocated, nothing synchronises, so the
 // call is capture-safe (the host mirror replays it from a hipGraph for tiny one-bag steps) and costs one foreign call.
+#include <stdlib.h>
+
 #include "mil_common.h"
+
+// gated_pool.hip: gate forward + (when the batch allows) the pool partial pass in the same launch
+int gate_fwd_with_pool(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* w,
+                       const float* b, float* scores, float* gates, int R, int L, int draw, uint32_t* xbits, float xscale,
+                       uint32_t* mbits, float mscale, int B, uint64_t seed, uint64_t mseed, uint64_t offset,
+                       const int32_t* offset_dev, const int32_t* tile_map, int T, float* partials, const float* Wf, float* hrow,
+                       int* fused, void* stream);
 
 static int step_check(const mil_image_only_step* a) {
     if (!a || a->struct_bytes != sizeof(mil_image_only_step)) return MIL_EINVAL;
@@ -21,6 +30,12 @@ static int step_check(const mil_image_only_step* a) {
     return MIL_OK;
 }
 
+// MIL_FUSE_POOL=0: keep the pool partial pass a launch of its own (A/B measurements, bit-equality tests)
+static bool fuse_pool_enabled() {
+    const char* e = getenv("MIL_FUSE_POOL");
+    return e == nullptr || e[0] != '0';
+}
+
 extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* stream) {
     int rc = step_check(a);
     if (rc != MIL_OK) return rc;
@@ -33,6 +48,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     const uint32_t* mbits = train ? a->mbits : nullptr;
     const bool use_h = a->hrow != nullptr && grads && a->C <= 4;
     bool adam_in_reduce = false;
+    int pool_fused = 0;
 
     if ((st & MIL_STAGE_TILEMAP) && a->bag_len_dev) {
         rc = mil_build_tile_map(a->bag_len_dev, a->B, const_cast<int32_t*>(a->tile_map), const_cast<int32_t*>(a->bag_tile_off),
@@ -56,6 +72,13 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
             rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores,
                                           g16 ? nullptr : gates, a->R, a->L, MIL_GATE_D, (grads && g16) ? a->gates16 : nullptr,
                                           xbits, xscale, stream);
+        else if ((st & MIL_STAGE_POOL) && (st & MIL_STAGE_POOL_FUSED) && use_h && a->C == 2 && !a->bag_len_dev &&
+                 (!train || draw_in_fwd) && fuse_pool_enabled())
+            // forward + pool partial pass in one launch (falls back inside when the tile map is not all full tiles)
+            rc = gate_fwd_with_pool((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R, a->L,
+                                    draw_in_fwd ? 1 : 0, a->xbits, xscale, a->mbits, mscale, a->B, a->seed,
+                                    a->seed ^ 0x9E3779B97F4A7C15ull, a->offset, a->offset_dev, a->tile_map, a->T, a->partials,
+                                    a->Wf, a->hrow, &pool_fused, stream);
         else if (draw_in_fwd)
             rc = mil_gate_scores_fwd_draw((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R,
                                           a->L, MIL_GATE_D, a->xbits, xscale, a->mbits, a->B, a->seed,
@@ -65,7 +88,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                                      MIL_GATE_D, xbits, xscale, stream);
         if (rc != MIL_OK) return rc;
     }
-    if (st & MIL_STAGE_POOL) {
+    if ((st & MIL_STAGE_POOL) && !pool_fused) {
         if (a->x_bf16) {
             rc = use_h ? mil_attn_pool_partial_h_bf16((const uint16_t*)a->x, a->scores, a->tile_map, a->T, a->L, a->partials,
                                                       a->Wf, a->C, a->hrow, xbits, xscale, mbits, mscale, stream)

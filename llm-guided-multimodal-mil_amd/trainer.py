@@ -225,6 +225,9 @@ class ImageOnlyTrainer:
         return a
 
     def _run(self, a, stages: int):
+        # plain single-segment layout with every bag a multiple of 32 rows: the pool partial pass may ride in the forward launch
+        if getattr(self._keep[2], "aligned32", False) and (stages & _lib.STAGE_GATE_FWD) and (stages & _lib.STAGE_POOL):
+            stages |= _lib.STAGE_POOL_FUSED
         a.stages = stages
         a.accumulate = int(self._micro > 0)
         a.lr = self.lr
@@ -346,6 +349,9 @@ class ImageOnlyTrainer:
         if a.x_bf16:        # the bf16 weight gradient's launch pair is one entry point: time it as a whole
             groups = [g for g in groups if g[0] not in ("gate_bwd_dw", "gate_bwd_reduce_and_head_params")]
             groups.append(("gate_bwd_dw", _lib.STAGE_GATE_BWD | _lib.STAGE_REDUCE))
+        if not a.x_bf16 and getattr(layout, "aligned32", False):
+            # what the step actually launches for such a batch: forward with the pool partial pass in its epilogue
+            groups.append(("gate_fwd_with_pool_fused", fwd | _lib.STAGE_POOL | _lib.STAGE_POOL_FUSED))
         out = {}
         ms = ctypes.c_float(0.0)
         for name, stg in groups:

@@ -1,0 +1,59 @@
+"""GPU: the attention-pool partial pass fused into the gate forward's epilogue (k_gate_fwd2<.., PQ = 2>, what the one-call
+step runs when every tile of the batch is a full 32-row tile) against the stand-alone k_pool_partial launch
+(MIL_FUSE_POOL=0): same partial sums, head projections, logits, loss and gradients - in eval mode and in model.train() mode
+(same Philox stream: the fused kernel re-draws the head mask words workgroup 0 writes out)."""
+import os
+
+import pytest
+import torch
+
+from mil_amd import synthetic as syn
+from mil_amd.bags import BagLayout
+from mil_amd.trainer import ImageOnlyTrainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(train_mode, fuse, B, N, L=512):
+    dev = torch.device("cuda")
+    old = os.environ.get("MIL_FUSE_POOL")
+    os.environ["MIL_FUSE_POOL"] = "1" if fuse else "0"
+    try:
+        p = syn.image_only_params(1234, L=L)
+        tr = ImageOnlyTrainer(p, dev, train_mode=train_mode)
+        x = syn.make_bags(4321, B, N, L).reshape(B * N, L).to(dev)
+        y = syn.make_labels(99, B).to(dev)
+        lay = BagLayout.uniform(B, N, dev)
+        tr.forward(x, lay, y)
+        tr.backward()
+        torch.cuda.synchronize()
+        T = lay.T
+        out = dict(partials=tr._keep[3]["partials"][:T * (L + 2)].clone(), hrow=tr.last["hrow"].clone(),
+                   logits=tr.last["logits"].clone(), ds=tr.last["ds"].clone(), grad=tr.fp.grad.clone(),
+                   loss=tr.loss_sum.clone(), scores=tr.last["scores"].clone())
+        if train_mode:
+            out["mbits"] = tr.last["mbits"].clone()
+            out["xbits"] = tr.last["xbits"].clone()
+        return out
+    finally:
+        if old is None:
+            os.environ.pop("MIL_FUSE_POOL", None)
+        else:
+            os.environ["MIL_FUSE_POOL"] = old
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+@pytest.mark.parametrize("B,N", [(32, 1024), (40, 832)])       # 40 x 832 = 260 workgroups: the last one has two live tiles
+def test_fused_pool_pass_equals_the_stand_alone_launch(train_mode, B, N):
+    a = _run(train_mode, True, B, N)
+    b = _run(train_mode, False, B, N)
+    assert torch.equal(a["scores"], b["scores"])
+    if train_mode:
+        assert torch.equal(a["xbits"], b["xbits"]) and torch.equal(a["mbits"], b["mbits"])
+    # same arithmetic, operation for operation; the compiler may contract the two kernels' dot products differently, so the
+    # comparison allows the last bits
+    for k in ("partials", "hrow", "logits", "ds", "grad", "loss"):
+        d = float((a[k] - b[k]).abs().max())
+        ref = float(b[k].abs().max())
+        assert d <= 2e-6 * max(1.0, ref), (k, d, ref)
+    assert bool(torch.isfinite(a["grad"]).all())
