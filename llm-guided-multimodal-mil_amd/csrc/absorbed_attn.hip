@@ -280,40 +280,85 @@ __global__ void k_apool_merge(const float* __restrict__ pacc, const float* __res
 // (v_mfma_f32_16x16x4_f32, operands straight from global memory: lane (r, kq) loads 16 bytes of row r at
 // k = 16t + 4kq and feeds four MFMAs), so columns 0-7 hold Qp_h . kin_n and columns 8-15 dpooled_h . keys_n.
 //   ad[n][h] = a_h[n],   ad[n][8 + h] = scale * a_h[n] (da_h[n] - cdot_h)
+// Round 2: the operands no longer come "straight from global memory".  In that form lane (r, kq) loaded 16 bytes of ITS
+// row, so the 16 lanes of a quarter-wave touched 16 different rows = 16 cache lines per quarter, 64 tag look-ups per load
+// instruction where a contiguous 1 KB needs 8 - the kernel ran at the L1's tag rate (25 us per site for 64 MB that take 7;
+// splitting the contraction over twice the waves changed nothing).  Now the workgroup streams K in chunks of 64 floats:
+// every wave instruction loads 4 rows x 256 contiguous bytes (keys and pe rows of the 64-key tile, the bag's 16-row
+// [Qp | dpooled] operand once for all four waves), registers -> LDS (row stride 68 floats: the 16 lanes of a fragment read
+// hit 64 different banks), double-buffered with the next chunk's loads in flight under this chunk's 32 MFMAs per wave.
+#define AD_KC 64
+#define AD_LS 68
 __global__ __launch_bounds__(256) void k_apool_dots(const float* __restrict__ keys, const float* __restrict__ pe,
                                                     const float* __restrict__ Qp, const float* __restrict__ lse,
                                                     const float* __restrict__ dpooled, const float* __restrict__ cdot,
                                                     const int32_t* __restrict__ k_off, const int32_t* __restrict__ tile_map,
                                                     float scale, float* __restrict__ ad) {
-    constexpr int E = 512;
+    constexpr int E = 512, NCH = E / AD_KC;
+    __shared__ __attribute__((aligned(16))) float lds[2][(2 * AP_TILE + 16) * AD_LS];      // [stage][keys 64 | pe 64 | B 16][68]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
     const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
-    if (16 * wave >= nkeys) return;
     const int pos0 = key0 - k_off[b];
+    const bool active = 16 * wave < nkeys;                       // wave-uniform
+    // staging map: thread -> (row srow + 16 i, 16-byte chunk sc) of the tile's [64][64] chunk; B: row srow (0..15), chunk sc
+    const int srow = tid >> 4, sc = tid & 15;
+    const float* kp[4];
+    const float* pp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rowc = max(min(srow + 16 * i, nkeys - 1), 0);
+        kp[i] = keys + (size_t)(key0 + rowc) * E + 4 * sc;
+        pp[i] = pe + (size_t)(pos0 + rowc) * E + 4 * sc;
+    }
+    const float* bsrc = (srow < 8 ? Qp + ((size_t)b * AP_H + srow) * E : dpooled + ((size_t)b * AP_H + (srow - 8)) * E) + 4 * sc;
+    f32x4 rk[4], rp[4], rb;
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rk[i] = *reinterpret_cast<const f32x4*>(kp[i] + AD_KC * c);
+            rp[i] = *reinterpret_cast<const f32x4*>(pp[i] + AD_KC * c);
+        }
+        rb = *reinterpret_cast<const f32x4*>(bsrc + AD_KC * c);
+    };
+    auto swrite = [&](int st) {
+        float* base = lds[st];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(base + (srow + 16 * i) * AD_LS + 4 * sc) = rk[i];
+            *reinterpret_cast<f32x4*>(base + (AP_TILE + srow + 16 * i) * AD_LS + 4 * sc) = rp[i];
+        }
+        *reinterpret_cast<f32x4*>(base + (2 * AP_TILE + srow) * AD_LS + 4 * sc) = rb;
+    };
     const int r = lane & 15, kq = lane >> 4;
-    const int rowc = min(16 * wave + r, nkeys - 1);
-    const float* kvp = keys + (size_t)(key0 + rowc) * E + 4 * kq;
-    const float* pep = pe + (size_t)(pos0 + rowc) * E + 4 * kq;
-    const float* bp = (r < 8 ? Qp + ((size_t)b * AP_H + r) * E : dpooled + ((size_t)b * AP_H + (r - 8)) * E) + 4 * kq;
     const float qmask = r < 8 ? 1.f : 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < E / 16; t += 4) {
-        f32x4 a1[4], a2[4], bb[4];
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int c = 0; c < NCH; ++c) {
+        const int st = c & 1;
+        if (c + 1 < NCH) gload(c + 1);
+        if (active) {
+            const float* ak = lds[st] + (16 * wave + r) * AD_LS + 4 * kq;
+            const float* ap = ak + AP_TILE * AD_LS;
+            const float* bq = lds[st] + (2 * AP_TILE + r) * AD_LS + 4 * kq;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a1[u] = *reinterpret_cast<const f32x4*>(kvp + 16 * (t + u));
-            a2[u] = *reinterpret_cast<const f32x4*>(pep + 16 * (t + u));
-            bb[u] = *reinterpret_cast<const f32x4*>(bp + 16 * (t + u));
-        }
+            for (int tt = 0; tt < AD_KC / 16; ++tt) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(ak + 16 * tt);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(ap + 16 * tt);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bq + 16 * tt);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][jj], bb[u][jj], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u][jj], bb[u][jj] * qmask, acc, 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jj], bb[jj], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[jj], bb[jj] * qmask, acc, 0, 0, 0);
+                }
             }
+        }
+        if (c + 1 < NCH) swrite(st ^ 1);
+        __syncthreads();
     }
+    if (!active) return;
     // lane (c, g4) holds column c of rows 4 g4 + i: columns c < 8 pair with c + 8
     const int h = r & 7;
     const float ls = lse[b * AP_H + h], cd = cdot[b * AP_H + h];
