@@ -62,37 +62,60 @@ __device__ __forceinline__ void sl_fold_store(float (*red)[4][64], const f32x4 a
     }
 }
 
+// Operands through LDS (round 2).  The first form loaded them "global -> registers" in the MFMA's own layout: lane (r, kq)
+// took 16 bytes of ITS row, so every quarter-wave touched 16 different rows - 64 cache-line look-ups per load instruction
+// where a contiguous 1 KB needs 8 - and a wave with fewer than 8 chunks of K re-issued its last chunk to fill the trip:
+// for a 512-deep layer 16 such instructions per wave, ~3.4 us of L1 tag time per workgroup out of a 6.4 us kernel
+// (the same finding as k_apool_dots).  Now the workgroup loads both 16-row operand slabs with contiguous 1 KB wave
+// instructions, K in chunks of 512 (the next chunk's loads in flight under this chunk's MFMAs), stages them in LDS (row
+// stride 516 floats: the 16 lanes of a fragment read hit 64 different banks) and the waves split the chunk's 16-k blocks.
+#define SL_KCH 512
+#define SL_LS (SL_KCH + 4)
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_small_fwd(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, int act,
                                                        const float* __restrict__ residual, int ldr,
                                                        float* __restrict__ y, int ldy, int M, int N, int K) {
     __shared__ float red[NW][4][64];
+    __shared__ __attribute__((aligned(16))) float opx[16 * SL_LS], opw[16 * SL_LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-    const int nk16 = K >> 4, per = (nk16 + NW - 1) / NW;
-    const int t0 = wave * per, t1 = min(nk16, t0 + per);
-    const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw + 4 * kq;
-    const float* xrow = x + (size_t)min(m0 + r, M - 1) * ldx + 4 * kq;
+    constexpr int NT = 64 * NW, LPT = (16 * SL_KCH / 4) / NT;          // 16-byte loads per thread, operand and chunk
+    f32x4 rx[LPT], rw[LPT];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + i * NT, row = idx >> 7, kk = k0 + 4 * (idx & 127);
+            if (kk < K) {
+                rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)min(m0 + row, M - 1) * ldx + kk);
+                rw[i] = *reinterpret_cast<const f32x4*>(W + (size_t)min(n0 + row, N - 1) * ldw + kk);
+            } else {
+                rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // 8 k-chunks of 16 per trip, every load issued before the first MFMA (the layer is one or two memory round
-    // trips deep: its time is latency, not bandwidth); chunks past the wave's range are clamped and zeroed
-    for (int t = t0; t < t1; t += 8) {
-        f32x4 fb[8], fa[8];
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += SL_KCH) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int tt = min(t + u, t1 - 1);
-            fb[u] = *reinterpret_cast<const f32x4*>(wrow + 16 * tt);
-            fa[u] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt);
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
+            *reinterpret_cast<f32x4*>(opx + row * SL_LS + 4 * c) = rx[i];
+            *reinterpret_cast<f32x4*>(opw + row * SL_LS + 4 * c) = rw[i];
         }
-        __builtin_amdgcn_sched_barrier(0);          // keep all 16 loads ahead of the first MFMA
+        __syncthreads();
+        if (k0 + SL_KCH < K) gload(k0 + SL_KCH);
+        const int nblk = min(SL_KCH, K - k0) >> 4, per = (nblk + NW - 1) / NW;
+        const int b1 = min(nblk, (wave + 1) * per);
+        for (int blk = wave * per; blk < b1; ++blk) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(opx + r * SL_LS + 16 * blk + 4 * kq);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(opw + r * SL_LS + 16 * blk + 4 * kq);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (t + u >= t1) fb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][jj], fb[u][jj], acc, 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[jj], fb[jj], acc, 0, 0, 0);
         }
+        __syncthreads();
     }
     sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, bias, act, residual, ldr, y, ldy);
 }
