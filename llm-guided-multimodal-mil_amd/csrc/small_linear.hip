@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
                                                        int lddx, float* __restrict__ dW, int lddw, float* __restrict__ db,
                                                        int M, int N, int K, int nW, int nKt) {
     __shared__ float red[NW][4][64];
+    __shared__ __attribute__((aligned(16))) float opa[16 * SL_LS];       // dx role: dpre of the tile's 16 rows, one n chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x < nW) {
         // ---- dW[n][k] = sum_m dpre[m][n] x[m][k]: 64 (n) x 128 (k) per workgroup, one 32 x 32 tile per wave (0..7)
@@ -173,39 +174,64 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
         }
         return;
     }
-    // ---- dx[m][k] = sum_n dpre[m][n] W[n][k]: one 16 x 16 tile per workgroup, the waves split n
+    // ---- dx[m][k] = sum_n dpre[m][n] W[n][k]: one 16 x 16 tile per workgroup, the waves split n.  dpre = dy * act'(.) of
+    // the tile's 16 rows is formed ONCE per workgroup from contiguous 1 KB wave loads and staged in LDS, n in chunks of 512
+    // (as k_small_fwd: in the MFMA's own layout a quarter-wave touched 16 rows per load instruction); the W^T operand is
+    // strided by nature (64 bytes per row of W) and stays on direct loads, all of a wave's blocks issued up front.
     const int r = lane & 15, kq = lane >> 4;
     const int bx = (int)blockIdx.x - nW;
     const int nK16 = (K + 15) >> 4;
     const int k0 = (bx % nK16) * 16, m0 = (bx / nK16) * 16;
-    const int nn16 = N >> 4, per = (nn16 + NW - 1) / NW;
-    const int t0 = wave * per, t1 = min(nn16, t0 + per);
     const int kc = min(k0 + r, K - 1);
-    const int mrow = min(m0 + r, M - 1);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = t0; t < t1; t += 8) {
-        f32x4 fa[8];
-        float fb[8][4];
+    constexpr int NT = 64 * NW, LPT = (16 * SL_KCH / 4) / NT, MAXPER = (SL_KCH / 16 + NW - 1) / NW;
+    f32x4 rg[LPT], ry[LPT];
+    auto gload = [&](int n0c) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int tt = min(t + u, t1 - 1);          // ragged tail: reload the last chunk, zeroed below
-            const int nb = 16 * tt + 4 * kq;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) fb[u][jj] = W[(size_t)(nb + jj) * ldw + kc];
-            f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)mrow * lddy + nb);
-            if (act != SL_NONE) {
-                const f32x4 yy = *reinterpret_cast<const f32x4*>(yv + (size_t)mrow * ldyv + nb);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) g[jj] = sl_dact(g[jj], yy[jj], act);
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + i * NT, row = idx >> 7, nn = n0c + 4 * (idx & 127);
+            const int mrow = min(m0 + row, M - 1);
+            if (nn < N) {
+                rg[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)mrow * lddy + nn);
+                if (act != SL_NONE) ry[i] = *reinterpret_cast<const f32x4*>(yv + (size_t)mrow * ldyv + nn);
+            } else {
+                rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ry[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (t + u >= t1) g = f32x4{0.f, 0.f, 0.f, 0.f};
-            fa[u] = g;
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    gload(0);
+    for (int n0c = 0; n0c < N; n0c += SL_KCH) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
+            f32x4 g = rg[i];
+            if (act != SL_NONE) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][jj], fb[u][jj], acc, 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj) g[jj] = sl_dact(g[jj], ry[i][jj], act);
+            }
+            *reinterpret_cast<f32x4*>(opa + row * SL_LS + 4 * c) = g;
+        }
+        __syncthreads();
+        if (n0c + SL_KCH < N) gload(n0c + SL_KCH);
+        const int nblk = min(SL_KCH, N - n0c) >> 4, per = (nblk + NW - 1) / NW;
+        const int b0 = wave * per, b1 = min(nblk, b0 + per);
+        float fb[MAXPER][4];
+#pragma unroll
+        for (int u = 0; u < MAXPER; ++u) {
+            const int nb = n0c + 16 * min(b0 + u, max(b1 - 1, 0)) + 4 * kq;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fb[u][jj] = (b0 + u < b1) ? W[(size_t)(nb + jj) * ldw + kc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXPER; ++u) {
+            if (b0 + u < b1) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(opa + r * SL_LS + 16 * (b0 + u) + 4 * kq);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[jj], fb[u][jj], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
     }
     sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, nullptr, SL_NONE, nullptr, 0, dx, lddx);
 }
