@@ -1696,7 +1696,17 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
     if (R == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool r32 = (R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4;
-    const int tail = (!r32 && gates != nullptr) ? gate_tail_rows(R, MIL_NUM_CU) : 0;   // the tail path keeps V, U in `gates`
+    int tail = (!r32 && gates != nullptr) ? gate_tail_rows(R, MIL_NUM_CU) : 0;   // the tail path keeps V, U in `gates`
+    if (!r32 && tail == 0) {
+        // A last round that would hold only a few workgroups (T text tokens per bag appended to 32 x 1024 patches: 259
+        // tiles on 256 CUs) costs a whole round: every row beyond the whole rounds, up to 1024 of them, goes through the
+        // 32-row kernel instead (10 workgroups of a quarter of the time)
+        const int per_round = GF_TM * MIL_NUM_CU;
+        const int over = R % per_round;
+        if (R >= per_round && over > 0 && over <= 1024) tail = -over;       // negative: "large tail", always the 32-row kernel
+    }
+    const bool big_tail = tail < 0;
+    if (big_tail) tail = -tail;
 #if defined(GF_NO_FWD2)
     const bool fwd2 = false;
 #else
@@ -1763,10 +1773,11 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
         hipLaunchKernelGGL(k_gate_fwd<false>, dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, Rm, L, xbits,
                            1.0f);
     MIL_CHECK_LAUNCH();
-    if (tail > 0 && xbits) {
+    if (tail > 0 && (xbits || big_tail)) {
         // train mode: the few rows beyond whole rounds go through the 32-row kernel (it applies the keep bits while staging)
-        return launch_gate_fwd_r32(x + (size_t)Rm * L, Wv, bv, Wu, bu, w, b, scores + Rm, gates + (size_t)Rm * GF_NG, tail, L,
-                                   xbits + (size_t)Rm * (L / 32), xscale, st);
+        return launch_gate_fwd_r32(x + (size_t)Rm * L, Wv, bv, Wu, bu, w, b, scores + Rm,
+                                   gates ? gates + (size_t)Rm * GF_NG : nullptr, tail, L,
+                                   xbits ? xbits + (size_t)Rm * (L / 32) : nullptr, xscale, st);
     }
     if (tail > 0) {
         const float* xt = x + (size_t)Rm * L;

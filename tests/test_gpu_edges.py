@@ -108,6 +108,33 @@ def test_rows_beyond_a_whole_round_of_tiles_take_the_few_rows_path():
     assert float(dx[:R - T].abs().sum()) > 0
 
 
+def test_a_last_round_of_a_few_tiles_goes_through_the_32_row_kernel():
+    """R = 256 * 128 + 320 (32 bags x (1024 patches + 10 text tokens)): the 320 rows beyond the whole round run on
+    k_gate_fwd_r32 instead of as a second, nearly empty round of 128-row tiles.  Same scores / gates as the tiled kernel on
+    those rows alone, in eval mode and with keep bits."""
+    from mil_amd import ops
+    L, T = 512, 320
+    R = 256 * 128 + T
+    p = {k: v.to(DEV) for k, v in syn.image_only_params(106, L=L).items()}
+    gp = [p["aggregator.attention_V.0.weight"], p["aggregator.attention_V.0.bias"], p["aggregator.attention_U.0.weight"],
+          p["aggregator.attention_U.0.bias"], p["aggregator.attention_weights.weight"].reshape(-1),
+          p["aggregator.attention_weights.bias"]]
+    x = torch.randn((R, L), generator=torch.Generator().manual_seed(11)).to(DEV)
+    for bits in (None, torch.randint(0, 2 ** 31 - 1, (R, L // 32), generator=torch.Generator().manual_seed(12),
+                                     dtype=torch.int32).to(DEV)):
+        kw = {} if bits is None else dict(xbits=bits, xscale=2.0)
+        scores, gates = ops.gate_scores_fwd(x, *gp, save_gates=True, **kw)
+        kt = {} if bits is None else dict(xbits=bits[R - T:].contiguous(), xscale=2.0)
+        s_ref, g_ref = ops.gate_scores_fwd(x[R - T:].contiguous(), *gp, save_gates=True, **kt)
+        assert float((scores[R - T:] - s_ref).abs().max()) <= 2e-6
+        assert float((gates[R - T:] - g_ref).abs().max()) <= 2e-6
+        kh = {} if bits is None else dict(xbits=bits[:256].contiguous(), xscale=2.0)
+        s_head, _ = ops.gate_scores_fwd(x[:256].contiguous(), *gp, save_gates=True, **kh)
+        assert float((scores[:256] - s_head).abs().max()) <= 2e-6
+        s_nog, _ = ops.gate_scores_fwd(x, *gp, save_gates=False, **kw)          # without saved gates: same split, same scores
+        assert float((s_nog - scores).abs().max()) <= 2e-6
+
+
 def test_more_than_two_classes_use_cross_entropy_on_the_sigmoid_outputs():
     """num_classes > 2: the reference's criterion is CrossEntropyLoss applied to the module's sigmoid outputs with the
     float one-hot labels as class probabilities (train_ddp.py:95-96,323-324)."""
