@@ -1074,6 +1074,7 @@ class _AddPE(torch.autograd.Function):
         out = torch.empty_like(x)
         rc = _lib.lib().mil_add_pe(_p(x), _p(pe), _p(row_bag), _p(row_off), rows, E, _p(out), _stream())
         _lib.check(rc, "mil_add_pe")
+        ctx.set_materialize_grads(False)      # an unused keys + pe must not send a [rows, E] tensor of zeros upstream
         return out
 
     @staticmethod
