@@ -106,3 +106,18 @@ def test_two_segment_layout_covers_patch_and_token_rows():
     for b in range(3):
         assert (owner[koff[b]:koff[b + 1]] == b).all()
         assert owner[sum(n) + b] == b
+
+
+def test_aligned32_marks_only_plain_layouts_of_whole_tiles():
+    """MIL_STAGE_POOL_FUSED may only be set for a single-segment map whose tile t covers rows 32 t .. 32 t + 31
+    (include/mil_hip.h): BagLayout.aligned32 is what ImageOnlyTrainer derives the hint from."""
+    from mil_amd.bags import BagLayout
+    dev = torch.device("cpu")
+    a = BagLayout.make([64, 96, 32], dev)
+    assert a.aligned32 and a.T * 32 == a.R
+    tm = a.tile_map.numpy()
+    assert (tm[:, 1] == 32 * np.arange(a.T)).all() and (tm[:, 2] == 32).all()
+    assert not BagLayout.make([64, 40], dev).aligned32                      # a bag ending in a partial tile
+    two = BagLayout.two_segment([64, 64], [32, 32], dev)                   # all lengths multiples of 32, but tiles bag-major
+    assert not two.aligned32 and two.T * 32 == two.R
+    assert (two.tile_map.numpy()[:, 1] != 32 * np.arange(two.T)).any()
