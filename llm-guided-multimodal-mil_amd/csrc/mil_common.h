@@ -36,39 +36,7 @@ static inline int mil_num_cu() {
         if (e_ != hipSuccess) return (int)e_;            \
     } while (0)
 
-// Butterfly all-reduce over the 64 lanes of a wave: every lane ends with the result.
-__device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-__device__ __forceinline__ float wave_allmax(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-}
-// All-reduce inside each 32-lane half (lanes l and l^32 stay separate).
-__device__ __forceinline__ float half_allsum(float v) {
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-
-// Sum over each 32-lane half with DPP adds only (no LDS round trips: __shfl_xor lowers to ds_bpermute_b32, one LDS
-// operation plus its latency per step - the gate epilogues ran 160 of them back to back).  The total of lanes 0-31 is
-// valid in lane 31, that of lanes 32-63 in lane 63; other lanes hold partial sums.
-__device__ __forceinline__ float half_sum_lane31(float v) {
-    // row_shr:n = 0x110 + n (shift right inside a row of 16, zeros shifted in), row_bcast:15 = 0x142 (lane 15 of each
-    // row to the next row; row_mask 0xa = rows 1 and 3 take it)
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));
-    return v;
-}
-
-// Cross-lane primitives of the transposing reductions below, none of which touches the LDS crossbar (ds_bpermute, what
+// Cross-lane primitives of the wave reductions below, none of which touches the LDS crossbar (ds_bpermute, what
 // __shfl_xor compiles to, costs an LDS issue slot per step; k_apool_partial spent a third of its time in them):
 //   swap32_add(x, y): lanes 0-31 get x[l] + x[l + 32], lanes 32-63 get y[l - 32] + y[l]      (v_permlane32_swap, gfx950)
 //   swap16_add(x, y): even 16-lane rows get x[l] + x[l + 16], odd rows y[l - 16] + y[l]     (v_permlane16_swap, gfx950)
@@ -100,6 +68,47 @@ __device__ __forceinline__ float dpp_xor4(float v) {
     int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xf, 0x5, false);
     t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x114, 0xf, 0xa, false);
     return __builtin_bit_cast(float, t);
+}
+
+// All-reduce over the 64 lanes of a wave, every lane ends with the result: quad permutations (xor 1, xor 2), the mirror
+// inside 8 lanes, the rotation by 8 inside a 16-lane row, then the 16- and 32-lane swaps - six VALU instructions, no LDS
+// crossbar (the butterfly of __shfl_xor steps this replaces was six ds_bpermute round trips; the row-per-wave kernels -
+// LayerNorm, pool tiles, tails - issue two to four of them per row).
+__device__ __forceinline__ float wave_allsum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x128>(v);
+    v = swap16_add(v, v);
+    return swap32_add(v, v);
+}
+__device__ __forceinline__ float wave_allmax(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = swap16_max(v, v);
+    return swap32_max(v, v);
+}
+// All-reduce inside each 32-lane half (lanes l and l^32 stay separate).
+__device__ __forceinline__ float half_allsum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Sum over each 32-lane half with DPP adds only (no LDS round trips: __shfl_xor lowers to ds_bpermute_b32, one LDS
+// operation plus its latency per step - the gate epilogues ran 160 of them back to back).  The total of lanes 0-31 is
+// valid in lane 31, that of lanes 32-63 in lane 63; other lanes hold partial sums.
+__device__ __forceinline__ float half_sum_lane31(float v) {
+    // row_shr:n = 0x110 + n (shift right inside a row of 16, zeros shifted in), row_bcast:15 = 0x142 (lane 15 of each
+    // row to the next row; row_mask 0xa = rows 1 and 3 take it)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));
+    return v;
 }
 
 // Sum 16 per-lane values over the 64 lanes of a wave: each step halves the number of values a lane carries while it
