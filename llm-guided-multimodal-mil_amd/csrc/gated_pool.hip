@@ -1539,7 +1539,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
                                                              const float* __restrict__ bu, const float* __restrict__ wvec,
                                                              const float* __restrict__ battn, float* __restrict__ scores,
                                                              float* __restrict__ gates, int R, int L,
-                                                             const uint32_t* __restrict__ xbits, float xscale) {
+                                                             const uint32_t* __restrict__ xbits, float xscale,
+                                                             const int32_t* __restrict__ rows_dev) {
+    // bucketed batches (one ragged bag per step: R is the capacity the launch is sized for): tiles beyond the true row
+    // count on the device have no reader - the tile map, the pool and the weight gradient all stop at that count
+    if (rows_dev != nullptr && (int)(blockIdx.x * GS_TM) >= __builtin_amdgcn_readfirstlane(rows_dev[0])) return;
     __shared__ __attribute__((aligned(16))) float smem[2 * (GS_TM + GF_NG) * GS_LS];
     float* xs = smem;                            // [2][32][36]
     float* ws = smem + 2 * GS_TM * GS_LS;        // [2][384][36]
@@ -1676,13 +1680,13 @@ static inline int gate_tail_rows(int R, int tiles_per_round) {
 
 static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                const float* w, const float* b, float* scores, float* gates, int R, int L,
-                               const uint32_t* xbits, float xscale, hipStream_t st) {
+                               const uint32_t* xbits, float xscale, hipStream_t st, const int32_t* rows_dev = nullptr) {
     if (xbits)
         hipLaunchKernelGGL(k_gate_fwd_r32<true>, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b,
-                           scores, gates, R, L, xbits, xscale);
+                           scores, gates, R, L, xbits, xscale, rows_dev);
     else
         hipLaunchKernelGGL(k_gate_fwd_r32<false>, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b,
-                           scores, gates, R, L, xbits, 1.0f);
+                           scores, gates, R, L, xbits, 1.0f, rows_dev);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -1690,7 +1694,7 @@ static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv,
 static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                 const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
                                 const uint32_t* xbits, float xscale, const GateFwdGen* gen, void* stream,
-                                const GateFwdPool* pool = nullptr, int* fused = nullptr) {
+                                const GateFwdPool* pool = nullptr, int* fused = nullptr, const int32_t* rows_dev = nullptr) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
@@ -1747,7 +1751,7 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
     }
     if (r32) {
         // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
-        return launch_gate_fwd_r32(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xscale, st);
+        return launch_gate_fwd_r32(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xscale, st, rows_dev);
     }
     const int Rm = R - tail;
     const int grid = (Rm + GF_TM - 1) / GF_TM;
@@ -1815,6 +1819,30 @@ extern "C" int mil_gate_scores_fwd_draw(const float* x, const float* Wv, const f
     g.offset = offset;
     g.offset_dev = offset_dev;
     return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, D, nullptr, xscale, &g, stream);
+}
+
+// Internal (step.hip): the gate forward of a bucketed batch (rows_dev = true row count on the device; R = capacity).
+int gate_fwd_rows_dev(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* w,
+                      const float* b, float* scores, float* gates, int R, int L, int draw, uint32_t* xbits, float xscale,
+                      uint32_t* mbits, int B, uint64_t seed, uint64_t mseed, uint64_t offset, const int32_t* offset_dev,
+                      const int32_t* rows_dev, void* stream) {
+    if (draw) {
+        if (!xbits || (L % 64) != 0 || (mbits && B <= 0)) return MIL_EINVAL;
+        GateFwdGen g{};
+        g.xbits_out = xbits;
+        g.mbits_out = mbits;
+        g.B = B;
+        g.seed_lo = (uint32_t)seed;
+        g.seed_hi = (uint32_t)(seed >> 32);
+        g.mseed_lo = (uint32_t)mseed;
+        g.mseed_hi = (uint32_t)(mseed >> 32);
+        g.offset = offset;
+        g.offset_dev = offset_dev;
+        return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, MIL_GATE_D, nullptr, xscale, &g, stream, nullptr,
+                                    nullptr, rows_dev);
+    }
+    return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, MIL_GATE_D, xbits, xscale, nullptr, stream, nullptr,
+                                nullptr, rows_dev);
 }
 
 // Internal (step.hip): gate forward with the pool partial pass in its epilogue when the batch allows it; *fused says

@@ -15,6 +15,12 @@ int gate_fwd_with_pool(const float* x, const float* Wv, const float* bv, const f
                        const int32_t* offset_dev, const int32_t* tile_map, int T, float* partials, const float* Wf, float* hrow,
                        int* fused, void* stream);
 
+// gated_pool.hip: gate forward of a bucketed batch - tiles beyond the true row count (rows_dev) are skipped
+int gate_fwd_rows_dev(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* w,
+                      const float* b, float* scores, float* gates, int R, int L, int draw, uint32_t* xbits, float xscale,
+                      uint32_t* mbits, int B, uint64_t seed, uint64_t mseed, uint64_t offset, const int32_t* offset_dev,
+                      const int32_t* rows_dev, void* stream);
+
 static int step_check(const mil_image_only_step* a) {
     if (!a || a->struct_bytes != sizeof(mil_image_only_step)) return MIL_EINVAL;
     if (!a->x || !a->tile_map || !a->bag_tile_off) return MIL_EINVAL;
@@ -79,6 +85,10 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                                     draw_in_fwd ? 1 : 0, a->xbits, xscale, a->mbits, mscale, a->B, a->seed,
                                     a->seed ^ 0x9E3779B97F4A7C15ull, a->offset, a->offset_dev, a->tile_map, a->T, a->partials,
                                     a->Wf, a->hrow, &pool_fused, stream);
+        else if (a->bag_len_dev && a->rows_dev)
+            rc = gate_fwd_rows_dev((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R, a->L,
+                                   draw_in_fwd ? 1 : 0, a->xbits, xscale, a->mbits, a->B, a->seed, a->seed ^ 0x9E3779B97F4A7C15ull,
+                                   a->offset, a->offset_dev, a->rows_dev, stream);
         else if (draw_in_fwd)
             rc = mil_gate_scores_fwd_draw((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R,
                                           a->L, MIL_GATE_D, a->xbits, xscale, a->mbits, a->B, a->seed,
