@@ -75,6 +75,48 @@ extern "C" int mil_dropout_keep_bits(uint32_t* bits, int rows, int cols, float p
     return MIL_OK;
 }
 
+// Both keep-bit tensors of a training step in ONE launch: the patch bits (p = 0.5, one Philox block = 4 words) by the first
+// workgroups, the head's [B, L/32] words (p = 0.25, one block = 2 words) by the workgroups behind them - the same words the
+// two stand-alone launches write (same block numbering per tensor, same keys), one launch of 4 us less per step where the
+// forward kernel does not draw them itself (bucketed one-bag steps, bf16 x).
+__global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __restrict__ xbits, size_t nx, uint32_t xs_lo,
+                                                                uint32_t xs_hi, uint32_t* __restrict__ mbits, size_t nm,
+                                                                uint32_t ms_lo, uint32_t ms_hi, uint64_t offset,
+                                                                const int32_t* __restrict__ offset_dev, unsigned xblocks) {
+    if (offset_dev != nullptr) offset += (uint64_t)(uint32_t)offset_dev[0];
+    const uint32_t o_lo = (uint32_t)offset, o_hi = (uint32_t)(offset >> 32);
+    if (blockIdx.x < xblocks) {
+        const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x, w0 = blk * 4;
+        if (w0 >= nx) return;
+        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), o_lo, o_hi, xs_lo, xs_hi);
+        if (w0 + 4 <= nx) {
+            *reinterpret_cast<uint4*>(xbits + w0) = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        } else {
+            for (int i = 0; i < 4 && w0 + i < nx; ++i) xbits[w0 + i] = r.v[i];
+        }
+    } else {
+        const size_t blk = (size_t)(blockIdx.x - xblocks) * 256 + threadIdx.x, w0 = blk * 2;
+        if (w0 >= nm) return;
+        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), o_lo, o_hi, ms_lo, ms_hi);
+        mbits[w0] = ~(r.v[0] & r.v[1]);
+        if (w0 + 1 < nm) mbits[w0 + 1] = ~(r.v[2] & r.v[3]);
+    }
+}
+
+// Internal (step.hip, gated_pool.hip): mil_dropout_keep_bits(xbits, R, L, 0.5, seed ..) + (mbits, B, L, 0.25, mseed ..)
+int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
+                           const int32_t* offset_dev, void* stream) {
+    if (!xbits || !mbits || R < 0 || B < 0 || L <= 0 || (L % 32) != 0) return MIL_EINVAL;
+    const size_t nx = (size_t)R * (L / 32), nm = (size_t)B * (L / 32);
+    if (nx + nm == 0) return MIL_OK;
+    const unsigned xblocks = (unsigned)(((nx + 3) / 4 + 255) / 256), mblocks = (unsigned)(((nm + 1) / 2 + 255) / 256);
+    hipLaunchKernelGGL(k_dropout_keep_bits_pair, dim3(xblocks + mblocks), dim3(256), 0, (hipStream_t)stream, xbits, nx,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), mbits, nm, (uint32_t)mseed, (uint32_t)(mseed >> 32), offset,
+                       offset_dev, xblocks);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 // dx[row][col] = keep ? dx * scale : 0 in place (autograd route: backward through the patch dropout when the gradient
 // of the bag rows is needed and no consumer kernel can fold the mask in).
 __global__ __launch_bounds__(256) void k_dropout_apply_bits(float* __restrict__ t, const uint32_t* __restrict__ bits,

@@ -66,7 +66,9 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
                                                                 float* __restrict__ dWu, float* __restrict__ dbu,
                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate,
                                                                 float wscale, int head_first = 1 << 30,
-                                                                HeadBwdArgs head = HeadBwdArgs{}, AdamFuse ad = AdamFuse{}) {
+                                                                HeadBwdArgs head = HeadBwdArgs{}, AdamFuse ad_in = AdamFuse{}) {
+    __shared__ float bcs[2];
+    const AdamFuse ad = adam_fuse_resolve(ad_in, bcs);
     if ((int)blockIdx.x >= head_first) {          // appended workgroups: the head's parameter gradients (uniform branch)
         __shared__ float hred[4][64];
         head_bwd_params_block(head, blockIdx.x - head_first, hred, ad);

@@ -1691,6 +1691,9 @@ static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv,
     return MIL_OK;
 }
 
+int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
+                           const int32_t* offset_dev, void* stream);      // dropout.hip
+
 static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                 const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
                                 const uint32_t* xbits, float xscale, const GateFwdGen* gen, void* stream,
@@ -1739,14 +1742,14 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
             MIL_CHECK_LAUNCH();
             return MIL_OK;
         }
-        int rc = mil_dropout_keep_bits(gen->xbits_out, R, L, 0.5f, ((uint64_t)gen->seed_hi << 32) | gen->seed_lo, gen->offset,
+        int rc;
+        if (gen->mbits_out != nullptr)
+            rc = dropout_keep_bits_pair(gen->xbits_out, R, gen->mbits_out, gen->B, L, ((uint64_t)gen->seed_hi << 32) | gen->seed_lo,
+                                        ((uint64_t)gen->mseed_hi << 32) | gen->mseed_lo, gen->offset, gen->offset_dev, stream);
+        else
+            rc = mil_dropout_keep_bits(gen->xbits_out, R, L, 0.5f, ((uint64_t)gen->seed_hi << 32) | gen->seed_lo, gen->offset,
                                        gen->offset_dev, stream);
         if (rc != MIL_OK) return rc;
-        if (gen->mbits_out != nullptr) {
-            rc = mil_dropout_keep_bits(gen->mbits_out, gen->B, L, 0.25f, ((uint64_t)gen->mseed_hi << 32) | gen->mseed_lo,
-                                       gen->offset, gen->offset_dev, stream);
-            if (rc != MIL_OK) return rc;
-        }
         xbits = gen->xbits_out;
     }
     if (r32) {
@@ -2125,6 +2128,13 @@ extern "C" int mil_gate_bwd_reduce_head(const float* workspace, int R, int L, fl
     return MIL_OK;
 }
 
+int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                                   float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
+                                   float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                                   float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
+                                   float* exp_avg_sq, int step, const int* step_dev, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, float grad_scale, void* stream);
+
 // mil_gate_bwd_reduce_head with Adam applied by the threads that produce the final gradients (world size 1: nothing sits
 // between the gradient and the update): param_flat / exp_avg / exp_avg_sq are indexed like grad_flat, in which dWv .. dbf all
 // lie; `step` >= 1 is the update's number (bias corrections on the host).  Saves the Adam launch of the image-only step.
@@ -2134,8 +2144,22 @@ extern "C" int mil_gate_bwd_reduce_head_adam(const float* workspace, int R, int 
                                              float* loss_out, float* param_flat, const float* grad_flat, size_t n_param,
                                              float* exp_avg, float* exp_avg_sq, int step, float lr, float beta1, float beta2,
                                              float eps, float weight_decay, float grad_scale, void* stream) {
+    return gate_bwd_reduce_head_adam_impl(workspace, R, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xscale, dz, M, dWf, dbf, B, C,
+                                          loss_bag, loss_out, param_flat, grad_flat, n_param, exp_avg, exp_avg_sq, step, nullptr,
+                                          lr, beta1, beta2, eps, weight_decay, grad_scale, stream);
+}
+
+// step_dev != NULL: the update's number is (*step_dev + 1), read on the device (hipGraph replay); the caller increments
+// the counter afterwards.  Internal (step.hip).
+int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                                   float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
+                                   float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                                   float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
+                                   float* exp_avg_sq, int step, const int* step_dev, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, float grad_scale, void* stream) {
     if (!workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
-    if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || step < 1) return MIL_EINVAL;
+    if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || (step_dev == nullptr && step < 1)) return MIL_EINVAL;
+    if (step_dev != nullptr) step = 1;
     if (L <= 0 || (L % 128) != 0 || R <= 0 || B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
     // every gradient this launch produces must lie inside the flat buffer (16-byte aligned where it is stored as float4)
     const float* outs[8] = {dWv, dbv, dWu, dbu, dw, db, dWf, dbf};
@@ -2155,7 +2179,7 @@ extern "C" int mil_gate_bwd_reduce_head_adam(const float* workspace, int R, int 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     // the same single-precision quotient k_adam forms (lr / (float)bc1): the two routes stay bit-identical
     const AdamFuse ad{param_flat, grad_flat, exp_avg, exp_avg_sq, lr / (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
-                      (float)sqrt(bc2)};
+                      (float)sqrt(bc2), step_dev, lr};
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
                        workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
                        accumulate, xscale, nred, head, ad);

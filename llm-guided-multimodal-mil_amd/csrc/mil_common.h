@@ -183,7 +183,24 @@ struct AdamFuse {
     float* m;
     float* v;
     float lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt;
+    const int* step_dev;      // or NULL.  Device counter of the steps ALREADY taken (a step replayed from a hipGraph): the
+    float lr;                 // kernel forms lr_bc1 / bc2_sqrt from it (adam_fuse_resolve) instead of taking them from the host
 };
+// With a device step counter every workgroup derives the two bias corrections itself (k_adam's expressions).
+__device__ __forceinline__ AdamFuse adam_fuse_resolve(const AdamFuse& ad, float* bcs /* __shared__ [2] */) {
+    AdamFuse r = ad;
+    if (ad.param != nullptr && ad.step_dev != nullptr) {
+        if (threadIdx.x == 0) {
+            const double st = (double)(*ad.step_dev + 1);
+            bcs[0] = (float)(1.0 - pow((double)ad.b1, st));
+            bcs[1] = (float)sqrt(1.0 - pow((double)ad.b2, st));
+        }
+        __syncthreads();
+        r.lr_bc1 = ad.lr / bcs[0];
+        r.bc2_sqrt = bcs[1];
+    }
+    return r;
+}
 __device__ __forceinline__ void adam_fused(const AdamFuse& ad, const float* gptr, float g) {
     if (ad.param == nullptr) return;
     const size_t i = (size_t)(gptr - ad.grad_base);

@@ -21,6 +21,18 @@ int gate_fwd_rows_dev(const float* x, const float* Wv, const float* bv, const fl
                       uint32_t* mbits, int B, uint64_t seed, uint64_t mseed, uint64_t offset, const int32_t* offset_dev,
                       const int32_t* rows_dev, void* stream);
 
+// gated_pool.hip: split-K fold + head gradients + Adam in one launch, the step number on the host or in a device counter
+int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
+                                   float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
+                                   float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                                   float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
+                                   float* exp_avg_sq, int step, const int* step_dev, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, float grad_scale, void* stream);
+
+// dropout.hip: both keep-bit tensors of a step in one launch
+int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
+                           const int32_t* offset_dev, void* stream);
+
 static int step_check(const mil_image_only_step* a) {
     if (!a || a->struct_bytes != sizeof(mil_image_only_step)) return MIL_EINVAL;
     if (!a->x || !a->tile_map || !a->bag_tile_off) return MIL_EINVAL;
@@ -64,11 +76,9 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     // keep bits drawn by the forward kernel itself (no generator launches) when both stages run in this call
     const bool draw_in_fwd = (st & MIL_STAGE_DROPBITS) && (st & MIL_STAGE_GATE_FWD) && train && !a->x_bf16;
     if ((st & MIL_STAGE_DROPBITS) && train && !draw_in_fwd) {
-        rc = mil_dropout_keep_bits(a->xbits, a->R, a->L, 0.5f, a->seed, a->offset, a->offset_dev, stream);
-        if (rc != MIL_OK) return rc;
-        // a second key for the head's mask: same stream position, different Philox key
-        rc = mil_dropout_keep_bits(a->mbits, a->B, a->L, 0.25f, a->seed ^ 0x9E3779B97F4A7C15ull, a->offset, a->offset_dev,
-                                   stream);
+        // patch bits and (a second key, same stream position) the head's mask, one launch
+        rc = dropout_keep_bits_pair(a->xbits, a->R, a->mbits, a->B, a->L, a->seed, a->seed ^ 0x9E3779B97F4A7C15ull, a->offset,
+                                    a->offset_dev, stream);
         if (rc != MIL_OK) return rc;
     }
     if (st & MIL_STAGE_GATE_FWD) {
@@ -158,14 +168,17 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
         if (st & MIL_STAGE_REDUCE) {
             // reduce and Adam in ONE launch when both stages run in this call with a host-side step number (world size 1,
             // no all-reduce in between): the threads that store the final gradients update their parameters on the spot
-            adam_in_reduce = (st & MIL_STAGE_ADAM) && !a->adam_step_dev && a->param_flat && a->grad_flat && a->exp_avg &&
-                             a->exp_avg_sq && a->adam_step >= 1;
-            if (adam_in_reduce)
-                rc = mil_gate_bwd_reduce_head_adam(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
-                                                   a->accumulate, xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag,
-                                                   a->loss_out, a->param_flat, a->grad_flat, (size_t)a->n_param, a->exp_avg,
-                                                   a->exp_avg_sq, a->adam_step, a->lr, a->beta1, a->beta2, a->eps,
-                                                   a->weight_decay, a->grad_scale, stream);
+            adam_in_reduce = (st & MIL_STAGE_ADAM) && a->param_flat && a->grad_flat && a->exp_avg && a->exp_avg_sq &&
+                             (a->adam_step_dev || a->adam_step >= 1);
+            if (adam_in_reduce) {
+                rc = gate_bwd_reduce_head_adam_impl(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
+                                                    a->accumulate, xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag,
+                                                    a->loss_out, a->param_flat, a->grad_flat, (size_t)a->n_param, a->exp_avg,
+                                                    a->exp_avg_sq, a->adam_step, a->adam_step_dev, a->lr, a->beta1, a->beta2,
+                                                    a->eps, a->weight_decay, a->grad_scale, stream);
+                // the device counter moves on after the update, as mil_adam_step_counted does
+                if (rc == MIL_OK && a->adam_step_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
+            }
             else
                 rc = mil_gate_bwd_reduce_head(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db, a->accumulate,
                                               xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag, a->loss_out, stream);
