@@ -1533,7 +1533,11 @@ extern "C" int mil_abi_version(void) { return 3; }
 #define GS_TM 32
 #define GS_LS 36
 #define GS_THREADS 768
-template <bool DROP>
+// RT row tiles of 32 per workgroup (1 .. 3): the launch picks the smallest RT that covers the rows in ONE round of the
+// grid - 384 workgroups of 32 rows are two rounds at one workgroup per CU (120 KB of LDS), 192 of 64 rows one round of
+// twice the length: a bucket of 12 288 rows 57 -> 46 us.  Every wave then carries RT accumulator tiles against the same B
+// fragments.
+template <bool DROP, int RT>
 __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __restrict__ x, const float* __restrict__ Wv,
                                                              const float* __restrict__ bv, const float* __restrict__ Wu,
                                                              const float* __restrict__ bu, const float* __restrict__ wvec,
@@ -1543,14 +1547,15 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
                                                              const int32_t* __restrict__ rows_dev) {
     // bucketed batches (one ragged bag per step: R is the capacity the launch is sized for): tiles beyond the true row
     // count on the device have no reader - the tile map, the pool and the weight gradient all stop at that count
-    if (rows_dev != nullptr && (int)(blockIdx.x * GS_TM) >= __builtin_amdgcn_readfirstlane(rows_dev[0])) return;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (GS_TM + GF_NG) * GS_LS];
-    float* xs = smem;                            // [2][32][36]
-    float* ws = smem + 2 * GS_TM * GS_LS;        // [2][384][36]
+    constexpr int TM = GS_TM * RT;
+    if (rows_dev != nullptr && (int)(blockIdx.x * TM) >= __builtin_amdgcn_readfirstlane(rows_dev[0])) return;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TM + GF_NG) * GS_LS];
+    float* xs = smem;                            // [2][32 RT][36]
+    float* ws = smem + 2 * TM * GS_LS;           // [2][384][36]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = wave >> 1, isu = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * GS_TM;
+    const int row0 = blockIdx.x * TM;
     const float* wsrc[4];
     int wdst[4];
 #pragma unroll
@@ -1559,7 +1564,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
         wsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 4 * ch;
         wdst[i] = wrow * GS_LS + 4 * ch;
     }
-    const int xrow = (tid & 255) >> 3, xch = tid & 7;
+    const int xrow = (tid % (256 * RT)) >> 3, xch = tid & 7;          // threads < 256 RT stage the x rows (768 = 3 x 256)
     const float* xsrc = x + (size_t)min(row0 + xrow, R - 1) * L + 4 * xch;
     const uint32_t* msrc = DROP ? xbits + (size_t)min(row0 + xrow, R - 1) * (L / 32) : nullptr;
     const int xdst = xrow * GS_LS + 4 * xch;
@@ -1574,19 +1579,21 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
     auto swrite = [&](int set, int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ws + buf * GF_NG * GS_LS + wdst[i]) = wreg[set][i];
-        if (tid < 256) {
+        if (tid < 256 * RT) {
             f32x4 v = xreg[set];
             if (DROP) {
                 const unsigned m = mreg[set] >> (4 * xch);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = keep_if(v[e], m, e) * xscale;
             }
-            *reinterpret_cast<f32x4*>(xs + buf * GS_TM * GS_LS + xdst) = v;
+            *reinterpret_cast<f32x4*>(xs + buf * TM * GS_LS + xdst) = v;
         }
     };
-    f32x16 acc;
+    f32x16 acc[RT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
     const int nslice = L / GF_BK;
     gload(0, 0);
     swrite(0, 0);
@@ -1595,12 +1602,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
     __syncthreads();
     auto iteration = [&](int s, int set) {                       // set = (s + 1) & 1
         const int buf = s & 1;
-        const float* xa = xs + buf * GS_TM * GS_LS + r * GS_LS + 4 * h;
+        const float* xa = xs + buf * TM * GS_LS + r * GS_LS + 4 * h;
         const float* wb = ws + buf * GF_NG * GS_LS + (192 * isu + 32 * c + r) * GS_LS + 4 * h;
-        f32x4 fa[4], fb[4];
+        f32x4 fa[RT][4], fb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            fa[t] = *reinterpret_cast<const f32x4*>(xa + 8 * t);
+#pragma unroll
+            for (int q = 0; q < RT; ++q) fa[q][t] = *reinterpret_cast<const f32x4*>(xa + q * GS_TM * GS_LS + 8 * t);
             fb[t] = *reinterpret_cast<const f32x4*>(wb + 8 * t);
         }
         swrite(set, buf ^ 1);                                    // slice s+1: registers -> the other buffer
@@ -1609,7 +1617,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fb[t][jj], acc, 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int q = 0; q < RT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][t][jj], fb[t][jj], acc[q], 0, 0, 0);
         __syncthreads();
     };
     for (int s = 0; s < nslice; s += 2) {
@@ -1619,42 +1629,46 @@ __global__ __launch_bounds__(GS_THREADS) void k_gate_fwd_r32(const float* __rest
     const int d = 32 * c + r;
     float* uex = smem;                           // [6][32][33]: sigmoid(U) tiles for the V partners
     float* sred = smem + 6 * 32 * 33;            // [6][32]
-    float gv[16];
-    if (isu) {
-        const float bud = bu[d];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            gv[i] = fast_sigmoid(acc[i] + bud);
-            uex[(c * 32 + mfma32_row(i, h)) * 33 + r] = gv[i];
+    for (int q = 0; q < RT; ++q) {
+        float gv[16];
+        if (q > 0) __syncthreads();              // the previous row tile's uex / sred have been read
+        if (isu) {
+            const float bud = bu[d];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                gv[i] = fast_sigmoid(acc[q][i] + bud);
+                uex[(c * 32 + mfma32_row(i, h)) * 33 + r] = gv[i];
+            }
+        } else {
+            const float bvd = bv[d];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gv[i] = fast_tanh(acc[q][i] + bvd);
         }
-    } else {
-        const float bvd = bv[d];
+        if (gates != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) gv[i] = fast_tanh(acc[i] + bvd);
-    }
-    if (gates != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int gr = row0 + mfma32_row(i, h);
-            if (gr < R) gates[(size_t)gr * GF_NG + 192 * isu + d] = gv[i];
+            for (int i = 0; i < 16; ++i) {
+                const int gr = row0 + GS_TM * q + mfma32_row(i, h);
+                if (gr < R) gates[(size_t)gr * GF_NG + 192 * isu + d] = gv[i];
+            }
         }
-    }
-    __syncthreads();
-    if (!isu) {
-        const float wd = wvec[d];
+        __syncthreads();
+        if (!isu) {
+            const float wd = wvec[d];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int lr = mfma32_row(i, h);
-            const float part = half_allsum(wd * gv[i] * uex[(c * 32 + lr) * 33 + r]);
-            if (r == 0) sred[c * GS_TM + lr] = part;
+            for (int i = 0; i < 16; ++i) {
+                const int lr = mfma32_row(i, h);
+                const float part = half_allsum(wd * gv[i] * uex[(c * 32 + lr) * 33 + r]);
+                if (r == 0) sred[c * GS_TM + lr] = part;
+            }
         }
-    }
-    __syncthreads();
-    if (tid < GS_TM && row0 + tid < R) {
-        float sc = battn[0];
+        __syncthreads();
+        if (tid < GS_TM && row0 + GS_TM * q + tid < R) {
+            float sc = battn[0];
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc) sc += sred[cc * GS_TM + tid];
-        scores[row0 + tid] = sc;
+            for (int cc = 0; cc < 6; ++cc) sc += sred[cc * GS_TM + tid];
+            scores[row0 + GS_TM * q + tid] = sc;
+        }
     }
 }
 
@@ -1681,12 +1695,15 @@ static inline int gate_tail_rows(int R, int tiles_per_round) {
 static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                const float* w, const float* b, float* scores, float* gates, int R, int L,
                                const uint32_t* xbits, float xscale, hipStream_t st, const int32_t* rows_dev = nullptr) {
-    if (xbits)
-        hipLaunchKernelGGL(k_gate_fwd_r32<true>, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b,
-                           scores, gates, R, L, xbits, xscale, rows_dev);
-    else
-        hipLaunchKernelGGL(k_gate_fwd_r32<false>, dim3((R + GS_TM - 1) / GS_TM), dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b,
-                           scores, gates, R, L, xbits, 1.0f, rows_dev);
+    // row tiles per workgroup: the smallest count that covers R in one round of one-workgroup-per-CU launches
+    const int tiles = (R + GS_TM - 1) / GS_TM;
+    const int rt = tiles <= MIL_NUM_CU ? 1 : tiles <= 2 * MIL_NUM_CU ? 2 : 3;
+    const dim3 grid((R + GS_TM * rt - 1) / (GS_TM * rt));
+    const float xs = xbits ? xscale : 1.0f;
+#define R32_LAUNCH(D_, RT_) hipLaunchKernelGGL((k_gate_fwd_r32<D_, RT_>), grid, dim3(GS_THREADS), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xs, rows_dev)
+    if (xbits) { if (rt == 1) R32_LAUNCH(true, 1); else if (rt == 2) R32_LAUNCH(true, 2); else R32_LAUNCH(true, 3); }
+    else { if (rt == 1) R32_LAUNCH(false, 1); else if (rt == 2) R32_LAUNCH(false, 2); else R32_LAUNCH(false, 3); }
+#undef R32_LAUNCH
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -135,6 +135,26 @@ def test_a_last_round_of_a_few_tiles_goes_through_the_32_row_kernel():
         assert float((s_nog - scores).abs().max()) <= 2e-6
 
 
+def test_row_tiles_per_workgroup_of_the_32_row_kernel_agree():
+    """k_gate_fwd_r32<., RT>: 20 000 rows take three row tiles per workgroup, their halves two, a 4 096-row slice one;
+    scores and gates of the same rows must agree whatever the tiling (eval mode and with keep bits)."""
+    from mil_amd import ops
+    L, R = 512, 20000
+    p = {k: v.to(DEV) for k, v in syn.image_only_params(107, L=L).items()}
+    gp = [p["aggregator.attention_V.0.weight"], p["aggregator.attention_V.0.bias"], p["aggregator.attention_U.0.weight"],
+          p["aggregator.attention_U.0.bias"], p["aggregator.attention_weights.weight"].reshape(-1),
+          p["aggregator.attention_weights.bias"]]
+    x = torch.randn((R, L), generator=torch.Generator().manual_seed(13)).to(DEV)
+    bits = torch.randint(0, 2 ** 31 - 1, (R, L // 32), generator=torch.Generator().manual_seed(14), dtype=torch.int32).to(DEV)
+    for kw_of in (lambda a, b: {}, lambda a, b: dict(xbits=bits[a:b].contiguous(), xscale=2.0)):
+        s3, g3 = ops.gate_scores_fwd(x, *gp, save_gates=True, **kw_of(0, R))
+        for a, b in ((0, 10000), (10000, R), (3000, 7096)):
+            s_, g_ = ops.gate_scores_fwd(x[a:b].contiguous(), *gp, save_gates=True, **kw_of(a, b))
+            assert float((s3[a:b] - s_).abs().max()) <= 2e-6
+            assert float((g3[a:b] - g_).abs().max()) <= 2e-6
+    assert bool(torch.isfinite(s3).all())
+
+
 def test_more_than_two_classes_use_cross_entropy_on_the_sigmoid_outputs():
     """num_classes > 2: the reference's criterion is CrossEntropyLoss applied to the module's sigmoid outputs with the
     float one-hot labels as class probabilities (train_ddp.py:95-96,323-324)."""
