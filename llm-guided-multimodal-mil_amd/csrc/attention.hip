@@ -510,6 +510,39 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
     if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
+// E = 512 with 16-byte accesses: lane l owns columns 4 l .. 4 l + 3 and 256 + 4 l .. (two loads and two stores per row where
+// the generic kernel issues eight 4-byte ones of each); same arithmetic, another summation order inside the row.
+__global__ __launch_bounds__(256) void k_layernorm_fwd512(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int rows, float eps,
+                                                          float* __restrict__ y, float* __restrict__ stats,
+                                                          const float* __restrict__ o, const int32_t* __restrict__ row_bag) {
+    constexpr int E = 512;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v[q] = *reinterpret_cast<const f32x4*>(x + (size_t)row * E + 256 * q + 4 * lane);
+    if (o != nullptr) {
+        const float* orow = o + (size_t)row_bag[row] * E;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) v[q] += *reinterpret_cast<const f32x4*>(orow + 256 * q + 4 * lane);
+    }
+    const f32x4 t = v[0] + v[1];
+    const float mean = wave_allsum((t[0] + t[1]) + (t[2] + t[3])) / E;
+    f32x4 d[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) d[q] = v[q] - mean;
+    const f32x4 sq = d[0] * d[0] + d[1] * d[1];
+    const float rstd = 1.0f / sqrtf(wave_allsum((sq[0] + sq[1]) + (sq[2] + sq[3])) / E + eps);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 256 * q + 4 * lane);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 256 * q + 4 * lane);
+        *reinterpret_cast<f32x4*>(y + (size_t)row * E + 256 * q + 4 * lane) = d[q] * rstd * g + b;
+    }
+    if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
 // dx = rstd (g - mean(g) - xhat mean(g xhat)) (+ dres), g = dy gamma;  per-workgroup partial dgamma/dbeta [nblk][2][E].
 // PARAMS = false: frozen gamma / beta (the CLIP tower): no parameter sums, no partials.  dres (optional): gradient that
 // reached x along the residual branch around the norm - added here instead of by a separate elementwise launch.
@@ -934,7 +967,7 @@ static int layernorm_fwd_impl(const float* x, const float* gamma, const float* b
         case 1: hipLaunchKernelGGL(k_layernorm_fwd<1>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
         case 2: hipLaunchKernelGGL(k_layernorm_fwd<2>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
         case 4: hipLaunchKernelGGL(k_layernorm_fwd<4>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
-        case 8: hipLaunchKernelGGL(k_layernorm_fwd<8>, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
+        case 8: hipLaunchKernelGGL(k_layernorm_fwd512, grid, blk, 0, st, x, gamma, beta, rows, eps, y, stats, o, row_bag); break;
         default: return MIL_EINVAL;
     }
     MIL_CHECK_LAUNCH();
