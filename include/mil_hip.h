@@ -40,7 +40,7 @@ extern "C" {
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
 
 /* Library/ABI version, for the host mirror's load-time check. */
-int mil_abi_version(void);   /* 3 */
+int mil_abi_version(void);   /* 4 */
 
 /* ---- dropout keep bits (train mode) -------------------------------------------------------
  * model.train() upstream drops the bag rows with p = 0.5 BEFORE the gate and pools the dropped rows
@@ -545,6 +545,13 @@ int mil_adam_step_counted_noinc(float* param, const float* grad, float* exp_avg,
                                 const int32_t* step_counter, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, float grad_scale, void* stream);
 
+/* mil_adam_step_counted with the learning rate in DEVICE memory too (lr_dev [1] float): the host writes the scheduled rate
+ * (utils.py:232-241 adjust_learning_rate) into it before a launch or a graph replay, so one captured step serves every
+ * epoch of a schedule.  inc != 0 advances the counter after the update. */
+int mil_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int32_t* step_counter,
+                      const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      int inc, void* stream);
+
 /* torch.optim.SGD step without momentum (train_ddp.py:103-108: the optimizer of the learnable-prompt runs) over a
  * flat fp32 buffer: g = grad_scale * grad + weight_decay * param;  param -= lr * g.  Both buffers 16-byte aligned. */
 int mil_sgd_step(float* param, const float* grad, size_t n, float lr, float weight_decay, float grad_scale,
@@ -629,6 +636,8 @@ typedef struct mil_image_only_step {
     int32_t adam_step;              /* 1-based step number (host bias corrections) ... */
     int32_t* adam_step_dev;         /* ... or a device counter of steps already taken (incremented by the launch) */
     float lr, beta1, beta2, eps, weight_decay, grad_scale;
+    const float* lr_dev;            /* nullable, needs adam_step_dev: [1] learning rate read on the device instead of `lr`, so a
+                                     * captured step follows the schedule of utils.py:232-241 without re-capture */
 } mil_image_only_step;
 
 int mil_image_only_step_run(const mil_image_only_step* a, void* stream);

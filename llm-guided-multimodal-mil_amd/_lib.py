@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mil_hip.h")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/mil_hip.h one to one
@@ -118,6 +118,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_adam_step": (c_int, [_P] * 4 + [c_size_t, c_int] + [c_float] * 6 + [_P]),
     "mil_adam_step_counted": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
     "mil_adam_step_counted_noinc": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
+    "mil_adam_step_dev": (c_int, [_P] * 4 + [c_size_t, _P, _P] + [c_float] * 5 + [c_int, _P]),
     "mil_sgd_step": (c_int, [_P, _P, c_size_t] + [c_float] * 3 + [_P]),
     "mil_linear_mid_fwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "mil_linear_mid_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int,
@@ -160,7 +161,8 @@ class ImageOnlyStep(ctypes.Structure):
            ("offset", c_uint64), ("offset_dev", _P)]
         + [(n, _P) for n in ("param_flat", "grad_flat", "exp_avg", "exp_avg_sq")]
         + [("n_param", c_uint64), ("adam_step", c_int32), ("adam_step_dev", _P)]
-        + [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")])
+        + [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")]
+        + [("lr_dev", _P)])
 
 
 _lib = None

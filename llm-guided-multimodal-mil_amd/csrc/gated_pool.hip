@@ -1521,7 +1521,7 @@ static inline int split_plan(int R, int L, int* KC_out) {
     return (R + kc - 1) / kc;
 }
 
-extern "C" int mil_abi_version(void) { return 3; }
+extern "C" int mil_abi_version(void) { return 4; }
 
 // Small batches (the authors train with ONE bag per GPU: R = 1 000 - 15 000 rows): 128-row tiles would leave most CUs
 // idle (8 workgroups for 1024 patches, each walking all of K: the kernel takes its full ~100 us for 1/32 of the
@@ -2149,8 +2149,8 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
                                    float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
                                    float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                                    float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
-                                   float* exp_avg_sq, int step, const int* step_dev, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, float grad_scale, void* stream);
+                                   float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
+                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
 // mil_gate_bwd_reduce_head with Adam applied by the threads that produce the final gradients (world size 1: nothing sits
 // between the gradient and the update): param_flat / exp_avg / exp_avg_sq are indexed like grad_flat, in which dWv .. dbf all
@@ -2163,7 +2163,7 @@ extern "C" int mil_gate_bwd_reduce_head_adam(const float* workspace, int R, int 
                                              float eps, float weight_decay, float grad_scale, void* stream) {
     return gate_bwd_reduce_head_adam_impl(workspace, R, L, dWv, dbv, dWu, dbu, dw, db, accumulate, xscale, dz, M, dWf, dbf, B, C,
                                           loss_bag, loss_out, param_flat, grad_flat, n_param, exp_avg, exp_avg_sq, step, nullptr,
-                                          lr, beta1, beta2, eps, weight_decay, grad_scale, stream);
+                                          lr, nullptr, beta1, beta2, eps, weight_decay, grad_scale, stream);
 }
 
 // step_dev != NULL: the update's number is (*step_dev + 1), read on the device (hipGraph replay); the caller increments
@@ -2172,8 +2172,8 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
                                    float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
                                    float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                                    float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
-                                   float* exp_avg_sq, int step, const int* step_dev, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, float grad_scale, void* stream) {
+                                   float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
+                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
     if (!workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
     if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || (step_dev == nullptr && step < 1)) return MIL_EINVAL;
     if (step_dev != nullptr) step = 1;
@@ -2194,9 +2194,9 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
     const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    // the same single-precision quotient k_adam forms (lr / (float)bc1): the two routes stay bit-identical
-    const AdamFuse ad{param_flat, grad_flat, exp_avg, exp_avg_sq, lr / (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
-                      (float)sqrt(bc2), step_dev, lr};
+    // the kernel forms the same single-precision quotient k_adam forms (lr / (float)bc1): the two routes stay bit-identical
+    const AdamFuse ad{param_flat, grad_flat, exp_avg, exp_avg_sq, (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
+                      (float)sqrt(bc2), step_dev, lr, lr_dev};
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
                        workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
                        accumulate, xscale, nred, head, ad);

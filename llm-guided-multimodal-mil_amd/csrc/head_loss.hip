@@ -138,7 +138,7 @@ template <int AD_U>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,
                                               float* __restrict__ m, float* __restrict__ v, size_t n, float lr, float b1,
                                               float b2, float eps, float wd, float gscale, float bc1, float bc2_sqrt,
-                                              const int* __restrict__ step_dev) {
+                                              const int* __restrict__ step_dev, const float* __restrict__ lr_dev) {
     __shared__ float bc[2];
     if (step_dev != nullptr) {
         if (threadIdx.x == 0) {
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const f
         bc1 = bc[0];
         bc2_sqrt = bc[1];
     }
+    if (lr_dev != nullptr) lr = *lr_dev;            // a schedule writes it between two replays of one captured graph
     const float lr_bc1 = lr / bc1;
     // workgroup = 256 threads x AD_U float4 each; the AD_U x 4 loads of a thread are issued before any arithmetic
     // (a 4-stream pass with one float4 in flight per stream and thread left the HBM pipe half empty: 3.4 TB/s)
@@ -557,13 +558,14 @@ extern "C" int mil_head_bwd_params(const float* dz, const float* M, float* dWf, 
 
 // small buffers (the image-only step: 0.2 M parameters) want many workgroups, large ones (fusion: 9.8 M) loads in flight
 static void launch_adam(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2,
-                        float eps, float wd, float gscale, float bc1, float bc2_sqrt, const int* step_dev, hipStream_t st) {
+                        float eps, float wd, float gscale, float bc1, float bc2_sqrt, const int* step_dev, hipStream_t st,
+                        const float* lr_dev = nullptr) {
     if (n >= ((size_t)1 << 21))
         hipLaunchKernelGGL(k_adam<4>, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, st, param, grad, m, v, n, lr, b1, b2, eps,
-                           wd, gscale, bc1, bc2_sqrt, step_dev);
+                           wd, gscale, bc1, bc2_sqrt, step_dev, lr_dev);
     else
         hipLaunchKernelGGL(k_adam<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, param, grad, m, v, n, lr, b1, b2, eps,
-                           wd, gscale, bc1, bc2_sqrt, step_dev);
+                           wd, gscale, bc1, bc2_sqrt, step_dev, lr_dev);
 }
 
 extern "C" int mil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step,
@@ -613,6 +615,28 @@ extern "C" int mil_adam_step_counted(float* param, const float* grad, float* exp
     }
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step_counter);
     MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// mil_adam_step_counted with the learning rate in device memory as well (lr_dev [1]): a captured step follows a learning-rate
+// schedule (utils.py:232-241 adjust_learning_rate) without re-capture.  inc != 0: advance the counter after the update.
+extern "C" int mil_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                 int32_t* step_counter, const float* lr_dev, float beta1, float beta2, float eps,
+                                 float weight_decay, float grad_scale, int inc, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter || !lr_dev) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n > 0) {
+        launch_adam(param, grad, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps, weight_decay, grad_scale, 1.f, 1.f,
+                    (const int*)step_counter, st, lr_dev);
+        MIL_CHECK_LAUNCH();
+    }
+    if (inc) {
+        hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step_counter);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
 }
 

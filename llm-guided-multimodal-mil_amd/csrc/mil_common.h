@@ -182,23 +182,29 @@ struct AdamFuse {
     const float* grad_base;   // flat gradients: index = (address the gradient is stored at) - grad_base
     float* m;
     float* v;
-    float lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt;
+    float lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt;   // lr_bc1: the host passes bc1 = 1 - beta1^t here; resolve turns it into lr / bc1
     const int* step_dev;      // or NULL.  Device counter of the steps ALREADY taken (a step replayed from a hipGraph): the
-    float lr;                 // kernel forms lr_bc1 / bc2_sqrt from it (adam_fuse_resolve) instead of taking them from the host
+    float lr;                 // kernel forms the bias corrections from it instead of taking them from the host
+    const float* lr_dev;      // or NULL.  Learning rate in device memory (a schedule changes it between replays of one graph)
 };
-// With a device step counter every workgroup derives the two bias corrections itself (k_adam's expressions).
+// lr / bc1 and sqrt(bc2) of this launch (k_adam's expressions).  With a device step counter every workgroup derives the two
+// bias corrections itself; with lr_dev the learning rate is read from device memory, so a captured graph follows the schedule.
 __device__ __forceinline__ AdamFuse adam_fuse_resolve(const AdamFuse& ad, float* bcs /* __shared__ [2] */) {
     AdamFuse r = ad;
-    if (ad.param != nullptr && ad.step_dev != nullptr) {
+    if (ad.param == nullptr) return r;
+    float bc1 = ad.lr_bc1;
+    if (ad.step_dev != nullptr) {
         if (threadIdx.x == 0) {
             const double st = (double)(*ad.step_dev + 1);
             bcs[0] = (float)(1.0 - pow((double)ad.b1, st));
             bcs[1] = (float)sqrt(1.0 - pow((double)ad.b2, st));
         }
         __syncthreads();
-        r.lr_bc1 = ad.lr / bcs[0];
+        bc1 = bcs[0];
         r.bc2_sqrt = bcs[1];
     }
+    const float lr = ad.lr_dev != nullptr ? *ad.lr_dev : ad.lr;
+    r.lr_bc1 = lr / bc1;
     return r;
 }
 __device__ __forceinline__ void adam_fused(const AdamFuse& ad, const float* gptr, float g) {

@@ -26,8 +26,8 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
                                    float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
                                    float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                                    float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
-                                   float* exp_avg_sq, int step, const int* step_dev, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, float grad_scale, void* stream);
+                                   float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
+                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
 // dropout.hip: both keep-bit tensors of a step in one launch
 int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
@@ -42,6 +42,7 @@ static int step_check(const mil_image_only_step* a) {
     if (a->x_bf16 && (!a->Wv16 || !a->Wu16)) return MIL_EINVAL;
     if (a->bag_len_dev && (a->x_bf16 || !a->rows_dev || a->B > 1024)) return MIL_EINVAL;
     if (a->train && (!a->xbits || !a->mbits || !a->Mdrop)) return MIL_EINVAL;
+    if (a->lr_dev && !a->adam_step_dev) return MIL_EINVAL;       // a device learning rate belongs to the replayable (counted) step
     if (a->y) {
         if ((!a->gates && !a->gates16) || !a->ds || !a->loss_bag || !a->dz || !a->dM || !a->cdot) return MIL_EINVAL;
     }
@@ -174,8 +175,8 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                 rc = gate_bwd_reduce_head_adam_impl(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
                                                     a->accumulate, xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag,
                                                     a->loss_out, a->param_flat, a->grad_flat, (size_t)a->n_param, a->exp_avg,
-                                                    a->exp_avg_sq, a->adam_step, a->adam_step_dev, a->lr, a->beta1, a->beta2,
-                                                    a->eps, a->weight_decay, a->grad_scale, stream);
+                                                    a->exp_avg_sq, a->adam_step, a->adam_step_dev, a->lr, a->lr_dev, a->beta1,
+                                                    a->beta2, a->eps, a->weight_decay, a->grad_scale, stream);
                 // the device counter moves on after the update, as mil_adam_step_counted does
                 if (rc == MIL_OK && a->adam_step_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
             }
@@ -187,7 +188,11 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     }
     if ((st & MIL_STAGE_ADAM) && !adam_in_reduce) {
         if (!a->param_flat || !a->grad_flat || !a->exp_avg || !a->exp_avg_sq) return MIL_EINVAL;
-        if (a->adam_step_dev)
+        if (a->adam_step_dev && a->lr_dev)
+            rc = mil_adam_step_dev(a->param_flat, a->grad_flat, a->exp_avg, a->exp_avg_sq, (size_t)a->n_param,
+                                   a->adam_step_dev, a->lr_dev, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale, 1,
+                                   stream);
+        else if (a->adam_step_dev)
             rc = mil_adam_step_counted(a->param_flat, a->grad_flat, a->exp_avg, a->exp_avg_sq, (size_t)a->n_param,
                                        a->adam_step_dev, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->grad_scale,
                                        stream);

@@ -27,6 +27,13 @@ def flush() -> None:
     """Form every queued weight / bias gradient (current stream); called by the engine at the end of the backward pass."""
     global _armed
     _armed = False
+    flush_pending()
+
+
+def flush_pending() -> None:
+    """Form what is queued so far, now (the end-of-pass callback stays registered for later entries).  ops.grad_slot calls
+    this when a parameter is met a second time in one pass: the slot the first use returned to autograd must hold that
+    use's gradient before autograd adds the second use's to it."""
     if not _queue:
         return
     stream = torch.cuda.current_stream().cuda_stream

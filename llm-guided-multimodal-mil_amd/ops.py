@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib, deferred, sidestream
+from . import _lib, deferred
 from .bags import BagLayout
 
 GATE_D = 192
@@ -574,6 +574,11 @@ def grad_slot(param):
     # flag is cleared by FlatAdam.zero_grad() / GraphedStep; a second request in the same pass gets None, i.e. a fresh
     # tensor that autograd then accumulates into the slot.
     if getattr(param, "_mil_slot_used", False):
+        # The first use's gradient may still be QUEUED (deferred.py forms it at the end of the pass): autograd is about to add
+        # this node's fresh tensor to the slot, so whatever is queued for the slot has to be in it first (a Linear
+        # used twice per forward - TwoWayTransformer_Both in the CT + pathology branch, aggregator.py:160-168 - lost the
+        # first use's gradient and picked up stale slot contents instead).
+        deferred.flush_pending()
         return None
     param._mil_slot_used = True
     # a fresh alias: autograd adopts a returned gradient without copying only if nothing else references that tensor
@@ -659,19 +664,6 @@ class _LinearAct(torch.autograd.Function):
                 # nothing else references that tensor object (see grad_slot)
                 dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False)
                 deferred.queue_dw(dy, y, x, W_slot.detach(), (b_slot.detach() if want_db else None), ctx.act)
-                return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None)
-            if (sidestream.enabled() and ctx.needs_input_grad[0] and want_dW and W_slot is not None and
-                    (not want_db or b_slot is not None)):
-                # the next layer's backward waits for dx only: dx on this stream, the weight / bias gradient (written
-                # straight into the flat gradient buffer) beside the chain on the side stream (sidestream.py)
-                dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False)
-                # the side kernel writes through aliases of its own: autograd adopts a returned gradient without a copy only
-                # while nothing else references that tensor object (see grad_slot)
-                W_side, b_side = W_slot.detach(), (b_slot.detach() if want_db else None)
-                act = ctx.act
-                sidestream.run_in_backward(
-                    lambda: linear_small_bwd(dy, y, act, x, W, False, True, want_db, W_side, b_side),
-                    (dy, y, x, W, W_side, b_side))
                 return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None)
             dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], want_dW, want_db, W_slot, b_slot)
             return dx, dW, db, None, (dy if ctx.has_res else None)

@@ -9,7 +9,14 @@ views of one contiguous buffer, so that per step there is
 Backward kernels that know a parameter's slot (ops.grad_slot: the Linear layers) write the gradient there directly,
 so the gather only moves what the other ops produced.  Same arithmetic as torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected, eps outside the
 sqrt); a parameter whose gradient is None is skipped altogether (no moments, no weight decay), as torch.optim.Adam
-skips it: the update runs over the contiguous live ranges of the flat buffer."""
+skips it: the update runs over the contiguous live ranges of the flat buffer.
+
+Deviations from torch.optim.Adam, both deliberate: (1) ONE step number serves the whole buffer, where torch keeps a step
+per parameter - a parameter that first receives a gradient at step k > 1 gets step-k bias corrections here and step-1
+corrections there (the modules of this model either always or never receive gradients, so the two agree on every run the
+reference can do); (2) the `_mil_zero_grad` mark (model/sam/transformer.py: a fast path left a parameter out of the graph
+whose upstream gradient is a dense zero) is sticky by design: a replayed hipGraph does not re-run the Python forward that
+sets it, so zero_grad() must not clear it."""
 from typing import Iterable, List
 
 import torch

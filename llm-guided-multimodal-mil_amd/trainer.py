@@ -107,6 +107,10 @@ class ImageOnlyTrainer:
         # counted: the step number lives on the device (Adam's bias corrections and the dropout stream position read it),
         # so the whole step - optimizer included - is the same launch sequence every time and can be replayed from a hipGraph
         self.step_counter = torch.zeros(1, device=device, dtype=torch.int32) if counted else None
+        # ... and so does the learning rate: train_ddp.py sets `tr.lr = scheduled_lr(...)` every epoch (utils.py:232-241),
+        # a captured step reads it from this word instead of a by-value kernel argument frozen at capture time
+        self.lr_dev = torch.full((1,), float(lr), device=device, dtype=torch.float32) if counted else None
+        self._lr_on_dev = float(lr)
         self._ws: Dict[str, torch.Tensor] = {}   # grow-only per-step state (scores, gates, partials, ...)
         self._args: Optional[_lib.ImageOnlyStep] = None
         self._args_key = None
@@ -208,6 +212,7 @@ class ImageOnlyTrainer:
         a.param_flat, a.grad_flat = fp.flat.data_ptr(), fp.grad.data_ptr()
         a.exp_avg, a.exp_avg_sq, a.n_param = fp.exp_avg.data_ptr(), fp.exp_avg_sq.data_ptr(), fp.flat.numel()
         a.adam_step_dev = pv(self.step_counter)
+        a.lr_dev = pv(self.lr_dev)
         a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale = self.betas[0], self.betas[1], self.eps, self.wd, 1.0
         self._args, self._args_key = a, key
         self._keep = (x, y, layout, dict(st), self._w16)
@@ -224,9 +229,18 @@ class ImageOnlyTrainer:
             self.last.update(xbits=st["xbits"][:R * (L // 32)].view(R, L // 32), mbits=st["mbits"][:B * (L // 32)].view(B, L // 32))
         return a
 
-    def _run(self, a, stages: int):
+    def _sync_lr(self):
+        """Counted mode: the scheduled learning rate goes to its device word (stream-ordered, before the next launch or
+        replay that reads it)."""
+        if self.lr_dev is not None and self._lr_on_dev != float(self.lr):
+            self.lr_dev.fill_(float(self.lr))
+            self._lr_on_dev = float(self.lr)
+
+    def _run(self, a, stages: int, keep=None):
+        self._sync_lr()
+        keep = self._keep if keep is None else keep
         # plain single-segment layout with every bag a multiple of 32 rows: the pool partial pass may ride in the forward launch
-        if getattr(self._keep[2], "aligned32", False) and (stages & _lib.STAGE_GATE_FWD) and (stages & _lib.STAGE_POOL):
+        if getattr(keep[2], "aligned32", False) and (stages & _lib.STAGE_GATE_FWD) and (stages & _lib.STAGE_POOL):
             stages |= _lib.STAGE_POOL_FUSED
         a.stages = stages
         a.accumulate = int(self._micro > 0)
@@ -262,18 +276,19 @@ class ImageOnlyTrainer:
         if self.world > 1 or self.force_collectives:
             allreduce_flat(self.fp.grad_ext)
 
-    def _adam(self):
-        self._run(self._args, _lib.STAGE_ADAM)
+    def _adam(self, a=None, keep=None):
+        a = self._args if a is None else a
+        self._run(a, _lib.STAGE_ADAM, keep)
         self.step_count += 1
         self._param_version += 1
-        if self._args.x_bf16:
+        if a.x_bf16:
             self._w16_version = self._param_version     # step.hip re-cast the shadows right after the update
 
-    def reduce_and_step(self):
+    def reduce_and_step(self, a=None, keep=None):
         """One all-reduce(sum) of the flat gradient over RCCL, then Adam.  The local loss was already
         normalised by the global bag count, so the sum IS DDP's mean-of-ranks gradient."""
         self.reduce_only()
-        self._adam()
+        self._adam(a, keep)
 
     def train_step(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
         """forward + backward (+ all-reduce + Adam once every `accum` calls).  World size 1, accum 1: ONE C call."""
@@ -377,6 +392,9 @@ class ImageOnlyTrainer:
         counter) is inside the graph as well when no all-reduce is needed.  The graph entry keeps references to every
         tensor its launches point at (layout, workspace, bf16 shadows), so later growth of the trainer's buffers or
         eviction from BagLayout's cache cannot free memory a replay reads."""
+        if self.accum != 1:
+            # the micro-batch index (dropout stream position) and the accumulate flag are launch arguments frozen at capture
+            raise _lib.MilHipError("ImageOnlyTrainer.capture: gradient accumulation (accum > 1) cannot be replayed from one graph")
         a = self._fill(x, layout, y, None)
         if a.train and self.step_counter is None:
             raise _lib.MilHipError("ImageOnlyTrainer.capture in train mode needs counted=True: the dropout stream position "
@@ -396,14 +414,17 @@ class ImageOnlyTrainer:
 
     def replay_step(self):
         g = self._graph
+        self._sync_lr()
         g["graph"].replay()
         self.last = g["last"]
         if g["adam"]:
             self.step_count += 1
             self._param_version += 1
         else:
-            self._args = g["args"]
-            self.reduce_and_step()
+            # the optimizer stage runs on the GRAPH's own descriptor: self._args / _args_key / _keep still describe the last
+            # eager batch, and _fill() must keep returning that struct for that key (a replay that overwrote
+            # self._args made the next capture of another bucket record the wrong bucket's buffers)
+            self.reduce_and_step(g["args"], g["keep"][0])
         return self.loss_sum, self.last["prob"]
 
 

@@ -63,8 +63,12 @@ def _args(**kw):
     return SimpleNamespace(**a)
 
 
-def test_ct_plus_pathology_module_vs_reference_wiring():
-    """aggregator(args) with modality ['CT', 'pathology']: returns (prob, x_CT2CI, x_Pth2CI) as aggregator.py:202-203."""
+@pytest.mark.parametrize("flat", [False, True])
+def test_ct_plus_pathology_module_vs_reference_wiring(flat):
+    """aggregator(args) with modality ['CT', 'pathology']: returns (prob, x_CT2CI, x_Pth2CI) as aggregator.py:202-203.
+    flat=True: under optim.FlatAdam the few-rows layers defer their weight gradients to one grouped launch; the layers of
+    TwoWayTransformer_Both run TWICE per forward (aggregator.py:160-168), so both uses' gradients must meet in the flat slot
+    (the first use's gradient was lost)."""
     g = load_golden("fused_ct_pth")
     seed = int(g["seed"])
     B, N, P, D, hw, clayers = [int(v) for v in g["cfg"]]
@@ -73,6 +77,12 @@ def test_ct_plus_pathology_module_vs_reference_wiring():
     missing, unexpected = model.load_state_dict(p, strict=False)
     assert not unexpected, unexpected
     model = model.to(DEV).eval()
+    opt = None
+    if flat:
+        from mil_amd.optim import FlatAdam
+        opt = FlatAdam([q for q in model.parameters() if q.requires_grad])
+        opt.grad.fill_(123.0)                       # stale slot contents must not leak into any gradient
+        opt.zero_grad()
     x = syn.make_bags(seed + 3, B, N, 768).to(DEV)
     ids = syn.make_token_ids(seed + 4, B, P).to(DEV)
     y = syn.make_labels(seed + 5, B).to(DEV)
@@ -80,6 +90,8 @@ def test_ct_plus_pathology_module_vs_reference_wiring():
     prob, q_ct, q_p = model([ct, x], ids)
     loss = torch.nn.BCELoss()(prob, y)
     loss.backward()
+    if flat:
+        opt.gather()
     assert float((model.last_logits.detach().cpu() - g["logits"]).abs().max()) <= 2e-5         # bar: 1e-3
     assert torch.equal(prob.detach().cpu().argmax(-1), g["prob"].argmax(-1))
     assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5
@@ -90,6 +102,8 @@ def test_ct_plus_pathology_module_vs_reference_wiring():
             continue
         gn = float(g["g." + k + ".norm"])
         got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        if flat and params[k].grad is not None:
+            got = params[k]._mil_grad               # what Adam will read: the flat buffer's slot after gather()
         if gn == 0.0:
             assert float(got.abs().max()) <= 1e-10, k
         else:

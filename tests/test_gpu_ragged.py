@@ -94,3 +94,69 @@ def test_bucketed_step_in_train_mode_matches_oracle_on_its_masks():
         g = leaves[k].grad
         if g is not None and float(g.norm()) > 1e-7:
             assert rel_err(tr.fp.g(k).cpu(), g) <= 2e-4, k
+
+
+def _lockstep(tr, st, lengths, lr_of_step, L, seed0=3000):
+    """Run the stepper over `lengths` with torch.optim.Adam + the oracle in lock-step; returns the reference leaves."""
+    ref = {k: v.clone().requires_grad_(True) for k, v in syn.image_only_params(41, L=L).items()}
+    opt = torch.optim.Adam(list(ref.values()), lr=lr_of_step(0), betas=(0.9, 0.999), weight_decay=1e-7)
+    lr_sum = 0.0
+    for step, n in enumerate(lengths):
+        lr = lr_of_step(step)
+        tr.lr = lr                                                         # what train_ddp.py does once per epoch
+        for gph in opt.param_groups:
+            gph["lr"] = lr
+        x = torch.randn((n, L), generator=torch.Generator().manual_seed(seed0 + step))
+        y = syn.make_labels(seed0 + 500 + step, 1)
+        slot = st.slot(n)
+        slot.x[:n].copy_(x.to(DEV))
+        slot.y.copy_(y.to(DEV))
+        loss, prob = st.step(slot, [n])
+        o = orc.image_only_forward(x, ref)
+        rloss = orc.bce_loss(o["prob"], y)
+        opt.zero_grad()
+        rloss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.item()) - float(rloss)) <= 2e-5, (step, n)
+        assert float((tr.last["logits"].cpu() - o["logits"]).abs().max()) <= 5e-5, (step, n)
+        opt.step()
+        lr_sum += lr
+        for k in ref:
+            if k.endswith("attention_weights.bias"):
+                continue
+            # a learning rate frozen at capture time would be off by ~lr of the first epoch per step
+            assert float((tr.fp.p(k).cpu() - ref[k].detach()).abs().max()) <= 0.05 * lr_sum, (step, k)
+    return ref
+
+
+def test_learning_rate_schedule_reaches_the_replayed_graph():
+    """Adam runs inside the captured graph at world size 1; the scheduled rate (utils.py:232-241) must
+    still reach it - it is read from a device word, not from a by-value kernel argument frozen at capture."""
+    L = 512
+    tr = ImageOnlyTrainer(syn.image_only_params(41, L=L), DEV, lr=1e-3, counted=True)
+    st = RaggedImageOnlyStepper(tr, B=1)
+    sched = lambda s: 1e-3 if s < 3 else (1e-5 if s < 6 else 3e-4)         # noqa: E731
+    _lockstep(tr, st, [2100, 2300, 2200, 2500, 2050, 2400, 2150, 2250], sched, L)
+    assert st.replays >= 6 and len(st.slots) == 1
+
+
+def test_two_buckets_with_the_optimizer_outside_the_graph():
+    """with an all-reduce between gradient and update (world > 1 / forced collectives) Adam stays outside
+    the graph; a replay of bucket A must not leave A's descriptor behind for bucket B's capture."""
+    L = 512
+    tr = ImageOnlyTrainer(syn.image_only_params(41, L=L), DEV, lr=1e-3, counted=True)
+    tr.force_collectives = True                                            # no process group here: the collective is a no-op
+    st = RaggedImageOnlyStepper(tr, B=1)
+    # bucket 3072 eager, bucket 2048 eager, 2048 capture + replay, 3072 capture (the stale-struct hazard), then both replay
+    lengths = [2900, 1900, 2000, 3000, 1800, 2800, 2040, 3050]
+    _lockstep(tr, st, lengths, lambda s: 1e-3, L)
+    assert len(st.slots) == 2 and all(s.graph is not None and not s.graph["adam"] for s in st.slots.values())
+
+
+def test_capture_refuses_gradient_accumulation():
+    from mil_amd._lib import MilHipError
+    L = 512
+    tr = ImageOnlyTrainer(syn.image_only_params(41, L=L), DEV, counted=True, accum=2)
+    x = torch.zeros((64, L), device=DEV)
+    with pytest.raises(MilHipError):
+        tr.capture(x, BagLayout.make([64], DEV), syn.make_labels(1, 1).to(DEV))
