@@ -15,7 +15,10 @@ ranks BEFORE touching a GPU (fresh python processes, rank r bound to GPU r, back
 them and exits non-zero if any rank fails or fewer than N devices are visible: it never falls back to one rank.
 
 Rank 0 prints ONE JSON line.  Extra objects on it:
-  roofline      dominant kernel (the gate GEMMs, fp32 MFMA bound), algorithmic flops / HIP-event time
+  roofline      dominant kernel AMONG THE LAUNCHES OF THE STEP (fp32 MFMA bound), algorithmic flops / its HIP-event time
+                measured inside the running step (an event between the step's launch groups, a second pass right after
+                the timed region); profiles/rNN_cfg2_kernel_stats.csv holds rocprofv3's average for the same kernel
+  roofline_step the whole driver-timed step: 2 x 4 R L D flop / ms_per_step against the same peak
   roofline_pool the HBM-bound attention-pool kernel at N=4096, D=512 (north_star's 30 % target)
   cpu_baseline  the CPU oracle (torch fp32, one bag per forward as the reference runs) on this host, at 1 thread
                 and at all physical cores
@@ -291,6 +294,18 @@ def config5_bf16(dev, steps=60, warmup=5):
         o = orc.image_only_forward(x32[b].to(torch.bfloat16).float(), pr)
         dl = max(dl, float((z[b].cpu() - o["logits"][0]).abs().max()))
         top1 = top1 and bool(torch.equal(prob[b].cpu().argmax(-1), o["prob"][0].argmax(-1)))
+    # gradient parity of the bf16-MFMA weight gradient (bf16 saved gates): bags 0 and B-1 as a 2-bag batch against the
+    # oracle's gradients on the same rounded inputs (the bar asserted in tests/test_gpu_bf16.py is 1.2e-2 for the gate
+    # parameters - 2^-9 relative rounding per bf16 factor -, 5e-4 for the fp32 head)
+    xb = torch.cat([x32[0], x32[B - 1]], 0)
+    y2 = torch.stack([y[0], y[B - 1]], 0)
+    tr.forward(xb.to(dev).to(torch.bfloat16), BagLayout.uniform(2, N, dev), y2)
+    tr.backward()
+    _, _, _, og = orc.batch_loss_and_grads([x32[0].to(torch.bfloat16).float(), x32[B - 1].to(torch.bfloat16).float()], y2.cpu(), pr)
+    rel = lambda a_, b_: float((a_.double() - b_.double()).norm() / (b_.double().norm() + 1e-30))      # noqa: E731
+    gerr = {k: rel(tr.fp.g(k).cpu(), og[k]) for k in og if float(og[k].norm()) > 1e-7}
+    gate_err = max(v for k, v in gerr.items() if k.startswith("aggregator.attention"))
+    head_err = max(v for k, v in gerr.items() if k.startswith("fc."))
     for _ in range(30):
         tr.forward(x, lay, y)
     for _ in range(warmup):
@@ -302,9 +317,11 @@ def config5_bf16(dev, steps=60, warmup=5):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     R = B * N
-    kb = tr.time_pieces(x, lay, y, 20)
-    dom = max(("gate_fwd", "gate_bwd_dw"), key=lambda k: kb[k])
+    kb, _ = tr.time_step_groups(x, lay, y, 30)
+    kb_alone = tr.time_pieces(x, lay, y, 20)
     flops = 4.0 * R * L * D_GATE
+    # in-step groups: the weight gradient's launch pair (+ head parameter gradients) is one entry point on this path
+    dom = max(("gate_fwd", "gate_bwd_dw_reduce_head"), key=lambda k: kb[k])
     hbm = R * L * 2 / (kb["gate_fwd"] * 1e-3) / 1e9
     # the same step in model.train() mode (in-kernel dropout through the keep-bit tensors; the forward then runs on the
     # 128-row kernel): reported beside the eval-mode figure the object is quoted on
@@ -323,14 +340,21 @@ def config5_bf16(dev, steps=60, warmup=5):
             "mode": "eval (no dropout)", "ms_per_step": round(ms, 4), "bags_per_s": round(B / (ms * 1e-3), 1), "dtype": "bf16",
             "train_mode_ms_per_step": round(ms_train, 4),
             "step_algorithmic_bytes": 2 * R * L * 2, "step_hbm_frac": round(2 * R * L * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "roofline": {"bound": "mfma", "kernel": "k_gate_fwd_bf16_deep" if dom == "gate_fwd" else "k_gate_bwd_dw_bf16",
+            "roofline": {"bound": "mfma", "kernel": "k_gate_fwd_bf16_deep" if dom == "gate_fwd" else "k_gate_bwd_dw_bf16 (+ its fold)",
                          "achieved": round(flops / (kb[dom] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(flops / (kb[dom] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                         "flops_per_launch": flops, "ms_per_launch": round(kb[dom], 4),
-                         "traffic": _pmc_traffic("cfg5_" + dom)},
+                         "flops_per_launch": flops, "ms_per_launch": round(kb[dom], 4), "timing": "HIP events inside the running step",
+                         "traffic": _pmc_traffic("cfg5_" + ("gate_fwd" if dom == "gate_fwd" else "gate_bwd_dw")),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, bytes per launch)"},
+            "roofline_step": {"bound": "mfma", "achieved": round(2 * flops / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(2 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                              "flops_per_step": 2 * flops},
+            "grad_rel_err": {"gate_params_max": gate_err, "head_params_max": head_err, "asserted_in_tests": "1.2e-2 / 5e-4",
+                             "batch": "bags 0 and 31 as a 2-bag batch vs the oracle on the same bf16-rounded inputs"},
             "roofline_hbm_gate_fwd": {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": round(hbm / PEAK_HBM_GBS, 4), "bytes_per_launch": R * L * 2},
             "kernels_ms": {k: round(v, 4) for k, v in kb.items()},
+            "kernels_ms_standalone": {k: round(v, 4) for k, v in kb_alone.items()},
             "parity": {"bags_checked": [0, B - 1], "max_abs_dlogit": dl, "top1_equal": top1,
                        "oracle": "fp32 oracle on the same bf16-rounded x and gate weights", "tolerance": 1e-3}}
 
@@ -395,6 +419,21 @@ def config3_fusion(dev, steps=30, warmup=4):
         g.replay()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    # the same step with the text tower INSIDE the loop, as model/dim1/CLIP.py:71-75 runs it (encode_text under no_grad every
+    # step, no per-note cache): frozen tower eagerly (its launch geometry follows the notes' lengths), then the replay
+    def cold():
+        with torch.no_grad():
+            tfeat.copy_(model.clinic_extractor(ids))
+        g.replay()
+    for _ in range(2):
+        cold()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ncold = max(4, steps // 3)
+    for _ in range(ncold):
+        cold()
+    torch.cuda.synchronize()
+    ms_cold = (time.perf_counter() - t0) / ncold * 1e3
     R = B * N
     # algorithmic flops of the trainable path per step: fc_pathology fwd + dW (2 x 2*R*768*512),
     # ABMIL gate fwd + dW + dx (3 x 4*R*512*192); the absorbed one-token attention sites are HBM-bound streams
@@ -402,6 +441,9 @@ def config3_fusion(dev, steps=30, warmup=4):
     return {"workload": f"{B} bags x {N} x 768 + one 77-token note per bag, aggregator(args) fwd+BCE+bwd+Adam "
                         "(BASELINE config 3; text embeddings of the frozen ViT-B/32 tower cached per note)",
             "ms_per_step": round(ms, 4), "bags_per_s": round(B / (ms * 1e-3), 1), "dtype": "f32", "launch": "hipGraph",
+            "cold_ms_per_step": round(ms_cold, 4), "cold_bags_per_s": round(B / (ms_cold * 1e-3), 1),
+            "cold_note": "encode_text of the 32 notes inside every step (no text cache; reference model/dim1/CLIP.py:71-75), "
+                         "frozen tower eager + trainable part replayed",
             "roofline": {"bound": "mfma", "kernel": "step (fc_pathology + gate GEMMs)", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                          "flops_per_step": flops, "traffic": None},
@@ -528,38 +570,48 @@ def run_rank(args):
         }
         if rccl is not None:
             line["rccl"] = rccl
+        R = B * N
+        gate_flops = 4.0 * R * L * D_GATE
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        line["roofline_step"] = {"bound": "mfma", "achieved": round(2 * gate_flops / (ms_step * 1e-3) / 1e12, 2), "peak": peak,
+                                 "unit": "TFLOP/s", "frac": round(2 * gate_flops / (ms_step * 1e-3) / 1e12 / peak, 4),
+                                 "flops_per_step": 2 * gate_flops,
+                                 "note": "gate GEMMs forward + weight gradient (2 x 4 R L D) over the driver-timed ms_per_step"}
         if not args.no_breakdown:
-            kb = kernel_breakdown(tr, x, lay, y)
-            R = B * N
-            flops = {"gate_fwd": 4.0 * R * L * D_GATE, "gate_bwd_dw": 4.0 * R * L * D_GATE}
-            dom = max(("gate_fwd", "gate_bwd_dw"), key=lambda k: kb[k])
-            ach = flops[dom] / (kb[dom] * 1e-3) / 1e12
+            # each launch group of the step, timed INSIDE the running step (HIP events between the groups, on the stream the
+            # kernels are launched on; mil_image_only_step_profile) - the figure rocprofv3's kernel trace of the step reports
+            kb, ev_step = tr.time_step_groups(x, lay, y, 50)
+            kb_alone = kernel_breakdown(tr, x, lay, y)
+            names = {"gate_fwd_with_pool_fused": "k_gate_fwd2<train, pool pass in the epilogue>", "gate_fwd": "k_gate_fwd2",
+                     "gate_bwd_dw": "k_gate_bwd_dw2", "gate_bwd_dw_reduce_head": "k_gate_bwd_dw_bf16 (+ fold)"}
             if args.dtype == "bf16":
-                line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd_bf16" if dom == "gate_fwd" else "k_gate_bwd_dw_bf16",
-                                    "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-                                    "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
-            else:
-                line["roofline"] = {"bound": "mfma", "kernel": "k_gate_fwd" if dom == "gate_fwd" else "k_gate_bwd_dw",
-                                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                                    "traffic": _pmc_traffic("cfg2_" + dom) if (B, N, L) == (32, 1024, 512) else None,
-                                    "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4)}
+                names.update(gate_fwd="k_gate_fwd_bf16")
+            flops = {k: gate_flops for k in names if k in kb}
+            dom = max(flops, key=lambda k: kb[k])
+            ach = flops[dom] / (kb[dom] * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": names[dom], "group": dom, "achieved": round(ach, 2), "peak": peak,
+                                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                                "traffic": _pmc_traffic("cfg2_" + ("gate_fwd" if dom.startswith("gate_fwd") else "gate_bwd_dw"))
+                                if (B, N, L, args.dtype) == (32, 1024, 512, "f32") else None,
+                                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, bytes per launch)",
+                                "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4),
+                                "timing": "HIP events inside the running step, 50 steps right after the timed region"}
             line["kernels_ms"] = {k: round(v, 4) for k, v in kb.items()}
-            line["kernels_ms_note"] = ("each launch group timed stand-alone through mil_image_only_step_time; in the step itself "
-                                       "the keep bits are drawn by gate_fwd, the pool partial pass runs in gate_fwd's epilogue "
-                                       "(gate_fwd_with_pool_fused is that one launch; gate_fwd and pool_partial are the two "
-                                       "stand-alone launches it replaces), and at world size 1 Adam is applied inside the "
-                                       "reduce launch (no separate adam launch)")
+            line["kernels_ms_sum"] = round(sum(kb.values()), 4)
+            line["kernels_ms_event_step"] = round(ev_step, 4)
+            line["kernels_ms_standalone"] = {k: round(v, 4) for k, v in kb_alone.items()}
+            line["kernels_ms_note"] = ("kernels_ms: launch groups of the step as it runs (world size 1: keep bits drawn by the "
+                                       "forward launch, pool partial pass in its epilogue, Adam inside the reduce launch); "
+                                       "kernels_ms_standalone: the same entry points repeated back to back on their own")
             line["kernels_tflops"] = {k: round(flops[k] / (kb[k] * 1e-3) / 1e12, 2) for k in flops}
             if args.train_mode and args.dtype == "f32" and world == 1:
                 # the same launches without dropout (model.eval() arithmetic): the keep-bit selects of train mode are work
                 # the 4 R L D flop count does not contain, so the MFMA fraction of the bare products is reported beside it
                 from mil_amd.trainer import ImageOnlyTrainer
                 tr_e = ImageOnlyTrainer(params, dev, train_mode=False)
-                kbe = tr_e.time_pieces(x, lay, y, 20)
+                kbe, _ = tr_e.time_step_groups(x, lay, y, 30)
                 line["roofline_eval_mode"] = {
-                    "bound": "mfma", "kernel": line["roofline"]["kernel"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "bound": "mfma", "kernel": names[dom], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "achieved": round(flops[dom] / (kbe[dom] * 1e-3) / 1e12, 2),
                     "frac": round(flops[dom] / (kbe[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "ms_per_launch": round(kbe[dom], 4), "kernels_ms": {k: round(v, 4) for k, v in kbe.items()}}

@@ -648,6 +648,13 @@ int mil_image_only_step_run(const mil_image_only_step* a, void* stream);
 int mil_image_only_step_time(const mil_image_only_step* a, uint32_t stages, int warm, int iters, float* ms_out,
                              void* stream);
 
+/* In-step timing (bench.py's `roofline` / `kernels_ms`): runs the whole step `iters` times as `ngroups` consecutive
+ * mil_image_only_step_run calls (groups[i] = stage mask of group i) with a HIP event recorded on `stream` between the
+ * groups; ms_out[i] = average duration of group i where it runs inside the step, ms_out[ngroups] = average first-to-last
+ * event.  Synchronises the stream.  The step really executes (parameters move on when MIL_STAGE_ADAM is in a group). */
+int mil_image_only_step_profile(const mil_image_only_step* a, const uint32_t* groups, int ngroups, int warm, int iters,
+                                float* ms_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

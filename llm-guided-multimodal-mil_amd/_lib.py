@@ -54,6 +54,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gate_bwd_input_pool": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "mil_image_only_step_run": (c_int, [_P, _P]),
     "mil_image_only_step_time": (c_int, [_P, c_uint32, c_int, c_int, _P, _P]),
+    "mil_image_only_step_profile": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
     "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_float, _P]),

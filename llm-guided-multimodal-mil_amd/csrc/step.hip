@@ -236,3 +236,45 @@ extern "C" int mil_image_only_step_time(const mil_image_only_step* a, uint32_t s
     (void)hipEventDestroy(e1);
     return rc;
 }
+
+// In-step timing: the WHOLE step `iters` times, a HIP event recorded between its launch groups, so that every group's
+// duration is measured where it runs - after its predecessor, with the caches in the state the step leaves them in -
+// and not as a stand-alone repetition of one kernel.  groups[i] is the stage mask of group i (run in order, each as
+// one mil_image_only_step_run call; MIL_STAGE_POOL_FUSED and friends ride along as given); ms_out[i] = average
+// duration of group i, ms_out[ngroups] = average of first-event -> last-event (the step with its event gaps).
+extern "C" int mil_image_only_step_profile(const mil_image_only_step* a, const uint32_t* groups, int ngroups, int warm,
+                                           int iters, float* ms_out, void* stream) {
+    if (!a || !groups || !ms_out || ngroups <= 0 || ngroups > 16 || iters <= 0 || iters > 256 || warm < 0) return MIL_EINVAL;
+    mil_image_only_step s = *a;
+    hipStream_t st = (hipStream_t)stream;
+    const int per = ngroups + 1, nev = per * iters;
+    hipEvent_t* ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * (size_t)nev);
+    if (!ev) return MIL_EINVAL;
+    int made = 0, rc = MIL_OK;
+    for (; made < nev; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) { rc = MIL_EINVAL; break; }
+    for (int i = 0; i < warm && rc == MIL_OK; ++i)
+        for (int g = 0; g < ngroups && rc == MIL_OK; ++g) { s.stages = groups[g]; rc = mil_image_only_step_run(&s, stream); }
+    for (int i = 0; i < iters && rc == MIL_OK; ++i) {
+        (void)hipEventRecord(ev[i * per], st);
+        for (int g = 0; g < ngroups && rc == MIL_OK; ++g) {
+            s.stages = groups[g];
+            rc = mil_image_only_step_run(&s, stream);
+            (void)hipEventRecord(ev[i * per + g + 1], st);
+        }
+    }
+    if (rc == MIL_OK && hipStreamSynchronize(st) != hipSuccess) rc = MIL_EINVAL;
+    if (rc == MIL_OK) {
+        for (int g = 0; g <= ngroups; ++g) ms_out[g] = 0.f;
+        for (int i = 0; i < iters; ++i) {
+            float ms = 0.f;
+            for (int g = 0; g < ngroups; ++g)
+                if (hipEventElapsedTime(&ms, ev[i * per + g], ev[i * per + g + 1]) == hipSuccess) ms_out[g] += ms;
+            if (hipEventElapsedTime(&ms, ev[i * per], ev[i * per + ngroups]) == hipSuccess) ms_out[ngroups] += ms;
+        }
+        for (int g = 0; g <= ngroups; ++g) ms_out[g] /= (float)iters;
+    }
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    free(ev);
+    return rc;
+}

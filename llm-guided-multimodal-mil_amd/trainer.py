@@ -385,6 +385,41 @@ class ImageOnlyTrainer:
         out["adam"] = float(ms.value)
         return out
 
+    def time_step_groups(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor, iters: int = 50, warm: int = 5):
+        """HIP-event duration (ms) of each launch group INSIDE the running step (mil_image_only_step_profile): the whole
+        step is executed `iters` times with an event between its groups, so each kernel is timed after its predecessor, on
+        the cache state the step leaves - the figure a rocprofv3 kernel trace of the step reports.  Adam runs on scratch
+        copies of the parameters and moments (same launch, the trainer's state stays put).  Returns ({group: ms}, step_ms);
+        step_ms is first-to-last event, i.e. the step plus its event gaps."""
+        a = self._fill(x, layout, y, None)
+        self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)          # state every stage reads exists
+        fp = self.fp
+        a2 = _lib.ImageOnlyStep.from_buffer_copy(a)
+        scratch = [fp.flat.clone(), fp.exp_avg.clone(), fp.exp_avg_sq.clone()]
+        a2.param_flat, a2.exp_avg, a2.exp_avg_sq = (t.data_ptr() for t in scratch)
+        a2.adam_step_dev, a2.lr_dev, a2.adam_step, a2.lr, a2.accumulate = None, None, 1, self.lr, 0
+        S = _lib
+        fwd = S.STAGE_TILEMAP | S.STAGE_DROPBITS | S.STAGE_GATE_FWD
+        fused_pool = (not a.x_bf16) and getattr(layout, "aligned32", False)
+        groups = []
+        if fused_pool:
+            groups.append(("gate_fwd_with_pool_fused", fwd | S.STAGE_POOL | S.STAGE_POOL_FUSED))
+        else:
+            groups += [("gate_fwd", fwd), ("pool_partial", S.STAGE_POOL)]
+        groups.append(("merge_head_loss_ds", S.STAGE_TAIL))
+        collective = self.world > 1 or self.force_collectives
+        if a.x_bf16:
+            groups += [("gate_bwd_dw_reduce_head", S.STAGE_GATE_BWD | S.STAGE_REDUCE), ("adam", S.STAGE_ADAM)]
+        elif collective:
+            groups += [("gate_bwd_dw", S.STAGE_GATE_BWD), ("gate_bwd_reduce_head", S.STAGE_REDUCE), ("adam", S.STAGE_ADAM)]
+        else:
+            groups += [("gate_bwd_dw", S.STAGE_GATE_BWD), ("gate_bwd_reduce_head_adam", S.STAGE_REDUCE | S.STAGE_ADAM)]
+        masks = (ctypes.c_uint32 * len(groups))(*[m for _, m in groups])
+        out = (ctypes.c_float * (len(groups) + 1))()
+        rc = _lib.lib().mil_image_only_step_profile(ctypes.byref(a2), masks, len(groups), warm, iters, out, ops._stream())
+        _lib.check(rc, "mil_image_only_step_profile")
+        return {n: float(out[i]) for i, (n, _) in enumerate(groups)}, float(out[len(groups)])
+
     # ------------------------------------------------------------------ hipGraph replay of the launch-bound part
     def capture(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
         """Capture forward+backward (static buffers) into one hipGraph.  ``x`` and ``y`` become the static input

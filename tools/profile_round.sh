@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun).  One run PER SHAPE, so that
 # every per-kernel average in profiles/ belongs to one workload:
-#   cfg2   bench.py default step (32 x 1024 x 512 fp32, train mode), step kernels only (--no-breakdown --no-configs)
+#   cfg2   bench.py default step (32 x 1024 x 512 fp32, train mode), step kernels only (--no-breakdown --no-configs), the
+#          bench's default priming; tools/summarize_profiles.py averages the dispatches of the TIMED region only
 #   pool   the attention-pool stage alone at 64 x 4096 x 512 (tools/prof_pool.py)
 #   cfg5   32 x 4096 x 1024 bf16 step (tools/prof_stage.py --bf16)
 #   cfg3   32 x 1024 x 768 fusion step (tools/bench_fusion.py --graph)
@@ -15,11 +16,19 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --no-configs --no-cpu-baseline --no-breakdown"
 declare -A CMD
-CMD[cfg2]="$BENCH --steps 40 --warmup 5 --prime 20"
+CMD[cfg2]="$BENCH --steps 200 --warmup 10"      # the bench's own priming (--prime 300): the chip at its steady clock
 CMD[pool]="python3 $ROOT/tools/prof_pool.py"
 CMD[cfg5]="python3 $ROOT/tools/prof_stage.py --bf16"
 CMD[cfg3]="python3 $ROOT/tools/bench_fusion.py --graph --steps 20 --warmup 3"
 MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
+# QUICK=1: the cfg2 kernel trace + one un-profiled bench line only (the HIP-event vs rocprofv3 cross-check)
+if [ "${QUICK:-0}" = "1" ]; then
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2 -- ${CMD[cfg2]} > $OUT/stats_cfg2.log 2>&1
+  python3 $ROOT/bench.py --steps 200 --warmup 20 --no-configs --no-cpu-baseline > $OUT/bench_line.json 2> $OUT/bench_line.err
+  find $OUT -name "*agent_info*" -delete
+  echo quick done
+  exit 0
+fi
 for w in cfg2 pool cfg5 cfg3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- ${CMD[$w]} > $OUT/stats_$w.log 2>&1
   echo "stats $w done"

@@ -5,9 +5,10 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-WORK = {"cfg2": "python3 bench.py --no-configs --no-cpu-baseline --no-breakdown --steps 40 --warmup 5 --prime 20   "
-                "(32 bags x 1024 x 512 fp32, train-mode step; kernels of the step only)",
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+CFG2_STEPS, CFG2_WARMUP = 200, 10
+WORK = {"cfg2": f"python3 bench.py --no-configs --no-cpu-baseline --no-breakdown --steps {CFG2_STEPS} --warmup {CFG2_WARMUP}   "
+                "(32 bags x 1024 x 512 fp32, train-mode step, default --prime 300; kernels of the step only)",
         "pool": "python3 tools/prof_pool.py   (attention-pool stage alone, 64 bags x 4096 x 512 fp32 = 512 MiB of x)",
         "cfg5": "python3 tools/prof_stage.py --bf16   (32 bags x 4096 x 1024, bf16 storage, 12 steps)",
         "cfg3": "python3 tools/bench_fusion.py --graph --steps 20 --warmup 3   (32 bags x 1024 x 768 + CLIP ViT-B/32 text, hipGraph replays)"}
@@ -41,12 +42,73 @@ def pmc(sub):
     return agg
 
 
+def timed_region_stats():
+    """cfg2: per-kernel averages over the dispatches of bench.py's TIMED region only (the 300 priming passes and the warm-up
+    steps run while the clock ramps and are not what ms_per_step measures).  The region is found in the kernel trace itself:
+    the weight-gradient kernel runs once per step, so its dispatches [warmup, warmup + steps) bracket the timed steps.
+    Returns {kernel: (calls_per_step, avg_ns)} and the profiled run's own ms_per_step."""
+    f = sorted(glob.glob(os.path.join(SRC, "stats_cfg2", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    if not f:
+        return None, None
+    rows = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f[0]))]
+    rows.sort(key=lambda r: r[1])
+    dw = [r for r in rows if r[0].startswith("k_gate_bwd_dw")]
+    if len(dw) < CFG2_WARMUP + CFG2_STEPS:
+        return None, None
+    fwd = [r for r in rows if r[0].startswith("k_gate_fwd")]
+    first_dw = dw[CFG2_WARMUP][1]
+    t0 = max(r[1] for r in fwd if r[1] < first_dw)            # the forward launch that opens the first timed step
+    t1 = dw[CFG2_WARMUP + CFG2_STEPS - 1][2]
+    agg = collections.defaultdict(list)
+    for n, a, b in rows:
+        if a >= t0 and b <= t1 + 50000:                        # + the reduce launch that closes the last step
+            agg[n].append(b - a)
+    out = {n: (len(v) / CFG2_STEPS, sum(v) / len(v)) for n, v in agg.items()}
+    ms = None
+    try:
+        txt = [l for l in open(os.path.join(SRC, "stats_cfg2.log")).read().splitlines() if l.startswith("{")][-1]
+        ms = json.loads(txt)["ms_per_step"]
+    except Exception:       # noqa: BLE001
+        pass
+    return out, ms
+
+
 os.makedirs(DST, exist_ok=True)
 for w in WORK:
     stats(w, top=60 if w == "cfg3" else 30)
+region, prof_ms = timed_region_stats()
+CHECK_FAILED = False
+if region:
+    try:
+        txt = [l for l in open(os.path.join(SRC, "bench_line.json")).read().splitlines() if l.startswith("{")][-1]
+        bl = json.loads(txt)
+    except Exception:       # noqa: BLE001
+        bl = {}
+    ev = bl.get("kernels_ms", {})
+    pair = {"k_gate_fwd": "gate_fwd_with_pool_fused", "k_gate_bwd_dw": "gate_bwd_dw", "k_pool_merge_head": "merge_head_loss_ds",
+            "k_gate_bwd_reduce": "gate_bwd_reduce_head_adam"}
+    with open(os.path.join(DST, f"{TAG}_cfg2_timed_region.csv"), "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace -- {WORK['cfg2']}\n")
+        o.write("# averages over the dispatches INSIDE the timed region (the 200 steps the line's ms_per_step is measured on), from the\n"
+                "# kernel trace; hip_event_us = the un-profiled bench.py run's in-step HIP-event time of the same launch (kernels_ms).\n")
+        o.write("kernel,calls_per_step,rocprof_avg_us,hip_event_us,rocprof_over_event\n")
+        tot = 0.0
+        for n, (cps, avg) in sorted(region.items(), key=lambda kv: -kv[1][1] * kv[1][0]):
+            tot += cps * avg
+            e = next((ev.get(v) for k, v in pair.items() if n.startswith(k)), None)
+            ratio = (avg / 1e3) / (e * 1e3) if e else None
+            o.write(f"{n},{cps:.2f},{avg / 1e3:.2f},{'' if e is None else f'{e * 1e3:.2f}'},{'' if ratio is None else f'{ratio:.3f}'}\n")
+            if ratio is not None and avg > 20000 and abs(ratio - 1.0) > 0.05:
+                CHECK_FAILED = True
+        o.write(f"# sum of rocprof averages per step: {tot / 1e3:.1f} us; ms_per_step of the profiled run: {prof_ms}; "
+                f"ms_per_step of the un-profiled run: {bl.get('ms_per_step')}\n")
+        if prof_ms and tot / 1e6 > prof_ms * 1.001:
+            CHECK_FAILED = True
+            o.write("# CHECK FAILED: the kernel durations add up to more than the step\n")
+    print(open(os.path.join(DST, f"{TAG}_cfg2_timed_region.csv")).read())
 traffic = {}
 with open(os.path.join(DST, f"{TAG}_hbm_traffic_pmc.csv"), "w") as o:
-    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, SEPARATE passes, one workload per pass (commands: r02_*_kernel_stats.csv headers)\n"
+    o.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, SEPARATE passes, one workload per pass (commands: {TAG}_*_kernel_stats.csv headers)\n"
             "# values are KiB per dispatch as reported; gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads,\n"
             "# so read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B stores.\n"
             "workload,kernel,counter,dispatches,mean_KiB,corrected_MiB\n")
@@ -106,3 +168,6 @@ for key, fn in (("bench", "bench_line.json"), ("bench_eval_mode", "bench_eval_li
         lines[key] = {"error": str(e)}
 json.dump(lines, open(os.path.join(DST, f"{TAG}_bench_line.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(DST)))
+if CHECK_FAILED:
+    print("CHECK FAILED: HIP-event and rocprofv3 durations of a step kernel differ by more than 5 % (or add up to more than the step)")
+    sys.exit(1)
