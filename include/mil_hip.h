@@ -234,7 +234,8 @@ int mil_gate_bwd_input(const float* gates, const float* ds, const float* w, cons
 /* The same with the pool's own input gradient formed in the epilogue instead of read from dx:
  * dx[row] = a_row dM[row_bag[row]] + dPreV Wv + dPreU Wu, a_row = exp(scores[row] - lse[bag]) (ABMIL.py:57-59: the
  * d/dx of M = sum_i a_i x_i at fixed weights; the part through the scores is the gate term).  dx is WRITTEN, never read:
- * no pool-backward pass over [R, L].  row_bag int32 [R] = the bag of every row; dM [B, L]. */
+ * no pool-backward pass over [R, L].  row_bag int32 [R] = the bag of every row (< 0: padding row of a capacity bucket -
+ * no pool term, see mil_build_fusion_segs); dM [B, L]. */
 int mil_gate_bwd_input_pool(const float* gates, const float* ds, const float* w, const float* Wv, const float* Wu, int R,
                             int L, int D, float* dx, const uint32_t* xbits, float xscale, const float* scores,
                             const float* lse, const int32_t* row_bag, const float* dM, void* stream);
@@ -647,6 +648,16 @@ int mil_image_only_step_run(const mil_image_only_step* a, void* stream);
  * are issued from C, so a 10 us kernel is not timed behind 30 us of interpreter. */
 int mil_image_only_step_time(const mil_image_only_step* a, uint32_t stages, int warm, int iters, float* ms_out,
                              void* stream);
+
+/* Device-side segments of the one-note fusion step for a CAPACITY bucket (cap patch rows, B bags, P text tokens per bag):
+ * every map model/aggregator.py:186-192 + sam/transformer.py need (patch offsets, row -> bag, 64-key tiles of the absorbed
+ * attention pool, 32-row tiles of the multi-modal bag [patch rows | token rows at cap + b P], row -> bag with -1 on padding
+ * rows) rebuilt from len_dev [B] inside the step, so one captured hipGraph per bucket serves every bag length (reference
+ * regime: one ragged bag per GPU, length changing every step, dataset.py:366-393, run_train.sh:81).
+ * T64 >= cap / 64 + B, T32 >= cap / 32 + B (1 + ceil(P / 32)); tile32 16-byte aligned. */
+int mil_build_fusion_segs(const int32_t* len_dev, int B, int P, int cap, int32_t* k_off, int32_t* k_bag, int32_t* tile64,
+                          int32_t* bag_tile64_off, int T64, int32_t* tile32, int32_t* bag_tile32_off, int T32,
+                          int32_t* row_bag, int32_t* rows_out, void* stream);
 
 /* In-step timing (bench.py's `roofline` / `kernels_ms`): runs the whole step `iters` times as `ngroups` consecutive
  * mil_image_only_step_run calls (groups[i] = stage mask of group i) with a HIP event recorded on `stream` between the

@@ -1076,6 +1076,92 @@ extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float
     return mil_layernorm_bwd_res(x, gamma, dy, stats, nullptr, rows, E, dx, dgamma, dbeta, workspace, stream);
 }
 
+// ---------------------------------------------------------------------------------------------- device-side segments
+// Every map the one-note fusion step reads, rebuilt ON THE DEVICE from the bags' true lengths, for a CAPACITY bucket of
+// `cap` patch rows (the authors' regime: one ragged bag per GPU whose length changes every step, dataset.py:366-393; a
+// captured hipGraph of the step is keyed by the bucket, not by the lengths).  Row layout of the bucket:
+//   patch rows   [0, cap):  bag b at [k_off[b], k_off[b + 1]), rows >= k_off[B] are padding (zero weight, zero gradient)
+//   token rows   [cap, cap + B P):  bag b at cap + b P .. + P   (the multi-modal bag of aggregator.py:192, no concat copy)
+// Outputs:
+//   k_off [B + 1], k_bag [cap] (padding rows: B - 1, a valid index for row-wise kernels whose gradient there is zero)
+//   tile64 [T64][3] = {bag, row0, nkeys}: 64-key tiles of the absorbed attention pool, bag_tile64_off [B + 1]; tiles past
+//     the last real one are {0, 0, 0} (the kernels emit neutral partials for nkeys == 0 and no bag's merge reads them)
+//   tile32 [T32][4] = {bag, row0, nrows, 0}: the ABMIL pool's tiles, per bag its patch tiles then its token tiles
+//     (bags.BagLayout.two_segment), bag_tile32_off [B + 1], padding tiles {0, 0, 0, 0}
+//   row_bag [cap + B P]: bag of every row of the multi-modal bag, -1 for padding rows (mil_gate_bwd_input_pool)
+//   rows_out [1] = sum of the lengths
+__global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __restrict__ len_dev, int B, int P, int cap,
+                                                            int32_t* __restrict__ k_off, int32_t* __restrict__ k_bag,
+                                                            int32_t* __restrict__ tile64, int32_t* __restrict__ bag_tile64_off,
+                                                            int T64, int32_t* __restrict__ tile32,
+                                                            int32_t* __restrict__ bag_tile32_off, int T32,
+                                                            int32_t* __restrict__ row_bag, int32_t* __restrict__ rows_out) {
+    __shared__ int s_row[1025], s_t64[1025], s_t32[1025];
+    const int tid = threadIdx.x;
+    const int tokt = (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+    if (tid == 0) {
+        int r = 0, a = 0, c = 0;
+        for (int b = 0; b < B; ++b) {
+            s_row[b] = r;
+            s_t64[b] = a;
+            s_t32[b] = c;
+            const int n = min(max(len_dev[b], 0), cap - r);              // never beyond the bucket
+            r += n;
+            a += (n + 63) / 64;
+            c += (n + MIL_POOL_TILE - 1) / MIL_POOL_TILE + tokt;
+        }
+        s_row[B] = r;
+        s_t64[B] = min(a, T64);
+        s_t32[B] = min(c, T32);
+        rows_out[0] = r;
+    }
+    __syncthreads();
+    for (int b = tid; b <= B; b += 1024) {
+        k_off[b] = s_row[b];
+        bag_tile64_off[b] = min(s_t64[b], T64);
+        bag_tile32_off[b] = min(s_t32[b], T32);
+    }
+    const int N = s_row[B];
+    for (int b = 0; b < B; ++b) {
+        const int r0 = s_row[b], r1 = s_row[b + 1];
+        for (int r = r0 + tid; r < r1; r += 1024) { k_bag[r] = b; row_bag[r] = b; }
+        const int a0 = s_t64[b], a1 = min(s_t64[b + 1], T64);
+        for (int t = a0 + tid; t < a1; t += 1024) {
+            const int row0 = r0 + (t - a0) * 64;
+            tile64[3 * t] = b; tile64[3 * t + 1] = row0; tile64[3 * t + 2] = min(64, r1 - row0);
+        }
+        const int c0 = s_t32[b], c1 = min(s_t32[b + 1], T32), np = (r1 - r0 + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+        for (int t = c0 + tid; t < c1; t += 1024) {
+            const int j = t - c0;
+            if (j < np) {
+                const int row0 = r0 + j * MIL_POOL_TILE;
+                reinterpret_cast<int4*>(tile32)[t] = make_int4(b, row0, min(MIL_POOL_TILE, r1 - row0), 0);
+            } else {
+                const int row0 = cap + b * P + (j - np) * MIL_POOL_TILE;
+                reinterpret_cast<int4*>(tile32)[t] = make_int4(b, row0, min(MIL_POOL_TILE, cap + (b + 1) * P - row0), 0);
+            }
+        }
+        for (int r = tid; r < P; r += 1024) row_bag[cap + b * P + r] = b;
+    }
+    for (int r = N + tid; r < cap; r += 1024) { k_bag[r] = B - 1; row_bag[r] = -1; }
+    for (int t = s_t64[B] + tid; t < T64; t += 1024) { tile64[3 * t] = 0; tile64[3 * t + 1] = 0; tile64[3 * t + 2] = 0; }
+    for (int t = s_t32[B] + tid; t < T32; t += 1024) reinterpret_cast<int4*>(tile32)[t] = make_int4(0, 0, 0, 0);
+}
+
+extern "C" int mil_build_fusion_segs(const int32_t* len_dev, int B, int P, int cap, int32_t* k_off, int32_t* k_bag,
+                                     int32_t* tile64, int32_t* bag_tile64_off, int T64, int32_t* tile32,
+                                     int32_t* bag_tile32_off, int T32, int32_t* row_bag, int32_t* rows_out, void* stream) {
+    if (!len_dev || !k_off || !k_bag || !tile64 || !bag_tile64_off || !tile32 || !bag_tile32_off || !row_bag || !rows_out)
+        return MIL_EINVAL;
+    if (B <= 0 || B > 1024 || P <= 0 || cap <= 0 || T64 < cap / 64 + B || T32 < cap / MIL_POOL_TILE + B * (1 + (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE))
+        return MIL_EINVAL;
+    if (reinterpret_cast<uintptr_t>(tile32) & 15) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_build_fusion_segs, dim3(1), dim3(1024), 0, (hipStream_t)stream, len_dev, B, P, cap, k_off, k_bag, tile64,
+                       bag_tile64_off, T64, tile32, bag_tile32_off, T32, row_bag, rows_out);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,
                           float* out, void* stream) {
     if (!x || !pe || !row_bag || !row_off || !out || rows < 0 || E <= 0 || (E & 3)) return MIL_EINVAL;

@@ -2366,9 +2366,9 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
     if (dM != nullptr) {
         if (tid < 128) {
             const int gr = min(row0 + tid, R - 1);
-            const int bg = row_bag[gr];
-            s_bag[tid] = bg;
-            s_arow[tid] = expf(scores[gr] - lse[bg]);
+            const int bg = row_bag[gr];                  // < 0: a padding row of a capacity bucket - no pool weight
+            s_bag[tid] = max(bg, 0);
+            s_arow[tid] = bg < 0 ? 0.f : expf(scores[gr] - lse[bg]);
         }
         __syncthreads();
     }
@@ -2472,7 +2472,7 @@ __global__ __launch_bounds__(512) void k_gate_bwd_dx_tail(const float* __restric
             float t;
             if (dM != nullptr) {
                 const int bg = row_bag[row];
-                t = expf(scores[row] - lse[bg]) * dM[(size_t)bg * L + col] + v;
+                t = bg < 0 ? v : expf(scores[row] - lse[bg]) * dM[(size_t)bg * L + col] + v;
             } else {
                 t = *o + v;
             }

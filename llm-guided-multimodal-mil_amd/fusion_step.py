@@ -1,0 +1,87 @@
+"""The authors' training regime for the FUSION model: one ragged bag per GPU, its length changing every step
+(reference run_train.sh:81 `--batch_size` = number of GPUs; dataset.py:366-393 drops a random 10-20 % of a bag's
+patches every epoch and bags hold 2 000 .. 15 592 patches).
+
+`graph_step.GraphedStep` keys a captured step by the exact bag lengths, so on such a cohort nothing ever replays and the
+paper's model runs eagerly - host-bound at ~190 launches per step.  `RaggedFusionStepper` does for `aggregator(args)` what
+`trainer.RaggedImageOnlyStepper` does for the image-only step: every batch goes into a CAPACITY bucket (bags.bucket_rows:
+2 048, 3 072, 4 096, ... patch rows), the bag lengths go to the device (segments.FusionBucket), every segment map the
+step reads is rebuilt there by its first launch, and the bucket's step - forward, loss, backward AND the Adam update, whose
+step number and learning rate live on the device too - is ONE hipGraph captured the second time the bucket is seen.  Padding
+rows carry zero softmax weight in all four pooling sites and receive exactly zero gradient.
+
+    stepper = RaggedFusionStepper(model, opt)          # opt = optim.FlatAdam(..., counted=True)
+    slot = stepper.slot(n)                             # static inputs of the bucket: slot.x[:n], slot.text, slot.y
+    loss, prob = stepper.step(slot, [n])
+
+One text token per bag (`CI_prompt_version='single'`, dataset.py:479-502); the frozen text tower runs outside the graph
+(its launch geometry follows the note's length) and hands `slot.text` its embedding."""
+from typing import Dict, Sequence
+
+import torch
+
+from .bags import bucket_rows
+from .graph_step import GraphedStep
+from .segments import FusionBucket
+
+
+class RaggedFusionStepper:
+    class Slot:
+        def __init__(self, cap: int, B: int, C: int, in_dim: int, device):
+            self.cap, self.B = cap, B
+            self.x = torch.zeros((cap, in_dim), device=device, dtype=torch.float32)    # rows beyond the bags: padding
+            self.text = torch.zeros((B, 1, 512), device=device, dtype=torch.float32)   # frozen-tower embedding per note
+            self.y = torch.zeros((B, C), device=device, dtype=torch.float32)
+            self.bucket = FusionBucket(cap, B, device)
+
+    def __init__(self, model, opt, B: int = 1, use_graph: bool = True, max_graphs: int = 16, in_dim: int = 768):
+        if use_graph and not getattr(opt, "counted", False):
+            raise ValueError("RaggedFusionStepper: graph replay needs optim.FlatAdam(counted=True) "
+                             "(step number and learning rate on the device)")
+        self.model, self.opt, self.B, self.use_graph, self.in_dim = model, opt, int(B), bool(use_graph), int(in_dim)
+        self.device = next(model.parameters()).device
+        self.C = int(model.args.num_classes)
+        self.slots: Dict[int, "RaggedFusionStepper.Slot"] = {}
+        self.gs = GraphedStep(list(opt.params), max_graphs=max_graphs)
+        self.eager_only = 0
+
+    @property
+    def replays(self):
+        return self.gs.replays
+
+    @property
+    def eager_steps(self):
+        return self.gs.eager_steps + self.eager_only
+
+    def slot(self, total_rows: int) -> "RaggedFusionStepper.Slot":
+        cap = bucket_rows(total_rows)
+        s = self.slots.get(cap)
+        if s is None:
+            s = self.slots[cap] = self.Slot(cap, self.B, self.C, self.in_dim, self.device)
+        return s
+
+    def encode_notes(self, slot, ids):
+        """Frozen text tower on this step's notes (token ids [B, 1, ctx]) -> slot.text; outside the graph."""
+        with torch.no_grad():
+            slot.text.copy_(self.model.clinic_extractor(ids))
+        return slot.text
+
+    def _body(self, slot):
+        m = self.model
+        prob, _ = m([slot.x], None, text_features=slot.text, labels=slot.y, bucket=slot.bucket)
+        return m.last_loss, prob, m.last_logits
+
+    def step(self, slot, lengths: Sequence[int]):
+        """One training step on the bags packed in slot.x (bag b at rows [sum(lengths[:b]), +lengths[b])).  Returns
+        (loss, prob, logits) - static tensors of the bucket's graph once it replays."""
+        slot.bucket.set_lengths(lengths)
+        body = lambda: self._body(slot)      # noqa: E731
+        if not self.use_graph:
+            self.eager_only += 1
+            self.gs._drop_grads()
+            out = body()
+            out[0].backward()
+            self.opt.step()
+            return tuple(o.detach() for o in out)
+        self.opt.sync_lr()                   # a changed learning rate reaches its device word before the replay reads it
+        return self.gs.run(("fusion-bucket", slot.cap, self.model.training), (), body, after_backward=self.opt.step)

@@ -43,7 +43,7 @@ class GraphedStep:
             p.grad = None
             p._mil_slot_used = False      # ops.grad_slot hands a parameter's flat slot out once per backward pass
 
-    def _eager(self, inputs, body):
+    def _eager(self, inputs, body, after_backward=None):
         # Every execution of the body - eager, warm-up, capture - runs on ONE side stream: autograd binds a parameter's
         # AccumulateGrad node to the stream of the forward that created it and keeps the node while anything (a loss the
         # caller still holds, model.last_logits) references that graph; a node left over from a default-stream step
@@ -54,12 +54,14 @@ class GraphedStep:
             self._drop_grads()
             out = body(*inputs)
             out[0].backward()
+            if after_backward is not None:
+                after_backward()
             out = tuple(o.detach() for o in out)
         cur.wait_stream(self.stream)
         self.eager_steps += 1
         return out
 
-    def _capture(self, inputs, body) -> _Entry:
+    def _capture(self, inputs, body, after_backward=None) -> _Entry:
         ent = _Entry()
         ent.inputs = [t.clone() for t in inputs]
         cur = torch.cuda.current_stream()
@@ -78,13 +80,17 @@ class GraphedStep:
             with torch.cuda.graph(ent.graph, stream=self.stream):
                 out = body(*ent.inputs)
                 out[0].backward()
+                if after_backward is not None:      # e.g. a counted FlatAdam step: the optimizer inside the graph (the
+                    after_backward()                # warm-up passes above leave it out - they must not train)
         ent.keep = keep
         ent.outputs = tuple(o.detach() for o in out)
         ent.grads = [p.grad for p in self.params]
         return ent
 
-    def run(self, key, inputs: Sequence[torch.Tensor], body: Callable[..., Tuple[torch.Tensor, ...]]):
-        """body(*inputs) -> (loss, *others); returns that tuple with loss.backward() done."""
+    def run(self, key, inputs: Sequence[torch.Tensor], body: Callable[..., Tuple[torch.Tensor, ...]], after_backward=None):
+        """body(*inputs) -> (loss, *others); returns that tuple with loss.backward() done.  after_backward(): runs right
+        after the backward on the same stream, and INSIDE the captured graph - for an optimizer whose step number and
+        learning rate live on the device (optim.FlatAdam(counted=True)), so that a whole training step is one replay."""
         sig = (key, tuple((tuple(t.shape), t.dtype) for t in inputs))
         ent = self._graphs.get(sig)
         if ent is None:
@@ -92,8 +98,8 @@ class GraphedStep:
             if n < 2 or len(self._graphs) >= self.max_graphs:
                 if len(self._seen) > 4096:
                     self._seen.clear()
-                return self._eager(inputs, body)
-            ent = self._graphs[sig] = self._capture(inputs, body)
+                return self._eager(inputs, body, after_backward)
+            ent = self._graphs[sig] = self._capture(inputs, body, after_backward)
         for dst, src in zip(ent.inputs, inputs):
             dst.copy_(src, non_blocking=True)
         ent.graph.replay()

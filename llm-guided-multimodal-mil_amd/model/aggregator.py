@@ -163,10 +163,28 @@ class aggregator(nn.Module):
         layout = BagLayout.multi_segment([n_len, [P] * B, [D] * B, [P] * B], dev)
         return self._pool_head(x0, layout), q_ct.view(B, P, EMBED), q_p.view(B, P, EMBED)     # :198-200,202-203
 
+    # ------------------------------------------------------------------ capacity-bucket form of the pathology branch
+    def _forward_bucket(self, x, t, bucket):
+        """The pathology + text branch (aggregator.py:186-192,207) on a segments.FusionBucket: x [cap, 768] holds the
+        patches of the B bags packed from row 0 (zero rows behind), the true lengths are on the device (bucket.len_dev),
+        and every launch below depends on (cap, B) only - so ONE captured graph per bucket serves every bag length the
+        authors' loader produces (dataset.py:366-393; fusion_step.RaggedFusionStepper).  One text token per bag."""
+        B, P, _ = t.shape
+        if x.dim() != 2 or x.shape[0] != bucket.cap or B != bucket.B or P != bucket.P:
+            raise ValueError(f"bucket of {bucket.B} bags x {bucket.cap} rows x {bucket.P} token(s): got x {tuple(x.shape)}, "
+                             f"text {tuple(t.shape)}")
+        bucket.refresh()                                                                   # maps from len_dev, on the device
+        xi = self._lin_tanh(self.fc_pathology, x)                                          # :149
+        point = self._lin_tanh(self.fc_CI2Pth, t.reshape(B * P, EMBED))                    # :190
+        q, k = self.TwoWayTransformer_Pth.flat(xi, point, self.pe_rows(bucket.cap, xi.device), None, None,
+                                               keys_tail_rows=B * P, segs=(bucket.s_tt, bucket.s_ti, bucket.s_it))
+        x0 = ops.append_rows(k, q, tail_reserved=True)                                     # :192 (no concat copy)
+        return self._pool_head(x0, bucket.layout), q.view(B, P, EMBED)                     # :198-200,207
+
     # ------------------------------------------------------------------ forward (aggregator.py:134-209)
     def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
                 text_features: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
-                loss_scale: Optional[float] = None):
+                loss_scale: Optional[float] = None, bucket=None):
         """x_list = [x_pathology [B, N, 768]] (or [] for CI only); x_CI int64 [B, P, ctx] token ids.
         `lengths` (optional) gives the true patch count of each zero-padded bag (dataset.py:386-391 pads to a
         fixed length when batch > 1); padded rows are then dropped instead of being attended to."""
@@ -181,6 +199,8 @@ class aggregator(nn.Module):
         B, P, _ = t.shape
         if "CT" in modality:
             return self._forward_ct(x_list, t, lengths)
+        if "pathology" in modality and bucket is not None:
+            return self._forward_bucket(x_list[0], t, bucket)
         if "pathology" in modality:
             x = x_list[0]
             if x.dim() == 2:

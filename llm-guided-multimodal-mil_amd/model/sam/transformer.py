@@ -189,14 +189,19 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = _LN(embedding_dim)
 
-    def flat(self, image, point, pe_table, n_lengths, t_lengths, keys_tail_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    def flat(self, image, point, pe_table, n_lengths, t_lengths, keys_tail_rows: int = 0,
+             segs=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """image [sum N_b, E] patch tokens, point [sum T_b, E] text tokens, pe_table [>= max N_b, E].
         Returns (queries [sum T_b, E], keys [sum N_b, E])  (sam/transformer.py:100-120).  keys_tail_rows: the returned
-        keys are allocated with room for that many more rows behind them (ops.append_rows)."""
+        keys are allocated with room for that many more rows behind them (ops.append_rows).  segs: (s_tt, s_ti, s_it) of a
+        segments.FusionBucket - bag lengths on the device, image = the bucket's `cap` rows - instead of host lengths."""
         dev = image.device
-        s_tt = AttnSegs.make(t_lengths, t_lengths, dev)
-        s_ti = AttnSegs.make(t_lengths, n_lengths, dev)
-        s_it = AttnSegs.make(n_lengths, t_lengths, dev)
+        if segs is not None:
+            s_tt, s_ti, s_it = segs
+        else:
+            s_tt = AttnSegs.make(t_lengths, t_lengths, dev)
+            s_ti = AttnSegs.make(t_lengths, n_lengths, dev)
+            s_it = AttnSegs.make(n_lengths, t_lengths, dev)
         keys_pe = lambda kk: ops.add_pe(kk, pe_table, s_ti.k_bag, s_ti.k_off)      # noqa: E731
         queries, keys = point, image
         for li, layer in enumerate(self.layers):

@@ -142,7 +142,8 @@ def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: 
         out.update(dz=torch.empty((B, C), device=dev), dM=torch.empty((B, L), device=dev),
                    cdot=torch.empty(B, device=dev), loss_bag=torch.empty(B, device=dev))
         if hrow is not None and scores is not None:
-            out["ds"] = torch.empty(scores.shape[0], device=dev)
+            # capacity bucket (segments.FusionBucket): rows outside every tile are padding and must read ds = 0
+            out["ds"] = (torch.zeros if getattr(layout, "device_lengths", False) else torch.empty)(scores.shape[0], device=dev)
     if mbits is not None:
         out["Mdrop"] = torch.empty((B, L), device=dev)
     rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
@@ -286,6 +287,14 @@ def adam_step_counted_noinc(param, grad, exp_avg, exp_avg_sq, step_counter, lr: 
                                                 _p(step_counter), lr, betas[0], betas[1], eps, weight_decay, grad_scale,
                                                 _stream())
     _lib.check(rc, "mil_adam_step_counted_noinc")
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, step_counter, lr_dev, betas=(0.9, 0.999), eps: float = 1e-8,
+                  weight_decay: float = 1e-7, grad_scale: float = 1.0, inc: bool = True):
+    """Counted Adam with the learning rate in device memory too (lr_dev [1]): a captured step follows the schedule."""
+    rc = _lib.lib().mil_adam_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(step_counter),
+                                      _p(lr_dev), betas[0], betas[1], eps, weight_decay, grad_scale, 1 if inc else 0, _stream())
+    _lib.check(rc, "mil_adam_step_dev")
 
 
 def sgd_step(param, grad, lr: float = 1e-3, weight_decay: float = 1e-7, grad_scale: float = 1.0):
@@ -1015,8 +1024,10 @@ def layer_norm_bag_row(x, o, segs, gamma, beta, eps: float = 1e-5, tail_rows: in
     when every bag is at least one backward workgroup's row range long (see mil_layernorm_bagrow_bwd) and the norm is
     trainable; otherwise add_bag_row followed by layer_norm."""
     rows = x.shape[0]
+    # device-side lengths (segments.FusionBucket): set_lengths() has checked every bag against the block's row range
     ok = (x.dim() == 2 and rows > 64 and gamma.requires_grad == beta.requires_grad and
-          min(segs.q_lengths, default=0) >= _lib.lib().mil_layernorm_bagrow_rows_per_block(rows))
+          (getattr(segs, "device_lengths", False) or
+           min(segs.q_lengths, default=0) >= _lib.lib().mil_layernorm_bagrow_rows_per_block(rows)))
     if not ok:
         return layer_norm(add_bag_row(x, o, segs), gamma, beta, eps, tail_rows)
     return _LayerNormBagRow.apply(x, o, gamma, beta, eps, segs, tail_rows)
@@ -1350,7 +1361,9 @@ class _AbsorbedPool(torch.autograd.Function):
         dpooled = _f32c(dpooled, "dpooled")
         acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
         cdot = rowdot(dpooled.view(B * H, E), pooled.view(B * H, E))
-        dkeys = torch.empty_like(keys)
+        # capacity bucket: the apply pass writes the rows of real tiles only; padding rows must hand ZERO upstream (their
+        # gradient feeds LayerNorm / bias sums of the layer below)
+        dkeys = torch.zeros_like(keys) if getattr(segs, "device_lengths", False) else torch.empty_like(keys)
         dQp = torch.empty_like(Qp)
         n_keys = keys.shape[0]
         ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)

@@ -62,6 +62,10 @@ class FlatAdam:
         self.step_count = 0
         self.counted = counted
         self.step_counter = torch.zeros(1, device=dev, dtype=torch.int32) if counted else None
+        # counted: the learning rate lives on the device as well, so a step captured into a hipGraph follows the schedule
+        # (utils.py:232-241 writes param_groups[0]["lr"] every epoch); sync_lr() pushes a changed value before a replay
+        self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32) if (counted and self.needs_moments) else None
+        self._lr_on_dev = float(lr)
 
     def zero_grad(self, set_to_none: bool = True):
         """Gradients are dropped (autograd then hands over fresh tensors without an accumulate kernel)."""
@@ -127,20 +131,27 @@ class FlatAdam:
             return 1.0 / self.world
         return 1.0
 
+    def sync_lr(self):
+        """Counted mode: push param_groups[0]["lr"] to its device word when it changed.  Call before replaying a graph that
+        contains step(); step() calls it itself when it runs eagerly (never while a stream capture is in progress: the
+        fill would be frozen into the graph with today's value)."""
+        if self.lr_dev is None:
+            return
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_dev and not torch.cuda.is_current_stream_capturing():
+            self.lr_dev.fill_(lr)
+            self._lr_on_dev = lr
+
     @torch.no_grad()
     def step(self):
         scale = self.reduce()
         g = self.param_groups[0]
         segs = self._segments()
         if self.counted:
-            if len(segs) == 1 and segs[0] == (0, self.flat.numel()):
-                ops.adam_step_counted(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_counter, g["lr"],
-                                      g["betas"], g["eps"], g["weight_decay"], scale)
-            else:
-                for a, b in segs:
-                    ops.adam_step_counted_noinc(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
-                                                self.step_counter, g["lr"], g["betas"], g["eps"], g["weight_decay"], scale)
-                ops.counter_add(self.step_counter, 1)
+            self.sync_lr()
+            for i, (a, b) in enumerate(segs):
+                ops.adam_step_dev(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.step_counter,
+                                  self.lr_dev, g["betas"], g["eps"], g["weight_decay"], scale, inc=(i == len(segs) - 1))
         else:
             self.step_count += 1
             for a, b in segs:

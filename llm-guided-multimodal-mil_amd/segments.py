@@ -70,3 +70,80 @@ class AttnSegs:
         else:
             cls._cache.move_to_end(key)
         return lifetime.note(hit)
+
+
+class _SegView:
+    """One AttnSegs-shaped face of a FusionBucket (the attribute names the attention wrappers in ops.py read)."""
+    device_lengths = True
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def blk_map(self):
+        raise NotImplementedError("rows-form attention backward is not built for device-side bag lengths (one text token per "
+                                  "bag takes the absorbed one-token path)")
+
+
+class FusionBucket:
+    """Device-side segments of the one-note fusion step for a capacity bucket: `cap` patch rows shared by B bags, P = 1 text
+    token per bag.  The reference trains one ragged bag per GPU with a fresh patch drop every epoch (dataset.py:366-393,
+    run_train.sh:81), so host-built segment maps keyed by the exact lengths (AttnSegs, BagLayout) never repeat and a captured
+    step never replays.  Here the lengths live in `len_dev`; `refresh()` - the first launch of the step, inside the captured
+    graph - rebuilds every map from them (mil_build_fusion_segs), launch grids and buffers depend on (cap, B) only, padding
+    rows carry zero softmax weight and receive exactly zero gradient.  Faces:
+        s_tt, s_ti, s_it   AttnSegs-shaped (token-token, token-image, image-token)
+        layout             BagLayout-shaped two-segment multi-modal bag: rows [cap patch rows | B token rows]."""
+
+    P = 1
+
+    def __init__(self, capacity_rows: int, B: int, device):
+        from . import _lib
+        from .bags import POOL_TILE
+        cap, B = int(capacity_rows), int(B)
+        if cap % 256 or cap <= 0 or not (0 < B <= 1024):
+            raise ValueError("FusionBucket: capacity must be a positive multiple of 256 rows, 1 <= B <= 1024")
+        P = self.P
+        self.cap, self.B, self.device = cap, B, device
+        i32 = lambda *shape: torch.zeros(shape, device=device, dtype=torch.int32)      # noqa: E731
+        self.len_dev, self.rows_dev = i32(B), i32(1)
+        self.k_off, self.k_bag = i32(B + 1), i32(cap)
+        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B, cap // POOL_TILE + 2 * B
+        self.tile64, self.bag_tile64_off = i32(self.T64, 3), i32(B + 1)
+        self.tile32, self.bag_tile32_off = i32(self.T32, 4), i32(B + 1)
+        self.row_bag_dev = i32(cap + B * P)
+        self.lengths = None
+        tok = AttnSegs.make([P] * B, [P] * B, device)
+        self.s_tt = tok
+        ones = [P] * B
+        # token -> image: queries = the B tokens (static), keys = the patch rows (device lengths).  Tk_max is the capacity.
+        self.s_ti = _SegView(B=B, q_lengths=ones, k_lengths=None, Tq=B * P, Tk=cap, Tq_max=P, Tk_max=cap, q_off=tok.q_off,
+                             q_bag=tok.q_bag, k_off=self.k_off, k_bag=self.k_bag, ntiles=self.T64, tile_map=self.tile64,
+                             bag_tile_off=self.bag_tile64_off)
+        # image -> token: queries = the patch rows, keys = the tokens
+        self.s_it = _SegView(B=B, q_lengths=None, k_lengths=ones, Tq=cap, Tk=B * P, Tq_max=cap, Tk_max=P, q_off=self.k_off,
+                             q_bag=self.k_bag, k_off=tok.k_off, k_bag=tok.k_bag)
+        self.layout = _SegView(B=B, R=cap + B * P, T=self.T32, tile_map=self.tile32, bag_tile_off=self.bag_tile32_off,
+                               bag_off=self.k_off, lengths=None, aligned32=False, row_bag=lambda: self.row_bag_dev)
+        self._lib = _lib
+        self._min_rows = _lib.lib().mil_layernorm_bagrow_rows_per_block(cap) if B > 1 else 1
+
+    def set_lengths(self, lengths):
+        """Upload this step's true patch counts (a tiny async copy); the maps follow on the device at refresh()."""
+        lengths = [int(v) for v in lengths]
+        if len(lengths) != self.B or sum(lengths) > self.cap or min(lengths) < self._min_rows:
+            raise ValueError(f"FusionBucket: lengths {lengths} do not fit {self.B} bags / {self.cap} rows "
+                             f"(every bag needs >= {self._min_rows} rows)")
+        self.lengths = lengths
+        self.len_dev.copy_(torch.tensor(lengths, dtype=torch.int32), non_blocking=True)
+        return self
+
+    def refresh(self):
+        """Rebuild every map from len_dev on the current stream (capture-safe: one launch, no host sync)."""
+        p = lambda t: t.data_ptr()      # noqa: E731
+        rc = self._lib.lib().mil_build_fusion_segs(p(self.len_dev), self.B, self.P, self.cap, p(self.k_off), p(self.k_bag),
+                                                   p(self.tile64), p(self.bag_tile64_off), self.T64, p(self.tile32),
+                                                   p(self.bag_tile32_off), self.T32, p(self.row_bag_dev), p(self.rows_dev),
+                                                   torch.cuda.current_stream().cuda_stream)
+        self._lib.check(rc, "mil_build_fusion_segs")
+        return lifetime.note(self)

@@ -1,0 +1,166 @@
+"""GPU: the fusion model (`aggregator(args)`, pathology + one clinical note per bag) in the authors' regime - ONE ragged bag
+per step whose length changes every step (reference run_train.sh:81; dataset.py:366-393).  Bag lengths live on the device
+(segments.FusionBucket), the step of a capacity bucket is one captured hipGraph (fusion_step.RaggedFusionStepper): a stream
+of 50 bags with 2 000 .. 15 592 patches must replay at most 8 graphs and match the oracle (orc.fused_forward) bag by bag."""
+import copy
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from mil_amd import ops, synthetic as syn
+from mil_amd.bags import BagLayout, bucket_rows
+from mil_amd.fusion_step import RaggedFusionStepper
+from mil_amd.model.utils import get_model
+from mil_amd.optim import FlatAdam
+from mil_amd.segments import AttnSegs, FusionBucket
+from oracle import mil_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def _model(layers=2, seed=11):
+    args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL",
+                           num_classes=2, learnablePrompt=0, n_ctx=4, clinical_features=["a", "b"], clip_layers=layers,
+                           cache_text=0)
+    torch.manual_seed(seed)
+    return get_model(args).to(DEV).eval()          # eval: no dropout, comparable with the oracle
+
+
+@pytest.mark.parametrize("lengths", [[2500], [300, 1, 77, 1500, 33], [3072], [1]])
+def test_device_built_segments_equal_the_host_ones(lengths):
+    B, N = len(lengths), sum(lengths)
+    cap = bucket_rows(N)
+    bk = FusionBucket(cap, B, DEV)
+    bk._min_rows = 1                                # this test only compares the maps
+    bk.set_lengths(lengths).refresh()
+    torch.cuda.synchronize()
+    ref = AttnSegs.make([1] * B, lengths, DEV)
+    assert int(bk.rows_dev.item()) == N
+    assert torch.equal(bk.k_off.cpu(), ref.k_off.cpu())
+    assert torch.equal(bk.k_bag[:N].cpu(), ref.k_bag.cpu()) and bool((bk.k_bag[N:] == B - 1).all())
+    assert torch.equal(bk.bag_tile64_off.cpu(), ref.bag_tile_off.cpu())
+    assert torch.equal(bk.tile64[:ref.ntiles].cpu(), ref.tile_map.cpu()) and int(bk.tile64[ref.ntiles:].abs().sum()) == 0
+    lay = BagLayout.two_segment(lengths, [1] * B, DEV)
+    tm = lay.tile_map.cpu().clone()
+    tok = tm[:, 1] >= N                              # host layout puts the token rows right behind the N patch rows ...
+    tm[tok, 1] += cap - N                            # ... the bucket keeps them behind its `cap` rows
+    assert torch.equal(bk.bag_tile32_off.cpu(), lay.bag_tile_off.cpu())
+    assert torch.equal(bk.tile32[:lay.T].cpu(), tm) and int(bk.tile32[lay.T:].abs().sum()) == 0
+    rb = bk.row_bag_dev.cpu()
+    assert torch.equal(rb[:N], ref.k_bag.cpu()) and bool((rb[N:cap] == -1).all())
+    assert torch.equal(rb[cap:], torch.arange(B, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("lengths", [[2500], [1100, 1300]])
+def test_bucket_step_equals_the_exact_shape_step(lengths):
+    """Same bags through aggregator.forward(lengths=...) (host-built maps, exact shapes) and through the bucket form: logits,
+    token outputs and every parameter gradient must agree - padding rows have zero weight and zero gradient."""
+    m = _model()
+    B, N = len(lengths), sum(lengths)
+    cap = bucket_rows(N)
+    gen = torch.Generator().manual_seed(5)
+    bags = [torch.randn((n, 768), generator=gen) for n in lengths]
+    ids = syn.make_token_ids(6, B, 1).to(DEV)
+    y = syn.make_labels(7, B).to(DEV)
+    with torch.no_grad():
+        t = m.clinic_extractor(ids)
+    pad = torch.zeros((B, max(lengths), 768))
+    for b, xb in enumerate(bags):
+        pad[b, :xb.shape[0]] = xb
+    m.zero_grad()
+    prob_a, q_a = m([pad.to(DEV)], None, lengths, text_features=t, labels=y)
+    za = m.last_logits.detach().clone()
+    m.last_loss.backward()
+    ga = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    bk = FusionBucket(cap, B, DEV).set_lengths(lengths)
+    x = torch.full((cap, 768), 3.0, device=DEV)      # stale rows behind the bags must not matter
+    x[:N] = torch.cat(bags, 0).to(DEV)
+    m.zero_grad()
+    prob_b, q_b = m([x], None, text_features=t, labels=y, bucket=bk)
+    zb = m.last_logits.detach().clone()
+    m.last_loss.backward()
+    torch.cuda.synchronize()
+    assert float((za - zb).abs().max()) <= 1e-6 and torch.equal(prob_a.argmax(-1), prob_b.argmax(-1))
+    assert rel_err(q_b.detach().cpu(), q_a.detach().cpu()) <= 1e-6
+    gb = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert set(ga) == set(gb)
+    for k in ga:
+        if float(ga[k].norm()) < 1e-9:
+            assert float(gb[k].abs().max()) < 1e-9, k
+        else:
+            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 2e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
+
+
+def test_stream_of_ragged_fusion_bags_replays_few_graphs_and_matches_the_oracle():
+    m = _model(layers=1)
+    lr = 1e-5
+    opt = FlatAdam([p for p in m.parameters() if p.requires_grad], lr=lr, weight_decay=1e-7, counted=True)
+    st = RaggedFusionStepper(m, opt, B=1)
+    rng = np.random.default_rng(5)
+    names = [k for k, p in m.named_parameters() if p.requires_grad]
+    frozen = {k: v.detach().cpu() for k, v in m.state_dict().items() if k not in names}
+    worst = 0.0
+    for step in range(50):
+        n = int(rng.integers(2000, 15593))
+        x = torch.randn((n, 768), generator=torch.Generator().manual_seed(1000 + step))
+        ids = syn.make_token_ids(2000 + step, 1, 1)
+        y = syn.make_labels(3000 + step, 1)
+        slot = st.slot(n)
+        slot.x[:n].copy_(x.to(DEV))
+        slot.y.copy_(y.to(DEV))
+        st.encode_notes(slot, ids.to(DEV))
+        # the oracle on the weights this step starts from (the fused update overwrites them)
+        sd = dict(frozen)
+        sd.update({k: p.detach().cpu().clone() for k, p in m.named_parameters() if p.requires_grad})
+        loss, prob, z = st.step(slot, [n])
+        torch.cuda.synchronize()
+        if step % 3 == 0 or n > 12000:               # every third bag and every long one against the CPU oracle
+            with torch.no_grad():
+                o = orc.fused_forward(x, ids[0], sd)
+            d = float((z.cpu() - o["logits"]).abs().max())
+            worst = max(worst, d)
+            assert d <= 1e-3, (step, n, d)                                  # north_star bar; measured ~1e-6
+            assert torch.equal(prob.cpu().argmax(-1), o["prob"].argmax(-1)), (step, n)
+            assert abs(float(loss) - float(orc.bce_loss(o["prob"], y))) <= 1e-4
+    assert len(st.slots) <= 8 and len(st.gs._graphs) <= 8
+    assert st.replays >= 50 - 2 * len(st.slots) and st.replays + st.eager_steps == 50
+    assert int(opt.step_counter.item()) == 50                               # every step updated the parameters once
+    print(f"fusion stream: {len(st.slots)} buckets, {st.replays} replays, max |dlogit| vs oracle {worst:.2e}")
+
+
+def test_bucketed_fusion_training_tracks_the_exact_shape_training():
+    """Optimizer inside the graph: 8 steps over two buckets with a learning-rate change half way must leave the same
+    parameters as eager exact-shape steps with the same FlatAdam arithmetic."""
+    ref = _model(layers=1)
+    ours = copy.deepcopy(ref)
+    mk = lambda mm, c: FlatAdam([p for p in mm.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-7, counted=c)   # noqa: E731
+    o_ref, o_our = mk(ref, False), mk(ours, True)
+    st = RaggedFusionStepper(ours, o_our, B=1)
+    lengths = [2100, 2900, 2000, 3000, 1900, 2800, 2040, 3050]
+    for step, n in enumerate(lengths):
+        lr = 1e-4 if step < 4 else 2e-6
+        o_ref.param_groups[0]["lr"] = lr
+        o_our.param_groups[0]["lr"] = lr
+        x = torch.randn((n, 768), generator=torch.Generator().manual_seed(50 + step)).to(DEV)
+        ids = syn.make_token_ids(60 + step, 1, 1).to(DEV)
+        y = syn.make_labels(70 + step, 1).to(DEV)
+        with torch.no_grad():
+            t = ref.clinic_extractor(ids)
+        o_ref.zero_grad()
+        ref([x.unsqueeze(0)], None, text_features=t, labels=y)
+        ref.last_loss.backward()
+        o_ref.step()
+        slot = st.slot(n)
+        slot.x[:n].copy_(x)
+        slot.y.copy_(y)
+        st.encode_notes(slot, ids)
+        loss, _, _ = st.step(slot, [n])
+        assert abs(float(loss) - float(ref.last_loss.detach())) <= 2e-6, step
+    torch.cuda.synchronize()
+    assert len(st.slots) == 2 and st.replays == 4
+    moved = float((o_ref.flat - mk(_model(layers=1), False).flat).abs().max())
+    assert float((o_our.flat - o_ref.flat).abs().max()) <= 0.02 * moved + 1e-9
