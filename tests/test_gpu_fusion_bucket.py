@@ -89,8 +89,8 @@ def test_bucket_step_equals_the_exact_shape_step(lengths):
     gb = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     assert set(ga) == set(gb)
     for k in ga:
-        if float(ga[k].norm()) < 1e-9:
-            assert float(gb[k].abs().max()) < 1e-9, k
+        if float(ga[k].norm()) < 1e-7:               # mathematically zero (softmax bias): rounding noise on both sides
+            assert float(gb[k].abs().max()) < 1e-6, k
         else:
             assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 2e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
 
@@ -161,6 +161,6 @@ def test_bucketed_fusion_training_tracks_the_exact_shape_training():
         loss, _, _ = st.step(slot, [n])
         assert abs(float(loss) - float(ref.last_loss.detach())) <= 2e-6, step
     torch.cuda.synchronize()
-    assert len(st.slots) == 2 and st.replays == 4
+    assert len(st.slots) == 2 and st.replays == 6              # per bucket: one eager visit, then capture + replays
     moved = float((o_ref.flat - mk(_model(layers=1), False).flat).abs().max())
     assert float((o_our.flat - o_ref.flat).abs().max()) <= 0.02 * moved + 1e-9

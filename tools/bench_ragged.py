@@ -1,6 +1,9 @@
-"""One ragged bag per step (the authors' regime), image-only fused step: bags with N ~ U[2000, 15592] patches, lengths on
-the device, one hipGraph per capacity bucket.  Prints ms/step for the bucketed-graph path and for the exact-length eager path."""
+"""One ragged bag per step (the authors' regime, run_train.sh:81 + dataset.py:366-393): bags with N ~ U[2000, 15592] patches,
+lengths on the device, one hipGraph per capacity bucket.  Prints ms/step for the bucketed-graph path and for the exact-length
+eager path.  Default: the image-only fused step; --fusion: aggregator(args) with one clinical note per bag (the paper's model;
+frozen ViT-B/32 text embedding cached per note, as training does)."""
 import json, os, sys, time
+from types import SimpleNamespace
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,33 +13,85 @@ from mil_amd.bags import BagLayout
 from mil_amd.trainer import ImageOnlyTrainer, RaggedImageOnlyStepper
 
 dev = torch.device("cuda")
-L, steps = 512, 300
-p = syn.image_only_params(1, L=L)
+fusion = "--fusion" in sys.argv
+steps = 300 if not fusion else 150
 rng = np.random.default_rng(0)
 lens = [int(v) for v in rng.integers(2000, 15593, size=steps)]
-xs = torch.randn((16384, L), device=dev)
-y = syn.make_labels(3, 1).to(dev)
 out = {}
-for mode in ("bucket_graph", "exact_eager"):
-    tr = ImageOnlyTrainer(p, dev, train_mode=True, counted=True)
-    st = RaggedImageOnlyStepper(tr, B=1)
-    def run(n):
+if not fusion:
+    L = 512
+    p = syn.image_only_params(1, L=L)
+    xs = torch.randn((16384, L), device=dev)
+    y = syn.make_labels(3, 1).to(dev)
+    for mode in ("bucket_graph", "exact_eager"):
+        tr = ImageOnlyTrainer(p, dev, train_mode=True, counted=True)
+        st = RaggedImageOnlyStepper(tr, B=1)
+        def run(n):
+            if mode == "bucket_graph":
+                slot = st.slot(n)
+                slot.x[:n].copy_(xs[:n], non_blocking=True)      # stands for the loader's H2D copy into the bucket's buffer
+                slot.y.copy_(y)
+                st.step(slot, [n])
+            else:
+                tr.train_step(xs[:n], BagLayout.make([n], dev), y)
+        for n in lens[:40]:
+            run(n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for n in lens:
+            run(n)
+        torch.cuda.synchronize()
+        out[mode] = round((time.perf_counter() - t0) / steps * 1e3, 4)
         if mode == "bucket_graph":
-            slot = st.slot(n)
-            slot.x[:n].copy_(xs[:n], non_blocking=True)      # stands for the loader's H2D copy into the bucket's buffer
-            slot.y.copy_(y)
-            st.step(slot, [n])
-        else:
-            tr.train_step(xs[:n], BagLayout.make([n], dev), y)
-    for n in lens[:40]:
-        run(n)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for n in lens:
-        run(n)
-    torch.cuda.synchronize()
-    out[mode] = round((time.perf_counter() - t0) / steps * 1e3, 4)
-    if mode == "bucket_graph":
-        out["graphs"] = sum(s.graph is not None for s in st.slots.values())
+            out["graphs"] = sum(s.graph is not None for s in st.slots.values())
+    work = "1 ragged bag/step, N~U[2000,15592] x 512, image-only train-mode step"
+else:
+    from mil_amd.fusion_step import RaggedFusionStepper
+    from mil_amd.model.utils import get_model
+    from mil_amd.optim import FlatAdam
+    args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
+                           learnablePrompt=0, n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI", model_CT="resnetMC3_18",
+                           clip_layers=12, cache_text=0)
+    xs = torch.randn((16384, 768), device=dev)
+    ids = syn.make_token_ids(2, 1, 1).to(dev)
+    y = syn.make_labels(3, 1).to(dev)
+    train = "--eval" not in sys.argv
+    for mode in ("bucket_graph", "exact_eager"):
+        torch.manual_seed(1234)
+        model = get_model(args).to(dev)
+        model.train(train)
+        opt = FlatAdam([q for q in model.parameters() if q.requires_grad], lr=1e-5, weight_decay=1e-7, counted=True)
+        st = RaggedFusionStepper(model, opt, B=1)
+        with torch.no_grad():
+            tfeat = model.clinic_extractor(ids)                   # frozen tower: cached per note (dim1/CLIP.py cache_text)
+        def run(n):
+            if mode == "bucket_graph":
+                slot = st.slot(n)
+                slot.x[:n].copy_(xs[:n], non_blocking=True)      # the loader's H2D copy into the bucket's buffer
+                slot.y.copy_(y)
+                slot.text.copy_(tfeat)
+                st.step(slot, [n])
+            else:
+                opt.zero_grad()
+                model([xs[:n].unsqueeze(0)], None, text_features=tfeat, labels=y)
+                model.last_loss.backward()
+                opt.step()
+        warm = lens[:40] if mode == "bucket_graph" else lens[:5]
+        for n in warm:
+            run(n)
+        torch.cuda.synchronize()
+        todo = lens if mode == "bucket_graph" else lens[:40]
+        t0 = time.perf_counter()
+        for n in todo:
+            run(n)
+        torch.cuda.synchronize()
+        out[mode] = round((time.perf_counter() - t0) / len(todo) * 1e3, 4)
+        if mode == "bucket_graph":
+            out["graphs"] = len(st.gs._graphs)
+            out["replays"] = st.replays
+        del model, opt, st
+        torch.cuda.empty_cache()
+    work = ("1 ragged bag/step, N~U[2000,15592] x 768 + one 77-token note, aggregator(args) fwd+BCE+bwd+Adam, "
+            + ("model.train()" if train else "model.eval()"))
 out["mean_patches"] = float(np.mean(lens))
-print(json.dumps({"workload": "1 ragged bag/step, N~U[2000,15592] x 512, image-only train-mode step", **out}))
+print(json.dumps({"workload": work, **out}))
