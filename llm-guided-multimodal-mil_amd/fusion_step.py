@@ -34,11 +34,15 @@ class RaggedFusionStepper:
             self.y = torch.zeros((B, C), device=device, dtype=torch.float32)
             self.bucket = FusionBucket(cap, B, device)
 
-    def __init__(self, model, opt, B: int = 1, use_graph: bool = True, max_graphs: int = 16, in_dim: int = 768):
-        if use_graph and not getattr(opt, "counted", False):
-            raise ValueError("RaggedFusionStepper: graph replay needs optim.FlatAdam(counted=True) "
+    def __init__(self, model, opt, B: int = 1, use_graph: bool = True, max_graphs: int = 16, in_dim: int = 768,
+                 opt_in_graph: bool = True):
+        """opt_in_graph=False keeps the optimizer (and, at world size > 1, its gradient all-reduce) outside the captured
+        graph, as graph_step.GraphedStep does."""
+        if use_graph and opt_in_graph and not getattr(opt, "counted", False):
+            raise ValueError("RaggedFusionStepper: an optimizer inside the graph needs optim.FlatAdam(counted=True) "
                              "(step number and learning rate on the device)")
         self.model, self.opt, self.B, self.use_graph, self.in_dim = model, opt, int(B), bool(use_graph), int(in_dim)
+        self.opt_in_graph = bool(opt_in_graph)
         self.device = next(model.parameters()).device
         self.C = int(model.args.num_classes)
         self.slots: Dict[int, "RaggedFusionStepper.Slot"] = {}
@@ -83,5 +87,10 @@ class RaggedFusionStepper:
             out[0].backward()
             self.opt.step()
             return tuple(o.detach() for o in out)
+        key = ("fusion-bucket", slot.cap, self.model.training)
+        if not self.opt_in_graph:
+            out = self.gs.run(key, (), body)
+            self.opt.step()
+            return out
         self.opt.sync_lr()                   # a changed learning rate reaches its device word before the replay reads it
-        return self.gs.run(("fusion-bucket", slot.cap, self.model.training), (), body, after_backward=self.opt.step)
+        return self.gs.run(key, (), body, after_backward=self.opt.step)

@@ -101,7 +101,12 @@ def main_worker(local_rank: int, nprocs: int, args):
                 optimizer = torch.optim.SGD(trainable, lr=lr0, weight_decay=1e-7)
         elif flat_opt:                                                                   # train_ddp.py:110-118, flat
             from .optim import FlatAdam
-            optimizer = FlatAdam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world)
+            # one clinical note per bag + --hip_graph: the capacity-bucket stepper below replays the whole step, optimizer
+            # included, so step number and learning rate live on the device
+            bucketed = (bool(getattr(args, "hip_graph", 0)) and args.variant != "image_only" and prompts == 1
+                        and list(args.modality) == ["pathology"])
+            optimizer = FlatAdam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world,
+                                 counted=bucketed)
         else:
             optimizer = torch.optim.Adam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7)
         if flat_opt and world > 1:
@@ -112,7 +117,12 @@ def main_worker(local_rank: int, nprocs: int, args):
 
         def loss_of(out_prob, y_):
             return model.last_loss if (fuse_loss and model.last_loss is not None) else criterion(out_prob, y_)
-        graphed = None
+        graphed = fstepper = None
+        if getattr(args, "hip_graph", 0) and flat_opt and getattr(optimizer, "counted", False):
+            # the authors' regime (one ragged bag per GPU, run_train.sh:81; a fresh patch drop every epoch,
+            # dataset.py:366-393): bag lengths on the device, one graph per capacity bucket (fusion_step.py)
+            from .fusion_step import RaggedFusionStepper
+            fstepper = RaggedFusionStepper(model, optimizer, B=per_gpu, opt_in_graph=(world == 1))
         if getattr(args, "hip_graph", 0):
             # replay the step body from a hipGraph once a batch shape repeats (graph_step.py); optimizer and the
             # gradient all-reduce stay outside, so this needs the flat optimizers when world > 1 (no DDP hooks)
@@ -157,7 +167,22 @@ def main_worker(local_rank: int, nprocs: int, args):
                 for g in optimizer.param_groups:
                     g["lr"] = lr
                 lengths = batch["lengths"]
-                if graphed is not None:
+                slot = None
+                if fstepper is not None and len(lengths) == per_gpu:
+                    slot = fstepper.slot(sum(lengths))
+                    try:
+                        slot.bucket.set_lengths(lengths)
+                    except ValueError:                       # a bag too short for the bucket's kernels: exact-shape step
+                        slot = None
+                if slot is not None:
+                    r0 = 0
+                    for b, n in enumerate(lengths):                                       # the bucket's static input buffers
+                        slot.x[r0:r0 + n].copy_(x[b, :n], non_blocking=True)
+                        r0 += n
+                    slot.y.copy_(y, non_blocking=True)
+                    fstepper.encode_notes(slot, batch["CI"].to(dev))                      # frozen tower: outside the graph
+                    loss, prob, _ = fstepper.step(slot, lengths)
+                elif graphed is not None:
                     key = (tuple(int(v) for v in lengths), args.variant)
                     if args.variant == "image_only":
                         def body(x_, y_):

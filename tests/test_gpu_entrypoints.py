@@ -78,3 +78,17 @@ def test_two_ranks_on_one_gpu_with_graph_replay_and_flat_optimizer(tmp_path):
     assert "Epoch: [0]" in out and "Loss" in out
     ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
     assert torch.isfinite(ck["state_dict"]["aggregator.attention_V.0.weight"]).all()
+
+
+def test_hip_graph_training_of_the_fusion_model_on_ragged_bags(tmp_path):
+    """The authors' regime through the entry point: one ragged bag per step, one note per bag, `--hip_graph 1` -> the
+    capacity-bucket stepper (fusion_step.py): bag lengths on the device, the whole step incl. Adam replayed per bucket,
+    the learning-rate schedule reaching the graph through device memory."""
+    out = run("train_ddp.py", "--synthetic", "[700, 768, 12]", "--ragged", "--clip_layers", "1", "--batch_size", "1",
+              "--hip_graph", "1", "--n_epochs", "2", "--iter_per_epoch", "6", "--cos", "--save_dir", str(tmp_path))
+    assert "Epoch: [1]" in out and "Loss" in out
+    ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
+    assert ck["optimizer"]["step"] == 12
+    assert all(torch.isfinite(v).all() for k, v in ck["state_dict"].items() if v.is_floating_point())
+    out = run("test_ddp.py", "--synthetic", "[700, 768, 12]", "--ragged", "--clip_layers", "1", "--test_pth", str(tmp_path))
+    assert "Time for inference" in out
