@@ -162,5 +162,10 @@ def test_bucketed_fusion_training_tracks_the_exact_shape_training():
         assert abs(float(loss) - float(ref.last_loss.detach())) <= 2e-6, step
     torch.cuda.synchronize()
     assert len(st.slots) == 2 and st.replays == 6              # per bucket: one eager visit, then capture + replays
-    moved = float((o_ref.flat - mk(_model(layers=1), False).flat).abs().max())
-    assert float((o_our.flat - o_ref.flat).abs().max()) <= 0.02 * moved + 1e-9
+    start = dict(_model(layers=1).named_parameters())
+    pr, po = dict(ref.named_parameters()), dict(ours.named_parameters())
+    for k, p0 in start.items():
+        if not p0.requires_grad or k.endswith("attention_weights.bias"):
+            continue          # softmax bias: a mathematically zero gradient, Adam normalises its rounding noise to +-lr
+        moved = float((pr[k].detach() - p0.detach()).abs().max())
+        assert float((po[k].detach() - pr[k].detach()).abs().max()) <= 0.02 * moved + 1e-9, (k, moved)
