@@ -649,6 +649,13 @@ int mil_image_only_step_run(const mil_image_only_step* a, void* stream);
 int mil_image_only_step_time(const mil_image_only_step* a, uint32_t stages, int warm, int iters, float* ms_out,
                              void* stream);
 
+/* torch.nn.CosineEmbeddingLoss()(x1, x2, target = +1), mean over the B rows, forward + backward in one launch: the optional
+ * 'textCosSim' term between the text-aligned tokens x_CT2CI and x_Pth2CI (reference train_ddp.py:102,266,325-329).
+ * x1, x2 [B, E]; loss [1] = scale * sum_b (1 - cos_b) (scale = weight / B); dx1, dx2 [B, E] = d loss / d x (both or neither).
+ * ATen's arithmetic: cos = x1.x2 / sqrt((|x1|^2 + 1e-12)(|x2|^2 + 1e-12)).  B <= 1024. */
+int mil_cosine_embedding_loss(const float* x1, const float* x2, int B, int E, float scale, float* loss, float* dx1,
+                              float* dx2, void* stream);
+
 /* Device-side segments of the one-note fusion step for a CAPACITY bucket (cap patch rows, B bags, P text tokens per bag):
  * every map model/aggregator.py:186-192 + sam/transformer.py need (patch offsets, row -> bag, 64-key tiles of the absorbed
  * attention pool, 32-row tiles of the multi-modal bag [patch rows | token rows at cap + b P], row -> bag with -1 on padding

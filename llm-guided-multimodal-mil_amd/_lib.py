@@ -37,6 +37,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_head_bwd_params": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, _P]),
     "mil_head_bwd_params_acc": (c_int, [_P] * 4 + [c_int, c_int, c_int, _P, _P, c_int, _P]),
     "mil_clip_contrastive_loss": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "mil_cosine_embedding_loss": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "mil_rowdot": (c_int, [_P] * 3 + [c_int, c_int, _P]),
     "mil_attn_pool_bwd": (c_int, [_P] * 6 + [c_int, c_int, _P, _P, _P, c_float, _P]),
     "mil_gate_bwd_workspace_floats": (c_size_t, [c_int, c_int]),

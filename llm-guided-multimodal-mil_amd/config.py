@@ -16,7 +16,7 @@ def arg_as_list(s):
 def create_arg_parser(argv=None):
     p = argparse.ArgumentParser(description="MI355X-native LLM-guided multi-modal MIL (hot path)")
     # ---- model (reference names; defaults chosen so the built path runs: upstream defaults select CT + TransMIL)
-    p.add_argument("--modality", default=["pathology"], type=arg_as_list, help="subset of ['pathology', 'CI']")
+    p.add_argument("--modality", default=["pathology"], type=arg_as_list, help="subset of ['CT', 'pathology', 'CI'] ('CT': the encoder's feature map is a synthetic input)")
     p.add_argument("--alignment_base", default="CI", type=str)
     p.add_argument("--model_CT", default="resnetMC3_18", type=str)
     p.add_argument("--model_pathology", default="ABMIL", type=str)
@@ -37,7 +37,11 @@ def create_arg_parser(argv=None):
     p.add_argument("--n_epochs", type=int, default=2)
     p.add_argument("--resume", default="", type=str)
     p.add_argument("--lr", type=float, default=1e-5)
-    p.add_argument("--loss", type=str, default="BCE")
+    p.add_argument("--loss", type=str, default="BCE", help="'BCE'; a name containing 'textCosSim' adds "
+                   "CosineEmbeddingLoss(x_CT2CI, x_Pth2CI, 1) when both tokens exist (train_ddp.py:102,325-329)")
+    p.add_argument("--train_contract", type=int, default=0, help="1: the module returns the tuple the reference's training "
+                   "loop unpacks, ([out, out, out], [CT2CI, Pth2CI], None) (train_ddp.py:300), instead of the shipped "
+                   "module's (aggregator.py:202-209)")
     p.add_argument("--loss_point", type=str, default="Last")
     p.add_argument("--schedule", default=[500], nargs="*", type=int)
     p.add_argument("--cos", action="store_true")

@@ -667,6 +667,53 @@ extern "C" int mil_sgd_step(float* param, const float* grad, size_t n, float lr,
     return MIL_OK;
 }
 
+// torch.nn.CosineEmbeddingLoss()(x1, x2, target) with target = +1 for every row and the default mean reduction - the
+// 'textCosSim' term between the two text-aligned tokens x_CT2CI and x_Pth2CI (reference train_ddp.py:102,266,325-329).
+// ATen's arithmetic (cosine_embedding_loss): cos = (x1 . x2) / sqrt((|x1|^2 + 1e-12) (|x2|^2 + 1e-12)), row loss 1 - cos.
+// Forward and backward in one launch of ONE workgroup (B is the per-GPU batch: a handful of rows): wave w takes rows w,
+// w + 16, ...;  d(1 - cos)/dx1 = -(x2 / den - cos x1 / m1), same for x2; `scale` (1 / B for the mean, times whatever weight
+// the caller gives the term) is folded into the gradients and the loss.  The row losses are summed in row order.
+__global__ __launch_bounds__(1024) void k_cosine_embedding_loss(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                                int B, int E, float scale, float* __restrict__ loss,
+                                                                float* __restrict__ dx1, float* __restrict__ dx2) {
+    __shared__ float rowloss[1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int b = b0 + w;
+        if (b < B) {
+            const float* a = x1 + (size_t)b * E;
+            const float* c = x2 + (size_t)b * E;
+            float dot = 0.f, m1 = 0.f, m2 = 0.f;
+            for (int j = lane; j < E; j += 64) { const float u = a[j], v = c[j]; dot += u * v; m1 += u * u; m2 += v * v; }
+            dot = wave_allsum(dot);
+            m1 = wave_allsum(m1) + 1e-12f;
+            m2 = wave_allsum(m2) + 1e-12f;
+            const float den = sqrtf(m1 * m2), cs = dot / den;
+            if (dx1 != nullptr)
+                for (int j = lane; j < E; j += 64) {
+                    const float u = a[j], v = c[j];
+                    dx1[(size_t)b * E + j] = -scale * (v / den - cs * u / m1);
+                    dx2[(size_t)b * E + j] = -scale * (u / den - cs * v / m2);
+                }
+            if (lane == 0) rowloss[b] = 1.0f - cs;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += rowloss[b];
+        loss[0] = v * scale;
+    }
+}
+
+extern "C" int mil_cosine_embedding_loss(const float* x1, const float* x2, int B, int E, float scale, float* loss,
+                                         float* dx1, float* dx2, void* stream) {
+    if (!x1 || !x2 || !loss || B <= 0 || B > 1024 || E <= 0 || ((dx1 == nullptr) != (dx2 == nullptr))) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_cosine_embedding_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, x1, x2, B, E, scale, loss, dx1, dx2);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 // out[b] = a[b] . c[b]   (row-wise dot of two [B, L] matrices; cdot for the pool backward).
 __global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ a, const float* __restrict__ c,
                                                 float* __restrict__ out, int L) {

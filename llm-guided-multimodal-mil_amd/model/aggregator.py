@@ -185,6 +185,23 @@ class aggregator(nn.Module):
     def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
                 text_features: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                 loss_scale: Optional[float] = None, bucket=None):
+        """The shipped module's return tuples (aggregator.py:202-209), which test_ddp.py:220 consumes.  With
+        `args.train_contract` set, the tuple the reference's TRAINING loop unpacks instead (train_ddp.py:300,305-316; no
+        shipped module provides it): CT + pathology -> ([out, out, out], [x_CT2CI, x_Pth2CI], None) - one head, so the three
+        outputs of loss_point 'CT-Pth-Last' are the same tensor -, a single modality -> (out, token, None), text only ->
+        (out, None)."""
+        out = self._forward(x_list, x_CI, lengths, text_features, labels, loss_scale, bucket)
+        if not _arg(self.args, "train_contract", 0):
+            return out
+        if not isinstance(out, tuple):
+            return out, None
+        if len(out) == 3:
+            return [out[0], out[0], out[0]], [out[1], out[2]], None
+        return out[0], out[1], None
+
+    def _forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
+                 text_features: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                 loss_scale: Optional[float] = None, bucket=None):
         """x_list = [x_pathology [B, N, 768]] (or [] for CI only); x_CI int64 [B, P, ctx] token ids.
         `lengths` (optional) gives the true patch count of each zero-padded bag (dataset.py:386-391 pads to a
         fixed length when batch > 1); padded rows are then dropped instead of being attended to."""

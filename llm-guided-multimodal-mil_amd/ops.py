@@ -1295,6 +1295,32 @@ def clip_contrastive_loss(out, feat):
     return _ClipContrastive.apply(out, feat)
 
 
+class _CosineEmbedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight: float):
+        x1, x2 = _f32c(x1, "x1"), _f32c(x2, "x2")
+        B, E = x1.shape
+        loss = torch.empty(1, device=x1.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d1 = torch.empty_like(x1) if need else None
+        d2 = torch.empty_like(x2) if need else None
+        rc = _lib.lib().mil_cosine_embedding_loss(_p(x1), _p(x2), B, E, float(weight) / B, _p(loss), _p(d1), _p(d2), _stream())
+        _lib.check(rc, "mil_cosine_embedding_loss")
+        ctx.save_for_backward(d1, d2)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2 = ctx.saved_tensors
+        return d1 * g, d2 * g, None
+
+
+def cosine_embedding_loss(x1, x2, weight: float = 1.0):
+    """torch.nn.CosineEmbeddingLoss()(x1, x2, ones): mean_b (1 - cos(x1_b, x2_b)) - the 'textCosSim' term of the reference's
+    training loop (train_ddp.py:102,325-329) between x_CT2CI and x_Pth2CI, [B, E] each (squeeze the token axis first)."""
+    return _CosineEmbedding.apply(x1, x2, float(weight))
+
+
 # --------------------------------------------------------------------------- one-text-token token->image attention
 class _AbsorbQuery(torch.autograd.Function):
     """Qp[b][h] = Wk_h^T qp[b][h]  (also the value projection's backward map)."""

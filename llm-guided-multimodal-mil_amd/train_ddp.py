@@ -117,6 +117,25 @@ def main_worker(local_rank: int, nprocs: int, args):
 
         def loss_of(out_prob, y_):
             return model.last_loss if (fuse_loss and model.last_loss is not None) else criterion(out_prob, y_)
+
+        def unpack(out):
+            """(prob, [tokens]) from either return contract (aggregator.py:202-209 / train_ddp.py:300)."""
+            if isinstance(out, tuple) and isinstance(out[0], list):
+                return out[0][0], [t_ for t_ in out[1] if t_ is not None]
+            if isinstance(out, tuple):
+                return out[0], [t_ for t_ in out[1:] if t_ is not None]
+            return out, []
+
+        def total_loss(prob_, toks, y_):
+            """train_ddp.py:318-329: 'Last' = criterion(out); 'CT-Pth-Last' sums the criterion over the three outputs (one
+            head here, so three times the same term); 'textCosSim' adds the cosine term between the two text-aligned tokens."""
+            loss_ = loss_of(prob_, y_)
+            if args.loss_point == "CT-Pth-Last" and len(toks) == 2:
+                loss_ = loss_ * 3.0
+            if "textCosSim" in args.loss and len(toks) == 2:
+                from . import ops
+                loss_ = loss_ + ops.cosine_embedding_loss(toks[0].squeeze(1), toks[1].squeeze(1))
+            return loss_
         graphed = fstepper = None
         if getattr(args, "hip_graph", 0) and flat_opt and getattr(optimizer, "counted", False):
             # the authors' regime (one ragged bag per GPU, run_train.sh:81; a fresh patch drop every epoch,
@@ -204,9 +223,18 @@ def main_worker(local_rank: int, nprocs: int, args):
                 else:
                     if args.variant == "image_only":
                         _, prob = generator([x], lengths)
+                        loss = criterion(prob, y)
                     else:
-                        prob, _ = generator([x], batch["CI"].to(dev), lengths, labels=y if fuse_loss else None)
-                    loss = loss_of(prob, y) if args.variant != "image_only" else criterion(prob, y)   # loss_point 'Last'
+                        xs = [x]
+                        if "CT" in args.modality:
+                            # the CT encoders are outside the hot path: their OUTPUT (the feature map of aggregator.py:139-140)
+                            # is an input here - synthetic, like the bags
+                            from . import synthetic as syn
+                            ct = syn.make_ct_map(args.seed + 7919 * epoch + it, x.shape[0], 160, 2).to(dev)
+                            xs = [ct, x] if "pathology" in args.modality else [ct]
+                        out = generator(xs, batch["CI"].to(dev), lengths, labels=y if fuse_loss else None)
+                        prob, toks = unpack(out)
+                        loss = total_loss(prob, toks, y)                                  # loss_point 'Last' by default
                     optimizer.zero_grad()
                     loss.backward()
                     optimizer.step()

@@ -353,6 +353,27 @@ def gen_fused(ab, tw, cm, tag, seed, B, N, P, clip_layers, clip_width, clip_voca
     npz(tag, **arrs)
 
 
+def gen_cossim(tag):
+    """The 'textCosSim' term of the reference's loop (train_ddp.py:102,266,325-329): torch.nn.CosineEmbeddingLoss() - the
+    reference calls torch's own op - on the two text-aligned tokens of the fused_ct_pth fixture (x_CT2CI, x_Pth2CI as the
+    reference's TwoWayTransformer produced them), target [1]; loss and both input gradients.  A second case with random rows
+    (one of them almost zero) pins the epsilon handling."""
+    z = np.load(os.path.join(OUT, "fused_ct_pth.npz"))
+    arrs = {}
+    gen = torch.Generator().manual_seed(97)
+    r1, r2 = torch.randn((5, 512), generator=gen), torch.randn((5, 512), generator=gen)
+    r1[3] *= 1e-7
+    for name, (a, b) in {"tok": (torch.from_numpy(z["x_CT2CI"]).squeeze(1), torch.from_numpy(z["x_Pth2CI"]).squeeze(1)),
+                         "rnd": (r1, r2)}.items():
+        a = a.clone().requires_grad_(True)
+        b = b.clone().requires_grad_(True)
+        loss = torch.nn.CosineEmbeddingLoss()(a, b, torch.tensor([1.0]))
+        loss.backward()
+        arrs.update({name + ".x1": a.detach(), name + ".x2": b.detach(), name + ".loss": loss.detach(),
+                     name + ".dx1": a.grad, name + ".dx2": b.grad})
+    npz(tag, **arrs)
+
+
 def main():
     torch.set_num_threads(8)
     ab, tw, cm = load_reference()
@@ -387,10 +408,13 @@ def main():
     gen_fused(ab, tw, cm, "fused_vitb32", 93, B=2, N=128, P=1, clip_layers=12, clip_width=512,
               clip_vocab=49408, clip_heads=8)
     gen_fused_ct_pth(ab, tw, cm, "fused_ct_pth", 95, B=2, N=96, P=1, D=160, hw=2, clip_layers=2)
+    gen_cossim("cossim_ct_pth")
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "ct":          # only the CT-map fixtures (round 2)
+    if len(sys.argv) > 1 and sys.argv[1] == "cossim":      # round 3: the textCosSim term on the fused_ct_pth tokens
+        gen_cossim("cossim_ct_pth")
+    elif len(sys.argv) > 1 and sys.argv[1] == "ct":          # only the CT-map fixtures (round 2)
         torch.set_num_threads(8)
         _ab, _tw, _cm = load_reference()
         gen_twoway_ctmap(_tw, "twoway_ctmap_T1", 75, 1, 160, 3)

@@ -314,6 +314,16 @@ def batch_loss_and_grads(bags: List[Tensor], labels: Tensor, p: Params, forward=
     return loss.detach(), logits.detach(), prob.detach(), grads
 
 
+def cosine_embedding_loss(x1: Tensor, x2: Tensor) -> Tensor:
+    """criterion_CosSim(train_CI[0].squeeze(1), train_CI[1].squeeze(1), label_for_CosSim = [1]) of the reference's loop
+    (train_ddp.py:102,266,325-329): torch.nn.CosineEmbeddingLoss with target +1, mean reduction, restated from ATen's
+    cosine_embedding_loss (EPSILON = 1e-12 added to both squared norms)."""
+    dot = (x1 * x2).sum(1)
+    m1 = (x1 * x1).sum(1) + 1e-12
+    m2 = (x2 * x2).sum(1) + 1e-12
+    return (1.0 - dot / torch.sqrt(m1 * m2)).mean()
+
+
 # --------------------------------------------------------------------------- CLIP-as-loss
 def clip_contrastive_loss(out: Tensor, feat: Tensor) -> Tensor:
     """utils.py:276-282 (CLIPloss_v1.forward after the text features are built): out [b, E], feat [b, F, E].

@@ -92,3 +92,15 @@ def test_hip_graph_training_of_the_fusion_model_on_ragged_bags(tmp_path):
     assert all(torch.isfinite(v).all() for k, v in ck["state_dict"].items() if v.is_floating_point())
     out = run("test_ddp.py", "--synthetic", "[700, 768, 12]", "--ragged", "--clip_layers", "1", "--test_pth", str(tmp_path))
     assert "Time for inference" in out
+
+
+def test_ct_plus_pathology_training_with_the_cossim_term_and_the_train_contract(tmp_path):
+    """modality ['CT', 'pathology'] through the entry point with `--loss BCE+textCosSim --loss_point CT-Pth-Last
+    --train_contract 1` (reference train_ddp.py:300,319-329): the module returns the training loop's 3-tuple and the cosine
+    term between x_CT2CI and x_Pth2CI joins the loss."""
+    out = run("train_ddp.py", "--synthetic", "[64, 768, 4]", "--clip_layers", "1", "--batch_size", "2", "--modality",
+              "['CT', 'pathology']", "--loss", "BCE+textCosSim", "--loss_point", "CT-Pth-Last", "--train_contract", "1",
+              "--n_epochs", "1", "--iter_per_epoch", "2", "--save_dir", str(tmp_path))
+    assert "Epoch: [0]" in out and "Loss" in out
+    ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
+    assert torch.isfinite(ck["state_dict"]["TwoWayTransformer_Both.layers.0.mlp.lin1.weight"]).all()

@@ -270,3 +270,15 @@ def test_fused_ct_and_pathology():
             assert float(got.abs().max()) <= 1e-12, k
         else:
             check_grad("g." + k, got, g, 5e-4)
+
+
+@pytest.mark.parametrize("case", ["tok", "rnd"])
+def test_cosine_embedding_loss_restatement_vs_torch(golden, case):
+    """The 'textCosSim' term (reference train_ddp.py:102,325-329 calls torch.nn.CosineEmbeddingLoss): restatement vs the
+    vectors torch's own op produced on the fused_ct_pth tokens (oracle/gen_golden.py cossim)."""
+    g = golden("cossim_ct_pth")
+    a, b = g[case + ".x1"].clone().requires_grad_(True), g[case + ".x2"].clone().requires_grad_(True)
+    loss = orc.cosine_embedding_loss(a, b)
+    loss.backward()
+    assert abs(float(loss) - float(g[case + ".loss"])) <= 1e-6
+    assert rel_err(a.grad, g[case + ".dx1"]) <= 1e-5 and rel_err(b.grad, g[case + ".dx2"]) <= 1e-5
