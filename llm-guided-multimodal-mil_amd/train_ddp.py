@@ -118,6 +118,8 @@ def main_worker(local_rank: int, nprocs: int, args):
         def loss_of(out_prob, y_):
             return model.last_loss if (fuse_loss and model.last_loss is not None) else criterion(out_prob, y_)
 
+        three_terms = args.loss_point == "CT-Pth-Last" and "CT" in args.modality and "pathology" in args.modality
+
         def unpack(out):
             """(prob, [tokens]) from either return contract (aggregator.py:202-209 / train_ddp.py:300)."""
             if isinstance(out, tuple) and isinstance(out[0], list):
@@ -129,8 +131,9 @@ def main_worker(local_rank: int, nprocs: int, args):
         def total_loss(prob_, toks, y_):
             """train_ddp.py:318-329: 'Last' = criterion(out); 'CT-Pth-Last' sums the criterion over the three outputs (one
             head here, so three times the same term); 'textCosSim' adds the cosine term between the two text-aligned tokens."""
+            fused_ = fuse_loss and model.last_loss is not None     # the factor 3 then sits in the fused node's loss_scale
             loss_ = loss_of(prob_, y_)
-            if args.loss_point == "CT-Pth-Last" and len(toks) == 2:
+            if three_terms and not fused_:
                 loss_ = loss_ * 3.0
             if "textCosSim" in args.loss and len(toks) == 2:
                 from . import ops
@@ -232,7 +235,8 @@ def main_worker(local_rank: int, nprocs: int, args):
                             from . import synthetic as syn
                             ct = syn.make_ct_map(args.seed + 7919 * epoch + it, x.shape[0], 160, 2).to(dev)
                             xs = [ct, x] if "pathology" in args.modality else [ct]
-                        out = generator(xs, batch["CI"].to(dev), lengths, labels=y if fuse_loss else None)
+                        ls = 3.0 / (x.shape[0] * (1 if args.num_classes > 2 else args.num_classes)) if three_terms else None
+                        out = generator(xs, batch["CI"].to(dev), lengths, labels=y if fuse_loss else None, loss_scale=ls)
                         prob, toks = unpack(out)
                         loss = total_loss(prob, toks, y)                                  # loss_point 'Last' by default
                     optimizer.zero_grad()
