@@ -524,6 +524,10 @@ def run_rank(args):
         tr.forward(x, lay, y)
     for _ in range(args.warmup):
         step()
+    # test hook (tests/test_gpu_bench_launcher.py): this rank dies between warm-up and the timed region, the others are
+    # left waiting in the barrier - the launcher must notice, stop them and return non-zero
+    if os.environ.get("MIL_BENCH_FAIL_RANK") == str(rank):
+        os._exit(3)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

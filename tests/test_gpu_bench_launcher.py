@@ -71,3 +71,22 @@ def test_more_ranks_than_gpus_is_refused_not_downgraded():
 def test_gpus_flag_must_match_torchrun_world_size():
     r = bench("--gpus", "2", *SMALL, env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_ok=False)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_a_dying_rank_takes_the_job_down():
+    """One of two ranks exits non-zero between warm-up and the timed region while the other waits in the barrier
+    (reference: mp.spawn joins and re-raises, train_ddp.py:622-624): bench.py must return non-zero well inside its
+    timeout and leave no rank behind."""
+    import time
+    import psutil
+    marker = "777.25"                                   # a unique --launch-timeout value to find the job's processes by
+    t0 = time.time()
+    r = bench("--gpus", "2", *SMALL, "--launch-timeout", marker, env={"MIL_BENCH_REHEARSAL": "1", "MIL_BENCH_FAIL_RANK": "1"},
+              expect_ok=False)
+    took = time.time() - t0
+    assert r.returncode != 0 and "rank 1 exited with 3" in r.stderr, r.stderr[-2000:]
+    assert took < 240, took
+    assert not r.stdout.strip().startswith("{")          # no result line from a broken job
+    time.sleep(1.0)
+    left = [p.pid for p in psutil.process_iter(["cmdline"]) if p.info["cmdline"] and marker in p.info["cmdline"]]
+    assert left == [], left
