@@ -321,7 +321,7 @@ def config5_bf16(dev, steps=60, warmup=5):
     kb_alone = tr.time_pieces(x, lay, y, 20)
     flops = 4.0 * R * L * D_GATE
     # in-step groups: the weight gradient's launch pair (+ head parameter gradients) is one entry point on this path
-    dom = max(("gate_fwd", "gate_bwd_dw_reduce_head"), key=lambda k: kb[k])
+    dom = max(("gate_fwd", "gate_bwd_dw_reduce_head_adam"), key=lambda k: kb[k])
     hbm = R * L * 2 / (kb["gate_fwd"] * 1e-3) / 1e9
     # the same step in model.train() mode (in-kernel dropout through the keep-bit tensors; the forward then runs on the
     # 128-row kernel): reported beside the eval-mode figure the object is quoted on
@@ -587,7 +587,7 @@ def run_rank(args):
             kb, ev_step = tr.time_step_groups(x, lay, y, 50)
             kb_alone = kernel_breakdown(tr, x, lay, y)
             names = {"gate_fwd_with_pool_fused": "k_gate_fwd2<train, pool pass in the epilogue>", "gate_fwd": "k_gate_fwd2",
-                     "gate_bwd_dw": "k_gate_bwd_dw2", "gate_bwd_dw_reduce_head": "k_gate_bwd_dw_bf16 (+ fold)"}
+                     "gate_bwd_dw": "k_gate_bwd_dw2", "gate_bwd_dw_reduce_head": "k_gate_bwd_dw_bf16 (+ fold)", "gate_bwd_dw_reduce_head_adam": "k_gate_bwd_dw_bf16 (+ fold with Adam)"}
             if args.dtype == "bf16":
                 names.update(gate_fwd="k_gate_fwd_bf16")
             flops = {k: gate_flops for k in names if k in kb}

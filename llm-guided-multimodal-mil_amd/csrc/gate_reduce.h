@@ -66,7 +66,11 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
                                                                 float* __restrict__ dWu, float* __restrict__ dbu,
                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate,
                                                                 float wscale, int head_first = 1 << 30,
-                                                                HeadBwdArgs head = HeadBwdArgs{}, AdamFuse ad_in = AdamFuse{}) {
+                                                                HeadBwdArgs head = HeadBwdArgs{}, AdamFuse ad_in = AdamFuse{},
+                                                                unsigned short* __restrict__ Wv16 = nullptr,
+                                                                unsigned short* __restrict__ Wu16 = nullptr) {
+    // Wv16 / Wu16 (bf16-storage step with Adam applied here): the bf16 shadows of the gate weights the forward reads are
+    // refreshed by the thread that has just updated their fp32 masters - no cast launches after the update
     __shared__ float bcs[2];
     const AdamFuse ad = adam_fuse_resolve(ad_in, bcs);
     if ((int)blockIdx.x >= head_first) {          // appended workgroups: the head's parameter gradients (uniform branch)
@@ -93,10 +97,19 @@ static __global__ __launch_bounds__(256) void k_gate_bwd_reduce(const float* __r
         for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
         v *= wscale;             // train mode: the 1/(1-p) of the patch dropout (x entered the product as keep-masked x)
         const int m = gi >> 7, ii = gi & 127;
-        float* dst = (ii < 64 ? dWv + (size_t)(64 * m + ii) * L : dWu + (size_t)(64 * m + ii - 64) * L) + 4 * c4;
+        const size_t woff = (size_t)(ii < 64 ? 64 * m + ii : 64 * m + ii - 64) * L + 4 * c4;
+        float* dst = (ii < 64 ? dWv : dWu) + woff;
         if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
-        adam_fused4(ad, dst, v);
+        const f32x4 pnew = adam_fused4(ad, dst, v);
+        if (Wv16 != nullptr && ad.param != nullptr) {
+            ushort4 o;                                  // the conversion k_cast_bf16 uses (round to nearest even)
+            o.x = __builtin_bit_cast(unsigned short, (__bf16)pnew[0]);
+            o.y = __builtin_bit_cast(unsigned short, (__bf16)pnew[1]);
+            o.z = __builtin_bit_cast(unsigned short, (__bf16)pnew[2]);
+            o.w = __builtin_bit_cast(unsigned short, (__bf16)pnew[3]);
+            *reinterpret_cast<ushort4*>((ii < 64 ? Wv16 : Wu16) + woff) = o;
+        }
     } else if (idx < nW + GR_NB * (3 * 192 + 1)) {
         // bias / w / b: GR_NB lanes per output, each sums every GR_NB-th slab (loads in flight), then a fixed-order
         // shuffle fold.  (One thread per output walked the S * NJ slabs of the low-VALU kernel serially: 9.5 us.)

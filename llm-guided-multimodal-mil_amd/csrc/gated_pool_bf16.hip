@@ -1426,6 +1426,60 @@ extern "C" size_t mil_gate_bwd_workspace_floats_bf16(int R, int L) {
     return (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
 }
 
+// The bf16-storage step's weight gradient with its whole tail in the fold launch (internal: step.hip): the split-K fold also
+// forms the head's parameter gradients and the loss (appended workgroups, as mil_gate_bwd_reduce_head) and, when the
+// optimizer stage runs in the same call (param_flat != NULL: world size 1, nothing between gradient and update), applies
+// Adam on the spot and refreshes the bf16 shadows Wv16 / Wu16 of the gate weights - round 2 ran k_head_bwd_params, k_adam
+// and two k_cast_bf16 launches behind the fold (~23 us of a 0.38 ms step).
+int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const float* ds, const float* w, int R, int L,
+                              float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu, float* dbu,
+                              float* dw, float* db, int accumulate, const uint32_t* xbits, float xscale, const float* dz,
+                              const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                              float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg, float* exp_avg_sq,
+                              int step, const int* step_dev, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream) {
+    if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
+    if (!dz || !M || !dWf || !dbf || B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
+    if (L <= 0 || (L % 256) != 0 || R <= 0) return MIL_EINVAL;
+    AdamFuse ad{};
+    if (param_flat != nullptr) {
+        if (!grad_flat || !exp_avg || !exp_avg_sq || !Wv16 || !Wu16 || (step_dev == nullptr && step < 1)) return MIL_EINVAL;
+        const float* outs[8] = {dWv, dbv, dWu, dbu, dw, db, dWf, dbf};
+        const size_t lens[8] = {(size_t)192 * L, 192, (size_t)192 * L, 192, 192, 1, (size_t)C * L, (size_t)C};
+        for (int i = 0; i < 8; ++i)
+            if (outs[i] < grad_flat || outs[i] + lens[i] > grad_flat + n_param) return MIL_EINVAL;
+        if (((dWv - grad_flat) | (dWu - grad_flat)) & 3) return MIL_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(param_flat) | reinterpret_cast<uintptr_t>(grad_flat) |
+             reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+            return MIL_EINVAL;
+        if (step_dev != nullptr) step = 1;
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step);
+        ad = AdamFuse{param_flat, grad_flat, exp_avg, exp_avg_sq, (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
+                      (float)sqrt(bc2), step_dev, lr, lr_dev};
+    }
+    int kc;
+    const int S = split_plan_bf16(R, L, &kc);
+    const size_t need = (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
+    if (workspace_floats < need) return MIL_ENOSPC;
+    float* part = workspace;
+    float* pbias = workspace + (size_t)S * HB_NG * L;
+    const int NJ = L / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (xbits != nullptr)
+        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<true>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    else
+        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<false>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    MIL_CHECK_LAUNCH();
+    const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);
+    const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
+    const HeadBwdArgs head{dz, M, dWf, dbf, loss_bag, loss_out, B, L, C, accumulate};
+    hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, st, part, pbias, S, S, L, dWv, dbv, dWu, dbu, dw, db,
+                       accumulate, xbits ? xscale : 1.0f, nred, head, ad, param_flat ? Wv16 : nullptr, param_flat ? Wu16 : nullptr);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates, const float* ds, const float* w, int R,
                                         int L, int D, float* workspace, size_t workspace_floats, float* dWv, float* dbv,
                                         float* dWu, float* dbu, float* dw, float* db, int accumulate,

@@ -216,8 +216,9 @@ __device__ __forceinline__ void adam_fused(const AdamFuse& ad, const float* gptr
     ad.m[i] = m;
     ad.v[i] = v;
 }
-__device__ __forceinline__ void adam_fused4(const AdamFuse& ad, const float* gptr, f32x4 g) {
-    if (ad.param == nullptr) return;
+// returns the updated parameters (the caller may have a bf16 shadow to refresh); g itself when there is no update
+__device__ __forceinline__ f32x4 adam_fused4(const AdamFuse& ad, const float* gptr, f32x4 g) {
+    if (ad.param == nullptr) return g;
     const size_t i = (size_t)(gptr - ad.grad_base);
     f32x4 p = *reinterpret_cast<const f32x4*>(ad.param + i), m = *reinterpret_cast<const f32x4*>(ad.m + i),
           v = *reinterpret_cast<const f32x4*>(ad.v + i);
@@ -230,6 +231,7 @@ __device__ __forceinline__ void adam_fused4(const AdamFuse& ad, const float* gpt
     *reinterpret_cast<f32x4*>(ad.param + i) = p;
     *reinterpret_cast<f32x4*>(ad.m + i) = m;
     *reinterpret_cast<f32x4*>(ad.v + i) = v;
+    return p;
 }
 
 // Row of a 32x32 MFMA accumulator register: C/D layout col = lane & 31,

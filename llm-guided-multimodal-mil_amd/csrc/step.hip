@@ -29,6 +29,16 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
                                    float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
                                    float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+// gated_pool_bf16.hip: bf16-MFMA weight gradient whose fold launch carries the head gradients, the loss and (param_flat != NULL)
+// Adam + the refresh of the bf16 weight shadows
+int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const float* ds, const float* w, int R, int L,
+                              float* workspace, size_t workspace_floats, float* dWv, float* dbv, float* dWu, float* dbu,
+                              float* dw, float* db, int accumulate, const uint32_t* xbits, float xscale, const float* dz,
+                              const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
+                              float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg, float* exp_avg_sq,
+                              int step, const int* step_dev, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream);
+
 // dropout.hip: both keep-bit tensors of a step in one launch
 int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
                            const int32_t* offset_dev, void* stream);
@@ -144,7 +154,23 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     const float* Mhead = train ? a->Mdrop : a->M;               // the M the head saw (dWf = dz^T M)
     if (a->x_bf16) {
         // bf16 storage: one entry point per weight-gradient flavour (its launch pair), then the head's parameter gradients
-        if (st & (MIL_STAGE_GATE_BWD | MIL_STAGE_REDUCE)) {
+        const bool tail16 = a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16 && (st & MIL_STAGE_GATE_BWD) &&
+                            (st & MIL_STAGE_REDUCE);
+        if (tail16) {
+            // weight gradient + ONE fold launch that also forms the head gradients / loss and, when the optimizer stage runs
+            // in this call, applies Adam and rewrites the bf16 shadows (no k_head_bwd_params / k_adam / k_cast_bf16 launches)
+            adam_in_reduce = (st & MIL_STAGE_ADAM) && a->param_flat && a->grad_flat && a->exp_avg && a->exp_avg_sq &&
+                             (a->adam_step_dev || a->adam_step >= 1);
+            rc = gate_bwd_params_bf16_tail((const uint16_t*)a->x, a->gates16, a->ds, a->w, a->R, a->L, a->dw_ws,
+                                           (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db, a->accumulate,
+                                           xbits, xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag, a->loss_out,
+                                           adam_in_reduce ? a->param_flat : nullptr, a->grad_flat, (size_t)a->n_param, a->exp_avg,
+                                           a->exp_avg_sq, a->adam_step, a->adam_step_dev, a->lr, a->lr_dev, a->beta1, a->beta2,
+                                           a->eps, a->weight_decay, a->grad_scale, const_cast<uint16_t*>(a->Wv16),
+                                           const_cast<uint16_t*>(a->Wu16), stream);
+            if (rc == MIL_OK && adam_in_reduce && a->adam_step_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
+            if (rc != MIL_OK) return rc;
+        } else if (st & (MIL_STAGE_GATE_BWD | MIL_STAGE_REDUCE)) {
             if (a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16)
                 rc = mil_gate_bwd_params_bf16((const uint16_t*)a->x, a->gates16, a->ds, a->w, a->R, a->L, MIL_GATE_D, a->dw_ws,
                                               (size_t)a->dw_ws_floats, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db,
@@ -155,7 +181,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                                              a->accumulate, xbits, xscale, stream);
             if (rc != MIL_OK) return rc;
         }
-        if (st & MIL_STAGE_REDUCE) {
+        if ((st & MIL_STAGE_REDUCE) && !tail16) {
             rc = mil_head_bwd_params_acc(a->dz, Mhead, a->dWf, a->dbf, a->B, a->L, a->C, a->loss_bag, a->loss_out, a->accumulate,
                                          stream);
             if (rc != MIL_OK) return rc;

@@ -408,8 +408,10 @@ class ImageOnlyTrainer:
             groups += [("gate_fwd", fwd), ("pool_partial", S.STAGE_POOL)]
         groups.append(("merge_head_loss_ds", S.STAGE_TAIL))
         collective = self.world > 1 or self.force_collectives
-        if a.x_bf16:
+        if a.x_bf16 and collective:
             groups += [("gate_bwd_dw_reduce_head", S.STAGE_GATE_BWD | S.STAGE_REDUCE), ("adam", S.STAGE_ADAM)]
+        elif a.x_bf16:      # weight gradient + its fold launch, which carries head gradients, Adam and the bf16 shadows
+            groups += [("gate_bwd_dw_reduce_head_adam", S.STAGE_GATE_BWD | S.STAGE_REDUCE | S.STAGE_ADAM)]
         elif collective:
             groups += [("gate_bwd_dw", S.STAGE_GATE_BWD), ("gate_bwd_reduce_head", S.STAGE_REDUCE), ("adam", S.STAGE_ADAM)]
         else:

@@ -102,3 +102,29 @@ def test_deep_pipeline_kernel_with_keep_bits_matches_the_128_row_kernel():
     s16, g16 = ops.gate_scores_fwd_bf16(x16, *args, save_gates=True, gates_bf16=True, xbits=bits, xscale=2.0)
     assert torch.equal(s16, s_all)
     assert torch.equal(g16, g_all.to(torch.bfloat16))
+
+
+def test_fused_bf16_tail_equals_the_separate_launches_bit_for_bit():
+    """World size 1: the fold launch of the bf16 weight gradient forms the head gradients, applies Adam and rewrites the bf16
+    weight shadows (csrc/step.hip `tail16`).  Three steps that way must leave exactly the bits of forward / backward /
+    stand-alone Adam + cast launches."""
+    L, lengths = 1024, [700, 300, 1048]
+    p = syn.image_only_params(77, L=L)
+    dev = torch.device(DEV)
+    x16 = torch.randn((sum(lengths), L), generator=torch.Generator().manual_seed(9)).to(DEV).to(torch.bfloat16)
+    y = syn.make_labels(10, len(lengths)).to(DEV)
+    lay = BagLayout.make(lengths, dev)
+    a = ImageOnlyTrainer(p, dev, lr=1e-3)
+    b = ImageOnlyTrainer(p, dev, lr=1e-3)
+    for _ in range(3):
+        la, _ = a.train_step(x16, lay, y)                      # one C call: ... -> fold with head gradients + Adam + shadows
+        b.forward(x16, lay, y)
+        b.backward()
+        b.reduce_and_step()                                    # stand-alone k_adam + two k_cast_bf16
+        assert float(la.item()) == float(b.loss_sum.item())
+    torch.cuda.synchronize()
+    assert torch.equal(a.fp.flat, b.fp.flat) and torch.equal(a.fp.exp_avg, b.fp.exp_avg) and torch.equal(a.fp.exp_avg_sq, b.fp.exp_avg_sq)
+    assert torch.equal(a.fp.grad, b.fp.grad)
+    for k in a._w16:
+        assert torch.equal(a._w16[k].view(torch.int16), b._w16[k].view(torch.int16)), k
+        assert torch.equal(a._w16[k], a.fp.p(k).to(torch.bfloat16)), k          # the shadow IS the rounded master
