@@ -454,12 +454,24 @@ int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int
 int mil_absorbed_pool_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
                           const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E,
                           float* pooled, float* lse, float* workspace, void* stream);
+/* pooled [B, H, E]: the forward's result; the softmax backward's row constant cdot_h = dpooled_h . pooled_h is formed inside
+ * (round 2 took it as an input computed by a mil_rowdot launch). */
 int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse, const float* dpooled,
-                          const float* cdot, const int32_t* k_off, const int32_t* tile_map,
+                          const float* pooled, const int32_t* k_off, const int32_t* tile_map,
                           const int32_t* bag_tile_off, int ntiles, int n_keys, int B, int H, int C, int E,
                           const float* dkeys_acc, float* dkeys, float* dQp, float* workspace, void* stream);
 int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
                    void* stream);
+/* Fewer launches on the token-side chain (each dependent launch costs ~4 us whatever it computes):
+ *   mil_absorbed_pool_value_fwd   mil_absorbed_pool_fwd whose merge launch also forms o = Wv pooled + bv [B, H C]
+ *   mil_value_proj_bwd            dpooled [B, H, E], dWv [H C, E], dbv [H C] (nullable) from do [B, H C] in one launch
+ * (mil_absorb_query_bwd likewise runs both of its halves in one launch when both are requested). */
+int mil_absorbed_pool_value_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
+                                const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E,
+                                const float* Wv, const float* bv, float* pooled, float* lse, float* o, float* workspace,
+                                void* stream);
+int mil_value_proj_bwd(const float* dO, const float* Wv, const float* pooled, int B, int H, int C, int E, float* dpooled,
+                       float* dWv, float* dbv, void* stream);
 /* Softmax stages of the multi-token absorbed attention (T text tokens per bag: T x H absorbed vectors, score matrix
  * [rows, ld] with column c = t H + h, columns >= T H are padding and come out as zeros):
  *   mil_grp_col_softmax      in place, over the ROWS of each group (bag) per column     (token -> image)

@@ -291,15 +291,32 @@ __global__ void k_apool_merge(const float* __restrict__ pacc, const float* __res
 #define AD_LS 68
 __global__ __launch_bounds__(256) void k_apool_dots(const float* __restrict__ keys, const float* __restrict__ pe,
                                                     const float* __restrict__ Qp, const float* __restrict__ lse,
-                                                    const float* __restrict__ dpooled, const float* __restrict__ cdot,
+                                                    const float* __restrict__ dpooled, const float* __restrict__ pooled,
                                                     const int32_t* __restrict__ k_off, const int32_t* __restrict__ tile_map,
                                                     float scale, float* __restrict__ ad) {
     constexpr int E = 512, NCH = E / AD_KC;
     __shared__ __attribute__((aligned(16))) float lds[2][(2 * AP_TILE + 16) * AD_LS];      // [stage][keys 64 | pe 64 | B 16][68]
+    __shared__ float cd_lds[AP_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
     const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
     const int pos0 = key0 - k_off[b];
+    {
+        // cdot_h = dpooled_h . pooled_h of this bag (the softmax backward's row constant): 32 lanes per head; 2 x 16 KB from
+        // L2, under the first chunk's loads - it used to be a launch of its own (k_rowdot) in front of this kernel
+        const int hh = tid >> 5, part = tid & 31;
+        const float* dpv = dpooled + ((size_t)b * AP_H + hh) * E + 16 * part;
+        const float* pv = pooled + ((size_t)b * AP_H + hh) * E + 16 * part;
+        float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(dpv + 4 * u), b4 = *reinterpret_cast<const f32x4*>(pv + 4 * u);
+            v += (a4[0] * b4[0] + a4[1] * b4[1]) + (a4[2] * b4[2] + a4[3] * b4[3]);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (part == 0) cd_lds[hh] = v;
+    }
     const bool active = 16 * wave < nkeys;                       // wave-uniform
     // staging map: thread -> (row srow + 16 i, 16-byte chunk sc) of the tile's [64][64] chunk; B: row srow (0..15), chunk sc
     const int srow = tid >> 4, sc = tid & 15;
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(256) void k_apool_dots(const float* __restrict__ ke
     if (!active) return;
     // lane (c, g4) holds column c of rows 4 g4 + i: columns c < 8 pair with c + 8
     const int h = r & 7;
-    const float ls = lse[b * AP_H + h], cd = cdot[b * AP_H + h];
+    const float ls = lse[b * AP_H + h], cd = cd_lds[h];         // written before the loop's first barrier
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float other = __shfl_xor(acc[i], 8);
@@ -492,6 +509,200 @@ __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ po
 
 // dpooled[b][h][:] = sum_c' do[b][hc + c'] Wv[hc + c'][:]     (same form as k_absorb_query)
 // dWv[hc + c'][:]   = sum_b do[b][hc + c'] pooled[b][h][:]    (same form as k_absorb_query_bwd_w)
+
+// One launch for both halves of the absorbed query's backward (they only share their inputs): workgroups [0, B H) form
+// dqp (k_absorb_query_bwd_q's arithmetic on the first 256 threads), workgroups behind them one row of dWk each
+// (k_absorb_query_bwd_w).  The token-side chain is a string of ~4 us launches whose cost is the launch itself.
+__global__ __launch_bounds__(512) void k_absorb_query_bwd_both(const float* __restrict__ qp, const float* __restrict__ Wk,
+                                                               const float* __restrict__ dQp, int B, int H, int C, int E,
+                                                               float* __restrict__ dqp, float* __restrict__ dWk) {
+    __shared__ __attribute__((aligned(16))) float red[(AQ_GROUPS - 1) * 1024];
+    const int nq = B * H, tid = threadIdx.x, I = H * C;
+    if ((int)blockIdx.x < nq) {
+        if (tid >= 256) return;
+        const int b = blockIdx.x / H, h = blockIdx.x % H;
+        const int per = 256 / C, c = tid / per, part = tid % per;
+        const float* g = dQp + ((size_t)b * H + h) * E;
+        const float* w = Wk + (size_t)(h * C + c) * E;
+        float v = 0.f;
+        for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {
+            f32x4 gv[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + 4 * per * u, E - 4);
+                gv[u] = *reinterpret_cast<const f32x4*>(g + j);
+                wv[u] = *reinterpret_cast<const f32x4*>(w + j);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
+        }
+        for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (part == 0) dqp[(size_t)b * I + h * C + c] = v;
+        return;
+    }
+    const int E4 = E / 4;
+    const int row = blockIdx.x - nq, h = row / C, j4 = tid % E4, grp = tid / E4;
+    f32x4 acc = {0, 0, 0, 0};
+    if (grp < AQ_GROUPS)
+        for (int b0 = 8 * grp; b0 < B; b0 += 8 * AQ_GROUPS) {
+            f32x4 gv[8];
+            float q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = min(b0 + u, B - 1);
+                gv[u] = *reinterpret_cast<const f32x4*>(dQp + ((size_t)b * H + h) * E + 4 * j4);
+                q[u] = b0 + u < B ? qp[(size_t)b * I + row] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += q[u] * gv[u];
+        }
+    if (grp > 0 && grp < AQ_GROUPS) *reinterpret_cast<f32x4*>(red + (grp - 1) * 1024 + 4 * j4) = acc;
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < AQ_GROUPS - 1; ++g) acc += *reinterpret_cast<const f32x4*>(red + g * 1024 + 4 * j4);
+        *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
+    }
+}
+
+// The value projection's whole backward in one launch (three results that only share `do`):
+//   workgroups [0, B H):           dpooled[b][h][:] = sum_c' do[b][hc + c'] Wv[hc + c'][:]      (k_absorb_query's form)
+//   workgroups [B H, B H + H C):   dWv[row][:]      = sum_b do[b][row] pooled[b][h][:]         (k_absorb_query_bwd_w's form)
+//   last workgroup:                dbv[i]           = sum_b do[b][i]
+// 512 threads, E = 512.
+__global__ __launch_bounds__(512) void k_value_proj_bwd(const float* __restrict__ dO, const float* __restrict__ Wv,
+                                                        const float* __restrict__ pooled, int B, int H, int C, int E,
+                                                        float* __restrict__ dpooled, float* __restrict__ dWv,
+                                                        float* __restrict__ dbv) {
+    __shared__ __attribute__((aligned(16))) float red[(AQ_GROUPS - 1) * 1024];
+    const int nq = B * H, nw = H * C, tid = threadIdx.x, I = H * C, E4 = E / 4;
+    if ((int)blockIdx.x < nq) {
+        if (tid >= E4) return;
+        const int b = blockIdx.x / H, h = blockIdx.x % H, j4 = tid;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            f32x4 wr[16];
+            float q[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                wr[u] = *reinterpret_cast<const f32x4*>(Wv + (size_t)(h * C + c0 + u) * E + 4 * j4);
+                q[u] = dO[(size_t)b * I + h * C + c0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += q[u] * wr[u];
+        }
+        *reinterpret_cast<f32x4*>(dpooled + ((size_t)b * H + h) * E + 4 * j4) = acc;
+        return;
+    }
+    if ((int)blockIdx.x < nq + nw) {
+        const int row = blockIdx.x - nq, h = row / C, j4 = tid % E4, grp = tid / E4;
+        f32x4 acc = {0, 0, 0, 0};
+        if (grp < AQ_GROUPS)
+            for (int b0 = 8 * grp; b0 < B; b0 += 8 * AQ_GROUPS) {
+                f32x4 gv[8];
+                float q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = min(b0 + u, B - 1);
+                    gv[u] = *reinterpret_cast<const f32x4*>(pooled + ((size_t)b * H + h) * E + 4 * j4);
+                    q[u] = b0 + u < B ? dO[(size_t)b * I + row] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += q[u] * gv[u];
+            }
+        if (grp > 0 && grp < AQ_GROUPS) *reinterpret_cast<f32x4*>(red + (grp - 1) * 1024 + 4 * j4) = acc;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 0; g < AQ_GROUPS - 1; ++g) acc += *reinterpret_cast<const f32x4*>(red + g * 1024 + 4 * j4);
+            *reinterpret_cast<f32x4*>(dWv + (size_t)row * E + 4 * j4) = acc;
+        }
+        return;
+    }
+    if (dbv != nullptr)
+        for (int i = tid; i < I; i += 512) {
+            float v = 0.f;
+            for (int b = 0; b < B; ++b) v += dO[(size_t)b * I + i];
+            dbv[i] = v;
+        }
+}
+
+// k_apool_merge followed by k_value_proj in one launch: grid (B, H), 256 threads.  Threads [0, E / 4) merge the bag's tile
+// partials (k_apool_merge's arithmetic), publish pooled[b][h] to global memory (the backward needs it) and to LDS; then all
+// 256 threads form this head's C outputs of the value projection from the LDS copy.
+__global__ __launch_bounds__(256) void k_apool_merge_value(const float* __restrict__ pacc, const float* __restrict__ pml,
+                                                           const int32_t* __restrict__ bag_tile_off, int E,
+                                                           float* __restrict__ pooled, float* __restrict__ lse,
+                                                           const float* __restrict__ Wv, const float* __restrict__ bv, int C,
+                                                           float* __restrict__ o) {
+    __shared__ __attribute__((aligned(16))) float pl[1024];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, H = AP_H, I = H * C;
+    if (tid < E / 4) {
+        const int j4 = tid;
+        const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
+        float m = -INFINITY;
+        {
+            int g = g0;
+            for (; g + 8 <= g1; g += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = pml[((size_t)(g + u) * AP_H + h) * 2];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m = fmaxf(m, t[u]);
+            }
+            for (; g < g1; ++g) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
+        }
+        float l = 0.f;
+        f32x4 acc = {0, 0, 0, 0};
+        {
+            int g = g0;
+            for (; g + 8 <= g1; g += 8) {
+                float2 ml[8];
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ml[u] = *reinterpret_cast<const float2*>(pml + ((size_t)(g + u) * AP_H + h) * 2);
+                    t[u] = *reinterpret_cast<const f32x4*>(pacc + ((size_t)(g + u) * AP_H + h) * E + 4 * j4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float sc = __expf(ml[u].x - m);
+                    l += sc * ml[u].y;
+                    acc += sc * t[u];
+                }
+            }
+            for (; g < g1; ++g) {
+                const float sc = __expf(pml[((size_t)g * AP_H + h) * 2] - m);
+                l += sc * pml[((size_t)g * AP_H + h) * 2 + 1];
+                acc += sc * *reinterpret_cast<const f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 4 * j4);
+            }
+        }
+        const float inv = g1 > g0 ? 1.0f / l : 0.f;
+        const f32x4 pv4 = acc * inv;
+        *reinterpret_cast<f32x4*>(pooled + ((size_t)b * AP_H + h) * E + 4 * j4) = pv4;
+        *reinterpret_cast<f32x4*>(pl + 4 * j4) = pv4;
+        if (j4 == 0) lse[b * AP_H + h] = g1 > g0 ? m + logf(l) : -INFINITY;
+    }
+    __syncthreads();
+    const int per = 256 / C, c = tid / per, part = tid % per;
+    const float* w = Wv + (size_t)(h * C + c) * E;
+    float v = 0.f;
+    for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {
+        f32x4 gv[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 4 * per * u, E - 4);
+            gv[u] = *reinterpret_cast<const f32x4*>(pl + j);
+            wv[u] = *reinterpret_cast<const f32x4*>(w + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
+    }
+    for (int m2 = per >> 1; m2 >= 1; m2 >>= 1) v += __shfl_xor(v, m2);
+    if (part == 0) o[(size_t)b * I + h * C + c] = v + bv[h * C + c];
+}
 
 // ---------------------------------------------------------------------------------------------- multi-token absorbed attention
 // With T text tokens per bag the same absorption yields T x H query (or key / value) vectors per bag and the image side
@@ -668,6 +879,11 @@ extern "C" int mil_absorb_query_bwd(const float* qp, const float* Wk, const floa
                                     float* dqp, float* dWk, void* stream) {
     AP_CHECK(qp && Wk && dQp && B > 0 && H > 0 && (C == 32 || C == 64) && E > 0 && (E & 3) == 0 && E <= 1024);
     hipStream_t st = (hipStream_t)stream;
+    if (dqp != nullptr && dWk != nullptr && E == 512) {          // both halves in one launch
+        hipLaunchKernelGGL(k_absorb_query_bwd_both, dim3(B * H + H * C), dim3(512), 0, st, qp, Wk, dQp, B, H, C, E, dqp, dWk);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     if (dqp != nullptr) {
         hipLaunchKernelGGL(k_absorb_query_bwd_q, dim3(B, H), dim3(256), 0, st, dQp, Wk, H, C, E, dqp);
         MIL_CHECK_LAUNCH();
@@ -698,12 +914,44 @@ extern "C" int mil_absorbed_pool_fwd(const float* keys, const float* pe, const f
     return MIL_OK;
 }
 
+// mil_absorbed_pool_fwd with the value projection (o = Wv pooled + bv, model/sam/transformer.py:441-448 with the
+// projections absorbed) formed by the merge launch itself.
+extern "C" int mil_absorbed_pool_value_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
+                                           const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int H,
+                                           int C, int E, const float* Wv, const float* bv, float* pooled, float* lse, float* o,
+                                           float* workspace, void* stream) {
+    AP_CHECK(keys && pe && Qp && k_off && tile_map && bag_tile_off && pooled && lse && workspace && Wv && bv && o);
+    AP_CHECK(H == AP_H && E == 512 && (C == 32 || C == 64) && B >= 0 && ntiles >= 0);
+    if (B == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* pacc = workspace;
+    float* pml = workspace + (size_t)ntiles * AP_H * E;
+    const float scale = 1.0f / sqrtf((float)C);
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_apool_partial, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_apool_merge_value, dim3(B, AP_H), dim3(256), 0, st, pacc, pml, bag_tile_off, E, pooled, lse, Wv, bv, C, o);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// The value projection's backward in one launch: dpooled [B, H, E], dWv [H C, E], dbv [H C] (nullable) from do [B, H C].
+extern "C" int mil_value_proj_bwd(const float* dO, const float* Wv, const float* pooled, int B, int H, int C, int E,
+                                  float* dpooled, float* dWv, float* dbv, void* stream) {
+    AP_CHECK(dO && Wv && pooled && dpooled && dWv && B > 0 && H > 0 && (C == 32 || C == 64) && E == 512);
+    hipLaunchKernelGGL(k_value_proj_bwd, dim3(B * H + H * C + 1), dim3(512), 0, (hipStream_t)stream, dO, Wv, pooled, B, H, C, E,
+                       dpooled, dWv, dbv);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse,
-                                     const float* dpooled, const float* cdot, const int32_t* k_off,
+                                     const float* dpooled, const float* pooled, const int32_t* k_off,
                                      const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int n_keys, int B,
                                      int H, int C, int E, const float* dkeys_acc, float* dkeys, float* dQp,
                                      float* workspace, void* stream) {
-    AP_CHECK(keys && pe && Qp && lse && dpooled && cdot && k_off && tile_map && bag_tile_off && dkeys && dQp && workspace);
+    AP_CHECK(keys && pe && Qp && lse && dpooled && pooled && k_off && tile_map && bag_tile_off && dkeys && dQp && workspace);
     AP_CHECK(H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0 && n_keys >= 0);
     if (B == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -711,7 +959,7 @@ extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const f
     float* pdq = workspace;                                    // [ntiles][H][E]
     float* ad = workspace + (size_t)ntiles * AP_H * E;         // [n_keys][16]
     if (ntiles > 0) {
-        hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, cdot, k_off, tile_map,
+        hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, pooled, k_off, tile_map,
                            scale, ad);
         MIL_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_apool_bwd_apply, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, dpooled, ad, k_off, tile_map,

@@ -1386,14 +1386,13 @@ class _AbsorbedPool(torch.autograd.Function):
             return dkeys_pass, None, None, None, None
         dpooled = _f32c(dpooled, "dpooled")
         acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
-        cdot = rowdot(dpooled.view(B * H, E), pooled.view(B * H, E))
         # capacity bucket: the apply pass writes the rows of real tiles only; padding rows must hand ZERO upstream (their
         # gradient feeds LayerNorm / bias sums of the layer below)
         dkeys = torch.zeros_like(keys) if getattr(segs, "device_lengths", False) else torch.empty_like(keys)
         dQp = torch.empty_like(Qp)
         n_keys = keys.shape[0]
         ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)
-        rc = _lib.lib().mil_absorbed_pool_bwd(_p(keys), _p(pe), _p(Qp), _p(lse), _p(dpooled), _p(cdot), _p(segs.k_off),
+        rc = _lib.lib().mil_absorbed_pool_bwd(_p(keys), _p(pe), _p(Qp), _p(lse), _p(dpooled), _p(pooled), _p(segs.k_off),
                                               _p(segs.tile_map), _p(segs.bag_tile_off), segs.ntiles, n_keys, B, H, C, E,
                                               _p(acc), _p(dkeys), _p(dQp), _p(ws), _stream())
         _lib.check(rc, "mil_absorbed_pool_bwd")
@@ -1421,15 +1420,74 @@ class _ValueProj(torch.autograd.Function):
         B, H, E = pooled.shape
         I = Wv.shape[0]
         do = _f32c(do, "do")
-        dpooled = torch.empty_like(pooled)
+        return _value_proj_bwd(do, Wv, ctx.bv_param, pooled)
+
+
+def _value_proj_bwd(do, Wv, bv, pooled):
+    """(dpooled, dWv, dbv) of o = Wv pooled + bv in ONE launch (mil_value_proj_bwd); parameter gradients go straight into
+    their flat-buffer slots when there are any."""
+    B, H, E = pooled.shape
+    I = Wv.shape[0]
+    dpooled = torch.empty_like(pooled)
+    dWv = grad_slot(Wv)
+    if dWv is None:
+        dWv = torch.empty_like(Wv)
+    dbv = grad_slot(bv)
+    if dbv is None:
+        dbv = torch.empty(I, device=do.device, dtype=torch.float32)
+    if E != 512:
         rc = _lib.lib().mil_absorb_query(_p(do), _p(Wv), B, H, I // H, E, _p(dpooled), _stream())
         _lib.check(rc, "mil_absorb_query")
-        dWv = grad_slot(Wv)
-        if dWv is None:
-            dWv = torch.empty_like(Wv)
         rc = _lib.lib().mil_absorb_query_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, None, _p(dWv), _stream())
         _lib.check(rc, "mil_absorb_query_bwd")
-        return dpooled, dWv, colsum(do, out=grad_slot(ctx.bv_param))
+        return dpooled, dWv, colsum(do, out=dbv)
+    rc = _lib.lib().mil_value_proj_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, _p(dpooled), _p(dWv), _p(dbv), _stream())
+    _lib.check(rc, "mil_value_proj_bwd")
+    return dpooled, dWv, dbv
+
+
+class _AbsorbedPoolValue(torch.autograd.Function):
+    """_AbsorbedPool followed by _ValueProj as ONE node: o[b] = Wv pooled[b] + bv comes out of the pool's merge launch
+    (mil_absorbed_pool_value_fwd) and the backward is four launches - value projection backward (dpooled, dWv, dbv), the
+    per-row dots (which form the softmax constant themselves), the apply pass, the merge - where the two nodes took eight.
+    Returns (o [B, H C], keys alias)."""
+
+    @staticmethod
+    def forward(ctx, keys, pe, Qp, Wv, bv, segs, C: int):
+        keys_in = keys
+        keys, pe, Qp, Wv = _f32c(keys, "keys"), _f32c(pe, "pe"), _f32c(Qp, "Qp"), _f32c(Wv, "Wv")
+        B, H, E = Qp.shape
+        pooled = torch.empty_like(Qp)
+        lse = torch.empty((B, H), device=keys.device, dtype=torch.float32)
+        o = torch.empty((B, Wv.shape[0]), device=keys.device, dtype=torch.float32)
+        ws = torch.empty(max(1, segs.ntiles) * H * (E + 2), device=keys.device, dtype=torch.float32)
+        rc = _lib.lib().mil_absorbed_pool_value_fwd(_p(keys), _p(pe), _p(Qp), _p(segs.k_off), _p(segs.tile_map),
+                                                    _p(segs.bag_tile_off), segs.ntiles, B, H, C, E, _p(Wv), _p(_f32c(bv, "bv")),
+                                                    _p(pooled), _p(lse), _p(o), _p(ws), _stream())
+        _lib.check(rc, "mil_absorbed_pool_value_fwd")
+        ctx.segs, ctx.C, ctx.bv_param = segs, C, bv
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(keys, pe, Qp, pooled, lse, Wv)
+        return o, keys_in.view_as(keys_in)
+
+    @staticmethod
+    def backward(ctx, do, dkeys_pass):
+        keys, pe, Qp, pooled, lse, Wv = ctx.saved_tensors
+        segs, C = ctx.segs, ctx.C
+        B, H, E = Qp.shape
+        if do is None:
+            return dkeys_pass, None, None, None, None, None, None
+        dpooled, dWv, dbv = _value_proj_bwd(_f32c(do, "do"), Wv, ctx.bv_param, pooled)
+        acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
+        dkeys = torch.zeros_like(keys) if getattr(segs, "device_lengths", False) else torch.empty_like(keys)
+        dQp = torch.empty_like(Qp)
+        n_keys = keys.shape[0]
+        ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)
+        rc = _lib.lib().mil_absorbed_pool_bwd(_p(keys), _p(pe), _p(Qp), _p(lse), _p(dpooled), _p(pooled), _p(segs.k_off),
+                                              _p(segs.tile_map), _p(segs.bag_tile_off), segs.ntiles, n_keys, B, H, C, E,
+                                              _p(acc), _p(dkeys), _p(dQp), _p(ws), _stream())
+        _lib.check(rc, "mil_absorbed_pool_bwd")
+        return dkeys, None, dQp, dWv, dbv, None, None
 
 
 def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
@@ -1440,6 +1498,8 @@ def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
     qp = linear_act(q_tok, Wq, bq)
     C = Wq.shape[0] // H
     Qp = _AbsorbQuery.apply(qp, Wk, H)
+    if Wk.shape[1] == 512 and H == 8 and Wv.requires_grad and bv.requires_grad:
+        return _AbsorbedPoolValue.apply(keys, pe, Qp, Wv, bv, segs, C)        # pool + value projection: one node
     pooled, keys_pass = _AbsorbedPool.apply(keys, pe, Qp, segs, C)
     return _ValueProj.apply(pooled, Wv, bv), keys_pass
 
