@@ -194,7 +194,7 @@ def lib() -> ctypes.CDLL:
                 f"{path} is missing: the HIP library is not built and there is no fallback path. "
                 "Run __graft_entry__.build() or `make -C llm-guided-multimodal-mil_amd/csrc`.")
         import torch  # noqa: F401  (loads torch's libamdhip64 first so the kernels share its runtime/streams)
-        handle = ctypes.CDLL(path)
+        handle = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res
@@ -204,6 +204,41 @@ def lib() -> ctypes.CDLL:
             raise MilHipError(f"libmil_hip.so ABI {got} != expected {ABI_VERSION}")
         _lib = handle
     return _lib
+
+
+SHIM_DIR = os.path.join(_HERE, "csrc", "shim_build")
+SHIM_SRC = os.path.join(_HERE, "csrc", "torch_shim.cpp")
+_shim = False
+
+
+def build_shim(verbose: bool = False):
+    """Compile csrc/torch_shim.cpp (a torch cpp_extension: pybind11 + at::Tensor, no kernels) against libmil_hip.so into
+    csrc/shim_build/mil_torch_shim.so - in-tree, so it travels to the GPU box with the library."""
+    from torch.utils.cpp_extension import load
+    os.makedirs(SHIM_DIR, exist_ok=True)
+    return load(name="mil_torch_shim", sources=[SHIM_SRC], extra_ldflags=[f"-L{_HERE}", "-lmil_hip", f"-Wl,-rpath,{_HERE}"],
+                extra_cflags=["-O2"], build_directory=SHIM_DIR, with_cuda=False, verbose=verbose)
+
+
+def shim():
+    """The torch cpp_extension binding of the token-side entries (csrc/torch_shim.cpp), or None when it has not been built
+    (or MIL_TORCH_SHIM=0): ops.py then reaches the same C functions through ctypes."""
+    global _shim
+    if _shim is False:
+        _shim = None
+        path = os.path.join(SHIM_DIR, "mil_torch_shim.so")
+        if os.environ.get("MIL_TORCH_SHIM", "1") != "0" and os.path.exists(path) and not os.environ.get("MIL_HIP_LIB"):
+            import importlib.util
+            lib()                                     # libmil_hip.so first: the extension's DT_NEEDED resolves to it by soname
+            try:
+                spec = importlib.util.spec_from_file_location("mil_torch_shim", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.abi_version() == ABI_VERSION:
+                    _shim = mod
+            except (ImportError, OSError, AttributeError):
+                _shim = None                          # stale build (another torch / ABI): the ctypes binding serves
+    return _shim
 
 
 def check(rc: int, what: str) -> None:

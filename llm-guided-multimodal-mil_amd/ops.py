@@ -560,11 +560,19 @@ def linear_mid_bwd(dy, y, act: int, x, W, need_dx: bool, need_dW: bool, need_db:
     return dx, dW, db
 
 
+def _stream_int() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
 def linear_small_fwd(x, W, b, act: int, residual=None):
     """Token-side nn.Linear (M <= 64 rows) in one launch (include/mil_hip.h: mil_linear_small_fwd)."""
     M, K = x.shape
     N = W.shape[0]
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    sh = _lib.shim()
+    if sh is not None:          # same C entry through the torch cpp_extension binding (csrc/torch_shim.cpp)
+        sh.linear_small_fwd(x, W, b, act, residual, y, _stream_int())
+        return y
     rc = _lib.lib().mil_linear_small_fwd(_p(x), x.stride(0), _p(W), W.stride(0), _p(b), act, _p(residual),
                                          residual.stride(0) if residual is not None else 0, _p(y), y.stride(0),
                                          M, N, K, _stream())
@@ -602,6 +610,10 @@ def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool,
     dW = (dW_out if dW_out is not None else torch.empty((N, K), device=x.device, dtype=torch.float32)) if want_dW else None
     db = (db_out if db_out is not None else torch.empty(N, device=x.device, dtype=torch.float32)) if want_db else None
     yv = y_or_pre if act != 0 else None
+    sh = _lib.shim()
+    if sh is not None:
+        sh.linear_small_bwd(dy, yv, act, x, W, dx, dW, db, _stream_int())
+        return dx, dW, db
     rc = _lib.lib().mil_linear_small_bwd(_p(dy), dy.stride(0), _p(yv), yv.stride(0) if yv is not None else 0, act,
                                          _p(x), x.stride(0), _p(W), W.stride(0), _p(dx), K, _p(dW), K, _p(db),
                                          M, N, K, _stream())
@@ -911,9 +923,13 @@ class _LayerNorm(torch.autograd.Function):
         # tail_rows > 0: allocate room for that many more rows behind the result (see append_rows)
         y = torch.empty((rows + tail_rows, E), device=x.device, dtype=torch.float32)[:rows] if tail_rows else torch.empty_like(x)
         stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
-        rc = _lib.lib().mil_layernorm_fwd(_p(x), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), rows, E, eps, _p(y),
-                                          _p(stats), _stream())
-        _lib.check(rc, "mil_layernorm_fwd")
+        sh = _lib.shim()
+        if sh is not None:
+            sh.layernorm_fwd(x, _f32c(gamma, "gamma"), _f32c(beta, "beta"), eps, y, stats, _stream_int())
+        else:
+            rc = _lib.lib().mil_layernorm_fwd(_p(x), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), rows, E, eps, _p(y),
+                                              _p(stats), _stream())
+            _lib.check(rc, "mil_layernorm_fwd")
         ctx.save_for_backward(x, gamma, stats)
         ctx.beta_param = beta               # only to look up its flat-gradient slot in backward
         return y
@@ -940,6 +956,10 @@ def _layer_norm_bwd(x, gamma, stats, dy, dres, want_params: bool, beta=None):
         if db is None:
             db = torch.empty(E, device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.lib().mil_layernorm_bwd_blocks(rows) * 2 * E, device=x.device, dtype=torch.float32)
+    sh = _lib.shim()
+    if sh is not None:
+        sh.layernorm_bwd_res(x, gamma, dy, stats, dres, dx, dg, db, ws, _stream_int())
+        return dx, dg, db
     rc = _lib.lib().mil_layernorm_bwd_res(_p(x), _p(gamma), _p(dy), _p(stats), _p(dres), rows, E, _p(dx), _p(dg), _p(db),
                                           _p(ws), _stream())
     _lib.check(rc, "mil_layernorm_bwd_res")
@@ -1331,8 +1351,12 @@ class _AbsorbQuery(torch.autograd.Function):
         B, I = qp.shape
         E = Wk.shape[1]
         Qp = torch.empty((B, H, E), device=qp.device, dtype=torch.float32)
-        rc = _lib.lib().mil_absorb_query(_p(qp), _p(Wk), B, H, I // H, E, _p(Qp), _stream())
-        _lib.check(rc, "mil_absorb_query")
+        sh = _lib.shim()
+        if sh is not None:
+            sh.absorb_query(qp, Wk, H, Qp, _stream_int())
+        else:
+            rc = _lib.lib().mil_absorb_query(_p(qp), _p(Wk), B, H, I // H, E, _p(Qp), _stream())
+            _lib.check(rc, "mil_absorb_query")
         ctx.H = H
         ctx.save_for_backward(qp, Wk)
         return Qp
@@ -1349,6 +1373,10 @@ class _AbsorbQuery(torch.autograd.Function):
             dWk = grad_slot(Wk)                       # straight into optim.FlatAdam's flat gradient buffer when there is one
             if dWk is None:
                 dWk = torch.empty_like(Wk)
+        sh = _lib.shim()
+        if sh is not None:
+            sh.absorb_query_bwd(qp, Wk, dQp, ctx.H, dqp, dWk, _stream_int())
+            return dqp, dWk, None
         rc = _lib.lib().mil_absorb_query_bwd(_p(qp), _p(Wk), _p(dQp), B, ctx.H, I // ctx.H, E, _p(dqp), _p(dWk), _stream())
         _lib.check(rc, "mil_absorb_query_bwd")
         return dqp, dWk, None
@@ -1441,6 +1469,10 @@ def _value_proj_bwd(do, Wv, bv, pooled):
         rc = _lib.lib().mil_absorb_query_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, None, _p(dWv), _stream())
         _lib.check(rc, "mil_absorb_query_bwd")
         return dpooled, dWv, colsum(do, out=dbv)
+    sh = _lib.shim()
+    if sh is not None:
+        sh.value_proj_bwd(do, Wv, pooled, dpooled, dWv, dbv, _stream_int())
+        return dpooled, dWv, dbv
     rc = _lib.lib().mil_value_proj_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, _p(dpooled), _p(dWv), _p(dbv), _stream())
     _lib.check(rc, "mil_value_proj_bwd")
     return dpooled, dWv, dbv

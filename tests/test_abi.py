@@ -71,3 +71,18 @@ def test_struct_layouts_match_the_header(tmp_path, cname, pyname):
     assert int(out["sizeof"]) == ctypes.sizeof(st)
     for f in fields:
         assert int(out[f]) == getattr(st, f).offset, f
+
+
+def test_torch_cpp_extension_shim_loads_and_binds_the_same_abi():
+    """csrc/torch_shim.cpp (built by __graft_entry__.build()): the torch cpp_extension binding north_star names, over the same
+    extern "C" entries.  Loads without a GPU and reports the library's ABI version; no compute here."""
+    import os
+    import pytest
+    from mil_amd import _lib
+    if not os.path.exists(os.path.join(_lib.SHIM_DIR, "mil_torch_shim.so")):
+        pytest.skip("shim not built (run __graft_entry__.build())")
+    sh = _lib.shim()
+    assert sh is not None and sh.abi_version() == _lib.ABI_VERSION
+    for name in ("linear_small_fwd", "linear_small_bwd", "layernorm_fwd", "layernorm_bwd_res", "absorb_query",
+                 "absorb_query_bwd", "value_proj_bwd"):
+        assert callable(getattr(sh, name))

@@ -48,3 +48,23 @@ def test_small_linear_partial_grads_and_limits():
     rc = _lib.lib().mil_linear_small_fwd(x.data_ptr(), 512, W.data_ptr(), 512, None, 0, None, 0, y.data_ptr(), 256,
                                          65, 256, 512, None)
     assert rc == -22                                        # more rows than MIL_SMALL_ROWS: refused, not truncated
+
+
+def test_cpp_extension_binding_equals_the_ctypes_binding():
+    """The same C entry through csrc/torch_shim.cpp (torch cpp_extension) and through ctypes: identical bits."""
+    from mil_amd import _lib
+    if _lib.shim() is None:
+        pytest.skip("torch shim not built")
+    gen = torch.Generator().manual_seed(3)
+    x, W, b = (torch.randn(s, generator=gen).cuda() for s in ((32, 512), (256, 512), (256,)))
+    dy = torch.randn((32, 256), generator=gen).cuda()
+    saved = _lib._shim
+    try:
+        y1 = ops.linear_small_fwd(x, W, b, 1)
+        g1 = ops.linear_small_bwd(dy, y1, 1, x, W, True, True, True)
+        _lib._shim = None
+        y0 = ops.linear_small_fwd(x, W, b, 1)
+        g0 = ops.linear_small_bwd(dy, y0, 1, x, W, True, True, True)
+    finally:
+        _lib._shim = saved
+    assert torch.equal(y0, y1) and all(torch.equal(a, c) for a, c in zip(g0, g1))
