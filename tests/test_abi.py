@@ -81,7 +81,13 @@ def test_torch_cpp_extension_shim_loads_and_binds_the_same_abi():
     from mil_amd import _lib
     if not os.path.exists(os.path.join(_lib.SHIM_DIR, "mil_torch_shim.so")):
         pytest.skip("shim not built (run __graft_entry__.build())")
-    sh = _lib.shim()
+    os.environ["MIL_TORCH_SHIM"] = "1"               # opt-in (it measured no faster than ctypes)
+    _lib._shim = False
+    try:
+        sh = _lib.shim()
+    finally:
+        os.environ.pop("MIL_TORCH_SHIM", None)
+        _lib._shim = False
     assert sh is not None and sh.abi_version() == _lib.ABI_VERSION
     for name in ("linear_small_fwd", "linear_small_bwd", "layernorm_fwd", "layernorm_bwd_res", "absorb_query",
                  "absorb_query_bwd", "value_proj_bwd"):

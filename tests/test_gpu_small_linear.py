@@ -52,8 +52,16 @@ def test_small_linear_partial_grads_and_limits():
 
 def test_cpp_extension_binding_equals_the_ctypes_binding():
     """The same C entry through csrc/torch_shim.cpp (torch cpp_extension) and through ctypes: identical bits."""
+    import os
     from mil_amd import _lib
-    if _lib.shim() is None:
+    os.environ["MIL_TORCH_SHIM"] = "1"
+    _lib._shim = False
+    try:
+        sh = _lib.shim()
+    finally:
+        os.environ.pop("MIL_TORCH_SHIM", None)
+    if sh is None:
+        _lib._shim = False
         pytest.skip("torch shim not built")
     gen = torch.Generator().manual_seed(3)
     x, W, b = (torch.randn(s, generator=gen).cuda() for s in ((32, 512), (256, 512), (256,)))
@@ -66,5 +74,5 @@ def test_cpp_extension_binding_equals_the_ctypes_binding():
         y0 = ops.linear_small_fwd(x, W, b, 1)
         g0 = ops.linear_small_bwd(dy, y0, 1, x, W, True, True, True)
     finally:
-        _lib._shim = saved
+        _lib._shim = False
     assert torch.equal(y0, y1) and all(torch.equal(a, c) for a, c in zip(g0, g1))
