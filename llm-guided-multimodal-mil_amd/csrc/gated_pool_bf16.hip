@@ -532,185 +532,6 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------- gate forward, fat waves
-// Eval-mode form of the deep pipeline with ONE wave per SIMD: the same 256 rows x 384 gate columns per workgroup, the same
-// LDS rings and LDS-DMA pieces, but four waves of 128 rows x 192 columns = 24 accumulator tiles (384 registers) each.
-// Why: per 32-k slice the eight-wave kernel reads 16 operand fragments per wave (2 A + 6 B per k-step, every fragment feeding
-// 2 or 6 MFMAs) = 128 KB of LDS reads + 40 KB of DMA writes per CU against 1536 MFMA clocks - 87 % of what the LDS can move
-// (128 B/clk), i.e. the kernel is LDS-bound before it is MFMA-bound.  A 4 x 6 wave tile needs 10 fragments per 24 MFMAs:
-// 80 + 40 KB per slice = 61 %.
-// 384 accumulator registers do not fit the 256 AGPRs, and left to itself hipcc shuttles tiles between the register files
-// around every MFMA (round 1: 240 us).  Here the MFMAs are inline asm whose accumulator operand is constrained per tile -
-// 16 tiles "+a" (AGPR), 8 tiles "+v" (VGPR) - so every tile has ONE home for the whole loop (checked in the ISA: no
-// v_accvgpr_* in the loop).  The hazard recogniser cannot see inside the asm: explicit s_nop after the zero-fill and
-// before the epilogue reads the accumulators.  Same k order per output as the eight-wave kernel: bit-identical results.
-// MEASURED (tools/kbench_fat.py, config 5, same box, one process each): 124 us against 110 us for the eight-wave kernel
-// without saved gates, 152 against 136 with them - the register trick works (main loop: 48 MFMAs, 20 ds_read_b128, 10 DMA
-// pieces, nothing else), but a lone in-order wave per SIMD exposes what a second wave used to cover: after every slice
-// barrier the first fragments of the new slice (6 reads, ~250 clk of 1536) and any lateness of a DMA piece stall the
-// matrix pipe outright.  Reading the next slice's first fragments BEFORE the barrier needs its pieces landed one slice
-// earlier, i.e. one more slot in both rings (176 KB > the 160 KB of LDS at 256 rows).  So it stays an opt-in experiment
-// (MIL_BF16_FAT=1) and the record of how to give hipcc more than 256 accumulator registers.
-#define FAT_IN_V(q, c) ((q) == 3 || ((q) == 2 && (c) == 2))
-#define FAT_MFMA(ACC, A, B, INV)                                                                             \
-    do {                                                                                                     \
-        if (INV) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B));       \
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B));           \
-    } while (0)
-
-template <int GMODE>      // saved gates: 0 none, 2 bf16 [R, 384]
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gate_fwd_bf16_fat(
-    const u16* __restrict__ x, const u16* __restrict__ Wv, const float* __restrict__ bv, const u16* __restrict__ Wu,
-    const float* __restrict__ bu, const float* __restrict__ wvec, const float* __restrict__ battn, float* __restrict__ scores,
-    int R, int L, u16* __restrict__ gates16) {
-    __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + HC_NW * HC_WS];      // 64 + 72 KB
-    u16* xring = smem;
-    u16* wring = smem + HC_NX * HC_XS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * HC_TM;
-    // DMA pieces of 16 rows x 64 B: x 16 per slice (wave takes w + 4 i, i < 4), weights 24 (w + 4 i, i < 6)
-    const int prow = lane >> 2, pch = lane & 3;
-    const u16* xsrc[4];
-    const u16* wsrc[6];
-    unsigned xdst[4], wdst[6];
-    const unsigned lds0 = (unsigned)(uintptr_t)(hb_lds_void*)smem;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = wave + 4 * i, lr = 16 * p + prow;
-        const int gr = min(row0 + lr, R - 1);
-        xsrc[i] = x + (size_t)gr * L + 8 * (pch ^ ((lr >> 2) & 3));
-        xdst[i] = __builtin_amdgcn_readfirstlane(lds0 + 2u * (unsigned)(16 * p * HC_BK));
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int p = wave + 4 * i, wrow = 16 * p + prow;
-        wsrc[i] = (wrow < 192 ? Wv + (size_t)wrow * L : Wu + (size_t)(wrow - 192) * L) + 8 * (pch ^ ((wrow >> 2) & 3));
-        wdst[i] = __builtin_amdgcn_readfirstlane(lds0 + 2u * (unsigned)(HC_NX * HC_XS + 16 * p * HC_BK));
-    }
-    auto dma_x = [&](int i, int slot, int k0) { dma16_raw(xsrc[i] + k0, xdst[i] + 2u * (unsigned)(slot * HC_XS)); };
-    auto dma_w = [&](int i, int slot, int k0) { dma16_raw(wsrc[i] + k0, wdst[i] + 2u * (unsigned)(slot * HC_WS)); };
-
-    f32x16 acc[4][3][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[q][c][u][i] = 0.f;
-
-    const int nslice = L / HC_BK;
-#pragma unroll
-    for (int qq = 0; qq < HC_NX - 1; ++qq) {
-        const int k0 = min(qq, nslice - 1) * HC_BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma_x(i, qq, k0);
-    }
-#pragma unroll
-    for (int qq = 0; qq < HC_NW - 1; ++qq) {
-        const int k0 = min(qq, nslice - 1) * HC_BK;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dma_w(i, qq, k0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-
-    const int fx = (r >> 2) & 3;
-    int xs = 0, wsl = 0;
-    for (int s = 0; s < nslice; ++s) {
-        const int kw = min(s + HC_NW - 1, nslice - 1) * HC_BK, kx = min(s + HC_NX - 1, nslice - 1) * HC_BK;
-        const int xnew = xs == 0 ? HC_NX - 1 : xs - 1;
-        const int wnew = wsl == 0 ? HC_NW - 1 : wsl - 1;
-        const u16* xa = xring + xs * HC_XS + (128 * wr + r) * HC_BK;
-        const u16* wb = wring + wsl * HC_WS + (96 * wc + r) * HC_BK;
-        u16x8 a[2][4], bs[3];
-        auto read_a = [&](int ks) {
-            const int ch = 8 * ((2 * ks + h) ^ fx);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[ks][q] = *reinterpret_cast<const u16x8*>(xa + 32 * q * HC_BK + ch);
-        };
-        auto read_b = [&](int j) {
-            const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
-            const int ch = 8 * ((2 * ks + h) ^ fx);
-            bs[j % 3] = *reinterpret_cast<const u16x8*>(wb + (u * 192 + 32 * c) * HC_BK + ch);
-        };
-        read_a(0);
-        read_b(0);
-        read_b(1);
-        // 12 B fragments per slice, each feeding the 4 row tiles; weight pieces of slice s + 2 first, x pieces of s + 3 last
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            if (j + 2 < 12) read_b(j + 2);
-            if (j == 2) read_a(1);
-            if (j < 6) dma_w(j, wnew, kw);
-            if (j >= 7 && j < 11) dma_x(j - 7, xnew, kx);
-            const int ks = j / 6, c = (j % 6) >> 1, u = j & 1;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) FAT_MFMA(acc[q][c][u], a[ks][q], bs[j % 3], FAT_IN_V(q, c));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // in order: x(s+1) [slice s-2] | W(s+1) 6, x(s+2) 4 [slice s-1] | W(s+2) 6, x(s+3) 4 [this slice]: all but the last
-        // 14 operations have landed = the weights and x of slice s + 1
-        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        xs = xs == HC_NX - 1 ? 0 : xs + 1;
-        wsl = wsl == HC_NW - 1 ? 0 : wsl + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // tail pieces landed; last MFMAs retired
-    __builtin_amdgcn_s_barrier();
-
-    float* sred = reinterpret_cast<float*>(smem) + 8 * (32 * 192) / 2;       // [2][256], behind the gate tiles
-    u16* tile_lds = smem + wave * (32 * 192);                               // this wave's [32][192] bf16 tile (12 KB)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float part[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) part[i] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int d = 32 * (3 * wc + c) + r;
-            const float bvd = bv[d], bud = bu[d], wd = wvec[d];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = fast_tanh(acc[q][c][0][i] + bvd);
-                const float u = fast_sigmoid(acc[q][c][1][i] + bud);
-                part[i] += wd * v * u;
-                if (GMODE == 2) {
-                    u16* t = tile_lds + mfma32_row(i, h) * 192 + 32 * c + r;
-                    t[0] = __builtin_bit_cast(u16, (__bf16)v);
-                    t[96] = __builtin_bit_cast(u16, (__bf16)u);
-                }
-            }
-        }
-        if (GMODE == 2) {
-            const int row_base = row0 + 128 * wr + 32 * q;
-#pragma unroll
-            for (int n = 0; n < 12; ++n) {
-                const int k = lane + 64 * n, row = k / 24, ch = k % 24;
-                const u16x8 vv = *reinterpret_cast<const u16x8*>(tile_lds + row * 192 + 8 * ch);
-                if (row_base + row < R)
-                    *reinterpret_cast<u16x8*>(gates16 + (size_t)(row_base + row) * HB_NG + (ch / 12) * 192 + 96 * wc + 8 * (ch % 12)) = vv;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = half_sum_lane31(part[i]);
-            if (r == 31) sred[wc * HC_TM + 128 * wr + 32 * q + mfma32_row(i, h)] = v;
-        }
-    }
-    __syncthreads();
-    {
-        const int gr = row0 + tid;
-        if (gr < R) scores[gr] = sred[tid] + sred[HC_TM + tid] + battn[0];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------- pool stages, bf16 x
 // Lane l owns the 8 columns 8l + 512q of a row (16-byte loads); NQ = L / 512.
 template <int NQ, bool DROP, bool NT>     // DROP: train mode (keep-bit tensors); the eval instantiation carries none of it.  NT: as k_pool_partial
@@ -1121,195 +942,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-#if defined(WB_ROLESPLIT)
-// EXPERIMENT, not built into the product (tools/build_variants.sh "-DWB_ROLESPLIT ..." + tools/kbench_dw16.py): producer /
-// consumer wave roles, see DESIGN.md (bf16 section).  Waves 0-3: transposed fragment reads + MFMA only; waves 4-7: staging
-// of x and dPre with RS_SETS register sets (loads RS_SETS slices ahead).  Measured at config 5 against the kernel above
-// (175-198 us in that harness): 203-205 us with one or two sets alike; no LDS writes / no staging at all 90 us (the
-// consumer loop alone), no global loads in the loop 108 us, no x staging 141 us, no gate staging 133 us - the producers'
-// global loads are what the time goes into, independent of how far ahead they are issued.  Partial tiles come out
-// intermittently wrong in a few workgroups (bias sums always right): the LDS hand-over between the roles has a race that
-// was not found - one more reason this stays an experiment.
-__global__ __launch_bounds__(512) void k_gate_bwd_dw_bf16_rs(const u16* __restrict__ x, const u16* __restrict__ gates,
-                                                             const float* __restrict__ ds, const float* __restrict__ wvec,
-                                                             float* __restrict__ part, float* __restrict__ pbias, int R, int L,
-                                                             int KC, int NJ) {
-    __shared__ __attribute__((aligned(16))) u16 smem[2 * (WB_BKR * WB_S + WB_BKR * 2 * WB_S)];
-    constexpr int ASZ = WB_BKR * WB_S, BSZ = WB_BKR * 2 * WB_S;
-    u16* ab = smem;
-    u16* xb = smem + 2 * ASZ;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    }
-    const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
-    const int j0 = jt * 256;
-    const int rbeg = s * KC, rend = min(R, rbeg + KC);
-    const int nslice = (rend - rbeg + WB_BKR - 1) / WB_BKR;
-    if (wave >= 4) {
-        const int tid = threadIdx.x - 256;
-        const int xrow = tid >> 5, xc = tid & 31;
-        const int arow = tid >> 4, ad4 = tid & 15;
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
-        // RS_SETS register sets: slice q lives in set q % RS_SETS from its loads (issued RS_SETS slices ahead) until it is
-        // written to its LDS stage.  (At most 20 x RS_SETS loads in flight per wave: the vmcnt counter has 6 bits.)
-#if !defined(RS_SETS)
-#define RS_SETS 2
-#endif
-        u16x8 rx[RS_SETS][8];
-        ushort4 hv[RS_SETS][4], hu[RS_SETS][4];
-        float rds[RS_SETS][4], rmask[RS_SETS][4];
-        f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
-        float acc_ds = 0.f;
-        auto load_slice = [&](auto set_c, int q) {               // slice q of the chunk (x rows clamped, dPre rows masked)
-            constexpr int z = decltype(set_c)::value;
-            const int rs = rbeg + q * WB_BKR;
-            const int rsx = rbeg + min(q, max(nslice - 1, 0)) * WB_BKR;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gr = min(rsx + xrow + 8 * i, rend - 1);
-                rx[z][i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gr = rs + arow + 16 * i;
-                const int gc = min(gr, rend - 1);
-                const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
-                hv[z][i] = *reinterpret_cast<const ushort4*>(gp);
-                hu[z][i] = *reinterpret_cast<const ushort4*>(gp + 192);
-                rds[z][i] = ds[gc];
-                rmask[z][i] = gr < rend ? 1.f : 0.f;
-            }
-        };
-        auto write_slice = [&](auto set_c, int buf) {
-            constexpr int z = decltype(set_c)::value;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
-                *reinterpret_cast<u16x8*>(dst) = rx[z][i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 v = {bf16_to_f32(hv[z][i].x), bf16_to_f32(hv[z][i].y), bf16_to_f32(hv[z][i].z), bf16_to_f32(hv[z][i].w)};
-                const f32x4 u = {bf16_to_f32(hu[z][i].x), bf16_to_f32(hu[z][i].y), bf16_to_f32(hu[z][i].z), bf16_to_f32(hu[z][i].w)};
-                const float dsv = rds[z][i] * rmask[z][i];
-                const f32x4 a = (dsv * w4) * u;
-                const f32x4 tt = a * v;
-                const f32x4 pv = a - tt * v;
-                const f32x4 pu = tt - tt * u;
-                u16* dst = ab + buf * ASZ + (arow + 16 * i) * WB_S + 4 * ad4;
-                *reinterpret_cast<ushort4*>(dst) = pack_bf16x4(pv);
-                *reinterpret_cast<ushort4*>(dst + 64) = pack_bf16x4(pu);
-                acc_bv += pv;
-                acc_bu += pu;
-                acc_w += (dsv * v) * u;
-                if (ad4 == 0) acc_ds += dsv;
-            }
-        };
-        using Z0 = std::integral_constant<int, 0>;
-        using Z1 = std::integral_constant<int, 1>;
-        load_slice(Z0{}, 0);
-        load_slice(Z1{}, 1);
-        write_slice(Z0{}, 0);
-        load_slice(Z0{}, 2);
-        __syncthreads();
-        // iteration sl (the consumers multiply slice sl): slice sl + 1 goes from its set to the other stage, the set takes
-        // slice sl + 3
-        auto step = [&](int sl, auto set_c) {
-            write_slice(set_c, (sl + 1) & 1);
-            load_slice(set_c, sl + 3);
-            __syncthreads();
-        };
-        {
-            int sl = 0;
-            for (; sl + 1 < nslice; sl += 2) {
-                step(sl, Z1{});
-                step(sl + 1, Z0{});
-            }
-            if (sl < nslice) step(sl, Z1{});
-        }
-        if (jt == 0) {
-            float* redf = reinterpret_cast<float*>(smem);
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                redf[(arow * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
-                redf[(arow * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
-                redf[(arow * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
-            }
-            redf[16 * 3 * 64 + tid] = acc_ds;
-            __syncthreads();
-            if (tid < 192) {
-                const int which = tid / 64, d = tid % 64;
-                float v = 0.f;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) v += redf[(g * 3 + which) * 64 + d];
-                pbias[((size_t)s * 4 + which) * 192 + 64 * m + d] = v;
-            }
-            if (m == 0 && tid == 0) {
-                float v = 0.f;
-                for (int g = 0; g < 256; g += 16) v += redf[16 * 3 * 64 + g];
-                pbias[((size_t)s * 4 + 3) * 192] = v;
-            }
-        }
-        return;
-    }
-    const int wi = wave >> 1, wj = wave & 1;
-    const int h = lane >> 5;
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    const int acol = 64 * wi + 16 * tg + 4 * tp;
-    const int bcol = 16 * tg + 4 * tp;
-    __syncthreads();
-    for (int sl = 0; sl < nslice; ++sl) {
-        const int buf = sl & 1;
-        const u16* ai = ab + buf * ASZ;
-        const u16* bi = xb + buf * BSZ + wj * ASZ;
-        u16x8 fa[2][2], fb[2][4];
-        auto frags = [&](int ks, int q) {
-            const int row = 16 * ks + 8 * h + tq;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) fa[q][a] = tr_frag(ai, row, acol + 32 * a);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) fb[q][b] = tr_frag(bi, row, bcol + 32 * b);
-        };
-        frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < WB_BKR / 16; ++ks) {
-            const int q = ks & 1;
-            if (ks + 1 < WB_BKR / 16) frags(ks + 1, q ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[q][a]),
-                                                                        __builtin_bit_cast(bf16x8, fb[q][b]), acc[a][b], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int r = lane & 31;
-    float* pt = part + ((size_t)s * HB_NG + 128 * m + 64 * wi) * L + j0 + 128 * wj + r;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
-    if (jt == 0) {
-        __syncthreads();
-        __syncthreads();
-    }
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------------- host entry points
 extern "C" int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
@@ -1333,13 +965,6 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
         const dim3 grid((R + HC_TM - 1) / HC_TM);
         const hipStream_t st_ = (hipStream_t)stream;
 #define HC_LAUNCH(G, D) hipLaunchKernelGGL((k_gate_fwd_bf16_deep<G, D>), grid, dim3(512), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, gates16, xbits, xbits ? xscale : 1.0f)
-        // EXPERIMENT (MIL_BF16_FAT=1; tools/kbench_fat.py): bit-identical to the eight-wave kernel and 12 % SLOWER at config 5
-        // (124 vs 110 us without saved gates) - see the comment above k_gate_fwd_bf16_fat
-        static const bool fat = []() { const char* e = getenv("MIL_BF16_FAT"); return e != nullptr && e[0] == '1'; }();
-        if (fat && !xbits && (gates16 || !gates)) {       // eval mode, bf16 (or no) saved gates: one wave per SIMD, 24 tiles each
-            if (gates16) hipLaunchKernelGGL((k_gate_fwd_bf16_fat<2>), grid, dim3(256), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, R, L, gates16);
-            else hipLaunchKernelGGL((k_gate_fwd_bf16_fat<0>), grid, dim3(256), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, R, L, gates16);
-        } else
         if (xbits) {
             if (gates16) HC_LAUNCH(2, true); else if (gates) HC_LAUNCH(1, true); else HC_LAUNCH(0, true);
         } else {
@@ -1494,11 +1119,6 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates
     float* pbias = workspace + (size_t)S * HB_NG * L;
     const int NJ = L / 256;
     hipStream_t st = (hipStream_t)stream;
-#if defined(WB_ROLESPLIT)
-    if (xbits == nullptr)
-        hipLaunchKernelGGL(k_gate_bwd_dw_bf16_rs, dim3(S * 3 * NJ), dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ);
-    else
-#endif
     if (xbits != nullptr)
         hipLaunchKernelGGL(k_gate_bwd_dw_bf16<true>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
     else
