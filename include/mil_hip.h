@@ -673,10 +673,12 @@ int mil_cosine_embedding_loss(const float* x1, const float* x2, int B, int E, fl
  * attention pool, 32-row tiles of the multi-modal bag [patch rows | token rows at cap + b P], row -> bag with -1 on padding
  * rows) rebuilt from len_dev [B] inside the step, so one captured hipGraph per bucket serves every bag length (reference
  * regime: one ragged bag per GPU, length changing every step, dataset.py:366-393, run_train.sh:81).
- * T64 >= cap / 64 + B, T32 >= cap / 32 + B (1 + ceil(P / 32)); tile32 16-byte aligned. */
+ * T64 >= cap / 64 + B + 2 (the 64-key tile map ends in PADDING tiles {0, row0, -count} over the rows beyond the bags: empty
+ * for the pool kernels, zero-gradient rows for mil_absorbed_pool_bwd), T32 >= cap / 32 + B (1 + ceil(P / 32)); tile32
+ * 16-byte aligned; ds_zero [cap + B P] float: the bucket's score-gradient buffer, padding rows zeroed here. */
 int mil_build_fusion_segs(const int32_t* len_dev, int B, int P, int cap, int32_t* k_off, int32_t* k_bag, int32_t* tile64,
                           int32_t* bag_tile64_off, int T64, int32_t* tile32, int32_t* bag_tile32_off, int T32,
-                          int32_t* row_bag, int32_t* rows_out, void* stream);
+                          int32_t* row_bag, int32_t* rows_out, float* ds_zero, void* stream);
 
 /* In-step timing (bench.py's `roofline` / `kernels_ms`): runs the whole step `iters` times as `ngroups` consecutive
  * mil_image_only_step_run calls (groups[i] = stage mask of group i) with a HIP event recorded on `stream` between the

@@ -416,6 +416,14 @@ __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict
             dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
             dq[h][q] = f32x4{0, 0, 0, 0};
         }
+    if (nkeys < 0) {
+        // padding tile of a capacity bucket (mil_build_fusion_segs): rows key0 .. key0 - nkeys - 1 lie beyond every bag; their
+        // gradient is exactly zero and is written here, so the caller need not clear dkeys
+        for (int rr = wave; rr < -nkeys; rr += 4)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                *reinterpret_cast<f32x4*>(dkeys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = f32x4{0, 0, 0, 0};
+    }
     for (int rr = wave; rr < nkeys; rr += 4) {
         const float* adr = ad + (size_t)(key0 + rr) * 16;          // wave-uniform: scalar loads
         float a[AP_H], ds[AP_H];
@@ -463,22 +471,30 @@ __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict
     }
 }
 
-// dQp[b][h][:] = sum over the bag's tiles.  grid (B, H), block E/4
-__global__ void k_apool_bwd_merge(const float* __restrict__ pdq, const int32_t* __restrict__ bag_tile_off, int E,
-                                  float* __restrict__ dQp) {
-    const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
+// dQp[b][h][:] = sum over the bag's tiles.  grid (B, H), 1024 threads = 8 groups x E / 4 column threads: group q sums the
+// tiles g0 + q, g0 + q + 8, ... (four loads in flight), the eight partial sums are folded through LDS in group order.
+__global__ __launch_bounds__(1024) void k_apool_bwd_merge(const float* __restrict__ pdq, const int32_t* __restrict__ bag_tile_off,
+                                                          int E, float* __restrict__ dQp) {
+    __shared__ __attribute__((aligned(16))) float red[8][512];
+    const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x & 127, q = threadIdx.x >> 7;
     f32x4 acc = {0, 0, 0, 0};
     const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
-    int g = g0;
-    for (; g + 8 <= g1; g += 8) {                     // eight tile loads in flight (the merge is pure latency)
-        f32x4 t[8];
+    int g = g0 + q;
+    for (; g + 24 < g1; g += 32) {
+        f32x4 t[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(pdq + ((size_t)(g + u) * AP_H + h) * E + 4 * j4);
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(pdq + ((size_t)(g + 8 * u) * AP_H + h) * E + 4 * j4);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += t[u];
+        for (int u = 0; u < 4; ++u) acc += t[u];
     }
-    for (; g < g1; ++g) acc += *reinterpret_cast<const f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 4 * j4);
-    *reinterpret_cast<f32x4*>(dQp + ((size_t)b * AP_H + h) * E + 4 * j4) = acc;
+    for (; g < g1; g += 8) acc += *reinterpret_cast<const f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 4 * j4);
+    *reinterpret_cast<f32x4*>(&red[q][4 * j4]) = acc;
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int u = 1; u < 8; ++u) acc += *reinterpret_cast<const f32x4*>(&red[u][4 * j4]);
+        *reinterpret_cast<f32x4*>(dQp + ((size_t)b * AP_H + h) * E + 4 * j4) = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- value projection
@@ -628,63 +644,71 @@ __global__ __launch_bounds__(512) void k_value_proj_bwd(const float* __restrict_
         }
 }
 
-// k_apool_merge followed by k_value_proj in one launch: grid (B, H), 256 threads.  Threads [0, E / 4) merge the bag's tile
-// partials (k_apool_merge's arithmetic), publish pooled[b][h] to global memory (the backward needs it) and to LDS; then all
-// 256 threads form this head's C outputs of the value projection from the LDS copy.
-__global__ __launch_bounds__(256) void k_apool_merge_value(const float* __restrict__ pacc, const float* __restrict__ pml,
-                                                           const int32_t* __restrict__ bag_tile_off, int E,
-                                                           float* __restrict__ pooled, float* __restrict__ lse,
-                                                           const float* __restrict__ Wv, const float* __restrict__ bv, int C,
-                                                           float* __restrict__ o) {
-    __shared__ __attribute__((aligned(16))) float pl[1024];
+// k_apool_merge followed by k_value_proj in one launch: grid (B, H), 1024 threads = 8 groups x E / 4 column threads.
+// Group q merges the bag's tiles g0 + q, g0 + q + 8, ... against the bag-wide maximum (formed first by all threads), the
+// eight partial sums are folded through LDS in group order; pooled[b][h] goes to global memory (the backward needs it) and
+// stays in LDS for the head's C outputs of the value projection (first 256 threads).  With ONE long bag per batch (the
+// authors' regime: ~200 tiles) the single-group form walked every tile in turn: 31 us per attention site.
+#define AMV_G 8
+__global__ __launch_bounds__(1024) void k_apool_merge_value(const float* __restrict__ pacc, const float* __restrict__ pml,
+                                                            const int32_t* __restrict__ bag_tile_off, int E,
+                                                            float* __restrict__ pooled, float* __restrict__ lse,
+                                                            const float* __restrict__ Wv, const float* __restrict__ bv, int C,
+                                                            float* __restrict__ o) {
+    __shared__ __attribute__((aligned(16))) float pl[AMV_G][512];
+    __shared__ float lred[AMV_G], mred[16];
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, H = AP_H, I = H * C;
-    if (tid < E / 4) {
-        const int j4 = tid;
-        const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
-        float m = -INFINITY;
-        {
-            int g = g0;
-            for (; g + 8 <= g1; g += 8) {
-                float t[8];
+    const int j4 = tid & 127, q = tid >> 7;                   // E == 512: 128 column threads per group
+    const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
+    float m = -INFINITY;
+    for (int g = g0 + tid; g < g1; g += 1024) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
+    m = wave_allmax(m);
+    if ((tid & 63) == 0) mred[tid >> 6] = m;
+    __syncthreads();
+    m = mred[0];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = pml[((size_t)(g + u) * AP_H + h) * 2];
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, mred[w]);
+    float l = 0.f;
+    f32x4 acc = {0, 0, 0, 0};
+    {
+        int g = g0 + q;
+        for (; g + 3 * AMV_G < g1; g += 4 * AMV_G) {          // four tiles of this group in flight
+            float2 ml[4];
+            f32x4 t[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) m = fmaxf(m, t[u]);
+            for (int u = 0; u < 4; ++u) {
+                ml[u] = *reinterpret_cast<const float2*>(pml + ((size_t)(g + AMV_G * u) * AP_H + h) * 2);
+                t[u] = *reinterpret_cast<const f32x4*>(pacc + ((size_t)(g + AMV_G * u) * AP_H + h) * E + 4 * j4);
             }
-            for (; g < g1; ++g) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
-        }
-        float l = 0.f;
-        f32x4 acc = {0, 0, 0, 0};
-        {
-            int g = g0;
-            for (; g + 8 <= g1; g += 8) {
-                float2 ml[8];
-                f32x4 t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    ml[u] = *reinterpret_cast<const float2*>(pml + ((size_t)(g + u) * AP_H + h) * 2);
-                    t[u] = *reinterpret_cast<const f32x4*>(pacc + ((size_t)(g + u) * AP_H + h) * E + 4 * j4);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float sc = __expf(ml[u].x - m);
-                    l += sc * ml[u].y;
-                    acc += sc * t[u];
-                }
-            }
-            for (; g < g1; ++g) {
-                const float sc = __expf(pml[((size_t)g * AP_H + h) * 2] - m);
-                l += sc * pml[((size_t)g * AP_H + h) * 2 + 1];
-                acc += sc * *reinterpret_cast<const f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 4 * j4);
+            for (int u = 0; u < 4; ++u) {
+                const float sc = __expf(ml[u].x - m);
+                l += sc * ml[u].y;
+                acc += sc * t[u];
             }
         }
-        const float inv = g1 > g0 ? 1.0f / l : 0.f;
-        const f32x4 pv4 = acc * inv;
-        *reinterpret_cast<f32x4*>(pooled + ((size_t)b * AP_H + h) * E + 4 * j4) = pv4;
-        *reinterpret_cast<f32x4*>(pl + 4 * j4) = pv4;
-        if (j4 == 0) lse[b * AP_H + h] = g1 > g0 ? m + logf(l) : -INFINITY;
+        for (; g < g1; g += AMV_G) {
+            const float sc = __expf(pml[((size_t)g * AP_H + h) * 2] - m);
+            l += sc * pml[((size_t)g * AP_H + h) * 2 + 1];
+            acc += sc * *reinterpret_cast<const f32x4*>(pacc + ((size_t)g * AP_H + h) * E + 4 * j4);
+        }
+    }
+    *reinterpret_cast<f32x4*>(&pl[q][4 * j4]) = acc;
+    if (j4 == 0) lred[q] = l;
+    __syncthreads();
+    if (q == 0) {                                              // pl[0] is this group's own slot: nobody else reads it
+        f32x4 v = acc;
+        float lt = lred[0];
+#pragma unroll
+        for (int u = 1; u < AMV_G; ++u) { v += *reinterpret_cast<const f32x4*>(&pl[u][4 * j4]); lt += lred[u]; }
+        const float inv = g1 > g0 ? 1.0f / lt : 0.f;
+        v = v * inv;
+        *reinterpret_cast<f32x4*>(pooled + ((size_t)b * AP_H + h) * E + 4 * j4) = v;
+        if (j4 == 0) lse[b * AP_H + h] = g1 > g0 ? m + logf(lt) : -INFINITY;
+        *reinterpret_cast<f32x4*>(&pl[0][4 * j4]) = v;
     }
     __syncthreads();
+    if (tid >= 256) return;
     const int per = 256 / C, c = tid / per, part = tid % per;
     const float* w = Wv + (size_t)(h * C + c) * E;
     float v = 0.f;
@@ -693,7 +717,7 @@ __global__ __launch_bounds__(256) void k_apool_merge_value(const float* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = min(j0 + 4 * per * u, E - 4);
-            gv[u] = *reinterpret_cast<const f32x4*>(pl + j);
+            gv[u] = *reinterpret_cast<const f32x4*>(&pl[0][j]);
             wv[u] = *reinterpret_cast<const f32x4*>(w + j);
         }
 #pragma unroll
@@ -931,7 +955,7 @@ extern "C" int mil_absorbed_pool_value_fwd(const float* keys, const float* pe, c
         hipLaunchKernelGGL(k_apool_partial, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml);
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_apool_merge_value, dim3(B, AP_H), dim3(256), 0, st, pacc, pml, bag_tile_off, E, pooled, lse, Wv, bv, C, o);
+    hipLaunchKernelGGL(k_apool_merge_value, dim3(B, AP_H), dim3(1024), 0, st, pacc, pml, bag_tile_off, E, pooled, lse, Wv, bv, C, o);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -966,7 +990,7 @@ extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const f
                            dkeys_acc, dkeys, pdq);
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(E / 4), 0, st, pdq, bag_tile_off, E, dQp);
+    hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(1024), 0, st, pdq, bag_tile_off, E, dQp);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

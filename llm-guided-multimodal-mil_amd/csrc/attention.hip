@@ -728,7 +728,19 @@ __global__ __launch_bounds__(1024) void k_layernorm_bagrow_fold(const float* __r
     const int lo = row_off[bag], hi = row_off[bag + 1];
     if (hi > lo) {
         const int b0 = lo / rows_per_blk, b1 = (hi - 1) / rows_per_blk;
-        for (int b = b0 + g; b <= b1; b += 16) {
+        int b = b0 + g;
+        // four (bag lookup, partial) pairs in flight per wave: with ONE long bag per batch (the authors' regime) a single
+        // workgroup column walks all 512 blocks, two dependent loads each - 18 us when taken one at a time
+        for (; b + 48 <= b1; b += 64) {
+            int rb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rb[u] = row_bag[(b + 16 * u) * rows_per_blk];
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = part[(size_t)(b + 16 * u) * st + (size_t)(rb[u] == bag ? 2 : 3) * E + c];
+            v += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+        for (; b <= b1; b += 16) {
             const int slot = row_bag[b * rows_per_blk] == bag ? 2 : 3;
             v += part[(size_t)b * st + (size_t)slot * E + c];
         }
@@ -1085,7 +1097,9 @@ extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float
 // Outputs:
 //   k_off [B + 1], k_bag [cap] (padding rows: B - 1, a valid index for row-wise kernels whose gradient there is zero)
 //   tile64 [T64][3] = {bag, row0, nkeys}: 64-key tiles of the absorbed attention pool, bag_tile64_off [B + 1]; tiles past
-//     the last real one are {0, 0, 0} (the kernels emit neutral partials for nkeys == 0 and no bag's merge reads them)
+//     the last real one are padding tiles {0, row0, -count} over the rows [N, cap) (the kernels emit neutral partials for
+//     nkeys <= 0, no bag's merge reads them, the apply pass zeroes those rows' gradient) or {0, 0, 0}
+//   ds_zero [cap + B P]: the ABMIL score-gradient buffer of the bucket; its padding rows are zeroed here
 //   tile32 [T32][4] = {bag, row0, nrows, 0}: the ABMIL pool's tiles, per bag its patch tiles then its token tiles
 //     (bags.BagLayout.two_segment), bag_tile32_off [B + 1], padding tiles {0, 0, 0, 0}
 //   row_bag [cap + B P]: bag of every row of the multi-modal bag, -1 for padding rows (mil_gate_bwd_input_pool)
@@ -1095,7 +1109,8 @@ __global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __res
                                                             int32_t* __restrict__ tile64, int32_t* __restrict__ bag_tile64_off,
                                                             int T64, int32_t* __restrict__ tile32,
                                                             int32_t* __restrict__ bag_tile32_off, int T32,
-                                                            int32_t* __restrict__ row_bag, int32_t* __restrict__ rows_out) {
+                                                            int32_t* __restrict__ row_bag, int32_t* __restrict__ rows_out,
+                                                            float* __restrict__ ds_zero) {
     __shared__ int s_row[1025], s_t64[1025], s_t32[1025];
     const int tid = threadIdx.x;
     const int tokt = (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
@@ -1144,20 +1159,31 @@ __global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __res
         for (int r = tid; r < P; r += 1024) row_bag[cap + b * P + r] = b;
     }
     for (int r = N + tid; r < cap; r += 1024) { k_bag[r] = B - 1; row_bag[r] = -1; }
-    for (int t = s_t64[B] + tid; t < T64; t += 1024) { tile64[3 * t] = 0; tile64[3 * t + 1] = 0; tile64[3 * t + 2] = 0; }
+    // behind the real 64-key tiles: PADDING tiles {0, row0, -count} that cover the rows [N, cap) - empty for every pool
+    // kernel (nkeys <= 0), and the backward's apply pass writes the zero gradient of those rows from them (no fill launch)
+    for (int t = s_t64[B] + tid; t < T64; t += 1024) {
+        const int i = t - s_t64[B];
+        const int r0 = i == 0 ? N : ((N + 63) / 64 + (i - 1)) * 64;       // first: N .. next multiple of 64, then whole blocks
+        const int r1 = i == 0 ? min(cap, (N + 63) / 64 * 64) : min(cap, r0 + 64);
+        const bool live = r0 < cap && r1 > r0;
+        tile64[3 * t] = 0; tile64[3 * t + 1] = live ? r0 : 0; tile64[3 * t + 2] = live ? -(r1 - r0) : 0;
+    }
+    for (int r = N + tid; r < cap + B * P; r += 1024) if (r < cap) ds_zero[r] = 0.f;      // score gradient of padding rows
     for (int t = s_t32[B] + tid; t < T32; t += 1024) reinterpret_cast<int4*>(tile32)[t] = make_int4(0, 0, 0, 0);
 }
 
 extern "C" int mil_build_fusion_segs(const int32_t* len_dev, int B, int P, int cap, int32_t* k_off, int32_t* k_bag,
                                      int32_t* tile64, int32_t* bag_tile64_off, int T64, int32_t* tile32,
-                                     int32_t* bag_tile32_off, int T32, int32_t* row_bag, int32_t* rows_out, void* stream) {
-    if (!len_dev || !k_off || !k_bag || !tile64 || !bag_tile64_off || !tile32 || !bag_tile32_off || !row_bag || !rows_out)
+                                     int32_t* bag_tile32_off, int T32, int32_t* row_bag, int32_t* rows_out, float* ds_zero,
+                                     void* stream) {
+    if (!len_dev || !k_off || !k_bag || !tile64 || !bag_tile64_off || !tile32 || !bag_tile32_off || !row_bag || !rows_out ||
+        !ds_zero)
         return MIL_EINVAL;
-    if (B <= 0 || B > 1024 || P <= 0 || cap <= 0 || T64 < cap / 64 + B || T32 < cap / MIL_POOL_TILE + B * (1 + (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE))
+    if (B <= 0 || B > 1024 || P <= 0 || cap <= 0 || T64 < cap / 64 + B + 2 || T32 < cap / MIL_POOL_TILE + B * (1 + (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE))
         return MIL_EINVAL;
     if (reinterpret_cast<uintptr_t>(tile32) & 15) return MIL_EINVAL;
     hipLaunchKernelGGL(k_build_fusion_segs, dim3(1), dim3(1024), 0, (hipStream_t)stream, len_dev, B, P, cap, k_off, k_bag, tile64,
-                       bag_tile64_off, T64, tile32, bag_tile32_off, T32, row_bag, rows_out);
+                       bag_tile64_off, T64, tile32, bag_tile32_off, T32, row_bag, rows_out, ds_zero);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

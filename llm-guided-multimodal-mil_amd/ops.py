@@ -142,8 +142,11 @@ def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: 
         out.update(dz=torch.empty((B, C), device=dev), dM=torch.empty((B, L), device=dev),
                    cdot=torch.empty(B, device=dev), loss_bag=torch.empty(B, device=dev))
         if hrow is not None and scores is not None:
-            # capacity bucket (segments.FusionBucket): rows outside every tile are padding and must read ds = 0
-            out["ds"] = (torch.zeros if getattr(layout, "device_lengths", False) else torch.empty)(scores.shape[0], device=dev)
+            # capacity bucket (segments.FusionBucket): rows outside every tile are padding and must read ds = 0 - the bucket
+            # owns the buffer and its refresh() launch zeroes those rows
+            dsb = getattr(layout, "ds_buffer", None)
+            out["ds"] = dsb if (dsb is not None and dsb.shape[0] == scores.shape[0]) else \
+                (torch.zeros if getattr(layout, "device_lengths", False) else torch.empty)(scores.shape[0], device=dev)
     if mbits is not None:
         out["Mdrop"] = torch.empty((B, L), device=dev)
     rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
@@ -1382,6 +1385,15 @@ class _AbsorbQuery(torch.autograd.Function):
         return dqp, dWk, None
 
 
+def _dkeys_buffer(keys, segs):
+    """Gradient buffer of the keys for the absorbed pool's backward.  Capacity bucket (segments.FusionBucket): padding rows
+    must hand ZERO upstream (their gradient feeds LayerNorm / bias sums of the layer below) - the bucket's padding tiles
+    make the apply pass write those zeros itself; a device-length layout without them gets a cleared buffer."""
+    if getattr(segs, "device_lengths", False) and not getattr(segs, "pad_tiles", False):
+        return torch.zeros_like(keys)
+    return torch.empty_like(keys)
+
+
 class _AbsorbedPool(torch.autograd.Function):
     """pooled[b][h] = sum_n softmax_n(Qp[b][h] . (keys_n + pe_n) / sqrt(C)) keys_n.
     Also returns the keys unchanged (an alias): the caller hands THAT to the keys' other consumer, so both gradients
@@ -1414,9 +1426,7 @@ class _AbsorbedPool(torch.autograd.Function):
             return dkeys_pass, None, None, None, None
         dpooled = _f32c(dpooled, "dpooled")
         acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
-        # capacity bucket: the apply pass writes the rows of real tiles only; padding rows must hand ZERO upstream (their
-        # gradient feeds LayerNorm / bias sums of the layer below)
-        dkeys = torch.zeros_like(keys) if getattr(segs, "device_lengths", False) else torch.empty_like(keys)
+        dkeys = _dkeys_buffer(keys, segs)
         dQp = torch.empty_like(Qp)
         n_keys = keys.shape[0]
         ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)
@@ -1511,7 +1521,7 @@ class _AbsorbedPoolValue(torch.autograd.Function):
             return dkeys_pass, None, None, None, None, None, None
         dpooled, dWv, dbv = _value_proj_bwd(_f32c(do, "do"), Wv, ctx.bv_param, pooled)
         acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
-        dkeys = torch.zeros_like(keys) if getattr(segs, "device_lengths", False) else torch.empty_like(keys)
+        dkeys = _dkeys_buffer(keys, segs)
         dQp = torch.empty_like(Qp)
         n_keys = keys.shape[0]
         ws = torch.empty(max(1, segs.ntiles) * H * E + 16 * n_keys, device=keys.device, dtype=torch.float32)

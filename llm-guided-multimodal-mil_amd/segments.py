@@ -108,10 +108,12 @@ class FusionBucket:
         i32 = lambda *shape: torch.zeros(shape, device=device, dtype=torch.int32)      # noqa: E731
         self.len_dev, self.rows_dev = i32(B), i32(1)
         self.k_off, self.k_bag = i32(B + 1), i32(cap)
-        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B, cap // POOL_TILE + 2 * B
+        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B + 2, cap // POOL_TILE + 2 * B
         self.tile64, self.bag_tile64_off = i32(self.T64, 3), i32(B + 1)
         self.tile32, self.bag_tile32_off = i32(self.T32, 4), i32(B + 1)
         self.row_bag_dev = i32(cap + B * P)
+        # the ABMIL pool's score gradient: real rows are written by the fused tail, padding rows zeroed by refresh()
+        self.ds = torch.zeros(cap + B * P, device=device, dtype=torch.float32)
         self.lengths = None
         tok = AttnSegs.make([P] * B, [P] * B, device)
         self.s_tt = tok
@@ -119,12 +121,13 @@ class FusionBucket:
         # token -> image: queries = the B tokens (static), keys = the patch rows (device lengths).  Tk_max is the capacity.
         self.s_ti = _SegView(B=B, q_lengths=ones, k_lengths=None, Tq=B * P, Tk=cap, Tq_max=P, Tk_max=cap, q_off=tok.q_off,
                              q_bag=tok.q_bag, k_off=self.k_off, k_bag=self.k_bag, ntiles=self.T64, tile_map=self.tile64,
-                             bag_tile_off=self.bag_tile64_off)
+                             bag_tile_off=self.bag_tile64_off, pad_tiles=True)
         # image -> token: queries = the patch rows, keys = the tokens
         self.s_it = _SegView(B=B, q_lengths=None, k_lengths=ones, Tq=cap, Tk=B * P, Tq_max=cap, Tk_max=P, q_off=self.k_off,
                              q_bag=self.k_bag, k_off=tok.k_off, k_bag=tok.k_bag)
         self.layout = _SegView(B=B, R=cap + B * P, T=self.T32, tile_map=self.tile32, bag_tile_off=self.bag_tile32_off,
-                               bag_off=self.k_off, lengths=None, aligned32=False, row_bag=lambda: self.row_bag_dev)
+                               bag_off=self.k_off, lengths=None, aligned32=False, row_bag=lambda: self.row_bag_dev,
+                               ds_buffer=self.ds)
         self._lib = _lib
         self._min_rows = _lib.lib().mil_layernorm_bagrow_rows_per_block(cap) if B > 1 else 1
 
@@ -144,6 +147,6 @@ class FusionBucket:
         rc = self._lib.lib().mil_build_fusion_segs(p(self.len_dev), self.B, self.P, self.cap, p(self.k_off), p(self.k_bag),
                                                    p(self.tile64), p(self.bag_tile64_off), self.T64, p(self.tile32),
                                                    p(self.bag_tile32_off), self.T32, p(self.row_bag_dev), p(self.rows_dev),
-                                                   torch.cuda.current_stream().cuda_stream)
+                                                   p(self.ds), torch.cuda.current_stream().cuda_stream)
         self._lib.check(rc, "mil_build_fusion_segs")
         return lifetime.note(self)

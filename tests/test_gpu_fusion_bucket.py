@@ -43,7 +43,13 @@ def test_device_built_segments_equal_the_host_ones(lengths):
     assert torch.equal(bk.k_off.cpu(), ref.k_off.cpu())
     assert torch.equal(bk.k_bag[:N].cpu(), ref.k_bag.cpu()) and bool((bk.k_bag[N:] == B - 1).all())
     assert torch.equal(bk.bag_tile64_off.cpu(), ref.bag_tile_off.cpu())
-    assert torch.equal(bk.tile64[:ref.ntiles].cpu(), ref.tile_map.cpu()) and int(bk.tile64[ref.ntiles:].abs().sum()) == 0
+    assert torch.equal(bk.tile64[:ref.ntiles].cpu(), ref.tile_map.cpu())
+    pad = bk.tile64[ref.ntiles:].cpu()                  # padding tiles {0, row0, -count}: exactly the rows [N, cap), in order
+    covered = []
+    for bag, row0, cnt in pad.tolist():
+        assert bag == 0 and cnt <= 0
+        covered += list(range(row0, row0 - cnt))
+    assert covered == list(range(N, cap))
     lay = BagLayout.two_segment(lengths, [1] * B, DEV)
     tm = lay.tile_map.cpu().clone()
     tok = tm[:, 1] >= N                              # host layout puts the token rows right behind the N patch rows ...
