@@ -382,6 +382,22 @@ int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int l
                          const float* W, int ldw, float* dx, int lddx, float* dW, int lddw, float* db, int M, int N,
                          int K, void* stream);
 
+/* LayerNorm folded into its neighbours on the token stream (P -> LayerNorm -> C, sam/transformer.py:287-300; E = 512):
+ *   mil_linear_small_ln_fwd   C's forward with the norm applied while its operand is staged:
+ *       xn = LN(u) gamma + beta;  xin = xn + x2 (x2 nullable: queries + query_pe);  y = act(xin W^T + b) (+ residual);
+ *       writes y [M, N], xn [M, 512], xin [M, 512] (with x2 only) and stats [M, 2] = (mean, rstd).
+ *   mil_linear_small_ln_bwd   input gradient of the layer P that feeds the norm, with the norm's backward applied while its
+ *       dy operand is staged: the gradient at the norm's output is g1 + g2 (g2 nullable - what the output's other consumer
+ *       sent, no add launch), du = LN backward of it, dx = du W_P [M, K]; du [M, 512] is written out as well (residual
+ *       branch, P's weight gradient), dgamma / dbeta [512] by one extra workgroup.  dx NULL: du and the sums only.
+ * M <= MIL_SMALL_ROWS rows. */
+int mil_linear_small_ln_fwd(const float* u, int ldu, const float* gamma, const float* beta, float eps, const float* x2,
+                            int ldx2, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr,
+                            float* y, int ldy, float* xn, float* xin, float* stats, int M, int N, void* stream);
+int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* u, int ldu,
+                            const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx, float* du,
+                            float* dgamma, float* dbeta, int M, int K, void* stream);
+
 /* The weight / bias gradients of up to MIL_SMALL_DW_MAX few-rows layers in ONE launch: dW_l = (dy_l (.) act'(y_l))^T x_l,
  * db_l = its column sums (the dW half of mil_linear_small_bwd, for every queued layer at once).  The backward chain of the
  * token side then only carries the dx launches; the host queues one descriptor per layer and calls this at the end of the

@@ -236,6 +236,173 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
     sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, nullptr, SL_NONE, nullptr, 0, dx, lddx);
 }
 
+// ---------------------------------------------------------------------------------------------- LayerNorm folded into its neighbours
+// The token stream of the two-way block is a string of dependent launches, P -> LayerNorm -> C (sam/transformer.py:287-300:
+// out_proj -> norm -> next projection), each ~4 us whatever it computes.  Two kernels remove the LayerNorm launches of both
+// directions (E = 512 = one operand chunk):
+//   k_small_fwd_ln   C's forward with the norm applied while its x operand is staged:  xn = LN(u) gamma + beta,
+//                    xin = xn + x2 (optional second addend: queries + query_pe), y = act(xin W^T + b) + residual.
+//                    Every workgroup normalises its 16 rows redundantly (it loads them whole anyway: the contraction runs
+//                    over the norm's width); the workgroups of column tile 0 write xn, xin and the row statistics.
+//   k_small_bwd_ln   P's input gradient with the norm's BACKWARD applied while its dy operand is staged: the gradient that
+//                    reaches the norm's output is g1 + g2 (C's dx plus whatever the output's other consumer sent - no add
+//                    launch), du = rstd (g - mean(g) - xhat mean(g xhat)), g = (g1 + g2) gamma, dx = du W_P; the
+//                    workgroups of k tile 0 write du (the residual branch's gradient and the dy of P's deferred weight
+//                    gradient), one extra workgroup forms dgamma / dbeta over the <= 64 rows.
+#define SLN_E 512
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_small_fwd_ln(const float* __restrict__ u, int ldu, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          const float* __restrict__ x2, int ldx2,
+                                                          const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                          int act, const float* __restrict__ residual, int ldr,
+                                                          float* __restrict__ y, int ldy, float* __restrict__ xn,
+                                                          float* __restrict__ xin, float* __restrict__ stats, int M, int N) {
+    static_assert(NW == 8, "16 rows x 32 threads");
+    __shared__ float red[NW][4][64];
+    __shared__ __attribute__((aligned(16))) float opx[16 * SL_LS], opw[16 * SL_LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    constexpr int K = SLN_E, NT = 64 * NW, LPT = (16 * SL_KCH / 4) / NT;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
+        *reinterpret_cast<f32x4*>(opx + row * SL_LS + 4 * c) =
+            *reinterpret_cast<const f32x4*>(u + (size_t)min(m0 + row, M - 1) * ldu + 4 * c);
+        *reinterpret_cast<f32x4*>(opw + row * SL_LS + 4 * c) =
+            *reinterpret_cast<const f32x4*>(W + (size_t)min(n0 + row, N - 1) * ldw + 4 * c);
+    }
+    __syncthreads();
+    {
+        // row (tid >> 5) by its 32 threads: columns 4 p + 128 j
+        const int row = tid >> 5, p = tid & 31, grow = m0 + row;
+        f32x4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = *reinterpret_cast<const f32x4*>(opx + row * SL_LS + 4 * p + 128 * j);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        const float mean = s / K;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = v[j] - mean;
+            const f32x4 q = v[j] * v[j];
+            ss += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+        const float rstd = 1.0f / sqrtf(ss / K + eps);
+        const bool wr = blockIdx.x == 0 && grow < M;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * p + 128 * j;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o = v[j] * rstd * g + bt;
+            if (wr) *reinterpret_cast<f32x4*>(xn + (size_t)grow * K + c) = o;
+            if (x2 != nullptr) {
+                o += *reinterpret_cast<const f32x4*>(x2 + (size_t)min(grow, M - 1) * ldx2 + c);
+                if (wr) *reinterpret_cast<f32x4*>(xin + (size_t)grow * K + c) = o;
+            }
+            *reinterpret_cast<f32x4*>(opx + row * SL_LS + c) = o;
+        }
+        if (wr && p == 0) { stats[2 * grow] = mean; stats[2 * grow + 1] = rstd; }
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int per = (K / 16) / NW;
+    for (int blk = wave * per; blk < (wave + 1) * per; ++blk) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(opx + r * SL_LS + 16 * blk + 4 * kq);
+        const f32x4 fb = *reinterpret_cast<const f32x4*>(opw + r * SL_LS + 16 * blk + 4 * kq);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[jj], fb[jj], acc, 0, 0, 0);
+    }
+    sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, bias, act, residual, ldr, y, ldy);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restrict__ g1, int ldg1, const float* __restrict__ g2,
+                                                          int ldg2, const float* __restrict__ u, int ldu,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ W, int ldw, float* __restrict__ dx,
+                                                          int lddx, float* __restrict__ du, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int M, int K, int nX) {
+    static_assert(NW == 8, "16 rows x 32 threads");
+    __shared__ float red[NW][4][64];
+    __shared__ __attribute__((aligned(16))) float opa[16 * SL_LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int N = SLN_E;
+    if ((int)blockIdx.x >= nX) {
+        // dgamma[c] = sum_m g[m][c] xhat[m][c], dbeta[c] = sum_m g[m][c]: thread = column, the <= 64 rows in turn
+        const int c = tid;
+        float dg = 0.f, db = 0.f;
+        for (int m = 0; m < M; ++m) {
+            float g = g1[(size_t)m * ldg1 + c];
+            if (g2 != nullptr) g += g2[(size_t)m * ldg2 + c];
+            dg += g * ((u[(size_t)m * ldu + c] - stats[2 * m]) * stats[2 * m + 1]);
+            db += g;
+        }
+        if (dgamma != nullptr) { dgamma[c] = dg; dbeta[c] = db; }
+        return;
+    }
+    const int r = lane & 15, kq = lane >> 4;
+    const int nK16 = (K + 15) >> 4;
+    const int k0 = ((int)blockIdx.x % nK16) * 16, m0 = ((int)blockIdx.x / nK16) * 16;
+    const int kc = min(k0 + r, K - 1);
+    {
+        const int row = tid >> 5, p = tid & 31, grow = min(m0 + row, M - 1);
+        const float mean = stats[2 * grow], rstd = stats[2 * grow + 1];
+        f32x4 gg[4], xh[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * p + 128 * j;
+            f32x4 g = *reinterpret_cast<const f32x4*>(g1 + (size_t)grow * ldg1 + c);
+            if (g2 != nullptr) g += *reinterpret_cast<const f32x4*>(g2 + (size_t)grow * ldg2 + c);
+            xh[j] = (*reinterpret_cast<const f32x4*>(u + (size_t)grow * ldu + c) - mean) * rstd;
+            gg[j] = g * *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 t = gg[j] * xh[j];
+            s1 += (gg[j][0] + gg[j][1]) + (gg[j][2] + gg[j][3]);
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        s1 /= N;
+        s2 /= N;
+        const bool wr = k0 == 0 && m0 + row < M && du != nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * p + 128 * j;
+            const f32x4 d = rstd * (gg[j] - s1 - xh[j] * s2);
+            *reinterpret_cast<f32x4*>(opa + row * SL_LS + c) = d;
+            if (wr) *reinterpret_cast<f32x4*>(du + (size_t)(m0 + row) * N + c) = d;
+        }
+    }
+    __syncthreads();
+    if (dx == nullptr) return;
+    constexpr int per = (N / 16) / NW;
+    const int b0 = wave * per;
+    float fb[per][4];
+#pragma unroll
+    for (int uu = 0; uu < per; ++uu) {
+        const int nb = 16 * (b0 + uu) + 4 * kq;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) fb[uu][jj] = W[(size_t)(nb + jj) * ldw + kc];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int uu = 0; uu < per; ++uu) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(opa + r * SL_LS + 16 * (b0 + uu) + 4 * kq);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[jj], fb[uu][jj], acc, 0, 0, 0);
+    }
+    sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, nullptr, SL_NONE, nullptr, 0, dx, lddx);
+}
+
 // Weight / bias gradients of up to MIL_SMALL_DW_MAX few-rows layers in ONE launch (grid.y = layer): the dW role of
 // k_small_bwd, taken out of the layer-by-layer backward chain.  In the backward pass of the token side every layer's dx is
 // needed before the previous layer can start, its dW only by the optimizer: the chain launches dx alone (half the time of
@@ -363,6 +530,46 @@ extern "C" int mil_linear_small_dw_grouped(const mil_small_dw_desc* descs, int n
     }
     batch.first[n] = total;
     hipLaunchKernelGGL(k_small_dw_grouped, dim3(total), dim3(512), 0, (hipStream_t)stream, batch);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+
+// y = act((LayerNorm(u) gamma + beta [+ x2]) W^T + b) [+ residual] in ONE launch; also writes xn = the norm's output, xin =
+// xn + x2 (only with x2) and the row statistics.  u [M, 512], W [N, 512]; see k_small_fwd_ln.
+extern "C" int mil_linear_small_ln_fwd(const float* u, int ldu, const float* gamma, const float* beta, float eps,
+                                       const float* x2, int ldx2, const float* W, int ldw, const float* bias, int act,
+                                       const float* residual, int ldr, float* y, int ldy, float* xn, float* xin, float* stats,
+                                       int M, int N, void* stream) {
+    if (!u || !gamma || !beta || !W || !y || !xn || !stats || M <= 0 || M > MIL_SMALL_ROWS || N <= 0) return MIL_EINVAL;
+    if ((x2 != nullptr) != (xin != nullptr)) return MIL_EINVAL;
+    if ((ldu & 3) || (ldw & 3) || (x2 && (ldx2 & 3)) || act < 0 || act > 4) return MIL_EINVAL;
+    if (!sl_aligned16(u) || !sl_aligned16(W) || !sl_aligned16(gamma) || !sl_aligned16(beta) || !sl_aligned16(xn) ||
+        (x2 && (!sl_aligned16(x2) || !sl_aligned16(xin))))
+        return MIL_EINVAL;
+    const dim3 grid((N + 15) / 16, (M + 15) / 16);
+    hipLaunchKernelGGL((k_small_fwd_ln<SL_WAVES>), grid, dim3(64 * SL_WAVES), 0, (hipStream_t)stream, u, ldu, gamma, beta, eps, x2,
+                       ldx2, W, ldw, bias, act, residual, ldr, y, ldy, xn, xin, stats, M, N);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// Input gradient of the layer P that FEEDS a LayerNorm, with the norm's backward applied on the way in (k_small_bwd_ln):
+// g1 (+ g2) [M, 512] = gradient at the norm's output, u = P's output (the norm's input), stats from the forward;
+// dx [M, K] = du W (W = P's weight [512, K]; NULL: du only), du [M, 512] (nullable), dgamma / dbeta [512] (both or neither).
+extern "C" int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* u, int ldu,
+                                       const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,
+                                       float* du, float* dgamma, float* dbeta, int M, int K, void* stream) {
+    if (!g1 || !u || !stats || !gamma || M <= 0 || M > MIL_SMALL_ROWS) return MIL_EINVAL;
+    if ((dx != nullptr) && (!W || K <= 0)) return MIL_EINVAL;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return MIL_EINVAL;
+    if ((ldg1 & 3) || (g2 && (ldg2 & 3)) || (ldu & 3) || !sl_aligned16(g1) || (g2 && !sl_aligned16(g2)) || !sl_aligned16(u) ||
+        !sl_aligned16(gamma) || (du && !sl_aligned16(du)))
+        return MIL_EINVAL;
+    const int kt = dx ? (K + 15) / 16 : 1;
+    const int nX = kt * ((M + 15) / 16);
+    hipLaunchKernelGGL((k_small_bwd_ln<SL_WAVES>), dim3(nX + (dgamma ? 1 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
+                       g2, ldg2, u, ldu, stats, gamma, W, ldw, dx, lddx, du, dgamma, dbeta, M, dx ? K : 16, nX);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

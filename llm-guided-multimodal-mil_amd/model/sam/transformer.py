@@ -115,6 +115,8 @@ class TwoWayAttentionBlock(nn.Module):
         """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe.  With pe_table
         given and exactly one text token per bag, both cross attentions take their one-token forms and keys + pe is
         never materialised."""
+        if self._one_token_fused_ok(queries, s_tt, s_ti, s_it, pe_table):
+            return self._flat_one_token_fused(queries, keys, query_pe, s_ti, s_it, pe_table, keys_tail_rows)
         if s_tt.Tk_max == 1 and min(s_tt.k_lengths, default=1) == 1:
             # One text token per bag: self-attention over a single key returns that key's value whatever q and k
             # are (softmax of one score = 1), so :282-287 reduce to out_proj(v_proj(queries)) and q_proj / k_proj
@@ -164,6 +166,41 @@ class TwoWayAttentionBlock(nn.Module):
                 k = keys_pe_fn(keys)
             keys = self.norm4(self.cross_attn_image_to_token.flat(k, q, queries, s_it, "rows", residual=keys), keys_tail_rows)
         return queries, keys
+
+    # ------------------------------------------------------------------ one text token per bag: the token stream in fused links
+    def _one_token_fused_ok(self, queries, s_tt, s_ti, s_it, pe_table) -> bool:
+        a, t2i, i2t = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token
+        return (s_tt.Tk_max == 1 and min(s_tt.k_lengths, default=1) == 1 and one_token_ok(t2i, s_ti, pe_table)
+                and s_it.Tk_max == 1 and min(s_it.k_lengths, default=1) == 1
+                and ops.lin_ln_lin_ok(queries, a.out_proj.weight, self.norm1.weight, t2i.q_proj.weight)
+                and t2i.out_proj.weight.shape == (512, t2i.internal_dim) and t2i.internal_dim % 16 == 0
+                and self.mlp.act == "relu" and self.mlp.lin1.weight.shape[1] == 512 and self.mlp.lin2.weight.shape[0] == 512
+                and i2t.v_proj.weight.shape[1] == 512 and all(n.eps == self.norm1.eps for n in (self.norm2, self.norm3)))
+
+    def _flat_one_token_fused(self, queries, keys, query_pe, s_ti, s_it, pe_table, keys_tail_rows):
+        """The block for ONE text token per bag (the reference's `CI_prompt_version='single'`) with the token stream in three
+        fused links P -> LayerNorm -> C (ops.lin_ln_lin: the norm rides in the operand load of the layer behind it, its
+        backward in the operand load of the layer in front of it, gradient sums of two-consumer tensors inside the kernels):
+          self-attention over one key = out_proj(v_proj(q)) (:282-287)  -> norm1 -> q_proj of the token->image attention (:291-295)
+          absorbed pool + value projection (one node)                   -> its out_proj + residual -> norm2 -> mlp.lin1 (:298)
+          mlp.lin2 + residual -> norm3 -> v_proj of the image->token attention (:303-307), out_proj, then LayerNorm(keys + row).
+        Same arithmetic as the op-by-op route up to summation order; 11 launches less per block and step."""
+        a, t2i, i2t, mlp = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token, self.mlp
+        _zero_grad_params(a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, t2i.k_proj.bias,
+                          i2t.q_proj.weight, i2t.q_proj.bias, i2t.k_proj.weight, i2t.k_proj.bias)
+        eps = self.norm1.eps
+        vp = ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias)
+        qp, q1 = ops.lin_ln_lin(vp, a.out_proj.weight, a.out_proj.bias, None if self.skip_first_layer_pe else queries,
+                                self.norm1.weight, self.norm1.bias, eps, query_pe, t2i.q_proj.weight, t2i.q_proj.bias)
+        o, keys = ops.one_token_attention(None, keys, pe_table, s_ti, t2i.q_proj.weight, t2i.q_proj.bias, t2i.k_proj.weight,
+                                          t2i.v_proj.weight, t2i.v_proj.bias, t2i.num_heads, qp=qp)
+        h, q2 = ops.lin_ln_lin(o, t2i.out_proj.weight, t2i.out_proj.bias, q1, self.norm2.weight, self.norm2.bias, eps, None,
+                               mlp.lin1.weight, mlp.lin1.bias, "relu")
+        vp3, q3 = ops.lin_ln_lin(h, mlp.lin2.weight, mlp.lin2.bias, q2, self.norm3.weight, self.norm3.bias, eps, None,
+                                 i2t.v_proj.weight, i2t.v_proj.bias)
+        row = ops.linear_act(vp3, i2t.out_proj.weight, i2t.out_proj.bias)
+        keys = ops.layer_norm_bag_row(keys, row, s_it, self.norm4.weight, self.norm4.bias, self.norm4.eps, keys_tail_rows)
+        return q3, keys
 
     def forward(self, queries, keys, query_pe, key_pe):
         B, T, E = queries.shape

@@ -715,6 +715,98 @@ class _LinearAct(torch.autograd.Function):
         return dx, dW, db, None, dres
 
 
+def _small_dw(dy, yv, x, W, b, act: int):
+    """(dW, db) of a few-rows layer: queued for the end-of-backward grouped launch straight into the flat gradient slots
+    when optim.FlatAdam owns the parameters (deferred.py), otherwise formed now (mil_linear_small_bwd, dW role only)."""
+    W_slot = grad_slot(W)
+    b_slot = grad_slot(b) if b is not None else None
+    if (deferred.enabled() and W_slot is not None and (b is None or b_slot is not None) and x.shape[1] % 4 == 0
+            and dy.data_ptr() % 16 == 0):
+        deferred.queue_dw(dy, yv, x, W_slot.detach(), (b_slot.detach() if b is not None else None), act)
+        return W_slot, b_slot
+    _, dW, db = linear_small_bwd(dy, yv, act, x, W, False, True, b is not None, W_slot, b_slot)
+    return dW, db
+
+
+class _LinLnLin(torch.autograd.Function):
+    """u = z Wp^T + bp (+ resp);  xn = LayerNorm(u);  y = act((xn [+ x2]) Wc^T + bc)  - the P -> norm -> C links of the
+    two-way block's token stream (sam/transformer.py:287-300) as ONE autograd node of two launches forward
+    (mil_linear_small_fwd, mil_linear_small_ln_fwd) and two backward (C's input gradient; P's input gradient with the norm's
+    backward and the sum of the two gradients that reach xn applied while its operand is staged, mil_linear_small_ln_bwd) -
+    the op-by-op route takes three and five (a LayerNorm launch each way and autograd's add).  Returns (y, xn): later
+    consumers of the norm's output use xn, whose gradient arrives here.  Weight gradients join the grouped launch."""
+
+    @staticmethod
+    def forward(ctx, z, Wp, bp, resp, gamma, beta, eps: float, x2, Wc, bc, actc: int):
+        z, Wp, Wc = _f32c(z, "z"), _f32c(Wp, "Wp"), _f32c(Wc, "Wc")
+        M = z.shape[0]
+        dev = z.device
+        resp_c = _f32c(resp, "residual") if resp is not None else None
+        u = linear_small_fwd(z, Wp, bp, 0, resp_c)
+        E, N = u.shape[1], Wc.shape[0]
+        y = torch.empty((M, N), device=dev, dtype=torch.float32)
+        xn = torch.empty((M, E), device=dev, dtype=torch.float32)
+        x2c = _f32c(x2, "x2") if x2 is not None else None
+        xin = torch.empty((M, E), device=dev, dtype=torch.float32) if x2c is not None else None
+        stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
+        rc = _lib.lib().mil_linear_small_ln_fwd(_p(u), u.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), float(eps),
+                                                _p(x2c), x2c.stride(0) if x2c is not None else 0, _p(Wc), Wc.stride(0), _p(bc),
+                                                int(actc), None, 0, _p(y), N, _p(xn), _p(xin), _p(stats), M, N, _stream())
+        _lib.check(rc, "mil_linear_small_ln_fwd")
+        ctx.actc, ctx.has_res, ctx.has_x2 = int(actc), resp is not None, x2 is not None
+        ctx.params = (bp, beta, bc)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, Wp, u, stats, gamma, xin if xin is not None else xn, Wc, y)
+        return y, xn
+
+    @staticmethod
+    def backward(ctx, dy, dxn):
+        z, Wp, u, stats, gamma, xin, Wc, y = ctx.saved_tensors
+        bp, beta, bc = ctx.params
+        M, E = u.shape
+        dev = u.device
+        if dy is not None:
+            dy = _f32c(dy, "dy")
+            if dy.data_ptr() % 16:
+                dy = dy.clone()
+            dxin, _, _ = linear_small_bwd(dy, y, ctx.actc, xin, Wc, True, False, False)      # C: input gradient now ...
+            dWc, dbc = _small_dw(dy, y, xin, Wc, bc, ctx.actc)                              # ... weight gradient grouped
+        else:
+            dxin, dWc, dbc = None, None, None
+        g1, g2 = (dxin, dxn) if dxin is not None else (dxn, None)
+        if g1 is None:
+            return (None,) * 11
+        g2 = _f32c(g2, "dxn") if g2 is not None else None
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        du = torch.empty((M, E), device=dev, dtype=torch.float32)
+        dg = grad_slot(gamma)
+        if dg is None:
+            dg = torch.empty(E, device=dev, dtype=torch.float32)
+        db = grad_slot(beta)
+        if db is None:
+            db = torch.empty(E, device=dev, dtype=torch.float32)
+        K = z.shape[1]
+        rc = _lib.lib().mil_linear_small_ln_bwd(_p(g1), g1.stride(0), _p(g2), g2.stride(0) if g2 is not None else 0, _p(u),
+                                                u.stride(0), _p(stats), _p(gamma), _p(Wp), Wp.stride(0), _p(dz), K, _p(du),
+                                                _p(dg), _p(db), M, K, _stream())
+        _lib.check(rc, "mil_linear_small_ln_bwd")
+        dWp, dbp = _small_dw(du, None, z, Wp, bp, 0)
+        return (dz, dWp, dbp, (du if ctx.has_res else None), dg, db, None, (dxin if ctx.has_x2 else None), dWc, dbc, None)
+
+
+def lin_ln_lin_ok(z, Wp, gamma, Wc) -> bool:
+    """Shapes the fused P -> LayerNorm -> C node is built for: <= 64 rows, norm width 512, 16-byte aligned operands."""
+    return (z.dim() == 2 and 0 < z.shape[0] <= SMALL_ROWS and Wp.shape[0] == 512 and gamma.shape[0] == 512 and
+            Wc.shape[1] == 512 and Wc.shape[0] % 16 == 0 and z.shape[1] % 16 == 0 and
+            _small_ok(z.shape[0], Wp.shape[0], z.shape[1], z, Wp) and Wc.data_ptr() % 16 == 0 and
+            gamma.requires_grad and Wp.requires_grad and Wc.requires_grad)
+
+
+def lin_ln_lin(z, Wp, bp, resp, gamma, beta, eps, x2, Wc, bc, actc: str = "none"):
+    """(y, xn) of _LinLnLin; see there."""
+    return _LinLnLin.apply(z, Wp, bp, resp, gamma, beta, float(eps), x2, Wc, bc, ACT[actc])
+
+
 class _MlpQuickGelu(torch.autograd.Function):
     """x + c_proj(QuickGELU(c_fc(x_ln)))  (clip/model.py:176-178,196-198) as one autograd node: the c_fc product stores
     its pre-activation from the epilogue, and in the backward the product dout . W2 is multiplied by QuickGELU' in its
@@ -1532,13 +1624,15 @@ class _AbsorbedPoolValue(torch.autograd.Function):
         return dkeys, None, dQp, dWv, dbv, None, None
 
 
-def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int):
+def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int, qp=None):
     """Token->image attention core for ONE text token per bag, projections absorbed (csrc/absorbed_attn.hip).
     q_tok [B, E] (query + its pe), keys [R, E] WITHOUT positional encoding, pe [>= max N, E].  Returns the
     pre-out_proj attention output [B, H*C] and an alias of `keys` to be used by the keys' other consumer (see
-    _AbsorbedPool).  k_proj.bias does not enter (softmax-invariant)."""
-    qp = linear_act(q_tok, Wq, bq)
-    C = Wq.shape[0] // H
+    _AbsorbedPool).  k_proj.bias does not enter (softmax-invariant).  qp: the projected query q_proj(q_tok) when the
+    caller has formed it already (ops.lin_ln_lin: the projection rides in the launch that applies the LayerNorm)."""
+    if qp is None:
+        qp = linear_act(q_tok, Wq, bq)
+    C = Wk.shape[0] // H
     Qp = _AbsorbQuery.apply(qp, Wk, H)
     if Wk.shape[1] == 512 and H == 8 and Wv.requires_grad and bv.requires_grad:
         return _AbsorbedPoolValue.apply(keys, pe, Qp, Wv, bv, segs, C)        # pool + value projection: one node
