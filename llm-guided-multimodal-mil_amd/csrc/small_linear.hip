@@ -337,16 +337,35 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int N = SLN_E;
     if ((int)blockIdx.x >= nX) {
-        // dgamma[c] = sum_m g[m][c] xhat[m][c], dbeta[c] = sum_m g[m][c]: thread = column, the <= 64 rows in turn
-        const int c = tid;
+        // dgamma[c] = sum_m g[m][c] xhat[m][c], dbeta[c] = sum_m g[m][c].  Four workgroups of 128 columns; thread (column,
+        // row group q) takes rows q, q + 4, ... with eight rows' loads in flight (one thread per column walking the rows in
+        // turn was a chain of up to 64 dependent round trips: 5 us of a 9 us launch), folded through LDS in group order.
+        float* fold = &red[0][0][0];                           // [2][3][128]
+        const int c = 128 * ((int)blockIdx.x - nX) + (tid & 127), q = tid >> 7;
         float dg = 0.f, db = 0.f;
-        for (int m = 0; m < M; ++m) {
-            float g = g1[(size_t)m * ldg1 + c];
-            if (g2 != nullptr) g += g2[(size_t)m * ldg2 + c];
-            dg += g * ((u[(size_t)m * ldu + c] - stats[2 * m]) * stats[2 * m + 1]);
-            db += g;
+        for (int mb = q; mb < M; mb += 32) {
+            float gv[8], uv[8], mu[8], rs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = min(mb + 4 * e, M - 1);
+                gv[e] = g1[(size_t)m * ldg1 + c];
+                if (g2 != nullptr) gv[e] += g2[(size_t)m * ldg2 + c];
+                uv[e] = u[(size_t)m * ldu + c];
+                mu[e] = stats[2 * m];
+                rs[e] = stats[2 * m + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (mb + 4 * e < M) { dg += gv[e] * ((uv[e] - mu[e]) * rs[e]); db += gv[e]; }
         }
-        if (dgamma != nullptr) { dgamma[c] = dg; dbeta[c] = db; }
+        if (q > 0) { fold[((q - 1) * 2 + 0) * 128 + (tid & 127)] = dg; fold[((q - 1) * 2 + 1) * 128 + (tid & 127)] = db; }
+        __syncthreads();
+        if (q == 0 && dgamma != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { dg += fold[(e * 2 + 0) * 128 + tid]; db += fold[(e * 2 + 1) * 128 + tid]; }
+            dgamma[c] = dg;
+            dbeta[c] = db;
+        }
         return;
     }
     const int r = lane & 15, kq = lane >> 4;
@@ -568,7 +587,7 @@ extern "C" int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g
         return MIL_EINVAL;
     const int kt = dx ? (K + 15) / 16 : 1;
     const int nX = kt * ((M + 15) / 16);
-    hipLaunchKernelGGL((k_small_bwd_ln<SL_WAVES>), dim3(nX + (dgamma ? 1 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
+    hipLaunchKernelGGL((k_small_bwd_ln<SL_WAVES>), dim3(nX + (dgamma ? 4 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
                        g2, ldg2, u, ldu, stats, gamma, W, ldw, dx, lddx, du, dgamma, dbeta, M, dx ? K : 16, nX);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
