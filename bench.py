@@ -554,9 +554,13 @@ def run_rank(args):
                 ver = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:       # noqa: BLE001
                 ver = None
+        ar_us = float(t.item()) * 1e3
         rccl = {"backend": backend, "world_size": dist.get_world_size(), "allreduce_bytes": buf.numel() * 4,
-                "allreduce_us": round(float(t.item()) * 1e3, 2), "version": ver,
-                "collectives_per_step": round(1.0 / args.accum, 4)}
+                "allreduce_us": round(ar_us, 2), "version": ver,
+                "collectives_per_step": round(1.0 / args.accum, 4),
+                # nothing of the step is left to overlap the collective with (the buffer is complete when the fold launch
+                # ends), so all of it is exposed: its share of the step as measured
+                "exposed_fraction_of_step": round(ar_us / args.accum / (elapsed / args.steps * 1e6), 4)}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

@@ -18,7 +18,7 @@ BENCH="python3 $ROOT/bench.py --no-configs --no-cpu-baseline --no-breakdown"
 declare -A CMD
 CMD[cfg2]="$BENCH --steps 200 --warmup 10"      # the bench's own priming (--prime 300): the chip at its steady clock
 CMD[pool]="python3 $ROOT/tools/prof_pool.py"
-CMD[cfg5]="python3 $ROOT/tools/prof_stage.py --bf16"
+CMD[cfg5]="python3 $ROOT/tools/prof_stage.py --bf16"           # STEPS=60 below: the last 30 steps are the steady state
 CMD[cfg3]="python3 $ROOT/tools/bench_fusion.py --graph --steps 20 --warmup 3"
 MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
 # QUICK=1: the cfg2 kernel trace + one un-profiled bench line only (the HIP-event vs rocprofv3 cross-check)
@@ -29,6 +29,7 @@ if [ "${QUICK:-0}" = "1" ]; then
   echo quick done
   exit 0
 fi
+export STEPS=60
 for w in cfg2 pool cfg5 cfg3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- ${CMD[$w]} > $OUT/stats_$w.log 2>&1
   echo "stats $w done"
@@ -46,6 +47,8 @@ python3 $ROOT/bench.py --steps 200 --warmup 20 > $OUT/bench_line.json 2> $OUT/be
 echo "bench done"
 python3 $ROOT/bench.py --steps 200 --warmup 20 --train-mode 0 --no-configs --no-cpu-baseline > $OUT/bench_eval_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py > $OUT/ragged_line.json 2>/dev/null
+python3 $ROOT/tools/bench_ragged.py --fusion > $OUT/ragged_fusion_line.json 2>/dev/null
+MIL_FORCE_COLLECTIVES=1 python3 $ROOT/bench.py --gpus 1 --no-configs --no-cpu-baseline > $OUT/bench_rccl1_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --steps 50 --warmup 5 > $OUT/fusion_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --prompts 10 --steps 20 --warmup 3 > $OUT/p10_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --coop --steps 10 --warmup 3 > $OUT/coop_line.json 2>/dev/null

@@ -157,8 +157,27 @@ with open(os.path.join(DST, f"{TAG}_mfma_busy_pmc.csv"), "w") as o:
             o.write(f"{w},{k},{len(v['SQ_VALU_MFMA_BUSY_CYCLES'])},{mean['SQ_VALU_MFMA_BUSY_CYCLES']:.0f},{gui:.0f},{frac:.3f},"
                     f"{mean.get('SQ_LDS_BANK_CONFLICT', 0):.0f},{mean.get('SQ_WAVE_CYCLES', 0):.0f},{mean.get('SQ_WAIT_ANY', 0):.0f},"
                     f"{mean.get('SQ_WAIT_INST_ANY', 0):.0f},{mean.get('SQ_INSTS_VALU', 0):.0f}\n")
+def steady_stats(w, last, out_name):
+    """Per-kernel averages over the LAST `last` dispatches of every kernel of workload w (a run of STEPS steps: the first ones
+    execute while the clock ramps)."""
+    f = sorted(glob.glob(os.path.join(SRC, "stats_" + w, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    if not f:
+        return
+    per = collections.defaultdict(list)
+    for r in sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"])):
+        per[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(DST, out_name), "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace -- STEPS=60 {WORK[w]}\n# averages over the last {last} dispatches of each kernel (steady clock)\n")
+        o.write("kernel,dispatches_total,steady_avg_us\n")
+        for n, v in sorted(per.items(), key=lambda kv: -sum(kv[1][-last:])):
+            if len(v) >= last and n.startswith("k_"):
+                o.write(f"{n},{len(v)},{sum(v[-last:]) / last / 1e3:.2f}\n")
+
+
+steady_stats("cfg5", 30, f"{TAG}_cfg5_steady.csv")
 lines = {}
 for key, fn in (("bench", "bench_line.json"), ("bench_eval_mode", "bench_eval_line.json"), ("ragged_one_bag", "ragged_line.json"),
+                ("ragged_fusion", "ragged_fusion_line.json"), ("bench_one_rank_through_rccl", "bench_rccl1_line.json"),
                 ("fusion", "fusion_line.json"), ("fusion_10_prompts", "p10_line.json"), ("fusion_coop", "coop_line.json"),
                 ("one_bag_4096_hipgraph", "one_bag_line.json")):
     try:
