@@ -639,7 +639,15 @@ __global__ __launch_bounds__(512) void k_value_proj_bwd(const float* __restrict_
     if (dbv != nullptr)
         for (int i = tid; i < I; i += 512) {
             float v = 0.f;
-            for (int b = 0; b < B; ++b) v += dO[(size_t)b * I + i];
+            int b = 0;
+            for (; b + 8 <= B; b += 8) {                    // eight rows in flight (the caller keeps B <= 64 on this path)
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = dO[(size_t)(b + e) * I + i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v += t[e];
+            }
+            for (; b < B; ++b) v += dO[(size_t)b * I + i];
             dbv[i] = v;
         }
 }

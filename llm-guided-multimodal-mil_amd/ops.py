@@ -1565,7 +1565,8 @@ def _value_proj_bwd(do, Wv, bv, pooled):
     dbv = grad_slot(bv)
     if dbv is None:
         dbv = torch.empty(I, device=do.device, dtype=torch.float32)
-    if E != 512:
+    if E != 512 or B > SMALL_ROWS:
+        # many rows (T text tokens per bag: B = bags x T): the one-launch form walks the rows of its bias role in turn
         rc = _lib.lib().mil_absorb_query(_p(do), _p(Wv), B, H, I // H, E, _p(dpooled), _stream())
         _lib.check(rc, "mil_absorb_query")
         rc = _lib.lib().mil_absorb_query_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, None, _p(dWv), _stream())
