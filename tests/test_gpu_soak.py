@@ -1,0 +1,21 @@
+"""GPU: a short soak of both ragged steppers on a learnable synthetic task (tools/soak.py: the label is carried by a weak
+per-patch signal the attention pool has to aggregate): hundreds of steps over bags of 2 000 - 15 592 patches, cosine
+learning-rate schedule THROUGH the captured graphs.  Losses must fall, parameters stay finite, at most 8 graphs each."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ragged_steppers_learn_and_stay_finite():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak.py"), "--steps", "500"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["image_only"]["last"] < 0.9 * out["image_only"]["first"]
+    assert out["fusion"]["last"] < 0.5 * out["fusion"]["first"] and out["fusion"]["adam_steps"] == 250
