@@ -15,6 +15,7 @@ from mil_amd.trainer import ImageOnlyTrainer, RaggedImageOnlyStepper
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=2000)
+ap.add_argument("--lr-scale", type=float, default=1.0, help="multiplies both base learning rates (short runs: 5)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 rng = np.random.default_rng(7)
@@ -38,12 +39,12 @@ losses = []
 t0 = time.time()
 for i in range(a.steps):
     n, cls = int(rng.integers(2000, 15593)), int(rng.integers(0, 2))
-    tr.lr = 3e-4 * (0.5 * (1 + np.cos(np.pi * i / a.steps)))
+    tr.lr = 3e-4 * a.lr_scale * (0.5 * (1 + np.cos(np.pi * i / a.steps)))
     slot = st.slot(n)
     slot.x[:n].copy_(bag(n, 512, cls))
     slot.y.copy_(label(cls))
     loss, _ = st.step(slot, [n])
-    if i % 20 == 0:
+    if i % 10 == 0:
         losses.append(float(loss.item()))
 torch.cuda.synchronize()
 out["image_only"] = {"first": float(np.mean(losses[:10])), "last": float(np.mean(losses[-10:])), "graphs": len(st.slots),
@@ -63,7 +64,7 @@ steps = a.steps // 2
 t0 = time.time()
 for i in range(steps):
     n, cls = int(rng.integers(2000, 15593)), int(rng.integers(0, 2))
-    opt.param_groups[0]["lr"] = 1e-4 * (0.5 * (1 + np.cos(np.pi * i / steps)))
+    opt.param_groups[0]["lr"] = 1e-4 * a.lr_scale * (0.5 * (1 + np.cos(np.pi * i / steps)))
     slot = fs.slot(n)
     slot.x[:n].copy_(bag(n, 768, cls))
     slot.y.copy_(label(cls))
@@ -72,7 +73,7 @@ for i in range(steps):
         text = slot.text.clone()
     slot.text.copy_(text)
     loss, _, _ = fs.step(slot, [n])
-    if i % 20 == 0:
+    if i % 10 == 0:
         losses.append(float(loss))
 torch.cuda.synchronize()
 out["fusion"] = {"first": float(np.mean(losses[:8])), "last": float(np.mean(losses[-8:])), "graphs": len(fs.gs._graphs),
