@@ -19,6 +19,7 @@ ap.add_argument("--lr-scale", type=float, default=1.0, help="multiplies both bas
 a = ap.parse_args()
 dev = torch.device("cuda")
 rng = np.random.default_rng(7)
+torch.manual_seed(7)                      # the bags are drawn on the device: same data every run
 out = {}
 
 
