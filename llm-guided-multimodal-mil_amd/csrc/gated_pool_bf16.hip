@@ -550,6 +550,17 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
     const int row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
+    // the tile's rows are requested FIRST: they depend on nothing, and their trip from HBM then runs under the softmax of
+    // the tile's scores (wave 0) and the barrier behind it
+    u16x8 v[MIL_POOL_TILE / 4][NQ];
+#pragma unroll
+    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+        const int rr = max(min(wave + 4 * i, nrows - 1), 0);
+        const u16* xr = x + (size_t)(row0 + rr) * L + 8 * lane;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            v[i][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(xr + 512 * q)) : *reinterpret_cast<const u16x8*>(xr + 512 * q);
+    }
     if (wave == 0) {
         const float s = lane < nrows ? scores[row0 + lane] : -INFINITY;
         const float m = wave_allmax(s);
@@ -564,15 +575,10 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
-    u16x8 v[MIL_POOL_TILE / 4][NQ];
+    if (DROP && xbits != nullptr) {
 #pragma unroll
-    for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-        const int rr = min(wave + 4 * i, nrows - 1);
-        const u16* xr = x + (size_t)(row0 + rr) * L + 8 * lane;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            v[i][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(xr + 512 * q)) : *reinterpret_cast<const u16x8*>(xr + 512 * q);
-        if (DROP && xbits != nullptr) {
+        for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+            const int rr = max(min(wave + 4 * i, nrows - 1), 0);
             const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 2);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) v[i][q] = keep_bf16x8(v[i][q], mr[16 * q] >> (8 * (lane & 3)));
