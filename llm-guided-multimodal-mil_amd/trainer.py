@@ -232,8 +232,8 @@ class ImageOnlyTrainer:
     def _sync_lr(self):
         """Counted mode: the scheduled learning rate goes to its device word (stream-ordered, before the next launch or
         replay that reads it)."""
-        if self.lr_dev is not None and self._lr_on_dev != float(self.lr):
-            self.lr_dev.fill_(float(self.lr))
+        if self.lr_dev is not None and self._lr_on_dev != float(self.lr) and not torch.cuda.is_current_stream_capturing():
+            self.lr_dev.fill_(float(self.lr))          # never while capturing: the fill would be frozen into the graph
             self._lr_on_dev = float(self.lr)
 
     def _run(self, a, stages: int, keep=None):
