@@ -14,8 +14,11 @@ rows carry zero softmax weight in all four pooling sites and receive exactly zer
     slot = stepper.slot(n)                             # static inputs of the bucket: slot.x[:n], slot.text, slot.y
     loss, prob = stepper.step(slot, [n])
 
-One text token per bag (`CI_prompt_version='single'`, dataset.py:479-502); the frozen text tower runs outside the graph
-(its launch geometry follows the note's length) and hands `slot.text` its embedding."""
+P text tokens per bag: 1 (`CI_prompt_version='single'`, dataset.py:479-502: the absorbed one-token kernels), or up to 12
+(`'devided'`, or upstream's default learnable-prompt branch with its len(clinical_features) + 1 prompts: the multi-token
+grouped products, whose outputs are cleared for the padding rows).  A frozen text tower runs outside the graph (its launch
+geometry follows the notes' lengths) and hands `slot.text` its embeddings; learnable prompts run the tower inside the step
+on `slot.ids` in its fixed-shape form."""
 from typing import Dict, Sequence
 
 import torch
@@ -27,22 +30,29 @@ from .segments import FusionBucket
 
 class RaggedFusionStepper:
     class Slot:
-        def __init__(self, cap: int, B: int, C: int, in_dim: int, device):
+        def __init__(self, cap: int, B: int, C: int, in_dim: int, device, P: int = 1, ctx_len: int = 77):
             self.cap, self.B = cap, B
             self.x = torch.zeros((cap, in_dim), device=device, dtype=torch.float32)    # rows beyond the bags: padding
-            self.text = torch.zeros((B, 1, 512), device=device, dtype=torch.float32)   # frozen-tower embedding per note
+            self.text = torch.zeros((B, P, 512), device=device, dtype=torch.float32)   # frozen-tower embedding per prompt
+            self.ids = torch.zeros((B, P, ctx_len), device=device, dtype=torch.int64)  # learnable prompts: the token ids
             self.y = torch.zeros((B, C), device=device, dtype=torch.float32)
-            self.bucket = FusionBucket(cap, B, device)
+            self.bucket = FusionBucket(cap, B, device, P)
 
     def __init__(self, model, opt, B: int = 1, use_graph: bool = True, max_graphs: int = 16, in_dim: int = 768,
-                 opt_in_graph: bool = True):
+                 opt_in_graph: bool = True, P: int = 1, learnable: bool = False, ctx_len: int = 77):
         """opt_in_graph=False keeps the optimizer (and, at world size > 1, its gradient all-reduce) outside the captured
-        graph, as graph_step.GraphedStep does."""
+        graph, as graph_step.GraphedStep does.  P: text tokens per bag (1 = one note; 10 = `CI_prompt_version='devided'` or
+        the learnable-prompt branch, whose P = len(clinical_features) + 1).  learnable=True: upstream's default
+        `--learnablePrompt 1` - the text tower runs INSIDE the step on `slot.ids` in its fixed-shape form
+        (`clinic_extractor.model.static_rows = True`, set here) and its context vectors are trained through it."""
         if use_graph and opt_in_graph and not getattr(opt, "counted", False):
             raise ValueError("RaggedFusionStepper: an optimizer inside the graph needs optim.FlatAdam(counted=True) "
                              "(step number and learning rate on the device)")
         self.model, self.opt, self.B, self.use_graph, self.in_dim = model, opt, int(B), bool(use_graph), int(in_dim)
         self.opt_in_graph = bool(opt_in_graph)
+        self.P, self.learnable, self.ctx_len = int(P), bool(learnable), int(ctx_len)
+        if self.learnable and use_graph:
+            model.clinic_extractor.model.static_rows = True      # the tower is inside the graph: no token-dependent host work
         self.device = next(model.parameters()).device
         self.C = int(model.args.num_classes)
         self.slots: Dict[int, "RaggedFusionStepper.Slot"] = {}
@@ -61,7 +71,7 @@ class RaggedFusionStepper:
         cap = bucket_rows(total_rows)
         s = self.slots.get(cap)
         if s is None:
-            s = self.slots[cap] = self.Slot(cap, self.B, self.C, self.in_dim, self.device)
+            s = self.slots[cap] = self.Slot(cap, self.B, self.C, self.in_dim, self.device, self.P, self.ctx_len)
         return s
 
     def encode_notes(self, slot, ids):
@@ -72,7 +82,10 @@ class RaggedFusionStepper:
 
     def _body(self, slot):
         m = self.model
-        prob, _ = m([slot.x], None, text_features=slot.text, labels=slot.y, bucket=slot.bucket)
+        if self.learnable:
+            prob, _ = m([slot.x], slot.ids, labels=slot.y, bucket=slot.bucket)
+        else:
+            prob, _ = m([slot.x], None, text_features=slot.text, labels=slot.y, bucket=slot.bucket)
         return m.last_loss, prob, m.last_logits
 
     def step(self, slot, lengths: Sequence[int]):

@@ -1653,17 +1653,19 @@ def _gg(A, a_mode, B, b_mode, grp_off, G, max_rows, M, N, K, strideB, strideC, o
     return out
 
 
-def _gg_nt(A, B, bias, grp_off, max_rows):
-    """C[rows_g] = A[rows_g] . B[g]^T + bias[g];  A [R, K], B [G, N, K], bias [G, N] or None -> [R, N]."""
+def _gg_nt(A, B, bias, grp_off, max_rows, zero: bool = False):
+    """C[rows_g] = A[rows_g] . B[g]^T + bias[g];  A [R, K], B [G, N, K], bias [G, N] or None -> [R, N].
+    zero: rows outside every group (the padding rows of a capacity bucket, segments.FusionBucket) must read 0, not
+    whatever the allocation holds - the grouped kernels only write the rows of their groups."""
     G, N, K = B.shape
-    out = torch.empty((A.shape[0], N), device=A.device, dtype=torch.float32)
+    out = (torch.zeros if zero else torch.empty)((A.shape[0], N), device=A.device, dtype=torch.float32)
     return _gg(A, 0, B, 0, grp_off, G, max_rows, 0, N, K, N * K, 0, out, bias, N if bias is not None else 0)
 
 
-def _gg_nn(A, B, bias, residual, grp_off, max_rows):
-    """C[rows_g] = A[rows_g] . B[g] + bias + residual;  A [R, K], B [G, K, N], bias [N] shared or None."""
+def _gg_nn(A, B, bias, residual, grp_off, max_rows, zero: bool = False):
+    """C[rows_g] = A[rows_g] . B[g] + bias + residual;  A [R, K], B [G, K, N], bias [N] shared or None.  zero: as _gg_nt."""
     G, K, N = B.shape
-    out = torch.empty((A.shape[0], N), device=A.device, dtype=torch.float32)
+    out = (torch.zeros if zero else torch.empty)((A.shape[0], N), device=A.device, dtype=torch.float32)
     return _gg(A, 0, B, 1, grp_off, G, max_rows, 0, N, K, K * N, 0, out, bias, 0, residual)
 
 
@@ -1815,7 +1817,8 @@ class _MultiTokenPoolCore(torch.autograd.Function):
         keys_in = keys
         keys, kin, Qp = _f32c(keys, "keys"), _f32c(kin.detach(), "kin"), _f32c(Qp, "Qp")
         B, off, mr = segs.B, segs.k_off, segs.Tk_max
-        A = _gg_nt(kin, Qp, None, off, mr)                                       # scores [R, THp]
+        z = getattr(segs, "device_lengths", False)                               # capacity bucket: padding rows read 0
+        A = _gg_nt(kin, Qp, None, off, mr, zero=z)                               # scores [R, THp]
         rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(off), B, mr, TH, _stream())
         _lib.check(rc, "mil_grp_col_softmax")
         pooled = _gg_tn(A, keys, off, B, mr)                                     # [B, THp, E]
@@ -1833,14 +1836,15 @@ class _MultiTokenPoolCore(torch.autograd.Function):
             return dkeys_pass, None, None, None, None
         dpooled = _f32c(dpooled, "dpooled")
         acc = _f32c(dkeys_pass, "dkeys") if dkeys_pass is not None else None
-        dA = _gg_nt(keys, dpooled, None, off, mr)                                # dA = keys . dpooled^T
-        dS = torch.empty_like(A)
+        z = getattr(segs, "device_lengths", False)
+        dA = _gg_nt(keys, dpooled, None, off, mr, zero=z)                        # dA = keys . dpooled^T
+        dS = torch.zeros_like(A) if z else torch.empty_like(A)
         rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(off), B, mr, TH, _p(dS), _stream())
         _lib.check(rc, "mil_grp_col_softmax_bwd")
         dkeys = None
         if ctx.needs_input_grad[0]:
-            dkeys = _gg_nn(A, dpooled, None, acc, off, mr)                       # values path (+ what came through the alias)
-            dkeys = _gg_nn(dS, Qp, None, dkeys, off, mr)                         # + scores path (d kin = d keys)
+            dkeys = _gg_nn(A, dpooled, None, acc, off, mr, zero=z)               # values path (+ what came through the alias)
+            dkeys = _gg_nn(dS, Qp, None, dkeys, off, mr, zero=z)                 # + scores path (d kin = d keys)
         dQp = _gg_tn(dS, kin, off, B, mr) if ctx.needs_input_grad[2] else None
         return dkeys, None, dQp, None, None
 
@@ -1854,10 +1858,11 @@ class _MultiTokenRowsCore(torch.autograd.Function):
         keys, kin = _f32c(keys, "keys"), _f32c(kin.detach(), "kin")
         Kp, cb, Vp, bo = _f32c(Kp, "Kp"), _f32c(cb, "cb"), _f32c(Vp, "Vp"), _f32c(bo, "bo")
         off, mr = segs.q_off, segs.Tq_max
-        A = _gg_nt(kin, Kp, cb, off, mr)
+        z = getattr(segs, "device_lengths", False)                               # capacity bucket: padding rows read 0
+        A = _gg_nt(kin, Kp, cb, off, mr, zero=z)
         rc = _lib.lib().mil_row_softmax_t(_p(A), A.stride(0), A.shape[0], T, H, _stream())
         _lib.check(rc, "mil_row_softmax_t")
-        out = _gg_nn(A, Vp, bo, keys, off, mr)
+        out = _gg_nn(A, Vp, bo, keys, off, mr, zero=z)
         ctx.segs, ctx.T, ctx.H = segs, T, H
         ctx.save_for_backward(kin, Kp, Vp, A)
         return out
@@ -1868,11 +1873,12 @@ class _MultiTokenRowsCore(torch.autograd.Function):
         segs, T, H = ctx.segs, ctx.T, ctx.H
         off, mr, B = segs.q_off, segs.Tq_max, segs.B
         dout = _f32c(dout, "dout")
-        dA = _gg_nt(dout, Vp, None, off, mr)                                     # [R, THp]
+        z = getattr(segs, "device_lengths", False)
+        dA = _gg_nt(dout, Vp, None, off, mr, zero=z)                             # [R, THp]
         dS = torch.empty_like(A)
         rc = _lib.lib().mil_row_softmax_t_bwd(_p(A), _p(dA), A.stride(0), A.shape[0], T, H, _p(dS), _stream())
         _lib.check(rc, "mil_row_softmax_t_bwd")
-        dkeys = _gg_nn(dS, Kp, None, dout, off, mr) if ctx.needs_input_grad[0] else None      # residual + scores path
+        dkeys = _gg_nn(dS, Kp, None, dout, off, mr, zero=z) if ctx.needs_input_grad[0] else None      # residual + scores path
         dKp = _gg_tn(dS, kin, off, B, mr) if ctx.needs_input_grad[2] else None
         dcb = _seg_colsum(dS, off, B, mr) if ctx.needs_input_grad[3] else None
         dVp = _gg_tn(A, dout, off, B, mr) if ctx.needs_input_grad[4] else None

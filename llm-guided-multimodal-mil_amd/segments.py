@@ -86,8 +86,9 @@ class _SegView:
 
 
 class FusionBucket:
-    """Device-side segments of the one-note fusion step for a capacity bucket: `cap` patch rows shared by B bags, P = 1 text
-    token per bag.  The reference trains one ragged bag per GPU with a fresh patch drop every epoch (dataset.py:366-393,
+    """Device-side segments of the fusion step for a capacity bucket: `cap` patch rows shared by B bags, P text tokens per
+    bag (1: one clinical note - the absorbed one-token kernels; 2 .. 12: the prompts of `CI_prompt_version='devided'` or of
+    the learnable-prompt branch - the multi-token grouped products).  The reference trains one ragged bag per GPU with a fresh patch drop every epoch (dataset.py:366-393,
     run_train.sh:81), so host-built segment maps keyed by the exact lengths (AttnSegs, BagLayout) never repeat and a captured
     step never replays.  Here the lengths live in `len_dev`; `refresh()` - the first launch of the step, inside the captured
     graph - rebuilds every map from them (mil_build_fusion_segs), launch grids and buffers depend on (cap, B) only, padding
@@ -95,20 +96,18 @@ class FusionBucket:
         s_tt, s_ti, s_it   AttnSegs-shaped (token-token, token-image, image-token)
         layout             BagLayout-shaped two-segment multi-modal bag: rows [cap patch rows | B token rows]."""
 
-    P = 1
-
-    def __init__(self, capacity_rows: int, B: int, device):
+    def __init__(self, capacity_rows: int, B: int, device, P: int = 1):
         from . import _lib
         from .bags import POOL_TILE
-        cap, B = int(capacity_rows), int(B)
-        if cap % 256 or cap <= 0 or not (0 < B <= 1024):
-            raise ValueError("FusionBucket: capacity must be a positive multiple of 256 rows, 1 <= B <= 1024")
-        P = self.P
+        cap, B, P = int(capacity_rows), int(B), int(P)
+        if cap % 256 or cap <= 0 or not (0 < B <= 1024) or not (1 <= P <= 12):
+            raise ValueError("FusionBucket: capacity must be a positive multiple of 256 rows, 1 <= B <= 1024, 1 <= P <= 12")
+        self.P = P
         self.cap, self.B, self.device = cap, B, device
         i32 = lambda *shape: torch.zeros(shape, device=device, dtype=torch.int32)      # noqa: E731
         self.len_dev, self.rows_dev = i32(B), i32(1)
         self.k_off, self.k_bag = i32(B + 1), i32(cap)
-        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B + 2, cap // POOL_TILE + 2 * B
+        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B + 2, cap // POOL_TILE + B * (1 + (P + POOL_TILE - 1) // POOL_TILE)
         self.tile64, self.bag_tile64_off = i32(self.T64, 3), i32(B + 1)
         self.tile32, self.bag_tile32_off = i32(self.T32, 4), i32(B + 1)
         self.row_bag_dev = i32(cap + B * P)

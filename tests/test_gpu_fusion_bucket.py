@@ -61,16 +61,17 @@ def test_device_built_segments_equal_the_host_ones(lengths):
     assert torch.equal(rb[cap:], torch.arange(B, dtype=torch.int32))
 
 
-@pytest.mark.parametrize("lengths", [[2500], [1100, 1300]])
-def test_bucket_step_equals_the_exact_shape_step(lengths):
+@pytest.mark.parametrize("lengths,P", [([2500], 1), ([1100, 1300], 1), ([2500], 10), ([700, 900], 3)])
+def test_bucket_step_equals_the_exact_shape_step(lengths, P):
     """Same bags through aggregator.forward(lengths=...) (host-built maps, exact shapes) and through the bucket form: logits,
-    token outputs and every parameter gradient must agree - padding rows have zero weight and zero gradient."""
+    token outputs and every parameter gradient must agree - padding rows have zero weight and zero gradient.  P = 1: the
+    absorbed one-token kernels; P = 10 / 3: the multi-token grouped products (`CI_prompt_version='devided'`)."""
     m = _model()
     B, N = len(lengths), sum(lengths)
     cap = bucket_rows(N)
     gen = torch.Generator().manual_seed(5)
     bags = [torch.randn((n, 768), generator=gen) for n in lengths]
-    ids = syn.make_token_ids(6, B, 1).to(DEV)
+    ids = syn.make_token_ids(6, B, P).to(DEV)
     y = syn.make_labels(7, B).to(DEV)
     with torch.no_grad():
         t = m.clinic_extractor(ids)
@@ -82,7 +83,7 @@ def test_bucket_step_equals_the_exact_shape_step(lengths):
     za = m.last_logits.detach().clone()
     m.last_loss.backward()
     ga = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-    bk = FusionBucket(cap, B, DEV).set_lengths(lengths)
+    bk = FusionBucket(cap, B, DEV, P).set_lengths(lengths)
     x = torch.full((cap, 768), 3.0, device=DEV)      # stale rows behind the bags must not matter
     x[:N] = torch.cat(bags, 0).to(DEV)
     m.zero_grad()
@@ -175,3 +176,81 @@ def test_bucketed_fusion_training_tracks_the_exact_shape_training():
             continue          # softmax bias: a mathematically zero gradient, Adam normalises its rounding noise to +-lr
         moved = float((pr[k].detach() - p0.detach()).abs().max())
         assert float((po[k].detach() - pr[k].detach()).abs().max()) <= 0.02 * moved + 1e-9, (k, moved)
+
+
+def test_bucket_step_with_learnable_prompts_equals_the_exact_shape_step():
+    """Upstream's default `--learnablePrompt 1`: P = len(clinical_features) + 1 prompts per bag, the context vectors trained
+    THROUGH the frozen text tower (model/dim1/CLIP.py:29-62).  Bucket form vs exact shapes: loss, logits, d ctx and the
+    fusion parameters' gradients."""
+    args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
+                           learnablePrompt=1, n_ctx=4, clinical_features=["a", "b"], clip_layers=2, cache_text=0)
+    torch.manual_seed(13)
+    m = get_model(args).to(DEV).eval()
+    n, P = 2300, 3
+    cap = bucket_rows(n)
+    xb = torch.randn((n, 768), generator=torch.Generator().manual_seed(8))
+    ids = syn.make_token_ids(9, 1, P).to(DEV)
+    y = syn.make_labels(10, 1).to(DEV)
+    m.zero_grad()
+    m([xb.unsqueeze(0).to(DEV)], ids, labels=y)
+    za, la = m.last_logits.detach().clone(), float(m.last_loss.detach())
+    m.last_loss.backward()
+    ga = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    bk = FusionBucket(cap, 1, DEV, P).set_lengths([n])
+    x = torch.full((cap, 768), -2.0, device=DEV)
+    x[:n] = xb.to(DEV)
+    m.zero_grad()
+    m([x], ids, labels=y, bucket=bk)
+    zb, lb = m.last_logits.detach().clone(), float(m.last_loss.detach())
+    m.last_loss.backward()
+    torch.cuda.synchronize()
+    assert float((za - zb).abs().max()) <= 1e-6 and abs(la - lb) <= 1e-6
+    gb = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert "clinic_extractor.ctx" in ga and set(ga) == set(gb)
+    for k in ga:
+        if float(ga[k].norm()) < 1e-7:
+            assert float(gb[k].abs().max()) < 1e-6, k
+        else:
+            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 5e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
+
+
+def test_ragged_stream_with_ten_prompts_and_with_learnable_prompts_replays():
+    """The stepper beyond one note per bag: 10 frozen prompts (Adam inside the graph) and learnable prompts (the tower inside
+    the step, flat SGD outside): two buckets, each captured on its second visit, losses equal to eager exact-shape steps of a
+    twin model."""
+    from mil_amd.optim import FlatSGD
+    for learnable in (0, 1):
+        P = 3 if learnable else 10
+        args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL",
+                               num_classes=2, learnablePrompt=learnable, n_ctx=4, clinical_features=["a", "b"], clip_layers=1,
+                               cache_text=0)
+        torch.manual_seed(21)
+        ref = get_model(args).to(DEV).eval()
+        ours = copy.deepcopy(ref)
+        mk = (lambda mm, c: FlatSGD([p for p in mm.parameters() if p.requires_grad], lr=1e-3)) if learnable else \
+             (lambda mm, c: FlatAdam([p for p in mm.parameters() if p.requires_grad], lr=1e-4, counted=c))
+        o_ref, o_our = mk(ref, False), mk(ours, True)
+        st = RaggedFusionStepper(ours, o_our, B=1, P=P, learnable=bool(learnable), opt_in_graph=not learnable)
+        for step, n in enumerate([2100, 2900, 2000, 3000, 1900, 2800]):
+            x = torch.randn((n, 768), generator=torch.Generator().manual_seed(150 + step)).to(DEV)
+            ids = syn.make_token_ids(160 + step, 1, P).to(DEV)
+            y = syn.make_labels(170 + step, 1).to(DEV)
+            o_ref.zero_grad()
+            if learnable:
+                ref([x.unsqueeze(0)], ids, labels=y)
+            else:
+                with torch.no_grad():
+                    t = ref.clinic_extractor(ids)
+                ref([x.unsqueeze(0)], None, text_features=t, labels=y)
+            ref.last_loss.backward()
+            o_ref.step()
+            slot = st.slot(n)
+            slot.x[:n].copy_(x)
+            slot.y.copy_(y)
+            if learnable:
+                slot.ids.copy_(ids)
+            else:
+                st.encode_notes(slot, ids)
+            loss, _, _ = st.step(slot, [n])
+            assert abs(float(loss) - float(ref.last_loss.detach())) <= 5e-6, (learnable, step)
+        assert len(st.slots) == 2 and st.replays == 4, (learnable, st.replays)
