@@ -99,7 +99,10 @@ def test_bucket_step_equals_the_exact_shape_step(lengths, P):
         if float(ga[k].norm()) < 1e-7:               # mathematically zero (softmax bias): rounding noise on both sides
             assert float(gb[k].abs().max()) < 1e-6, k
         else:
-            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 2e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
+            # P > 1: the grouped products are launched for `cap` rows per group instead of the longest bag - other split
+            # counts and tile shapes, i.e. another summation order (4e-5 on the smallest gradients; the module bar is 1e-3)
+            tol = 2e-5 if P == 1 else 2e-4
+            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= tol, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
 
 
 def test_stream_of_ragged_fusion_bags_replays_few_graphs_and_matches_the_oracle():
@@ -211,7 +214,7 @@ def test_bucket_step_with_learnable_prompts_equals_the_exact_shape_step():
         if float(ga[k].norm()) < 1e-7:
             assert float(gb[k].abs().max()) < 1e-6, k
         else:
-            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 5e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
+            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 2e-4, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
 
 
 def test_ragged_stream_with_ten_prompts_and_with_learnable_prompts_replays():
