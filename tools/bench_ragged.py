@@ -48,39 +48,50 @@ if not fusion:
 else:
     from mil_amd.fusion_step import RaggedFusionStepper
     from mil_amd.model.utils import get_model
-    from mil_amd.optim import FlatAdam
+    from mil_amd.optim import FlatAdam, FlatSGD
+    coop = "--coop" in sys.argv                       # upstream's default --learnablePrompt 1: 10 prompts, tower in the step
+    P = 10 if (coop or "--prompts10" in sys.argv) else 1
+    if coop:
+        steps = 60
+        lens = lens[:steps]
     args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
-                           learnablePrompt=0, n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI", model_CT="resnetMC3_18",
-                           clip_layers=12, cache_text=0)
+                           learnablePrompt=int(coop), n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI",
+                           model_CT="resnetMC3_18", clip_layers=12, cache_text=0)
     xs = torch.randn((16384, 768), device=dev)
-    ids = syn.make_token_ids(2, 1, 1).to(dev)
+    ids = syn.make_token_ids(2, 1, P).to(dev)
     y = syn.make_labels(3, 1).to(dev)
     train = "--eval" not in sys.argv
     for mode in ("bucket_graph", "exact_eager"):
         torch.manual_seed(1234)
         model = get_model(args).to(dev)
         model.train(train)
-        opt = FlatAdam([q for q in model.parameters() if q.requires_grad], lr=1e-5, weight_decay=1e-7, counted=True)
-        st = RaggedFusionStepper(model, opt, B=1)
-        with torch.no_grad():
-            tfeat = model.clinic_extractor(ids)                   # frozen tower: cached per note (dim1/CLIP.py cache_text)
+        trainable = [q for q in model.parameters() if q.requires_grad]
+        opt = FlatSGD(trainable, lr=1e-3, weight_decay=1e-7) if coop else FlatAdam(trainable, lr=1e-5, weight_decay=1e-7, counted=True)
+        st = RaggedFusionStepper(model, opt, B=1, P=P, learnable=coop, opt_in_graph=not coop)
+        tfeat = None
+        if not coop:
+            with torch.no_grad():
+                tfeat = model.clinic_extractor(ids)               # frozen tower: cached per note (dim1/CLIP.py cache_text)
         def run(n):
             if mode == "bucket_graph":
                 slot = st.slot(n)
                 slot.x[:n].copy_(xs[:n], non_blocking=True)      # the loader's H2D copy into the bucket's buffer
                 slot.y.copy_(y)
-                slot.text.copy_(tfeat)
+                if coop:
+                    slot.ids.copy_(ids)
+                else:
+                    slot.text.copy_(tfeat)
                 st.step(slot, [n])
             else:
                 opt.zero_grad()
-                model([xs[:n].unsqueeze(0)], None, text_features=tfeat, labels=y)
+                model([xs[:n].unsqueeze(0)], ids if coop else None, text_features=tfeat, labels=y)
                 model.last_loss.backward()
                 opt.step()
-        warm = lens[:40] if mode == "bucket_graph" else lens[:5]
+        warm = lens[:(20 if coop else 40)] if mode == "bucket_graph" else lens[:5]
         for n in warm:
             run(n)
         torch.cuda.synchronize()
-        todo = lens if mode == "bucket_graph" else lens[:40]
+        todo = lens if mode == "bucket_graph" else lens[:(20 if coop else 40)]
         t0 = time.perf_counter()
         for n in todo:
             run(n)
@@ -91,7 +102,8 @@ else:
             out["replays"] = st.replays
         del model, opt, st
         torch.cuda.empty_cache()
-    work = ("1 ragged bag/step, N~U[2000,15592] x 768 + one 77-token note, aggregator(args) fwd+BCE+bwd+Adam, "
-            + ("model.train()" if train else "model.eval()"))
+    work = (f"1 ragged bag/step, N~U[2000,15592] x 768 + {P} prompt(s) of 77 tokens"
+            + (" (learnable context through the frozen ViT-B/32 tower, SGD)" if coop else "") + ", aggregator(args) fwd+BCE+bwd+"
+            + ("SGD, " if coop else "Adam, ") + ("model.train()" if train else "model.eval()"))
 out["mean_patches"] = float(np.mean(lens))
 print(json.dumps({"workload": work, **out}))
