@@ -696,6 +696,15 @@ int mil_build_fusion_segs(const int32_t* len_dev, int B, int P, int cap, int32_t
                           int32_t* bag_tile64_off, int T64, int32_t* tile32, int32_t* bag_tile32_off, int T32,
                           int32_t* row_bag, int32_t* rows_out, float* ds_zero, void* stream);
 
+/* mil_build_fusion_segs for a multi-modal bag with several static segments behind the patch rows (aggregator.py:173, CT +
+ * pathology: P text-from-CT tokens, D CT tokens, P text-from-pathology tokens per bag): seg_rows is a HOST array of nseg <= 4
+ * per-bag row counts; segment s of bag b sits at cap + B (seg_rows[0] + .. + seg_rows[s-1]) + b seg_rows[s].
+ * T32 >= cap / 32 + B (1 + sum ceil(seg_rows[s] / 32)); row_bag / ds_zero cover cap + B sum(seg_rows) rows. */
+int mil_build_fusion_segs_tail(const int32_t* len_dev, int B, int nseg, const int32_t* seg_rows, int cap, int32_t* k_off,
+                               int32_t* k_bag, int32_t* tile64, int32_t* bag_tile64_off, int T64, int32_t* tile32,
+                               int32_t* bag_tile32_off, int T32, int32_t* row_bag, int32_t* rows_out, float* ds_zero,
+                               void* stream);
+
 /* In-step timing (bench.py's `roofline` / `kernels_ms`): runs the whole step `iters` times as `ngroups` consecutive
  * mil_image_only_step_run calls (groups[i] = stage mask of group i) with a HIP event recorded on `stream` between the
  * groups; ms_out[i] = average duration of group i where it runs inside the step, ms_out[ngroups] = average first-to-last

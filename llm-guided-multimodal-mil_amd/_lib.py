@@ -116,6 +116,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_layernorm_bagrow_bwd": (c_int, [_P] * 4 + [c_int] + [_P] * 3 + [c_int, c_int] + [_P] * 5 + [_P]),
     "mil_layernorm_bagrow_rows_per_block": (c_int, [c_int]),
     "mil_build_fusion_segs": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),
+    "mil_build_fusion_segs_tail": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),
     "mil_add_pe": (c_int, [_P] * 4 + [c_int, c_int, _P, _P]),
     "mil_add_bag_row": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "mil_segment_colsum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),

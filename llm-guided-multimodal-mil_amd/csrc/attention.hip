@@ -1104,7 +1104,11 @@ extern "C" int mil_layernorm_bwd(const float* x, const float* gamma, const float
 //     (bags.BagLayout.two_segment), bag_tile32_off [B + 1], padding tiles {0, 0, 0, 0}
 //   row_bag [cap + B P]: bag of every row of the multi-modal bag, -1 for padding rows (mil_gate_bwd_input_pool)
 //   rows_out [1] = sum of the lengths
-__global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __restrict__ len_dev, int B, int P, int cap,
+struct FusionTail {              // the static row segments behind the `cap` patch rows: seg s holds rows[s] rows per bag
+    int nseg;
+    int rows[4];
+};
+__global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __restrict__ len_dev, int B, FusionTail tail, int cap,
                                                             int32_t* __restrict__ k_off, int32_t* __restrict__ k_bag,
                                                             int32_t* __restrict__ tile64, int32_t* __restrict__ bag_tile64_off,
                                                             int T64, int32_t* __restrict__ tile32,
@@ -1113,7 +1117,14 @@ __global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __res
                                                             float* __restrict__ ds_zero) {
     __shared__ int s_row[1025], s_t64[1025], s_t32[1025];
     const int tid = threadIdx.x;
-    const int tokt = (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+    int tokt = 0, tail_rows = 0;                    // tail tiles / tail rows per bag
+    int seg_base[4], seg_t0[4];
+    for (int sgm = 0; sgm < tail.nseg; ++sgm) {
+        seg_base[sgm] = cap + B * tail_rows;        // segment s of bag b starts at seg_base[s] + b rows[s]
+        seg_t0[sgm] = tokt;
+        tokt += (tail.rows[sgm] + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+        tail_rows += tail.rows[sgm];
+    }
     if (tid == 0) {
         int r = 0, a = 0, c = 0;
         for (int b = 0; b < B; ++b) {
@@ -1152,11 +1163,15 @@ __global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __res
                 const int row0 = r0 + j * MIL_POOL_TILE;
                 reinterpret_cast<int4*>(tile32)[t] = make_int4(b, row0, min(MIL_POOL_TILE, r1 - row0), 0);
             } else {
-                const int row0 = cap + b * P + (j - np) * MIL_POOL_TILE;
-                reinterpret_cast<int4*>(tile32)[t] = make_int4(b, row0, min(MIL_POOL_TILE, cap + (b + 1) * P - row0), 0);
+                int sgm = tail.nseg - 1;
+                while (sgm > 0 && j - np < seg_t0[sgm]) --sgm;           // the tail segment this tile belongs to
+                const int first = seg_base[sgm] + b * tail.rows[sgm];
+                const int row0 = first + (j - np - seg_t0[sgm]) * MIL_POOL_TILE;
+                reinterpret_cast<int4*>(tile32)[t] = make_int4(b, row0, min(MIL_POOL_TILE, first + tail.rows[sgm] - row0), 0);
             }
         }
-        for (int r = tid; r < P; r += 1024) row_bag[cap + b * P + r] = b;
+        for (int sgm = 0; sgm < tail.nseg; ++sgm)
+            for (int r = tid; r < tail.rows[sgm]; r += 1024) row_bag[seg_base[sgm] + b * tail.rows[sgm] + r] = b;
     }
     for (int r = N + tid; r < cap; r += 1024) { k_bag[r] = B - 1; row_bag[r] = -1; }
     // behind the real 64-key tiles: PADDING tiles {0, row0, -count} that cover the rows [N, cap) - empty for every pool
@@ -1168,24 +1183,53 @@ __global__ __launch_bounds__(1024) void k_build_fusion_segs(const int32_t* __res
         const bool live = r0 < cap && r1 > r0;
         tile64[3 * t] = 0; tile64[3 * t + 1] = live ? r0 : 0; tile64[3 * t + 2] = live ? -(r1 - r0) : 0;
     }
-    for (int r = N + tid; r < cap + B * P; r += 1024) if (r < cap) ds_zero[r] = 0.f;      // score gradient of padding rows
+    for (int r = N + tid; r < cap; r += 1024) ds_zero[r] = 0.f;           // score gradient of padding rows
     for (int t = s_t32[B] + tid; t < T32; t += 1024) reinterpret_cast<int4*>(tile32)[t] = make_int4(0, 0, 0, 0);
+}
+
+static int build_fusion_segs_impl(const int32_t* len_dev, int B, FusionTail tail, int cap, int32_t* k_off, int32_t* k_bag,
+                                  int32_t* tile64, int32_t* bag_tile64_off, int T64, int32_t* tile32,
+                                  int32_t* bag_tile32_off, int T32, int32_t* row_bag, int32_t* rows_out, float* ds_zero,
+                                  void* stream) {
+    if (!len_dev || !k_off || !k_bag || !tile64 || !bag_tile64_off || !tile32 || !bag_tile32_off || !row_bag || !rows_out ||
+        !ds_zero)
+        return MIL_EINVAL;
+    int tokt = 0;
+    if (tail.nseg < 1 || tail.nseg > 4) return MIL_EINVAL;
+    for (int sgm = 0; sgm < tail.nseg; ++sgm) {
+        if (tail.rows[sgm] <= 0) return MIL_EINVAL;
+        tokt += (tail.rows[sgm] + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+    }
+    if (B <= 0 || B > 1024 || cap <= 0 || T64 < cap / 64 + B + 2 || T32 < cap / MIL_POOL_TILE + B * (1 + tokt)) return MIL_EINVAL;
+    if (reinterpret_cast<uintptr_t>(tile32) & 15) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_build_fusion_segs, dim3(1), dim3(1024), 0, (hipStream_t)stream, len_dev, B, tail, cap, k_off, k_bag, tile64,
+                       bag_tile64_off, T64, tile32, bag_tile32_off, T32, row_bag, rows_out, ds_zero);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
 }
 
 extern "C" int mil_build_fusion_segs(const int32_t* len_dev, int B, int P, int cap, int32_t* k_off, int32_t* k_bag,
                                      int32_t* tile64, int32_t* bag_tile64_off, int T64, int32_t* tile32,
                                      int32_t* bag_tile32_off, int T32, int32_t* row_bag, int32_t* rows_out, float* ds_zero,
                                      void* stream) {
-    if (!len_dev || !k_off || !k_bag || !tile64 || !bag_tile64_off || !tile32 || !bag_tile32_off || !row_bag || !rows_out ||
-        !ds_zero)
-        return MIL_EINVAL;
-    if (B <= 0 || B > 1024 || P <= 0 || cap <= 0 || T64 < cap / 64 + B + 2 || T32 < cap / MIL_POOL_TILE + B * (1 + (P + MIL_POOL_TILE - 1) / MIL_POOL_TILE))
-        return MIL_EINVAL;
-    if (reinterpret_cast<uintptr_t>(tile32) & 15) return MIL_EINVAL;
-    hipLaunchKernelGGL(k_build_fusion_segs, dim3(1), dim3(1024), 0, (hipStream_t)stream, len_dev, B, P, cap, k_off, k_bag, tile64,
-                       bag_tile64_off, T64, tile32, bag_tile32_off, T32, row_bag, rows_out, ds_zero);
-    MIL_CHECK_LAUNCH();
-    return MIL_OK;
+    FusionTail tail{1, {P, 0, 0, 0}};
+    return build_fusion_segs_impl(len_dev, B, tail, cap, k_off, k_bag, tile64, bag_tile64_off, T64, tile32, bag_tile32_off, T32,
+                                  row_bag, rows_out, ds_zero, stream);
+}
+
+// The same for a multi-modal bag with SEVERAL static segments behind the patch rows (model/aggregator.py:173: the CT +
+// pathology bag [x_CT2CI | x_CI2CT | x_Pth2CI | x_CI2Pth] = patch rows, then P text-from-CT tokens, D CT tokens, P
+// text-from-pathology tokens per bag): seg_rows[s] rows per bag in segment s, nseg <= 4; rows of segment s of bag b at
+// cap + B (seg_rows[0] + .. + seg_rows[s-1]) + b seg_rows[s].  T32 >= cap / 32 + B (1 + sum ceil(seg_rows / 32)).
+extern "C" int mil_build_fusion_segs_tail(const int32_t* len_dev, int B, int nseg, const int32_t* seg_rows, int cap,
+                                          int32_t* k_off, int32_t* k_bag, int32_t* tile64, int32_t* bag_tile64_off, int T64,
+                                          int32_t* tile32, int32_t* bag_tile32_off, int T32, int32_t* row_bag,
+                                          int32_t* rows_out, float* ds_zero, void* stream) {
+    if (!seg_rows || nseg < 1 || nseg > 4) return MIL_EINVAL;
+    FusionTail tail{nseg, {0, 0, 0, 0}};
+    for (int sgm = 0; sgm < nseg; ++sgm) tail.rows[sgm] = seg_rows[sgm];           // a HOST array (launch arguments)
+    return build_fusion_segs_impl(len_dev, B, tail, cap, k_off, k_bag, tile64, bag_tile64_off, T64, tile32, bag_tile32_off, T32,
+                                  row_bag, rows_out, ds_zero, stream);
 }
 
 extern "C" int mil_add_pe(const float* x, const float* pe, const int32_t* row_bag, const int32_t* row_off, int rows, int E,

@@ -30,16 +30,20 @@ from .segments import FusionBucket
 
 class RaggedFusionStepper:
     class Slot:
-        def __init__(self, cap: int, B: int, C: int, in_dim: int, device, P: int = 1, ctx_len: int = 77):
+        def __init__(self, cap: int, B: int, C: int, in_dim: int, device, P: int = 1, ctx_len: int = 77, ct_shape=None,
+                     ct_tokens: int = 0):
             self.cap, self.B = cap, B
+            # CT + pathology (aggregator.py:155-173): the CT encoder's feature map is an input of the step as well
+            self.ct = torch.zeros((B,) + tuple(ct_shape), device=device, dtype=torch.float32) if ct_shape else None
             self.x = torch.zeros((cap, in_dim), device=device, dtype=torch.float32)    # rows beyond the bags: padding
             self.text = torch.zeros((B, P, 512), device=device, dtype=torch.float32)   # frozen-tower embedding per prompt
             self.ids = torch.zeros((B, P, ctx_len), device=device, dtype=torch.int64)  # learnable prompts: the token ids
             self.y = torch.zeros((B, C), device=device, dtype=torch.float32)
-            self.bucket = FusionBucket(cap, B, device, P)
+            self.bucket = FusionBucket(cap, B, device, P, tail=[P, ct_tokens, P] if ct_shape else None)
 
     def __init__(self, model, opt, B: int = 1, use_graph: bool = True, max_graphs: int = 16, in_dim: int = 768,
-                 opt_in_graph: bool = True, P: int = 1, learnable: bool = False, ctx_len: int = 77):
+                 opt_in_graph: bool = True, P: int = 1, learnable: bool = False, ctx_len: int = 77, ct_shape=None,
+                 loss_mult: float = 1.0, cossim: bool = False):
         """opt_in_graph=False keeps the optimizer (and, at world size > 1, its gradient all-reduce) outside the captured
         graph, as graph_step.GraphedStep does.  P: text tokens per bag (1 = one note; 10 = `CI_prompt_version='devided'` or
         the learnable-prompt branch, whose P = len(clinical_features) + 1).  learnable=True: upstream's default
@@ -51,6 +55,15 @@ class RaggedFusionStepper:
         self.model, self.opt, self.B, self.use_graph, self.in_dim = model, opt, int(B), bool(use_graph), int(in_dim)
         self.opt_in_graph = bool(opt_in_graph)
         self.P, self.learnable, self.ctx_len = int(P), bool(learnable), int(ctx_len)
+        # ct_shape (E, D, h, w): modality ['CT', 'pathology'] - slot.ct holds the CT feature map, the multi-modal bag has
+        # four segments.  loss_mult: 3 for `--loss_point CT-Pth-Last` (train_ddp.py:319-322: the criterion on three outputs,
+        # one head here).  cossim: add CosineEmbeddingLoss(x_CT2CI, x_Pth2CI, 1) ('textCosSim', train_ddp.py:325-329).
+        self.ct_shape = tuple(ct_shape) if ct_shape else None
+        self.ct_tokens = 0
+        if self.ct_shape:
+            E_, D_, h_, w_ = self.ct_shape
+            self.ct_tokens = D_ * h_ * w_ if getattr(model.args, "model_CT", "resnetMC3_18") == "medicalNet" else D_
+        self.loss_mult, self.cossim = float(loss_mult), bool(cossim)
         if self.learnable and use_graph:
             model.clinic_extractor.model.static_rows = True      # the tower is inside the graph: no token-dependent host work
         self.device = next(model.parameters()).device
@@ -71,7 +84,8 @@ class RaggedFusionStepper:
         cap = bucket_rows(total_rows)
         s = self.slots.get(cap)
         if s is None:
-            s = self.slots[cap] = self.Slot(cap, self.B, self.C, self.in_dim, self.device, self.P, self.ctx_len)
+            s = self.slots[cap] = self.Slot(cap, self.B, self.C, self.in_dim, self.device, self.P, self.ctx_len,
+                                           self.ct_shape, self.ct_tokens)
         return s
 
     def encode_notes(self, slot, ids):
@@ -82,11 +96,20 @@ class RaggedFusionStepper:
 
     def _body(self, slot):
         m = self.model
-        if self.learnable:
-            prob, _ = m([slot.x], slot.ids, labels=slot.y, bucket=slot.bucket)
+        xs = [slot.x] if slot.ct is None else [slot.ct, slot.x]
+        scale = self.loss_mult / (self.B * (1 if self.C > 2 else self.C)) if self.loss_mult != 1.0 else None
+        kw = dict(labels=slot.y, bucket=slot.bucket, loss_scale=scale)
+        out = m(xs, slot.ids, **kw) if self.learnable else m(xs, None, text_features=slot.text, **kw)
+        if isinstance(out[0], list):                   # args.train_contract: ([x, x, x], [CT2CI, Pth2CI], None)
+            prob, toks = out[0][0], out[1]
         else:
-            prob, _ = m([slot.x], None, text_features=slot.text, labels=slot.y, bucket=slot.bucket)
-        return m.last_loss, prob, m.last_logits
+            prob, toks = out[0], list(out[1:])
+        toks = [t_ for t_ in toks if t_ is not None]
+        loss = m.last_loss
+        if self.cossim and len(toks) == 2:
+            from . import ops
+            loss = loss + ops.cosine_embedding_loss(toks[0].squeeze(1), toks[1].squeeze(1))
+        return loss, prob, m.last_logits
 
     def step(self, slot, lengths: Sequence[int]):
         """One training step on the bags packed in slot.x (bag b at rows [sum(lengths[:b]), +lengths[b])).  Returns

@@ -181,6 +181,33 @@ class aggregator(nn.Module):
         x0 = ops.append_rows(k, q, tail_reserved=True)                                     # :192 (no concat copy)
         return self._pool_head(x0, bucket.layout), q.view(B, P, EMBED)                     # :198-200,207
 
+    def _forward_ct_bucket(self, x_list, t, bucket):
+        """The CT + pathology branch (aggregator.py:155-173,202-203) on a segments.FusionBucket whose tail is [P, D, P]:
+        x_list = [CT feature map [B, 512, 160, h, w] (or tokens [B, D, 512]), patches [cap, 768] packed from row 0].  The CT
+        side is static (D tokens per bag) and runs on host-built maps; the pathology side and the 4-segment multi-modal bag
+        follow the device-side bag lengths.  This is the authors' own run (run_train.sh:81: `--modality ['CT','pathology']
+        --CI_prompt_version single --learnablePrompt 0 --loss_point CT-Pth-Last`, one bag per GPU)."""
+        B, P, _ = t.shape
+        dev = t.device
+        ct, x = x_list[0], x_list[1]
+        if ct.dim() == 5:
+            ct_rows, D = ops.ct_map_tokens(ct, _arg(self.args, "model_CT", "resnetMC3_18"))     # sam/transformer.py:86-98
+        else:
+            D = ct.shape[1]
+            ct_rows = ct.reshape(B * D, EMBED).contiguous()
+        if x.dim() != 2 or x.shape[0] != bucket.cap or B != bucket.B or list(bucket.tail) != [P, D, P]:
+            raise ValueError(f"bucket of {bucket.B} bags x {bucket.cap} rows with tail {bucket.tail}: got x {tuple(x.shape)}, "
+                             f"text {tuple(t.shape)}, {D} CT tokens per bag")
+        bucket.refresh()
+        tflat = t.reshape(B * P, EMBED)
+        tw = self.TwoWayTransformer_Both                                                      # :160,168: one module, twice
+        q_ct, k_ct = tw.flat(ct_rows, self._lin_tanh(self.fc_CI2CT, tflat), self.pe_rows(D, dev), [D] * B, [P] * B)
+        xi = self._lin_tanh(self.fc_pathology, x)                                             # :141
+        q_p, k_p = tw.flat(xi, self._lin_tanh(self.fc_CI2Pth, tflat), self.pe_rows(bucket.cap, dev), None, None,
+                           keys_tail_rows=bucket.tail_rows, segs=(bucket.s_tt, bucket.s_ti, bucket.s_it))
+        x0 = ops.append_rows(k_p, torch.cat([q_ct, k_ct, q_p], 0), tail_reserved=True)        # :173 (no concat of the patches)
+        return self._pool_head(x0, bucket.layout), q_ct.view(B, P, EMBED), q_p.view(B, P, EMBED)
+
     # ------------------------------------------------------------------ forward (aggregator.py:134-209)
     def forward(self, x_list: List[torch.Tensor], x_CI: torch.Tensor, lengths: Optional[List[int]] = None,
                 text_features: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
@@ -214,6 +241,8 @@ class aggregator(nn.Module):
         # `self.clinic_extractor(x_CI)`; lets a captured hipGraph replay the trainable part only
         t = text_features if text_features is not None else self.clinic_extractor(x_CI)   # :151  [B, P, 512]
         B, P, _ = t.shape
+        if "CT" in modality and "pathology" in modality and bucket is not None:
+            return self._forward_ct_bucket(x_list, t, bucket)
         if "CT" in modality:
             return self._forward_ct(x_list, t, lengths)
         if "pathology" in modality and bucket is not None:

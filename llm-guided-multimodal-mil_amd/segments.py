@@ -4,6 +4,7 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import ctypes
 from collections import OrderedDict
 
 import numpy as np
@@ -96,23 +97,33 @@ class FusionBucket:
         s_tt, s_ti, s_it   AttnSegs-shaped (token-token, token-image, image-token)
         layout             BagLayout-shaped two-segment multi-modal bag: rows [cap patch rows | B token rows]."""
 
-    def __init__(self, capacity_rows: int, B: int, device, P: int = 1):
+    def __init__(self, capacity_rows: int, B: int, device, P: int = 1, tail=None):
+        """tail: per-bag row counts of the static segments behind the patch rows, in row order.  Default [P] - the bag of
+        aggregator.py:192, [patch rows | P text tokens].  The CT + pathology bag of aggregator.py:173 is [P, D, P]: patch rows,
+        then P text-from-CT tokens, D CT tokens, P text-from-pathology tokens per bag."""
         from . import _lib
         from .bags import POOL_TILE
         cap, B, P = int(capacity_rows), int(B), int(P)
         if cap % 256 or cap <= 0 or not (0 < B <= 1024) or not (1 <= P <= 12):
             raise ValueError("FusionBucket: capacity must be a positive multiple of 256 rows, 1 <= B <= 1024, 1 <= P <= 12")
         self.P = P
+        self.tail = [int(v) for v in (tail if tail is not None else [P])]
+        if not (1 <= len(self.tail) <= 4) or min(self.tail) <= 0:
+            raise ValueError("FusionBucket: 1 .. 4 tail segments of >= 1 row per bag")
+        tail_rows = sum(self.tail)
+        tail_tiles = sum((v + POOL_TILE - 1) // POOL_TILE for v in self.tail)
         self.cap, self.B, self.device = cap, B, device
         i32 = lambda *shape: torch.zeros(shape, device=device, dtype=torch.int32)      # noqa: E731
         self.len_dev, self.rows_dev = i32(B), i32(1)
         self.k_off, self.k_bag = i32(B + 1), i32(cap)
-        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B + 2, cap // POOL_TILE + B * (1 + (P + POOL_TILE - 1) // POOL_TILE)
+        self.T64, self.T32 = cap // POOL_KEYS_PER_TILE + B + 2, cap // POOL_TILE + B * (1 + tail_tiles)
         self.tile64, self.bag_tile64_off = i32(self.T64, 3), i32(B + 1)
         self.tile32, self.bag_tile32_off = i32(self.T32, 4), i32(B + 1)
-        self.row_bag_dev = i32(cap + B * P)
+        self.row_bag_dev = i32(cap + B * tail_rows)
+        self.tail_rows = B * tail_rows
+        self._tail_host = (ctypes.c_int32 * len(self.tail))(*self.tail)
         # the ABMIL pool's score gradient: real rows are written by the fused tail, padding rows zeroed by refresh()
-        self.ds = torch.zeros(cap + B * P, device=device, dtype=torch.float32)
+        self.ds = torch.zeros(cap + B * tail_rows, device=device, dtype=torch.float32)
         self.lengths = None
         tok = AttnSegs.make([P] * B, [P] * B, device)
         self.s_tt = tok
@@ -124,7 +135,7 @@ class FusionBucket:
         # image -> token: queries = the patch rows, keys = the tokens
         self.s_it = _SegView(B=B, q_lengths=None, k_lengths=ones, Tq=cap, Tk=B * P, Tq_max=cap, Tk_max=P, q_off=self.k_off,
                              q_bag=self.k_bag, k_off=tok.k_off, k_bag=tok.k_bag)
-        self.layout = _SegView(B=B, R=cap + B * P, T=self.T32, tile_map=self.tile32, bag_tile_off=self.bag_tile32_off,
+        self.layout = _SegView(B=B, R=cap + B * tail_rows, T=self.T32, tile_map=self.tile32, bag_tile_off=self.bag_tile32_off,
                                bag_off=self.k_off, lengths=None, aligned32=False, row_bag=lambda: self.row_bag_dev,
                                ds_buffer=self.ds)
         self._lib = _lib
@@ -143,9 +154,10 @@ class FusionBucket:
     def refresh(self):
         """Rebuild every map from len_dev on the current stream (capture-safe: one launch, no host sync)."""
         p = lambda t: t.data_ptr()      # noqa: E731
-        rc = self._lib.lib().mil_build_fusion_segs(p(self.len_dev), self.B, self.P, self.cap, p(self.k_off), p(self.k_bag),
-                                                   p(self.tile64), p(self.bag_tile64_off), self.T64, p(self.tile32),
-                                                   p(self.bag_tile32_off), self.T32, p(self.row_bag_dev), p(self.rows_dev),
-                                                   p(self.ds), torch.cuda.current_stream().cuda_stream)
-        self._lib.check(rc, "mil_build_fusion_segs")
+        rc = self._lib.lib().mil_build_fusion_segs_tail(p(self.len_dev), self.B, len(self.tail), self._tail_host, self.cap,
+                                                        p(self.k_off), p(self.k_bag), p(self.tile64), p(self.bag_tile64_off),
+                                                        self.T64, p(self.tile32), p(self.bag_tile32_off), self.T32,
+                                                        p(self.row_bag_dev), p(self.rows_dev), p(self.ds),
+                                                        torch.cuda.current_stream().cuda_stream)
+        self._lib.check(rc, "mil_build_fusion_segs_tail")
         return lifetime.note(self)

@@ -104,7 +104,7 @@ def main_worker(local_rank: int, nprocs: int, args):
             # one clinical note per bag + --hip_graph: the capacity-bucket stepper below replays the whole step, optimizer
             # included, so step number and learning rate live on the device
             bucketed = (bool(getattr(args, "hip_graph", 0)) and args.variant != "image_only" and prompts <= 12
-                        and list(args.modality) == ["pathology"])
+                        and list(args.modality) in (["pathology"], ["CT", "pathology"]))
             optimizer = FlatAdam(trainable, lr=lr0, betas=(args.b1, args.b2), weight_decay=1e-7, world_size=world,
                                  counted=bucketed)
         else:
@@ -140,15 +140,19 @@ def main_worker(local_rank: int, nprocs: int, args):
                 loss_ = loss_ + ops.cosine_embedding_loss(toks[0].squeeze(1), toks[1].squeeze(1))
             return loss_
         graphed = fstepper = None
+        CT_SHAPE = (512, 160, 2, 2)          # synthetic stand-in for the CT encoder's feature map (aggregator.py:139-140)
         if (getattr(args, "hip_graph", 0) and flat_opt and args.variant != "image_only" and prompts <= 12
-                and list(args.modality) == ["pathology"]):
+                and list(args.modality) in (["pathology"], ["CT", "pathology"])):
             # the authors' regime (one ragged bag per GPU, run_train.sh:81; a fresh patch drop every epoch,
             # dataset.py:366-393): bag lengths on the device, one graph per capacity bucket (fusion_step.py).  Adam with its
             # step number and rate on the device rides inside the graph at world size 1; the learnable-prompt runs' SGD
             # (train_ddp.py:104-109) and any multi-GPU all-reduce stay outside.
             from .fusion_step import RaggedFusionStepper
             fstepper = RaggedFusionStepper(model, optimizer, B=per_gpu, P=prompts, learnable=bool(args.learnablePrompt),
-                                           opt_in_graph=(world == 1 and getattr(optimizer, "counted", False)))
+                                           opt_in_graph=(world == 1 and getattr(optimizer, "counted", False)),
+                                           ct_shape=CT_SHAPE if "CT" in args.modality else None,
+                                           loss_mult=3.0 if (args.loss_point == "CT-Pth-Last" and "CT" in args.modality) else 1.0,
+                                           cossim="textCosSim" in args.loss)
         if getattr(args, "hip_graph", 0):
             # replay the step body from a hipGraph once a batch shape repeats (graph_step.py); optimizer and the
             # gradient all-reduce stay outside, so this needs the flat optimizers when world > 1 (no DDP hooks)
@@ -206,6 +210,10 @@ def main_worker(local_rank: int, nprocs: int, args):
                         slot.x[r0:r0 + n].copy_(x[b, :n], non_blocking=True)
                         r0 += n
                     slot.y.copy_(y, non_blocking=True)
+                    if slot.ct is not None:
+                        from . import synthetic as syn
+                        slot.ct.copy_(syn.make_ct_map(args.seed + 7919 * epoch + it, x.shape[0], CT_SHAPE[1], CT_SHAPE[2]),
+                                      non_blocking=True)
                     if args.learnablePrompt:
                         slot.ids.copy_(batch["CI"], non_blocking=True)                    # the tower runs inside the step
                     else:

@@ -104,3 +104,16 @@ def test_ct_plus_pathology_training_with_the_cossim_term_and_the_train_contract(
     assert "Epoch: [0]" in out and "Loss" in out
     ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
     assert torch.isfinite(ck["state_dict"]["TwoWayTransformer_Both.layers.0.mlp.lin1.weight"]).all()
+
+
+def test_the_authors_run_ct_plus_pathology_one_ragged_bag_per_gpu_with_graph_replay(tmp_path):
+    """run_train.sh:81 in miniature: `--modality ['CT','pathology'] --CI_prompt_version single --learnablePrompt 0
+    --loss_point CT-Pth-Last`, one ragged bag per step, `--hip_graph 1`: the CT + pathology bucket (four-segment multi-modal
+    bag, device-side bag lengths) replays the whole step incl. Adam; the 'textCosSim' term rides along."""
+    out = run("train_ddp.py", "--synthetic", "[700, 768, 10]", "--ragged", "--clip_layers", "1", "--batch_size", "1",
+              "--modality", "['CT', 'pathology']", "--loss", "BCE+textCosSim", "--loss_point", "CT-Pth-Last", "--hip_graph", "1",
+              "--n_epochs", "2", "--iter_per_epoch", "5", "--save_dir", str(tmp_path))
+    assert "Epoch: [1]" in out and "Loss" in out
+    ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
+    assert ck["optimizer"]["step"] == 10
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())

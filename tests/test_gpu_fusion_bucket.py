@@ -257,3 +257,73 @@ def test_ragged_stream_with_ten_prompts_and_with_learnable_prompts_replays():
             loss, _, _ = st.step(slot, [n])
             assert abs(float(loss) - float(ref.last_loss.detach())) <= 5e-6, (learnable, step)
         assert len(st.slots) == 2 and st.replays == 4, (learnable, st.replays)
+
+
+def test_multi_tail_layout_equals_the_host_multi_segment_layout():
+    """The CT + pathology bag (aggregator.py:173): bucket tail [P, D, P] against BagLayout.multi_segment."""
+    lengths, P, D = [300, 77, 1500], 1, 160
+    B, N = len(lengths), sum(lengths)
+    cap = bucket_rows(N)
+    bk = FusionBucket(cap, B, DEV, P, tail=[P, D, P])
+    bk._min_rows = 1
+    bk.set_lengths(lengths).refresh()
+    torch.cuda.synchronize()
+    lay = BagLayout.multi_segment([lengths, [P] * B, [D] * B, [P] * B], DEV)
+    tm = lay.tile_map.cpu().clone()
+    tail = tm[:, 1] >= N
+    tm[tail, 1] += cap - N
+    assert bk.layout.R == cap + B * (2 * P + D)
+    assert torch.equal(bk.bag_tile32_off.cpu(), lay.bag_tile_off.cpu())
+    assert torch.equal(bk.tile32[:lay.T].cpu(), tm) and int(bk.tile32[lay.T:].abs().sum()) == 0
+    rb = bk.row_bag_dev.cpu()
+    want = torch.cat([torch.arange(B).repeat_interleave(P), torch.arange(B).repeat_interleave(D),
+                      torch.arange(B).repeat_interleave(P)]).to(torch.int32)
+    assert bool((rb[N:cap] == -1).all()) and torch.equal(rb[cap:], want)
+
+
+def test_ct_plus_pathology_bucket_step_equals_the_exact_shape_step():
+    """The authors' own run (run_train.sh:81: CT + pathology, one note, frozen tower, loss_point CT-Pth-Last) in bucket form
+    vs exact shapes: logits, both text-aligned tokens, the cosine term and every gradient - TwoWayTransformer_Both is used
+    twice per forward, once on static CT tokens and once on the device-length patch rows."""
+    args = SimpleNamespace(modality=["CT", "pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL",
+                           num_classes=2, learnablePrompt=0, alignment_base="CI", model_CT="resnetMC3_18", clip_layers=1,
+                           cache_text=0)
+    torch.manual_seed(17)
+    m = get_model(args).to(DEV).eval()
+    lengths, D, hw = [1200, 900], 160, 2
+    B, N = len(lengths), sum(lengths)
+    cap = bucket_rows(N)
+    gen = torch.Generator().manual_seed(19)
+    bags = [torch.randn((n, 768), generator=gen) for n in lengths]
+    ids = syn.make_token_ids(20, B, 1).to(DEV)
+    y = syn.make_labels(21, B).to(DEV)
+    ct = syn.make_ct_map(22, B, D, hw).to(DEV)
+    with torch.no_grad():
+        t = m.clinic_extractor(ids)
+    pad = torch.zeros((B, max(lengths), 768))
+    for b, xb in enumerate(bags):
+        pad[b, :xb.shape[0]] = xb
+    scale = 3.0 / (B * 2)                                                    # loss_point CT-Pth-Last: three terms, one head
+
+    def run(**kw):
+        m.zero_grad()
+        prob, q_ct, q_p = m(kw.pop("xs"), None, text_features=t, labels=y, loss_scale=scale, **kw)
+        cs = ops.cosine_embedding_loss(q_ct.squeeze(1), q_p.squeeze(1))
+        (m.last_loss + cs).backward()
+        return (m.last_logits.detach().clone(), q_ct.detach().clone(), q_p.detach().clone(), float(cs.detach()),
+                {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+
+    za, qa, pa, ca, ga = run(xs=[ct, pad.to(DEV)], lengths=lengths)
+    bk = FusionBucket(cap, B, DEV, 1, tail=[1, D, 1]).set_lengths(lengths)
+    x = torch.full((cap, 768), 1.5, device=DEV)
+    x[:N] = torch.cat(bags, 0).to(DEV)
+    zb, qb, pb, cb, gb = run(xs=[ct, x], bucket=bk)
+    torch.cuda.synchronize()
+    assert float((za - zb).abs().max()) <= 1e-6 and abs(ca - cb) <= 1e-6
+    assert rel_err(qb.cpu(), qa.cpu()) <= 1e-6 and rel_err(pb.cpu(), pa.cpu()) <= 1e-6
+    assert set(ga) == set(gb)
+    for k in ga:
+        if float(ga[k].norm()) < 1e-7:
+            assert float(gb[k].abs().max()) < 1e-6, k
+        else:
+            assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 5e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
