@@ -51,12 +51,15 @@ else:
     from mil_amd.optim import FlatAdam, FlatSGD
     coop = "--coop" in sys.argv                       # upstream's default --learnablePrompt 1: 10 prompts, tower in the step
     P = 10 if (coop or "--prompts10" in sys.argv) else 1
+    with_ct = "--ct" in sys.argv                     # the authors' own run (run_train.sh:81): CT + pathology, CT-Pth-Last
+    CT_SHAPE = (512, 160, 2, 2)
     if coop:
         steps = 60
         lens = lens[:steps]
-    args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
-                           learnablePrompt=int(coop), n_ctx=8, clinical_features=["f"] * 9, alignment_base="CI",
-                           model_CT="resnetMC3_18", clip_layers=12, cache_text=0)
+    args = SimpleNamespace(modality=["CT", "pathology"] if with_ct else ["pathology"], model_pathology="ABMIL", model_CI="CLIP",
+                           aggregator="ABMIL", num_classes=2, learnablePrompt=int(coop), n_ctx=8, clinical_features=["f"] * 9,
+                           alignment_base="CI", model_CT="resnetMC3_18", clip_layers=12, cache_text=0)
+    ct = syn.make_ct_map(5, 1, CT_SHAPE[1], CT_SHAPE[2]).to(dev) if with_ct else None
     xs = torch.randn((16384, 768), device=dev)
     ids = syn.make_token_ids(2, 1, P).to(dev)
     y = syn.make_labels(3, 1).to(dev)
@@ -67,7 +70,8 @@ else:
         model.train(train)
         trainable = [q for q in model.parameters() if q.requires_grad]
         opt = FlatSGD(trainable, lr=1e-3, weight_decay=1e-7) if coop else FlatAdam(trainable, lr=1e-5, weight_decay=1e-7, counted=True)
-        st = RaggedFusionStepper(model, opt, B=1, P=P, learnable=coop, opt_in_graph=not coop)
+        st = RaggedFusionStepper(model, opt, B=1, P=P, learnable=coop, opt_in_graph=not coop,
+                                 ct_shape=CT_SHAPE if with_ct else None, loss_mult=3.0 if with_ct else 1.0, cossim=with_ct)
         tfeat = None
         if not coop:
             with torch.no_grad():
@@ -77,6 +81,8 @@ else:
                 slot = st.slot(n)
                 slot.x[:n].copy_(xs[:n], non_blocking=True)      # the loader's H2D copy into the bucket's buffer
                 slot.y.copy_(y)
+                if with_ct:
+                    slot.ct.copy_(ct)
                 if coop:
                     slot.ids.copy_(ids)
                 else:
@@ -84,8 +90,13 @@ else:
                 st.step(slot, [n])
             else:
                 opt.zero_grad()
-                model([xs[:n].unsqueeze(0)], ids if coop else None, text_features=tfeat, labels=y)
-                model.last_loss.backward()
+                xl = [ct, xs[:n].unsqueeze(0)] if with_ct else [xs[:n].unsqueeze(0)]
+                out_ = model(xl, ids if coop else None, text_features=tfeat, labels=y, loss_scale=(3.0 / 2 if with_ct else None))
+                loss_ = model.last_loss
+                if with_ct:
+                    from mil_amd import ops as _ops
+                    loss_ = loss_ + _ops.cosine_embedding_loss(out_[1].squeeze(1), out_[2].squeeze(1))
+                loss_.backward()
                 opt.step()
         warm = lens[:(20 if coop else 40)] if mode == "bucket_graph" else lens[:5]
         for n in warm:
@@ -103,6 +114,7 @@ else:
         del model, opt, st
         torch.cuda.empty_cache()
     work = (f"1 ragged bag/step, N~U[2000,15592] x 768 + {P} prompt(s) of 77 tokens"
+            + (" + CT feature map [512, 160, 2, 2] (CT + pathology, loss_point CT-Pth-Last + textCosSim: run_train.sh:81)" if with_ct else "")
             + (" (learnable context through the frozen ViT-B/32 tower, SGD)" if coop else "") + ", aggregator(args) fwd+BCE+bwd+"
             + ("SGD, " if coop else "Adam, ") + ("model.train()" if train else "model.eval()"))
 out["mean_patches"] = float(np.mean(lens))
