@@ -50,6 +50,7 @@ python3 $ROOT/tools/bench_ragged.py > $OUT/ragged_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion > $OUT/ragged_fusion_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion --prompts10 > $OUT/ragged_fusion_p10_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion --coop > $OUT/ragged_fusion_coop_line.json 2>/dev/null
+python3 $ROOT/tools/bench_ragged.py --fusion --ct > $OUT/ragged_fusion_ct_line.json 2>/dev/null
 MIL_FORCE_COLLECTIVES=1 python3 $ROOT/bench.py --gpus 1 --no-configs --no-cpu-baseline > $OUT/bench_rccl1_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --steps 50 --warmup 5 > $OUT/fusion_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --prompts 10 --steps 20 --warmup 3 > $OUT/p10_line.json 2>/dev/null

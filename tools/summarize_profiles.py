@@ -179,6 +179,7 @@ lines = {}
 for key, fn in (("bench", "bench_line.json"), ("bench_eval_mode", "bench_eval_line.json"), ("ragged_one_bag", "ragged_line.json"),
                 ("ragged_fusion", "ragged_fusion_line.json"), ("ragged_fusion_10_prompts", "ragged_fusion_p10_line.json"),
                 ("ragged_fusion_learnable_prompts", "ragged_fusion_coop_line.json"),
+                ("ragged_fusion_ct_plus_pathology", "ragged_fusion_ct_line.json"),
                 ("bench_one_rank_through_rccl", "bench_rccl1_line.json"),
                 ("fusion", "fusion_line.json"), ("fusion_10_prompts", "p10_line.json"), ("fusion_coop", "coop_line.json"),
                 ("one_bag_4096_hipgraph", "one_bag_line.json")):
