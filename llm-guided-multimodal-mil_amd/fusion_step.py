@@ -130,3 +130,73 @@ class RaggedFusionStepper:
             return out
         self.opt.sync_lr()                   # a changed learning rate reaches its device word before the replay reads it
         return self.gs.run(key, (), body, after_backward=self.opt.step)
+
+
+class RaggedFusionInference:
+    """Evaluation of the fusion model (reference test_ddp.py:187-253: eval mode, one bag per forward, per-sample inference
+    time) on capacity buckets: the forward of a bucket is captured into a hipGraph the second time the bucket is seen and
+    replayed afterwards - a forward is ~70 short launches, eagerly the host sets the pace.  Same slots and device-side
+    segments as RaggedFusionStepper; no gradients, no optimizer.
+
+        inf = RaggedFusionInference(model, P=1)              # model.eval()
+        slot = inf.slot(n); slot.x[:n].copy_(bag); inf.encode_notes(slot, ids)
+        prob = inf.forward(slot, [n])                        # [B, C], valid until the next replay of that bucket"""
+
+    def __init__(self, model, B: int = 1, P: int = 1, in_dim: int = 768, ctx_len: int = 77, ct_shape=None, use_graph: bool = True):
+        self.model, self.B, self.P, self.in_dim, self.ctx_len = model, int(B), int(P), int(in_dim), int(ctx_len)
+        self.device = next(model.parameters()).device
+        self.C = int(model.args.num_classes)
+        self.ct_shape = tuple(ct_shape) if ct_shape else None
+        self.ct_tokens = 0
+        if self.ct_shape:
+            E_, D_, h_, w_ = self.ct_shape
+            self.ct_tokens = D_ * h_ * w_ if getattr(model.args, "model_CT", "resnetMC3_18") == "medicalNet" else D_
+        self.use_graph = bool(use_graph)
+        self.slots: Dict[int, RaggedFusionStepper.Slot] = {}
+        self._graphs: Dict[int, tuple] = {}
+        self._seen: Dict[int, int] = {}
+        self.replays = self.eager = 0
+        self.stream = torch.cuda.Stream()
+
+    def slot(self, total_rows: int):
+        cap = bucket_rows(total_rows)
+        s = self.slots.get(cap)
+        if s is None:
+            s = self.slots[cap] = RaggedFusionStepper.Slot(cap, self.B, self.C, self.in_dim, self.device, self.P, self.ctx_len,
+                                                           self.ct_shape, self.ct_tokens)
+        return s
+
+    def encode_notes(self, slot, ids):
+        with torch.no_grad():
+            slot.text.copy_(self.model.clinic_extractor(ids))
+        return slot.text
+
+    def _body(self, slot):
+        xs = [slot.x] if slot.ct is None else [slot.ct, slot.x]
+        out = self.model(xs, None, text_features=slot.text, bucket=slot.bucket)
+        prob = out[0][0] if isinstance(out[0], list) else out[0]
+        return prob
+
+    @torch.no_grad()
+    def forward(self, slot, lengths: Sequence[int]):
+        slot.bucket.set_lengths(lengths)
+        ent = self._graphs.get(slot.cap)
+        if ent is None:
+            n = self._seen[slot.cap] = self._seen.get(slot.cap, 0) + 1
+            if not self.use_graph or n < 2:
+                self.eager += 1
+                return self._body(slot)
+            from . import lifetime
+            cur = torch.cuda.current_stream()
+            with lifetime.recording() as keep:
+                self.stream.wait_stream(cur)
+                with torch.cuda.stream(self.stream):
+                    self._body(slot)                                   # caches (positional rows, segment maps) fill here
+                cur.wait_stream(self.stream)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    prob = self._body(slot)
+            ent = self._graphs[slot.cap] = (g, prob, keep)
+        ent[0].replay()
+        self.replays += 1
+        return ent[1]

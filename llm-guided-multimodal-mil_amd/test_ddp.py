@@ -33,16 +33,38 @@ def test(args):
         model.load_state_dict(ck["state_dict"])                       # strict, as test_ddp.py:99
     model.eval()
     preds, labels, times = [], [], []
+    CT_SHAPE = (512, 160, 2, 2)              # synthetic stand-in for the CT encoder's feature map (aggregator.py:139-140)
+    with_ct = args.variant != "image_only" and "CT" in args.modality
+    inf = None
+    if (getattr(args, "hip_graph", 0) and args.variant != "image_only" and not args.learnablePrompt and prompts <= 12
+            and list(args.modality) in (["pathology"], ["CT", "pathology"])):
+        # one forward is ~70 short launches: replay it from a hipGraph per capacity bucket (fusion_step.RaggedFusionInference)
+        from .fusion_step import RaggedFusionInference
+        inf = RaggedFusionInference(model, B=1, P=prompts, in_dim=args.patch_dim, ct_shape=CT_SHAPE if with_ct else None)
     with torch.no_grad():
         for i in range(len(data)):                                     # batch_size = 1 (test_ddp.py:73)
             b = collate_bags([data[i]])
             x = b["pathology"].to(dev)
+            ct = None
+            if with_ct:
+                from . import synthetic as syn
+                ct = syn.make_ct_map(args.seed + 104729 + i, 1, CT_SHAPE[1], CT_SHAPE[2]).to(dev)
             torch.cuda.synchronize()
             t0 = time.time()
             if args.variant == "image_only":
                 _, out = model([x])
+            elif inf is not None:
+                n = int(b["lengths"][0])
+                slot = inf.slot(n)
+                slot.x[:n].copy_(x[0, :n], non_blocking=True)
+                if ct is not None:
+                    slot.ct.copy_(ct, non_blocking=True)
+                inf.encode_notes(slot, b["CI"].to(dev))
+                out = inf.forward(slot, [n])
             else:
-                out, _ = model([x], b["CI"].to(dev))
+                xs = [x] if ct is None else ([ct, x] if "pathology" in args.modality else [ct])
+                out = model(xs, b["CI"].to(dev))
+                out = out[0][0] if isinstance(out[0], list) else (out[0] if isinstance(out, tuple) else out)
             torch.cuda.synchronize()
             times.append(time.time() - t0)
             preds.append(float(out[0, 1]))

@@ -117,3 +117,10 @@ def test_the_authors_run_ct_plus_pathology_one_ragged_bag_per_gpu_with_graph_rep
     ck = torch.load(tmp_path / "checkpoint_best.pth.tar", weights_only=True)
     assert ck["optimizer"]["step"] == 10
     assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
+    # evaluation of that checkpoint (reference test_ddp.py): eager, then forward-only graphs per capacity bucket
+    common = ["--synthetic", "[700, 768, 10]", "--ragged", "--clip_layers", "1", "--modality", "['CT', 'pathology']",
+              "--test_pth", str(tmp_path)]
+    a = run("test_ddp.py", *common)
+    b = run("test_ddp.py", *common, "--hip_graph", "1")
+    assert "Time for inference" in a and "Time for inference" in b
+    assert a.split("Time for inference")[0] == b.split("Time for inference")[0]        # same bags, same accuracy

@@ -327,3 +327,23 @@ def test_ct_plus_pathology_bucket_step_equals_the_exact_shape_step():
             assert float(gb[k].abs().max()) < 1e-6, k
         else:
             assert rel_err(gb[k].cpu(), ga[k].cpu()) <= 5e-5, (k, rel_err(gb[k].cpu(), ga[k].cpu()))
+
+
+def test_bucketed_inference_replays_and_equals_the_exact_forward():
+    """Evaluation (reference test_ddp.py:187-253: eval mode, one bag per forward): forward-only graphs per capacity bucket
+    (fusion_step.RaggedFusionInference) against the exact-shape eager forward, bag by bag."""
+    from mil_amd.fusion_step import RaggedFusionInference
+    m = _model(layers=1)
+    inf = RaggedFusionInference(m, B=1, P=1)
+    for step, n in enumerate([2100, 2900, 2000, 3000, 1900, 2800, 2500]):
+        x = torch.randn((n, 768), generator=torch.Generator().manual_seed(400 + step)).to(DEV)
+        ids = syn.make_token_ids(410 + step, 1, 1).to(DEV)
+        with torch.no_grad():
+            want, _ = m([x.unsqueeze(0)], ids)
+        slot = inf.slot(n)
+        slot.x[:n].copy_(x)
+        inf.encode_notes(slot, ids)
+        got = inf.forward(slot, [n])
+        torch.cuda.synchronize()
+        assert float((got - want).abs().max()) <= 1e-6, (step, n)
+    assert len(inf.slots) == 2 and inf.replays == 5 and inf.eager == 2
