@@ -43,7 +43,7 @@ class RaggedFusionStepper:
 
     def __init__(self, model, opt, B: int = 1, use_graph: bool = True, max_graphs: int = 16, in_dim: int = 768,
                  opt_in_graph: bool = True, P: int = 1, learnable: bool = False, ctx_len: int = 77, ct_shape=None,
-                 loss_mult: float = 1.0, cossim: bool = False):
+                 loss_mult: float = 1.0, cossim: bool = False, tower_in_graph: bool = False):
         """opt_in_graph=False keeps the optimizer (and, at world size > 1, its gradient all-reduce) outside the captured
         graph, as graph_step.GraphedStep does.  P: text tokens per bag (1 = one note; 10 = `CI_prompt_version='devided'` or
         the learnable-prompt branch, whose P = len(clinical_features) + 1).  learnable=True: upstream's default
@@ -64,7 +64,11 @@ class RaggedFusionStepper:
             E_, D_, h_, w_ = self.ct_shape
             self.ct_tokens = D_ * h_ * w_ if getattr(model.args, "model_CT", "resnetMC3_18") == "medicalNet" else D_
         self.loss_mult, self.cossim = float(loss_mult), bool(cossim)
-        if self.learnable and use_graph:
+        # tower_in_graph (frozen prompts): the reference runs encode_text on every step's notes (model/dim1/CLIP.py:71-75).
+        # Outside the graph that is ~100 eager launches per note (3-4 ms of host time against a 1 ms step); inside, in the
+        # tower's fixed-shape form, it is part of the replay: fill slot.ids instead of calling encode_notes().
+        self.tower_inside = self.learnable or bool(tower_in_graph)
+        if self.tower_inside and use_graph:
             model.clinic_extractor.model.static_rows = True      # the tower is inside the graph: no token-dependent host work
         self.device = next(model.parameters()).device
         self.C = int(model.args.num_classes)
@@ -99,7 +103,7 @@ class RaggedFusionStepper:
         xs = [slot.x] if slot.ct is None else [slot.ct, slot.x]
         scale = self.loss_mult / (self.B * (1 if self.C > 2 else self.C)) if self.loss_mult != 1.0 else None
         kw = dict(labels=slot.y, bucket=slot.bucket, loss_scale=scale)
-        out = m(xs, slot.ids, **kw) if self.learnable else m(xs, None, text_features=slot.text, **kw)
+        out = m(xs, slot.ids, **kw) if self.tower_inside else m(xs, None, text_features=slot.text, **kw)
         if isinstance(out[0], list):                   # args.train_contract: ([x, x, x], [CT2CI, Pth2CI], None)
             prob, toks = out[0][0], out[1]
         else:
@@ -142,8 +146,13 @@ class RaggedFusionInference:
         slot = inf.slot(n); slot.x[:n].copy_(bag); inf.encode_notes(slot, ids)
         prob = inf.forward(slot, [n])                        # [B, C], valid until the next replay of that bucket"""
 
-    def __init__(self, model, B: int = 1, P: int = 1, in_dim: int = 768, ctx_len: int = 77, ct_shape=None, use_graph: bool = True):
+    def __init__(self, model, B: int = 1, P: int = 1, in_dim: int = 768, ctx_len: int = 77, ct_shape=None, use_graph: bool = True,
+                 tower_in_graph: bool = True):
         self.model, self.B, self.P, self.in_dim, self.ctx_len = model, int(B), int(P), int(in_dim), int(ctx_len)
+        # the text tower inside the replayed forward (fixed-shape form, fill slot.ids) or outside (encode_notes -> slot.text)
+        self.tower_inside = bool(tower_in_graph) and bool(use_graph)
+        if self.tower_inside:
+            model.clinic_extractor.model.static_rows = True
         self.device = next(model.parameters()).device
         self.C = int(model.args.num_classes)
         self.ct_shape = tuple(ct_shape) if ct_shape else None
@@ -173,7 +182,10 @@ class RaggedFusionInference:
 
     def _body(self, slot):
         xs = [slot.x] if slot.ct is None else [slot.ct, slot.x]
-        out = self.model(xs, None, text_features=slot.text, bucket=slot.bucket)
+        if self.tower_inside:
+            out = self.model(xs, slot.ids, bucket=slot.bucket)
+        else:
+            out = self.model(xs, None, text_features=slot.text, bucket=slot.bucket)
         prob = out[0][0] if isinstance(out[0], list) else out[0]
         return prob
 

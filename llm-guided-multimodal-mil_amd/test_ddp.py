@@ -59,7 +59,7 @@ def test(args):
                 slot.x[:n].copy_(x[0, :n], non_blocking=True)
                 if ct is not None:
                     slot.ct.copy_(ct, non_blocking=True)
-                inf.encode_notes(slot, b["CI"].to(dev))
+                slot.ids.copy_(b["CI"], non_blocking=True)                 # the text tower is part of the replayed forward
                 out = inf.forward(slot, [n])
             else:
                 xs = [x] if ct is None else ([ct, x] if "pathology" in args.modality else [ct])

@@ -334,16 +334,17 @@ def test_bucketed_inference_replays_and_equals_the_exact_forward():
     (fusion_step.RaggedFusionInference) against the exact-shape eager forward, bag by bag."""
     from mil_amd.fusion_step import RaggedFusionInference
     m = _model(layers=1)
-    inf = RaggedFusionInference(m, B=1, P=1)
+    ref = copy.deepcopy(m)                              # the twin keeps the live-prefix text tower
+    inf = RaggedFusionInference(m, B=1, P=1)            # text tower inside the replayed forward (fixed-shape form)
     for step, n in enumerate([2100, 2900, 2000, 3000, 1900, 2800, 2500]):
         x = torch.randn((n, 768), generator=torch.Generator().manual_seed(400 + step)).to(DEV)
         ids = syn.make_token_ids(410 + step, 1, 1).to(DEV)
         with torch.no_grad():
-            want, _ = m([x.unsqueeze(0)], ids)
+            want, _ = ref([x.unsqueeze(0)], ids)
         slot = inf.slot(n)
         slot.x[:n].copy_(x)
-        inf.encode_notes(slot, ids)
+        slot.ids.copy_(ids)
         got = inf.forward(slot, [n])
         torch.cuda.synchronize()
-        assert float((got - want).abs().max()) <= 1e-6, (step, n)
+        assert float((got - want).abs().max()) <= 2e-6, (step, n)
     assert len(inf.slots) == 2 and inf.replays == 5 and inf.eager == 2

@@ -51,6 +51,7 @@ else:
     from mil_amd.optim import FlatAdam, FlatSGD
     coop = "--coop" in sys.argv                       # upstream's default --learnablePrompt 1: 10 prompts, tower in the step
     P = 10 if (coop or "--prompts10" in sys.argv) else 1
+    tower_in = "--tower-in-graph" in sys.argv        # frozen tower recomputed every step INSIDE the replay (no text cache)
     with_ct = "--ct" in sys.argv                     # the authors' own run (run_train.sh:81): CT + pathology, CT-Pth-Last
     CT_SHAPE = (512, 160, 2, 2)
     if coop:
@@ -71,7 +72,8 @@ else:
         trainable = [q for q in model.parameters() if q.requires_grad]
         opt = FlatSGD(trainable, lr=1e-3, weight_decay=1e-7) if coop else FlatAdam(trainable, lr=1e-5, weight_decay=1e-7, counted=True)
         st = RaggedFusionStepper(model, opt, B=1, P=P, learnable=coop, opt_in_graph=not coop,
-                                 ct_shape=CT_SHAPE if with_ct else None, loss_mult=3.0 if with_ct else 1.0, cossim=with_ct)
+                                 ct_shape=CT_SHAPE if with_ct else None, loss_mult=3.0 if with_ct else 1.0, cossim=with_ct,
+                                 tower_in_graph=tower_in)
         tfeat = None
         if not coop:
             with torch.no_grad():
@@ -83,7 +85,7 @@ else:
                 slot.y.copy_(y)
                 if with_ct:
                     slot.ct.copy_(ct)
-                if coop:
+                if coop or tower_in:
                     slot.ids.copy_(ids)
                 else:
                     slot.text.copy_(tfeat)
@@ -91,7 +93,8 @@ else:
             else:
                 opt.zero_grad()
                 xl = [ct, xs[:n].unsqueeze(0)] if with_ct else [xs[:n].unsqueeze(0)]
-                out_ = model(xl, ids if coop else None, text_features=tfeat, labels=y, loss_scale=(3.0 / 2 if with_ct else None))
+                out_ = model(xl, ids if (coop or tower_in) else None, text_features=None if tower_in else tfeat, labels=y,
+                             loss_scale=(3.0 / 2 if with_ct else None))
                 loss_ = model.last_loss
                 if with_ct:
                     from mil_amd import ops as _ops
@@ -114,6 +117,7 @@ else:
         del model, opt, st
         torch.cuda.empty_cache()
     work = (f"1 ragged bag/step, N~U[2000,15592] x 768 + {P} prompt(s) of 77 tokens"
+            + (" [text tower run every step, inside the replay]" if tower_in else "")
             + (" + CT feature map [512, 160, 2, 2] (CT + pathology, loss_point CT-Pth-Last + textCosSim: run_train.sh:81)" if with_ct else "")
             + (" (learnable context through the frozen ViT-B/32 tower, SGD)" if coop else "") + ", aggregator(args) fwd+BCE+bwd+"
             + ("SGD, " if coop else "Adam, ") + ("model.train()" if train else "model.eval()"))
