@@ -39,6 +39,9 @@ def create_arg_parser(argv=None):
     p.add_argument("--lr", type=float, default=1e-5)
     p.add_argument("--loss", type=str, default="BCE", help="'BCE'; a name containing 'textCosSim' adds "
                    "CosineEmbeddingLoss(x_CT2CI, x_Pth2CI, 1) when both tokens exist (train_ddp.py:102,325-329)")
+    p.add_argument("--cache_text", type=int, default=0, help="1: frozen text tower (learnablePrompt 0) - keep every note's "
+                   "embedding after its first encode_text instead of recomputing it each step as model/dim1/CLIP.py:71-75 does "
+                   "(same values: the tower is frozen)")
     p.add_argument("--train_contract", type=int, default=0, help="1: the module returns the tuple the reference's training "
                    "loop unpacks, ([out, out, out], [CT2CI, Pth2CI], None) (train_ddp.py:300), instead of the shipped "
                    "module's (aggregator.py:202-209)")

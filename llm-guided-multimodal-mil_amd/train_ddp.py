@@ -153,7 +153,8 @@ def main_worker(local_rank: int, nprocs: int, args):
                                            ct_shape=CT_SHAPE if "CT" in args.modality else None,
                                            loss_mult=3.0 if (args.loss_point == "CT-Pth-Last" and "CT" in args.modality) else 1.0,
                                            cossim="textCosSim" in args.loss,
-                                           tower_in_graph=not args.learnablePrompt)      # frozen tower: inside the replay too
+                                           # frozen tower: inside the replay too, unless its embeddings are cached per note
+                                           tower_in_graph=not args.learnablePrompt and not getattr(args, "cache_text", 0))
         if getattr(args, "hip_graph", 0):
             # replay the step body from a hipGraph once a batch shape repeats (graph_step.py); optimizer and the
             # gradient all-reduce stay outside, so this needs the flat optimizers when world > 1 (no DDP hooks)
@@ -215,7 +216,10 @@ def main_worker(local_rank: int, nprocs: int, args):
                         from . import synthetic as syn
                         slot.ct.copy_(syn.make_ct_map(args.seed + 7919 * epoch + it, x.shape[0], CT_SHAPE[1], CT_SHAPE[2]),
                                       non_blocking=True)
-                    slot.ids.copy_(batch["CI"], non_blocking=True)                        # the text tower runs inside the step
+                    if fstepper.tower_inside:
+                        slot.ids.copy_(batch["CI"], non_blocking=True)                    # the text tower runs inside the step
+                    else:
+                        fstepper.encode_notes(slot, batch["CI"].to(dev))                  # --cache_text 1: a lookup per note
                     loss, prob, _ = fstepper.step(slot, lengths)
                 elif graphed is not None:
                     key = (tuple(int(v) for v in lengths), args.variant)
