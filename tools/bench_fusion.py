@@ -20,6 +20,8 @@ ap.add_argument("--coop", action="store_true", help="learnable prompts (upstream
 ap.add_argument("--clip_gemm_pieces", type=int, default=0, help="2 / 3: split-bf16 products for the frozen text tower's GEMMs")
 ap.add_argument("--torch_adam", action="store_true", help="torch.optim.Adam / SGD instead of the flat one-launch optimizers")
 ap.add_argument("--op_tail", action="store_true", help="criterion outside the module (op-by-op pool/head/loss tail) instead of forward(labels=y)")
+ap.add_argument("--tower_in_graph", action="store_true", help="frozen prompts: run the text tower inside the captured step "
+                "(fixed-shape form) instead of caching its output per note")
 ap.add_argument("--graph", action="store_true", help="capture fwd+bwd+Adam of the trainable part in one hipGraph")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -63,7 +65,9 @@ def step():
 
 if a.graph:
     tfeat = None
-    if not a.coop:
+    if a.tower_in_graph:
+        model.clinic_extractor.model.static_rows = True
+    elif not a.coop:
         with torch.no_grad():
             tfeat = model.clinic_extractor(ids)      # frozen tower: outside the graph (cached per note in training)
     def gstep():
