@@ -465,6 +465,17 @@ int mil_quickgelu(const float* x, const float* dy, float* out, size_t n, void* s
  * mil_absorb_query_bwd: dqp [B, H*C] and/or dWk [H*C, E] (either may be NULL) from dQp [B, H, E]; the same two
  * entry points give the value projection's backward (dpooled = absorb_query(do, Wv); dWv = absorb_query_bwd(do, pooled)). */
 int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream);
+/* The same for T text tokens per bag (B = bags x T rows of qp): the output goes straight into the padded operand layout of
+ * the grouped products, Qp [B / T, THp, E] with row t H + h of group g and rows T H .. THp - 1 written as zeros, multiplied
+ * by `scale` (the 1 / sqrt(c) of the scores) - no pad / scale launches around it; _bwd_pad reads dQp in that layout.
+ * bias [H C] and cb [B / T, THp] (both or neither): cb[g][t H + h] = scale * bias_h . qp[b][h], the constant the OTHER
+ * projection's bias adds to a score column (sam/transformer.py:113-118 with q_proj.bias), zeros in the padding.  In the
+ * backward dcb (needs bias) adds scale * dcb * bias to dqp and dbias (needs dcb and dWk) receives the bias gradient. */
+int mil_absorb_query_pad(const float* qp, const float* Wk, int B, int H, int C, int E, int T, int THp, float scale,
+                         const float* bias, float* Qp, float* cb, void* stream);
+int mil_absorb_query_bwd_pad(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E, int T, int THp,
+                             float scale, const float* bias, const float* dcb, float* dqp, float* dWk, float* dbias,
+                             void* stream);
 int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E, float* dqp,
                          float* dWk, void* stream);
 int mil_absorbed_pool_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
@@ -478,6 +489,9 @@ int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, c
                           const float* dkeys_acc, float* dkeys, float* dQp, float* workspace, void* stream);
 int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
                    void* stream);
+/* pooled in the grouped layout [B / T, THp, E] (mil_absorb_query_pad's; the multi-token pool's result as it stands). */
+int mil_value_proj_pad(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, int T, int THp,
+                       float* o, void* stream);
 /* Fewer launches on the token-side chain (each dependent launch costs ~4 us whatever it computes):
  *   mil_absorbed_pool_value_fwd   mil_absorbed_pool_fwd whose merge launch also forms o = Wv pooled + bv [B, H C]
  *   mil_value_proj_bwd            dpooled [B, H, E], dWv [H C, E], dbv [H C] (nullable) from do [B, H C] in one launch

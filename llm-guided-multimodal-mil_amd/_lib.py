@@ -99,6 +99,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_quickgelu": (c_int, [_P, _P, _P, c_size_t, _P]),
     "mil_absorb_query": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_absorb_query_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "mil_absorb_query_pad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "mil_absorb_query_bwd_pad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     "mil_absorbed_pool_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
     "mil_absorbed_pool_bwd": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 4 + [_P]),
     "mil_absorbed_pool_value_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 6 + [_P]),
@@ -108,6 +110,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_row_softmax_t": (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     "mil_row_softmax_t_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_value_proj": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "mil_value_proj_pad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_layernorm_fwd": (c_int, [_P] * 3 + [c_int, c_int, c_float, _P, _P, _P]),
     "mil_layernorm_bwd_blocks": (c_int, [c_int]),
     "mil_layernorm_bwd": (c_int, [_P] * 4 + [c_int, c_int] + [_P] * 4 + [_P]),

@@ -20,12 +20,27 @@
 #define AP_TILE 64
 
 // ---------------------------------------------------------------------------------------------- absorbed query
-// grid (B, H), block E/4 threads (float4 per thread)
+// grid (B + pad blocks, H), block E/4 threads (float4 per thread).  Output layout: row b of qp (b = g T + t: token t of group
+// g) goes to Qp[(g THp + t H + h)] - with T = 1, THp = H the plain [B, H, E]; with T text tokens per bag the [bags, THp, E]
+// operand of the grouped products, whose rows T H .. THp - 1 of every group (padding up to a multiple of 32) are written as
+// zeros by the blocks blockIdx.x >= B (they used to be a torch pad: a fill and a copy per call).  scale multiplies the
+// result (the 1 / sqrt(c) of the scores).  bias / cb (both or neither): cb[g][t H + h] = scale * bias_h . qp[b][h], the
+// column constant the other projection's bias adds to the scores (zeros in the padding), in the same launch.
 __global__ void k_absorb_query(const float* __restrict__ qp, const float* __restrict__ Wk, int H, int C, int E,
-                               float* __restrict__ Qp) {
+                               float* __restrict__ Qp, int B, int T, int THp, float scale,
+                               const float* __restrict__ bias, float* __restrict__ cb) {
     const int b = blockIdx.x, h = blockIdx.y, j4 = threadIdx.x;
+    if (b >= B) {
+        const int g = b - B;
+        for (int r = T * H + h; r < THp; r += H) {
+            *reinterpret_cast<f32x4*>(Qp + ((size_t)g * THp + r) * E + 4 * j4) = f32x4{0, 0, 0, 0};
+            if (cb != nullptr && j4 == 0) cb[(size_t)g * THp + r] = 0.f;
+        }
+        return;
+    }
     const int I = H * C;
     f32x4 acc = {0, 0, 0, 0};
+    float cbv = 0.f;
     for (int c0 = 0; c0 < C; c0 += 16) {            // C is 32 or 64: 16 rows of Wk in flight per trip
         f32x4 wr[16];
         float q[16];
@@ -36,18 +51,25 @@ __global__ void k_absorb_query(const float* __restrict__ qp, const float* __rest
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc += q[u] * wr[u];
+        if (cb != nullptr && j4 == 0)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) cbv += q[u] * bias[h * C + c0 + u];
     }
-    *reinterpret_cast<f32x4*>(Qp + ((size_t)b * H + h) * E + 4 * j4) = acc;
+    const size_t orow = (size_t)(b / T) * THp + (b % T) * H + h;
+    *reinterpret_cast<f32x4*>(Qp + orow * E + 4 * j4) = acc * scale;
+    if (cb != nullptr && j4 == 0) cb[orow] = cbv * scale;        // the scores' column constant scale * bias_h . qp[b][h]
 }
 
 // dqp[b][hc + c'] = dQp[b][h] . Wk[hc + c'];   grid (B, H), 256 threads: 8 threads per c' (c <= 32) then shuffle
 __global__ __launch_bounds__(256) void k_absorb_query_bwd_q(const float* __restrict__ dQp, const float* __restrict__ Wk,
-                                                            int H, int C, int E, float* __restrict__ dqp) {
+                                                            int H, int C, int E, float* __restrict__ dqp, int T, int THp,
+                                                            float scale, const float* __restrict__ bias,
+                                                            const float* __restrict__ dcb) {
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
     const int I = H * C;
     const int per = 256 / C;                       // threads per output (8 for C = 32, 4 for C = 64)
     const int c = tid / per, part = tid % per;
-    const float* g = dQp + ((size_t)b * H + h) * E;
+    const float* g = dQp + ((size_t)(b / T) * THp + (b % T) * H + h) * E;
     const float* w = Wk + (size_t)(h * C + c) * E;
     float v = 0.f;
     for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {      // 4 x 16-byte loads of each operand in flight
@@ -63,7 +85,10 @@ __global__ __launch_bounds__(256) void k_absorb_query_bwd_q(const float* __restr
             if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
     }
     for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if (part == 0) dqp[(size_t)b * I + h * C + c] = v;
+    if (part == 0) {
+        if (dcb != nullptr) v += dcb[(size_t)(b / T) * THp + (b % T) * H + h] * bias[h * C + c];
+        dqp[(size_t)b * I + h * C + c] = v * scale;
+    }
 }
 
 // dWk[hc + c'][j] = sum_b qp[b][hc + c'] dQp[b][h][j];   grid H*C, block E/4
@@ -72,29 +97,36 @@ __global__ __launch_bounds__(256) void k_absorb_query_bwd_q(const float* __restr
 // fold through LDS in a fixed order.
 #define AQ_GROUPS 4
 __global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* __restrict__ dQp, int B, int H, int C,
-                                     int E, float* __restrict__ dWk) {
+                                     int E, float* __restrict__ dWk, int T, int THp, float scale,
+                                     const float* __restrict__ dcb, float* __restrict__ dbias) {
     __shared__ __attribute__((aligned(16))) float red[(AQ_GROUPS - 1) * 1024];        // E <= 1024
+    __shared__ float redb[AQ_GROUPS];
     const int E4 = E / 4;
     const int row = blockIdx.x, h = row / C, j4 = threadIdx.x % E4, grp = threadIdx.x / E4, I = H * C;
     f32x4 acc = {0, 0, 0, 0};
+    float bacc = 0.f;
     for (int b0 = 8 * grp; b0 < B; b0 += 8 * AQ_GROUPS) {
         f32x4 gv[8];
-        float q[8];
+        float q[8], dc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int b = min(b0 + u, B - 1);
-            gv[u] = *reinterpret_cast<const f32x4*>(dQp + ((size_t)b * H + h) * E + 4 * j4);
+            const size_t orow = (size_t)(b / T) * THp + (b % T) * H + h;
+            gv[u] = *reinterpret_cast<const f32x4*>(dQp + orow * E + 4 * j4);
             q[u] = b0 + u < B ? qp[(size_t)b * I + row] : 0.f;
+            dc[u] = dcb != nullptr && j4 == 0 ? dcb[orow] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += q[u] * gv[u];
+        for (int u = 0; u < 8; ++u) { acc += q[u] * gv[u]; bacc += q[u] * dc[u]; }
     }
     if (grp > 0) *reinterpret_cast<f32x4*>(red + (grp - 1) * 1024 + 4 * j4) = acc;
+    if (j4 == 0) redb[grp] = bacc;
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
         for (int g = 0; g < AQ_GROUPS - 1; ++g) acc += *reinterpret_cast<const f32x4*>(red + g * 1024 + 4 * j4);
-        *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
+        *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc * scale;
+        if (dbias != nullptr && j4 == 0) dbias[row] = ((redb[0] + redb[1]) + (redb[2] + redb[3])) * scale;
     }
 }
 
@@ -501,10 +533,10 @@ __global__ __launch_bounds__(1024) void k_apool_bwd_merge(const float* __restric
 // o[b][hc + c'] = Wv[hc + c'] . pooled[b][h] + bv[hc + c'];   grid (B, H), 256 threads
 __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ pooled, const float* __restrict__ Wv,
                                                     const float* __restrict__ bv, int H, int C, int E,
-                                                    float* __restrict__ o) {
+                                                    float* __restrict__ o, int T, int THp) {
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, I = H * C;
     const int per = 256 / C, c = tid / per, part = tid % per;
-    const float* pv = pooled + ((size_t)b * H + h) * E;
+    const float* pv = pooled + ((size_t)(b / T) * THp + (b % T) * H + h) * E;
     const float* w = Wv + (size_t)(h * C + c) * E;
     float v = 0.f;
     for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {
@@ -531,14 +563,17 @@ __global__ __launch_bounds__(256) void k_value_proj(const float* __restrict__ po
 // (k_absorb_query_bwd_w).  The token-side chain is a string of ~4 us launches whose cost is the launch itself.
 __global__ __launch_bounds__(512) void k_absorb_query_bwd_both(const float* __restrict__ qp, const float* __restrict__ Wk,
                                                                const float* __restrict__ dQp, int B, int H, int C, int E,
-                                                               float* __restrict__ dqp, float* __restrict__ dWk) {
+                                                               float* __restrict__ dqp, float* __restrict__ dWk, int T,
+                                                               int THp, float scale, const float* __restrict__ bias,
+                                                               const float* __restrict__ dcb, float* __restrict__ dbias) {
     __shared__ __attribute__((aligned(16))) float red[(AQ_GROUPS - 1) * 1024];
+    __shared__ float redb[AQ_GROUPS];
     const int nq = B * H, tid = threadIdx.x, I = H * C;
     if ((int)blockIdx.x < nq) {
         if (tid >= 256) return;
         const int b = blockIdx.x / H, h = blockIdx.x % H;
         const int per = 256 / C, c = tid / per, part = tid % per;
-        const float* g = dQp + ((size_t)b * H + h) * E;
+        const float* g = dQp + ((size_t)(b / T) * THp + (b % T) * H + h) * E;
         const float* w = Wk + (size_t)(h * C + c) * E;
         float v = 0.f;
         for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {
@@ -554,31 +589,39 @@ __global__ __launch_bounds__(512) void k_absorb_query_bwd_both(const float* __re
                 if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
         }
         for (int m = per >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        if (part == 0) dqp[(size_t)b * I + h * C + c] = v;
+        if (part == 0) {
+            if (dcb != nullptr) v += dcb[(size_t)(b / T) * THp + (b % T) * H + h] * bias[h * C + c];
+            dqp[(size_t)b * I + h * C + c] = v * scale;
+        }
         return;
     }
     const int E4 = E / 4;
     const int row = blockIdx.x - nq, h = row / C, j4 = tid % E4, grp = tid / E4;
     f32x4 acc = {0, 0, 0, 0};
+    float bacc = 0.f;
     if (grp < AQ_GROUPS)
         for (int b0 = 8 * grp; b0 < B; b0 += 8 * AQ_GROUPS) {
             f32x4 gv[8];
-            float q[8];
+            float q[8], dc[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int b = min(b0 + u, B - 1);
-                gv[u] = *reinterpret_cast<const f32x4*>(dQp + ((size_t)b * H + h) * E + 4 * j4);
+                const size_t orow = (size_t)(b / T) * THp + (b % T) * H + h;
+                gv[u] = *reinterpret_cast<const f32x4*>(dQp + orow * E + 4 * j4);
                 q[u] = b0 + u < B ? qp[(size_t)b * I + row] : 0.f;
+                dc[u] = dcb != nullptr && j4 == 0 ? dcb[orow] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += q[u] * gv[u];
+            for (int u = 0; u < 8; ++u) { acc += q[u] * gv[u]; bacc += q[u] * dc[u]; }
         }
     if (grp > 0 && grp < AQ_GROUPS) *reinterpret_cast<f32x4*>(red + (grp - 1) * 1024 + 4 * j4) = acc;
+    if (j4 == 0 && grp < AQ_GROUPS) redb[grp] = bacc;
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
         for (int g = 0; g < AQ_GROUPS - 1; ++g) acc += *reinterpret_cast<const f32x4*>(red + g * 1024 + 4 * j4);
-        *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc;
+        *reinterpret_cast<f32x4*>(dWk + (size_t)row * E + 4 * j4) = acc * scale;
+        if (dbias != nullptr && j4 == 0) dbias[row] = ((redb[0] + redb[1]) + (redb[2] + redb[3])) * scale;
     }
 }
 
@@ -899,32 +942,52 @@ __global__ __launch_bounds__(256) void k_row_softmax_t_bwd(const float* __restri
 
 #define AP_CHECK(cond) do { if (!(cond)) return MIL_EINVAL; } while (0)
 
-extern "C" int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream) {
+// T text tokens per group, output rows in the grouped products' padded layout [B / T, THp, E] (THp >= T H: rows T H .. THp - 1
+// of every group written as zeros), result scaled by `scale`.  T = 1, THp = H, scale = 1: the plain [B, H, E].
+// bias [H C] / cb [B / T, THp] (both or neither): cb = scale * bias_h . qp[b][h] in the same layout.
+extern "C" int mil_absorb_query_pad(const float* qp, const float* Wk, int B, int H, int C, int E, int T, int THp, float scale,
+                                    const float* bias, float* Qp, float* cb, void* stream) {
     AP_CHECK(qp && Wk && Qp && B >= 0 && H > 0 && C > 0 && (C % 16) == 0 && E > 0 && (E & 3) == 0 && E <= 4096);
+    AP_CHECK(T >= 1 && THp >= T * H && (B % T) == 0 && (bias != nullptr) == (cb != nullptr));
     if (B == 0) return MIL_OK;
-    hipLaunchKernelGGL(k_absorb_query, dim3(B, H), dim3(E / 4), 0, (hipStream_t)stream, qp, Wk, H, C, E, Qp);
+    const int pad_blocks = THp > T * H ? B / T : 0;
+    hipLaunchKernelGGL(k_absorb_query, dim3(B + pad_blocks, H), dim3(E / 4), 0, (hipStream_t)stream, qp, Wk, H, C, E, Qp, B, T, THp,
+                       scale, bias, cb);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
+extern "C" int mil_absorb_query(const float* qp, const float* Wk, int B, int H, int C, int E, float* Qp, void* stream) {
+    return mil_absorb_query_pad(qp, Wk, B, H, C, E, 1, H, 1.0f, nullptr, Qp, nullptr, stream);
+}
 
-extern "C" int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E,
-                                    float* dqp, float* dWk, void* stream) {
+// dcb [B / T, THp] (the gradient of cb; with bias) adds scale * dcb bias to dqp and yields dbias [H C] (with dWk).
+extern "C" int mil_absorb_query_bwd_pad(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E, int T,
+                                        int THp, float scale, const float* bias, const float* dcb, float* dqp, float* dWk,
+                                        float* dbias, void* stream) {
     AP_CHECK(qp && Wk && dQp && B > 0 && H > 0 && (C == 32 || C == 64) && E > 0 && (E & 3) == 0 && E <= 1024);
+    AP_CHECK(T >= 1 && THp >= T * H && (B % T) == 0);
+    AP_CHECK((dcb == nullptr || bias != nullptr) && (dbias == nullptr || (dcb != nullptr && dWk != nullptr)));
     hipStream_t st = (hipStream_t)stream;
     if (dqp != nullptr && dWk != nullptr && E == 512) {          // both halves in one launch
-        hipLaunchKernelGGL(k_absorb_query_bwd_both, dim3(B * H + H * C), dim3(512), 0, st, qp, Wk, dQp, B, H, C, E, dqp, dWk);
+        hipLaunchKernelGGL(k_absorb_query_bwd_both, dim3(B * H + H * C), dim3(512), 0, st, qp, Wk, dQp, B, H, C, E, dqp, dWk, T, THp,
+                           scale, bias, dcb, dbias);
         MIL_CHECK_LAUNCH();
         return MIL_OK;
     }
     if (dqp != nullptr) {
-        hipLaunchKernelGGL(k_absorb_query_bwd_q, dim3(B, H), dim3(256), 0, st, dQp, Wk, H, C, E, dqp);
+        hipLaunchKernelGGL(k_absorb_query_bwd_q, dim3(B, H), dim3(256), 0, st, dQp, Wk, H, C, E, dqp, T, THp, scale, bias, dcb);
         MIL_CHECK_LAUNCH();
     }
     if (dWk != nullptr) {
-        hipLaunchKernelGGL(k_absorb_query_bwd_w, dim3(H * C), dim3(AQ_GROUPS * (E / 4)), 0, st, qp, dQp, B, H, C, E, dWk);
+        hipLaunchKernelGGL(k_absorb_query_bwd_w, dim3(H * C), dim3(AQ_GROUPS * (E / 4)), 0, st, qp, dQp, B, H, C, E, dWk, T, THp, scale,
+                           dcb, dbias);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
+}
+extern "C" int mil_absorb_query_bwd(const float* qp, const float* Wk, const float* dQp, int B, int H, int C, int E,
+                                    float* dqp, float* dWk, void* stream) {
+    return mil_absorb_query_bwd_pad(qp, Wk, dQp, B, H, C, E, 1, H, 1.0f, nullptr, nullptr, dqp, dWk, nullptr, stream);
 }
 
 extern "C" int mil_absorbed_pool_fwd(const float* keys, const float* pe, const float* Qp, const int32_t* k_off,
@@ -1003,13 +1066,19 @@ extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const f
     return MIL_OK;
 }
 
-extern "C" int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
-                              void* stream) {
+// pooled in the grouped layout [B / T, THp, E] (row t H + h of group b / T; mil_absorb_query_pad): T = 1, THp = H is [B, H, E]
+extern "C" int mil_value_proj_pad(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, int T,
+                                  int THp, float* o, void* stream) {
     AP_CHECK(pooled && Wv && bv && o && B >= 0 && H > 0 && (C == 32 || C == 64) && E > 0);
+    AP_CHECK(T >= 1 && THp >= T * H && (B % T) == 0);
     if (B == 0) return MIL_OK;
-    hipLaunchKernelGGL(k_value_proj, dim3(B, H), dim3(256), 0, (hipStream_t)stream, pooled, Wv, bv, H, C, E, o);
+    hipLaunchKernelGGL(k_value_proj, dim3(B, H), dim3(256), 0, (hipStream_t)stream, pooled, Wv, bv, H, C, E, o, T, THp);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+extern "C" int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
+                              void* stream) {
+    return mil_value_proj_pad(pooled, Wv, bv, B, H, C, E, 1, H, o, stream);
 }
 
 extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH,

@@ -1438,27 +1438,41 @@ def cosine_embedding_loss(x1, x2, weight: float = 1.0):
 
 # --------------------------------------------------------------------------- one-text-token token->image attention
 class _AbsorbQuery(torch.autograd.Function):
-    """Qp[b][h] = Wk_h^T qp[b][h]  (also the value projection's backward map)."""
+    """Qp[b][h] = scale * Wk_h^T qp[b][h]  (also the value projection's backward map).  T > 1: the B = bags x T rows are
+    the T text tokens of each bag and the result is the grouped products' operand [bags, T H padded to a multiple of 32, E]
+    with zero rows behind (written by the same launch: include/mil_hip.h mil_absorb_query_pad).  With `bias` [H C] a second
+    result cb [bags, THp] = scale * bias_h . qp[b][h] (the score column constant of the other projection's bias)."""
 
     @staticmethod
-    def forward(ctx, qp, Wk, H: int):
+    def forward(ctx, qp, Wk, H: int, T: int = 1, scale: float = 1.0, bias=None):
         qp, Wk = _f32c(qp, "qp"), _f32c(Wk, "Wk")
         B, I = qp.shape
         E = Wk.shape[1]
-        Qp = torch.empty((B, H, E), device=qp.device, dtype=torch.float32)
-        sh = _lib.shim()
+        THp = H if T == 1 else T * H + (-T * H) % 32
+        Qp = torch.empty((B, H, E) if T == 1 else (B // T, THp, E), device=qp.device, dtype=torch.float32)
+        cb = None
+        if bias is not None:
+            bias = _f32c(bias, "bias")
+            cb = torch.empty((B // T, THp), device=qp.device, dtype=torch.float32)
+        sh = _lib.shim() if T == 1 and scale == 1.0 and bias is None else None
         if sh is not None:
             sh.absorb_query(qp, Wk, H, Qp, _stream_int())
         else:
-            rc = _lib.lib().mil_absorb_query(_p(qp), _p(Wk), B, H, I // H, E, _p(Qp), _stream())
-            _lib.check(rc, "mil_absorb_query")
-        ctx.H = H
-        ctx.save_for_backward(qp, Wk)
-        return Qp
+            rc = _lib.lib().mil_absorb_query_pad(_p(qp), _p(Wk), B, H, I // H, E, T, THp, scale, _p(bias), _p(Qp), _p(cb),
+                                                 _stream())
+            _lib.check(rc, "mil_absorb_query_pad")
+        ctx.H, ctx.T, ctx.THp, ctx.scale = H, T, THp, scale
+        ctx.with_bias = bias is not None
+        if bias is None:
+            ctx.save_for_backward(qp, Wk)
+            return Qp
+        ctx.save_for_backward(qp, Wk, bias)
+        return Qp, cb
 
     @staticmethod
-    def backward(ctx, dQp):
-        qp, Wk = ctx.saved_tensors
+    def backward(ctx, dQp, dcb=None):
+        qp, Wk = ctx.saved_tensors[:2]
+        bias = ctx.saved_tensors[2] if ctx.with_bias else None
         B, I = qp.shape
         E = Wk.shape[1]
         dQp = _f32c(dQp, "dQp")
@@ -1468,13 +1482,24 @@ class _AbsorbQuery(torch.autograd.Function):
             dWk = grad_slot(Wk)                       # straight into optim.FlatAdam's flat gradient buffer when there is one
             if dWk is None:
                 dWk = torch.empty_like(Wk)
-        sh = _lib.shim()
+        sh = _lib.shim() if ctx.T == 1 and ctx.scale == 1.0 and bias is None else None
         if sh is not None:
             sh.absorb_query_bwd(qp, Wk, dQp, ctx.H, dqp, dWk, _stream_int())
-            return dqp, dWk, None
-        rc = _lib.lib().mil_absorb_query_bwd(_p(qp), _p(Wk), _p(dQp), B, ctx.H, I // ctx.H, E, _p(dqp), _p(dWk), _stream())
-        _lib.check(rc, "mil_absorb_query_bwd")
-        return dqp, dWk, None
+            return dqp, dWk, None, None, None, None
+        dbias = None
+        if bias is not None:
+            dcb = _f32c(dcb, "dcb")
+            if ctx.needs_input_grad[5] and dWk is not None:
+                dbias = grad_slot(bias)
+                if dbias is None:
+                    dbias = torch.empty_like(bias)
+        rc = _lib.lib().mil_absorb_query_bwd_pad(_p(qp), _p(Wk), _p(dQp), B, ctx.H, I // ctx.H, E, ctx.T, ctx.THp, ctx.scale,
+                                                 _p(bias), _p(dcb) if bias is not None else None, _p(dqp), _p(dWk), _p(dbias),
+                                                 _stream())
+        _lib.check(rc, "mil_absorb_query_bwd_pad")
+        if bias is not None and ctx.needs_input_grad[5] and dbias is None:      # frozen weight, trainable bias: not a model case
+            dbias = (qp.view(B, ctx.H, -1) * dcb.view(-1, ctx.THp)[:, :ctx.T * ctx.H].reshape(B, ctx.H, 1)).sum(0).reshape(-1) * ctx.scale
+        return dqp, dWk, None, None, None, dbias
 
 
 def _dkeys_buffer(keys, segs):
@@ -1530,33 +1555,41 @@ class _AbsorbedPool(torch.autograd.Function):
 
 
 class _ValueProj(torch.autograd.Function):
-    """o[b][hC + c] = Wv[hC + c] . pooled[b][h] + bv[hC + c]."""
+    """o[b][hC + c] = Wv[hC + c] . pooled[b][h] + bv[hC + c].  T > 1: pooled is the multi-token pool's result as it stands,
+    [bags, T H padded to a multiple of 32, E] (row t H + h of a bag; b = bag x T + t), and its gradient comes back in that
+    layout with zero padding rows - no slice / pad copies around the node."""
 
     @staticmethod
-    def forward(ctx, pooled, Wv, bv):
+    def forward(ctx, pooled, Wv, bv, H: int, T: int = 1):
         pooled, Wv = _f32c(pooled, "pooled"), _f32c(Wv, "Wv")
-        B, H, E = pooled.shape
+        E = pooled.shape[-1]
         I = Wv.shape[0]
+        THp = pooled.shape[1]
+        B = pooled.shape[0] * T
+        if T == 1 and THp != H:
+            raise ValueError("pooled must be [B, H, E]")
         o = torch.empty((B, I), device=pooled.device, dtype=torch.float32)
-        rc = _lib.lib().mil_value_proj(_p(pooled), _p(Wv), _p(_f32c(bv, "bv")), B, H, I // H, E, _p(o), _stream())
-        _lib.check(rc, "mil_value_proj")
+        rc = _lib.lib().mil_value_proj_pad(_p(pooled), _p(Wv), _p(_f32c(bv, "bv")), B, H, I // H, E, T, THp, _p(o), _stream())
+        _lib.check(rc, "mil_value_proj_pad")
         ctx.save_for_backward(pooled, Wv)
         ctx.bv_param = bv                   # only to look up its flat-gradient slot in backward
+        ctx.H, ctx.T = H, T
         return o
 
     @staticmethod
     def backward(ctx, do):
         pooled, Wv = ctx.saved_tensors
-        B, H, E = pooled.shape
-        I = Wv.shape[0]
-        do = _f32c(do, "do")
-        return _value_proj_bwd(do, Wv, ctx.bv_param, pooled)
+        dpooled, dWv, dbv = _value_proj_bwd(_f32c(do, "do"), Wv, ctx.bv_param, pooled, ctx.H, ctx.T)
+        return dpooled, dWv, dbv, None, None
 
 
-def _value_proj_bwd(do, Wv, bv, pooled):
+def _value_proj_bwd(do, Wv, bv, pooled, H: int = 0, T: int = 1):
     """(dpooled, dWv, dbv) of o = Wv pooled + bv in ONE launch (mil_value_proj_bwd); parameter gradients go straight into
     their flat-buffer slots when there are any."""
-    B, H, E = pooled.shape
+    E = pooled.shape[-1]
+    H = H or pooled.shape[1]
+    THp = pooled.shape[1]
+    B = pooled.shape[0] * T
     I = Wv.shape[0]
     dpooled = torch.empty_like(pooled)
     dWv = grad_slot(Wv)
@@ -1565,12 +1598,13 @@ def _value_proj_bwd(do, Wv, bv, pooled):
     dbv = grad_slot(bv)
     if dbv is None:
         dbv = torch.empty(I, device=do.device, dtype=torch.float32)
-    if E != 512 or B > SMALL_ROWS:
+    if E != 512 or B > SMALL_ROWS or T > 1:
         # many rows (T text tokens per bag: B = bags x T): the one-launch form walks the rows of its bias role in turn
-        rc = _lib.lib().mil_absorb_query(_p(do), _p(Wv), B, H, I // H, E, _p(dpooled), _stream())
-        _lib.check(rc, "mil_absorb_query")
-        rc = _lib.lib().mil_absorb_query_bwd(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, None, _p(dWv), _stream())
-        _lib.check(rc, "mil_absorb_query_bwd")
+        rc = _lib.lib().mil_absorb_query_pad(_p(do), _p(Wv), B, H, I // H, E, T, THp, 1.0, None, _p(dpooled), None, _stream())
+        _lib.check(rc, "mil_absorb_query_pad")
+        rc = _lib.lib().mil_absorb_query_bwd_pad(_p(do), _p(Wv), _p(pooled), B, H, I // H, E, T, THp, 1.0, None, None, None,
+                                                 _p(dWv), None, _stream())
+        _lib.check(rc, "mil_absorb_query_bwd_pad")
         return dpooled, dWv, colsum(do, out=dbv)
     sh = _lib.shim()
     if sh is not None:
@@ -1638,7 +1672,7 @@ def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int, qp=No
     if Wk.shape[1] == 512 and H == 8 and Wv.requires_grad and bv.requires_grad:
         return _AbsorbedPoolValue.apply(keys, pe, Qp, Wv, bv, segs, C)        # pool + value projection: one node
     pooled, keys_pass = _AbsorbedPool.apply(keys, pe, Qp, segs, C)
-    return _ValueProj.apply(pooled, Wv, bv), keys_pass
+    return _ValueProj.apply(pooled, Wv, bv, H), keys_pass
 
 
 # --------------------------------------------------------------------------- multi-token absorbed attention (1 < T <= 12)
@@ -1792,14 +1826,6 @@ class _RowSoftmaxT(torch.autograd.Function):
         return dS, None, None
 
 
-def _pad_vectors(V, B: int, TH: int):
-    """[B * T, H, E] absorbed vectors -> [B, TH padded to a multiple of 32, E] (zero rows behind)."""
-    E = V.shape[-1]
-    V = V.reshape(B, TH, E)
-    pad = (-TH) % 32
-    return torch.nn.functional.pad(V, (0, 0, 0, pad)) if pad else V
-
-
 def multi_token_ok(E: int, H: int, t_lengths) -> bool:
     T = t_lengths[0] if len(t_lengths) else 0
     return E == 512 and H == 8 and 1 < T <= 12 and all(t == T for t in t_lengths)
@@ -1895,10 +1921,10 @@ def multi_token_pool_attention(q_tok, keys, kin, segs, Wq, bq, Wk, Wv, bv, H: in
     B, T = segs.B, segs.Tq_max
     TH = T * H
     C = Wq.shape[0] // H
-    qp = linear_act(q_tok, Wq, bq) * (1.0 / C ** 0.5)
-    Qp = _pad_vectors(_AbsorbQuery.apply(qp, Wk, H), B, TH)                      # k_proj.bias is softmax-invariant
-    pooled, keys_pass = _MultiTokenPoolCore.apply(keys, kin, Qp.contiguous(), segs, TH)      # [B, THp, E]
-    return _ValueProj.apply(pooled[:, :TH].reshape(B * T, H, keys.shape[1]), Wv, bv), keys_pass
+    qp = linear_act(q_tok, Wq, bq)
+    Qp = _AbsorbQuery.apply(qp, Wk, H, T, 1.0 / C ** 0.5)                        # k_proj.bias is softmax-invariant
+    pooled, keys_pass = _MultiTokenPoolCore.apply(keys, kin, Qp, segs, TH)       # [B, THp, E]
+    return _ValueProj.apply(pooled, Wv, bv, H, T), keys_pass
 
 
 def multi_token_rows_attention(kin, k_tok, v_tok, segs, Wq, bq, Wk, bk, Wv, bv, Wo, bo, H: int, residual=None):
@@ -1911,16 +1937,13 @@ def multi_token_rows_attention(kin, k_tok, v_tok, segs, Wq, bq, Wk, bk, Wv, bv, 
     scale = 1.0 / C ** 0.5
     kp = linear_act(k_tok, Wk, bk)                                                # [B * T, H * C]
     vp = linear_act(v_tok, Wv, bv)
-    Kp = _pad_vectors(_AbsorbQuery.apply(kp * scale, Wq, H), B, TH)
-    cb = ((kp.view(B * T, H, C) * bq.view(1, H, C)).sum(-1) * scale).reshape(B, TH)
-    pad = (-TH) % 32
-    cb = torch.nn.functional.pad(cb, (0, pad)) if pad else cb
-    Vp = _pad_vectors(_AbsorbQuery.apply(vp, Wo.t().contiguous(), H), B, TH)      # Vp[t, h] = Wo[:, hC:(h+1)C] v_th
+    Kp, cb = _AbsorbQuery.apply(kp, Wq, H, T, scale, bq)                          # cb[b, t H + h] = scale * bq_h . k_th
+    Vp = _AbsorbQuery.apply(vp, Wo.t().contiguous(), H, T, 1.0)                   # Vp[t, h] = Wo[:, hC:(h+1)C] v_th
     if residual is None:
-        S = _GroupedNT.apply(kin, Kp, cb.contiguous(), segs.q_off, segs.Tq_max)
+        S = _GroupedNT.apply(kin, Kp, cb, segs.q_off, segs.Tq_max)
         return _GroupedNN.apply(_RowSoftmaxT.apply(S, T, H), Vp, bo, None, segs.q_off, segs.Tq_max)
     # with the keys as residual (the block form, sam/transformer.py:303-309) kin = keys + pe: one fused node
-    return _MultiTokenRowsCore.apply(residual, kin, Kp.contiguous(), cb.contiguous(), Vp.contiguous(), bo, segs, T, H)
+    return _MultiTokenRowsCore.apply(residual, kin, Kp, cb, Vp, bo, segs, T, H)
 
 
 # --------------------------------------------------------------------------- split-bf16 products for frozen weights (opt-in)
