@@ -485,6 +485,288 @@ __global__ __launch_bounds__(NT) void k_pool_merge_head(const float* __restrict_
     }
 }
 
+// The same per-bag tail split over TWO workgroups per bag that run side by side (round 3; C <= 4, labels, hrow and ds
+// present - the training step).  k_pool_merge_head walks  tile statistics -> m -> l -> merge of the partials (64 KB per
+// bag) -> M -> head dot products -> z -> loss -> dz -> M . dM -> ds  through nine barriers in one workgroup, but nothing the
+// backward waits for needs M:
+//     z_c - bf_c = sum_n a_n h_n[c]            (h_n[c] = x~_n . (Wf[c] keep_b mscale), the pool pass's by-product)
+//     M . dM     = sum_c dz_c (z_c - bf_c)     (dM = dz Wf keep)
+//     ds_n       = a_n (sum_c dz_c h_n[c] - M . dM)
+// blockIdx.y = 0: row scores -> m -> {l, sum e_n h_n[c]} -> (per thread) z, p, loss, dz, cdot -> ds, dM: two block
+// reductions over values the threads already hold.  blockIdx.y = 1: the merge of the partials -> M, Mdrop (what the
+// head's weight gradient reads).  z is now the weighted sum of the rows' projections instead of the projection of the
+// weighted sum: the same number up to summation order (1e-7); a first version that did both halves in ONE workgroup, chain
+// first, was slower than k_pool_merge_head (13.3 vs 12.3 us in the step) - the next kernel waits for the launch, not for ds.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pool_tail_h(const float* __restrict__ partials, const int32_t* __restrict__ bag_tile_off,
+                                                     int T, int L, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                     int C, const float* __restrict__ y, float scale, float* __restrict__ M,
+                                                     float* __restrict__ lse, float* __restrict__ z, float* __restrict__ p,
+                                                     float* __restrict__ loss_sum, float* __restrict__ dz,
+                                                     float* __restrict__ dM, float* __restrict__ cdot,
+                                                     const int32_t* __restrict__ tile_map, const float* __restrict__ scores,
+                                                     const float* __restrict__ hrow, float* __restrict__ ds,
+                                                     const uint32_t* __restrict__ mbits, float mscale,
+                                                     float* __restrict__ Mdrop, int loss_kind) {
+    constexpr int NW = NT / 64;
+    constexpr int JP = 1024 / NT;                 // columns per thread (L <= 1024)
+    constexpr int DSP = 4;                        // row passes held in registers (NT / 32 tiles per pass)
+    __shared__ float red[NW][8];
+    __shared__ float scale_lds[1024];
+    __shared__ __attribute__((aligned(16))) float part_lds[4 * 1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
+    const float* ml = partials + (size_t)T * L;
+    if (blockIdx.y == 1) {
+        // ------------------------------------------------------------------ merge of the partials -> M, Mdrop
+        float mt = -INFINITY, lt = 0.f;
+        if (tid < nt) { mt = ml[2 * (t0 + tid)]; lt = ml[2 * (t0 + tid) + 1]; }
+        float keepv[JP];
+#pragma unroll
+        for (int q = 0; q < JP; ++q) {
+            const int j = tid + q * NT;
+            keepv[q] = 1.0f;
+            if (j < L && mbits != nullptr) keepv[q] = ((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f;
+        }
+        const int L4 = L >> 2, NG = NT / L4;      // NT = 256: L in {256, 512, 768, 1024} -> NG in {4, 2, 1, 1}; NT = 1024: 4x
+        const int c4 = tid % L4, g = tid / L4;
+        const bool worker = g < NG;                // L = 768 leaves 64 threads without a column group
+        f32x4 pre[8];                              // the first eight partial rows of this thread: requested before the statistics
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pre[e] = f32x4{0, 0, 0, 0};
+            if (worker && g + e * NG < min(nt, 1024)) pre[e] = *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + g + e * NG) * L + 4 * c4);
+        }
+        float m = mt;
+        for (int t = t0 + tid + NT; t < t1; t += NT) m = fmaxf(m, ml[2 * t]);
+        m = wave_allmax(m);
+        if (lane == 0) red[wv][0] = m;
+        __syncthreads();
+        m = red[0][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w][0]);
+        const float sc0 = tid < nt ? expf(mt - m) : 0.f;
+        float l = lt * sc0;
+        for (int t = t0 + tid + NT; t < t1; t += NT) l += ml[2 * t + 1] * expf(ml[2 * t] - m);
+        l = wave_allsum(l);
+        if (lane == 0) red[wv][1] = l;
+        scale_lds[tid] = sc0;
+        for (int k = tid + NT; k < 1024; k += NT) scale_lds[k] = (k < nt) ? expf(ml[2 * (t0 + k)] - m) : 0.f;
+        __syncthreads();
+        l = red[0][1];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) l += red[w][1];
+        const float inv = nt > 0 ? 1.0f / l : 0.f;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int tb = 0; tb < nt; tb += 1024) {
+            if (tb > 0) {
+                __syncthreads();
+                for (int k = tid; k < 1024; k += NT) scale_lds[k] = (tb + k < nt) ? expf(ml[2 * (t0 + tb + k)] - m) : 0.f;
+                __syncthreads();
+            }
+            const int cnt = worker ? min(1024, nt - tb) : 0;
+            int k = g;
+            if (tb == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k + e * NG < cnt) acc += scale_lds[k + e * NG] * pre[e];
+                k += 8 * NG;
+            }
+            for (; k + 7 * NG < cnt; k += 8 * NG) {
+                f32x4 v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + tb + k + e * NG) * L + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += scale_lds[k + e * NG] * v[e];
+            }
+            for (; k < cnt; k += NG)
+                acc += scale_lds[k] * *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + tb + k) * L + 4 * c4);
+        }
+        if (worker) *reinterpret_cast<f32x4*>(part_lds + g * L + 4 * c4) = acc;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < JP; ++q) {
+            const int j = tid + q * NT;
+            if (j < L) {
+                float v = 0.f;
+                for (int gg = 0; gg < NG; ++gg) v += part_lds[gg * L + j];
+                v *= inv;
+                M[(size_t)b * L + j] = v;
+                if (Mdrop != nullptr) Mdrop[(size_t)b * L + j] = v * keepv[q];
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- logits, loss, dz, ds from the rows
+    int ds_row[DSP];
+    float ds_sc[DSP], ds_h[DSP][4];
+#pragma unroll
+    for (int k = 0; k < DSP; ++k) {
+        ds_row[k] = -1;
+        ds_sc[k] = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ds_h[k][c] = 0.f;
+        const int g8 = t0 + (tid >> 5) + k * (NT / 32);
+        if (g8 < t1) {
+            const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+            if (lr < nrows) ds_row[k] = row0 + lr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DSP; ++k)
+        if (ds_row[k] >= 0) {
+            ds_sc[k] = scores[ds_row[k]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) ds_h[k][c] = hrow[(size_t)ds_row[k] * C + c];
+        }
+    float keepv[JP], wf[JP][4];
+#pragma unroll
+    for (int q = 0; q < JP; ++q) {
+        const int j = tid + q * NT;
+        keepv[q] = 1.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wf[q][c] = 0.f;
+        if (j < L) {
+            if (mbits != nullptr) keepv[q] = ((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) wf[q][c] = Wf[(size_t)c * L + j];
+        }
+    }
+    float bfr[4], yr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bfr[c] = c < C ? bf[c] : 0.f;
+        yr[c] = c < C ? y[b * C + c] : 0.f;
+    }
+    // ---- step 1: the bag's maximum over the row scores
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < DSP; ++k) m = fmaxf(m, ds_sc[k]);
+    for (int g8 = t0 + (tid >> 5) + DSP * (NT / 32); g8 < t1; g8 += NT / 32) {        // bags of more than DSP * NT / 32 tiles
+        const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+        if (lr < nrows) m = fmaxf(m, scores[row0 + lr]);
+    }
+    m = wave_allmax(m);
+    if (lane == 0) red[wv][0] = m;
+    __syncthreads();
+    m = red[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w][0]);
+    // ---- step 2: normaliser and the head's pre-activations from the rows
+    float ek[DSP], sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < DSP; ++k) {
+        ek[k] = ds_row[k] >= 0 ? expf(ds_sc[k] - m) : 0.f;
+        sums[0] += ek[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sums[1 + c] += ek[k] * ds_h[k][c];
+    }
+    for (int g8 = t0 + (tid >> 5) + DSP * (NT / 32); g8 < t1; g8 += NT / 32) {
+        const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+        if (lr < nrows) {
+            const size_t row = (size_t)(row0 + lr);
+            const float e = expf(scores[row] - m);
+            sums[0] += e;
+            for (int c = 0; c < C; ++c) sums[1 + c] += e * hrow[row * C + c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sums[i] = wave_allsum(sums[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) red[wv][1 + i] = sums[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float v = red[0][1 + i];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w][1 + i];
+        sums[i] = v;
+    }
+    const float l = sums[0];
+    const float inv = nt > 0 ? 1.0f / l : 0.f;
+    // ---- step 3 (every thread, no exchange): z, p, loss, dz, M . dM
+    float zz[4], pp[4], dzr[4];
+    float lossacc = 0.f, dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        zz[c] = sums[1 + c] * inv + bfr[c];
+        pp[c] = 1.0f / (1.0f + expf(-zz[c]));
+        dzr[c] = 0.f;
+    }
+    if (loss_kind == 0) {
+        // BCELoss on the sigmoid outputs vs one-hot float labels (train_ddp.py:98,323-324); log clamped at -100
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                lossacc += -(yr[c] * fmaxf(logf(pp[c]), -100.0f) + (1.0f - yr[c]) * fmaxf(logf(1.0f - pp[c]), -100.0f));
+                dzr[c] = (pp[c] - yr[c]) * scale;
+            }
+    } else {
+        // CrossEntropyLoss applied to the SIGMOID outputs with the one-hot labels as class probabilities (see k_pool_merge_head)
+        float mx = -INFINITY, se = 0.f, sy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) mx = fmaxf(mx, pp[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) se += expf(pp[c] - mx);
+        const float lse_p = mx + logf(se);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                sy += yr[c];
+                lossacc += -yr[c] * (pp[c] - lse_p);
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) dzr[c] = (expf(pp[c] - lse_p) * sy - yr[c]) * scale * pp[c] * (1.0f - pp[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dot += dzr[c] * (zz[c] - bfr[c]);
+    // ---- step 4: the score gradient of the bag's rows
+#pragma unroll
+    for (int k = 0; k < DSP; ++k)
+        if (ds_row[k] >= 0) {
+            float gd = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gd += dzr[c] * ds_h[k][c];
+            ds[ds_row[k]] = ek[k] * inv * (gd - dot);
+        }
+    for (int g8 = t0 + (tid >> 5) + DSP * (NT / 32); g8 < t1; g8 += NT / 32) {
+        const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+        if (lr < nrows) {
+            const size_t row = (size_t)(row0 + lr);
+            float gd = 0.f;
+            for (int c = 0; c < C; ++c) gd += dzr[c] * hrow[row * C + c];
+            ds[row] = expf(scores[row] - m) * inv * (gd - dot);
+        }
+    }
+    if (tid == 0) {
+        lse[b] = nt > 0 ? m + logf(l) : -INFINITY;
+        cdot[b] = dot;
+        loss_sum[b] = lossacc * scale;              // per-bag loss; summed (fixed order) by k_head_bwd_params
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (tid == c && c < C) {
+            z[b * C + c] = zz[c];
+            p[b * C + c] = pp[c];
+            dz[b * C + c] = dzr[c];
+        }
+#pragma unroll
+    for (int q = 0; q < JP; ++q) {
+        const int j = tid + q * NT;
+        if (j < L) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d += dzr[c] * wf[q][c];
+            dM[(size_t)b * L + j] = d * keepv[q];
+        }
+    }
+}
+
 extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
                                    const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
                                    float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
@@ -498,6 +780,20 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
     if (B == 0) return MIL_OK;
     // one workgroup per bag; bags of many tiles (>= 48 on average: 1536 rows) get 1024 threads - four times the tile
     // groups walking the partials and the rows of the ds pass (config 5, 128 tiles per bag: 21 -> see DESIGN.md)
+    const char* tail_env = getenv("MIL_TAIL_H");                     // "0": the long-chain form (A/B runs, equivalence test)
+    const bool short_chain = C <= 4 && y && ds && hrow && !(tail_env != nullptr && tail_env[0] == '0');
+    if (short_chain) {
+        if (T >= 48 * B)
+            hipLaunchKernelGGL(k_pool_tail_h<1024>, dim3(B, 2), dim3(1024), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf, bf,
+                               C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop,
+                               loss_kind);
+        else
+            hipLaunchKernelGGL(k_pool_tail_h<256>, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf, bf,
+                               C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop,
+                               loss_kind);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     if (T >= 48 * B)
         hipLaunchKernelGGL(k_pool_merge_head<1024>, dim3(B), dim3(1024), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf,
                            bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale,

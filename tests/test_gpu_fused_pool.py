@@ -57,3 +57,30 @@ def test_fused_pool_pass_equals_the_stand_alone_launch(train_mode, B, N):
         ref = float(b[k].abs().max())
         assert d <= 2e-6 * max(1.0, ref), (k, d, ref)
     assert bool(torch.isfinite(a["grad"]).all())
+
+
+def _run_tail(train_mode, short, B, N):
+    old = os.environ.get("MIL_TAIL_H")
+    os.environ["MIL_TAIL_H"] = "1" if short else "0"
+    try:
+        return _run(train_mode, True, B, N)
+    finally:
+        if old is None:
+            os.environ.pop("MIL_TAIL_H", None)
+        else:
+            os.environ["MIL_TAIL_H"] = old
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+@pytest.mark.parametrize("B,N", [(32, 1024), (40, 832), (3, 5000)])      # 5000 rows: more tiles than the register passes hold
+def test_short_chain_tail_equals_the_merge_first_tail(train_mode, B, N):
+    """k_pool_tail_h (logits from the rows' head projections, M merged behind the ds stores) against k_pool_merge_head (M
+    first, logits from M): the same numbers up to summation order."""
+    a = _run_tail(train_mode, True, B, N)
+    b = _run_tail(train_mode, False, B, N)
+    assert torch.equal(a["scores"], b["scores"]) and torch.equal(a["partials"], b["partials"])
+    for k in ("logits", "ds", "grad", "loss"):
+        d = float((a[k] - b[k]).abs().max())
+        ref = float(b[k].abs().max())
+        assert d <= 3e-6 * max(1.0, ref), (k, d, ref)
+    assert bool(torch.isfinite(a["grad"]).all())
