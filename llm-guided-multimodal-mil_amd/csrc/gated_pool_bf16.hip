@@ -19,7 +19,11 @@ typedef unsigned short u16;
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
 
 // Train mode (ABMIL.py:49): zero the dropped elements of 8 consecutive bf16 values; bits8 = their 8 keep bits (bit e =
-// element e).  Per dword (two values): y = bits b0 -> bit 0, b1 -> bit 16; y * 0xffff = the 16-bit lane masks.
+// element e).  Two forms, chosen per kernel by measurement (32 x 4096 x 1024, one box, A/B libraries):
+//   keep_bf16x8   per dword (two values): y = bits b0 -> bit 0, b1 -> bit 16; y * 0xffff = the 16-bit lane masks.  The
+//                 gate forward's hand-scheduled loop wants this one (137 us; the bit-field form: 196 us).
+//   keep_bf16x8_b two one-bit signed fields (all ones / zero) merged into the dword's two lanes (v_bfe_i32 x 2, v_bfi,
+//                 v_and: 4 instead of 6 VALU per dword).  Pool pass 72 -> 69 us, weight gradient 192 -> 186 us.
 __device__ __forceinline__ u16x8 keep_bf16x8(const u16x8 v, unsigned bits8) {
     typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
     u32x4k d = __builtin_bit_cast(u32x4k, v);
@@ -28,6 +32,17 @@ __device__ __forceinline__ u16x8 keep_bf16x8(const u16x8 v, unsigned bits8) {
         const unsigned m2 = (bits8 >> (2 * e)) & 3u;
         const unsigned y = (m2 | (m2 << 15)) & 0x00010001u;
         d[e] &= (y << 16) - y;
+    }
+    return __builtin_bit_cast(u16x8, d);
+}
+__device__ __forceinline__ u16x8 keep_bf16x8_b(const u16x8 v, unsigned bits8) {
+    typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+    u32x4k d = __builtin_bit_cast(u32x4k, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)bits8, 2 * e, 1);
+        const unsigned hi = (unsigned)__builtin_amdgcn_sbfe((int)bits8, 2 * e + 1, 1);
+        d[e] &= (lo & 0x0000ffffu) | (hi & 0xffff0000u);
     }
     return __builtin_bit_cast(u16x8, d);
 }
@@ -561,6 +576,18 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         for (int q = 0; q < NQ; ++q)
             v[i][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(xr + 512 * q)) : *reinterpret_cast<const u16x8*>(xr + 512 * q);
     }
+    // the keep words of those rows travel with them (behind the barrier they were a second, exposed round trip per tile:
+    // 51 -> 75 us for the pass at 32 x 4096 x 1024)
+    unsigned mw[MIL_POOL_TILE / 4][NQ];
+    if (DROP && xbits != nullptr) {
+#pragma unroll
+        for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
+            const int rr = max(min(wave + 4 * i, nrows - 1), 0);
+            const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mw[i][q] = mr[16 * q];
+        }
+    }
     if (wave == 0) {
         const float s = lane < nrows ? scores[row0 + lane] : -INFINITY;
         const float m = wave_allmax(s);
@@ -577,12 +604,9 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
         for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
     if (DROP && xbits != nullptr) {
 #pragma unroll
-        for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
-            const int rr = max(min(wave + 4 * i, nrows - 1), 0);
-            const uint32_t* mr = xbits + (size_t)(row0 + rr) * (L >> 5) + (lane >> 2);
+        for (int i = 0; i < MIL_POOL_TILE / 4; ++i)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v[i][q] = keep_bf16x8(v[i][q], mr[16 * q] >> (8 * (lane & 3)));
-        }
+            for (int q = 0; q < NQ; ++q) v[i][q] = keep_bf16x8_b(v[i][q], mw[i][q] >> (8 * (lane & 3)));
     }
 #pragma unroll
     for (int i = 0; i < MIL_POOL_TILE / 4; ++i) {
@@ -811,7 +835,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto xwrite = [&](int i, int buf) {
         // columns 0..127 -> panel 0, 128..255 -> panel 1 (each panel is its own 160-stride image)
         u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
-        *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
+        *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8_b(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
     };
     auto aload = [&](int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
