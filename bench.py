@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--prime", type=int, default=300, help="untimed forward passes before the warm-up steps (clock ramp)")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="distinct synthetic batches resident in HBM that the steps cycle through (1: the same 64 MiB every "
+                         "step, which then sits in the 256 MB Infinity Cache from one step to the next - no loader does that)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bags-per-gpu", type=int, default=32)
@@ -496,10 +499,12 @@ def run_rank(args):
     B, N, L, C = args.bags_per_gpu, args.patches, args.dim, 2
     params = syn.image_only_params(1234, L=L)
     tr = ImageOnlyTrainer(params, dev, world_size=world, train_mode=bool(args.train_mode), accum=args.accum)
-    x = syn.make_bags(4321 + rank, B, N, L).reshape(B * N, L).to(dev)       # resident in HBM before timing
+    nb = max(1, args.batches) if not args.graph else 1       # a captured step replays its static buffers
+    xs = [syn.make_bags(4321 + rank + 1000 * i, B, N, L).reshape(B * N, L).to(dev) for i in range(nb)]   # resident in HBM before timing
     if args.dtype == "bf16":
-        x = x.to(torch.bfloat16)
-    y = syn.make_labels(99 + rank, B, C).to(dev)
+        xs = [t.to(torch.bfloat16) for t in xs]
+    ys = [syn.make_labels(99 + rank + 1000 * i, B, C).to(dev) for i in range(nb)]
+    x, y = xs[0], ys[0]
     lay = BagLayout.uniform(B, N, dev)
 
     def barrier():
@@ -518,15 +523,20 @@ def run_rank(args):
         tr.reset_dropout_stream()
 
     if not args.graph:
-        step = lambda: tr.train_step(x, lay, y)     # noqa: E731
+        turn = [0]
+
+        def step():
+            i = turn[0] % nb
+            turn[0] += 1
+            return tr.train_step(xs[i], lay, ys[i])
     else:
         tr.capture(x, lay, y)                        # forward+backward as one hipGraph on static buffers
         step = tr.replay_step
     # Clock priming (every rank, before the W warm-up steps): the chip needs ~10-30 ms of sustained load to reach its
     # steady clock, and a short run (50 steps = 13 ms) otherwise reads 8 % slower than a long one of the very same loop.
     # Forward passes only: no optimizer update, so the parameter trajectory of "W warm-up + K timed steps" is untouched.
-    for _ in range(args.prime):
-        tr.forward(x, lay, y)
+    for i in range(args.prime):
+        tr.forward(xs[i % nb], lay, ys[i % nb])
     for _ in range(args.warmup):
         step()
     # test hook (tests/test_gpu_bench_launcher.py): this rank dies between warm-up and the timed region, the others are
@@ -579,6 +589,7 @@ def run_rank(args):
                                    f"fwd+BCE+bwd+allreduce+Adam (BASELINE config 2; x{world} GPUs = {world * B} bags)",
                        "bags_per_gpu": B, "patches": N, "dim": L, "global_bags": world * B,
                        "parallelism": f"dp{world}", "loss": round(loss, 6), "mode": mode, "accum": args.accum,
+                       "batches_cycled": nb,
                        "launch": "eager" if not args.graph else "hipGraph(fwd+bwd)+eager(allreduce,adam)"},
         }
         if rccl is not None:
