@@ -40,7 +40,7 @@ extern "C" {
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
 
 /* Library/ABI version, for the host mirror's load-time check. */
-int mil_abi_version(void);   /* 4 */
+int mil_abi_version(void);   /* 5 */
 
 /* ---- dropout keep bits (train mode) -------------------------------------------------------
  * model.train() upstream drops the bag rows with p = 0.5 BEFORE the gate and pools the dropped rows
@@ -132,6 +132,16 @@ int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int 
                         float* lse, float* z, float* p, float* loss_bag, float* dz, float* dM, float* cdot,
                         const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
                         const uint32_t* mbits, float mscale, float* Mdrop, int loss_kind, void* stream);
+/* The same with a workspace (mil_pool_tail_workspace_floats(B) floats, contents irrelevant): a batch of at most 8 LONG bags (on
+ * average >= 64 tiles = 2048 rows per bag - the authors' one-bag-per-GPU regime, run_train.sh:81) then spreads every bag's
+ * tail over up to 16 + L / 64 workgroups in two short launches instead of walking it in one or two workgroups (ragged
+ * image-only step 0.157 -> 0.150 ms).  tail_ws NULL = mil_pool_merge_head. */
+size_t mil_pool_tail_workspace_floats(int B);
+int mil_pool_merge_head_ws(const float* partials, const int32_t* bag_tile_off, int T, int B, int L, const float* Wf,
+                           const float* bf, int C, const float* y, float scale, float* M, float* lse, float* z, float* p,
+                           float* loss_sum, float* dz, float* dM, float* cdot, const int32_t* tile_map,
+                           const float* scores, const float* hrow, float* ds, const uint32_t* mbits, float mscale,
+                           float* Mdrop, int loss_kind, float* tail_ws, void* stream);
 /* mbits / mscale (nullable / 1): keep bits of the head's Dropout(.25); M stays the un-dropped pool output, the head
  * reads M * keep * mscale (also written to Mdrop [B, L] when given: it is the M of dWf = dz^T M), dM carries the mask. */
 
@@ -681,6 +691,7 @@ typedef struct mil_image_only_step {
     float lr, beta1, beta2, eps, weight_decay, grad_scale;
     const float* lr_dev;            /* nullable, needs adam_step_dev: [1] learning rate read on the device instead of `lr`, so a
                                      * captured step follows the schedule of utils.py:232-241 without re-capture */
+    float* tail_ws;                 /* nullable: mil_pool_tail_workspace_floats(B) floats for MIL_STAGE_TAIL (long bags) */
 } mil_image_only_step;
 
 int mil_image_only_step_run(const mil_image_only_step* a, void* stream);

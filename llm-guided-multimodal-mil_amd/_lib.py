@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mil_hip.h")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/mil_hip.h one to one
@@ -31,6 +31,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_attn_pool_bwd_from_h": (c_int, [_P] * 6 + [c_int, c_int, _P, _P]),
     "mil_pool_merge_head": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12
                             + [_P, c_float, _P, c_int, _P]),
+    "mil_pool_merge_head_ws": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12
+                               + [_P, c_float, _P, c_int, _P, _P]),
+    "mil_pool_tail_workspace_floats": (c_size_t, [c_int]),
     "mil_head_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P]),
     "mil_bce_fwd_bwd": (c_int, [_P] * 4 + [c_int, c_int, c_float, _P]),
     "mil_head_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
@@ -174,7 +177,7 @@ class ImageOnlyStep(ctypes.Structure):
         + [(n, _P) for n in ("param_flat", "grad_flat", "exp_avg", "exp_avg_sq")]
         + [("n_param", c_uint64), ("adam_step", c_int32), ("adam_step_dev", _P)]
         + [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")]
-        + [("lr_dev", _P)])
+        + [("lr_dev", _P), ("tail_ws", _P)])
 
 
 _lib = None

@@ -767,11 +767,249 @@ __global__ __launch_bounds__(NT) void k_pool_tail_h(const float* __restrict__ pa
     }
 }
 
-extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
-                                   const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
-                                   float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
-                                   const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
-                                   const uint32_t* mbits, float mscale, float* Mdrop, int loss_kind, void* stream) {
+// ---------------------------------------------------------------------------------------------
+// The per-bag tail for LONG bags (the authors' regime: ONE bag of 2 000 - 15 592 patches per GPU and step, run_train.sh:81;
+// config 5's 4096-patch bags): one or two workgroups per bag walk hundreds of tiles one pass after the other (22 us for a
+// 10 000-patch bag).  Two short launches spread the bag over many workgroups instead:
+//   k_tail_stats  grid (B, S): workgroup (b, s) takes every S-th group of eight tiles of bag b: its rows' maximum m_w and,
+//                 relative to it, l_w = sum e_n and z_w[c] = sum e_n h_n[c]  ->  ws[b][s][0..5]
+//   k_tail_apply  grid (B, S + L / 64): every workgroup folds the S partial statistics of its bag (same order, same bits
+//                 everywhere) into m, l, z -> p, loss, dz, M . dM (k_pool_tail_h's arithmetic); workgroups y < S write
+//                 ds for the rows they took in the first launch, workgroup y = 0 also the bag's scalars and dM; workgroups
+//                 y >= S merge the tile partials of one 64-column chunk -> M, Mdrop (tile weight exp(m_t - lse)).
+// No atomics, no counters: the second launch is the barrier.
+#define TAIL_S_MAX 16
+template <int DSP>
+__device__ __forceinline__ void tail_rows_load(const int32_t* __restrict__ tile_map, const float* __restrict__ scores,
+                                               const float* __restrict__ hrow, int C, int t0, int t1, int s, int S, int tid,
+                                               int (&row)[DSP], float (&sc)[DSP], float (&hh)[DSP][4]) {
+#pragma unroll
+    for (int k = 0; k < DSP; ++k) {
+        row[k] = -1;
+        sc[k] = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hh[k][c] = 0.f;
+        const int g8 = t0 + (k * S + s) * 8 + (tid >> 5);
+        if (g8 < t1) {
+            const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+            if (lr < nrows) row[k] = row0 + lr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DSP; ++k)
+        if (row[k] >= 0) {
+            sc[k] = scores[row[k]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) hh[k][c] = hrow[(size_t)row[k] * C + c];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_tail_stats(const int32_t* __restrict__ bag_tile_off, const int32_t* __restrict__ tile_map,
+                                                    const float* __restrict__ scores, const float* __restrict__ hrow, int C,
+                                                    int S, float* __restrict__ ws) {
+    constexpr int DSP = 4;
+    __shared__ float red[4][8];
+    const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1];
+    int row[DSP];
+    float sc[DSP], hh[DSP][4];
+    tail_rows_load<DSP>(tile_map, scores, hrow, C, t0, t1, s, S, tid, row, sc, hh);
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < DSP; ++k) m = fmaxf(m, sc[k]);
+    for (int g8 = t0 + (DSP * S + s) * 8 + (tid >> 5); g8 < t1; g8 += 8 * S) {        // more than DSP passes: from memory
+        const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+        if (lr < nrows) m = fmaxf(m, scores[row0 + lr]);
+    }
+    m = wave_allmax(m);
+    if (lane == 0) red[wv][0] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m > -INFINITY) {
+#pragma unroll
+        for (int k = 0; k < DSP; ++k) {
+            const float e = row[k] >= 0 ? expf(sc[k] - m) : 0.f;
+            sums[0] += e;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sums[1 + c] += e * hh[k][c];
+        }
+        for (int g8 = t0 + (DSP * S + s) * 8 + (tid >> 5); g8 < t1; g8 += 8 * S) {
+            const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+            if (lr < nrows) {
+                const size_t r_ = (size_t)(row0 + lr);
+                const float e = expf(scores[r_] - m);
+                sums[0] += e;
+                for (int c = 0; c < C; ++c) sums[1 + c] += e * hrow[r_ * C + c];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sums[i] = wave_allsum(sums[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) red[wv][1 + i] = sums[i];
+    __syncthreads();
+    if (tid < 6) {
+        float* o = ws + ((size_t)b * TAIL_S_MAX + s) * 8;
+        o[tid] = tid == 0 ? m : (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tail_apply(const float* __restrict__ partials, const int32_t* __restrict__ bag_tile_off,
+                                                    int T, int L, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                    int C, const float* __restrict__ y, float scale, float* __restrict__ M,
+                                                    float* __restrict__ lse, float* __restrict__ z, float* __restrict__ p,
+                                                    float* __restrict__ loss_sum, float* __restrict__ dz,
+                                                    float* __restrict__ dM, float* __restrict__ cdot,
+                                                    const int32_t* __restrict__ tile_map, const float* __restrict__ scores,
+                                                    const float* __restrict__ hrow, float* __restrict__ ds,
+                                                    const uint32_t* __restrict__ mbits, float mscale,
+                                                    float* __restrict__ Mdrop, int loss_kind, int S,
+                                                    const float* __restrict__ ws) {
+    constexpr int DSP = 4;
+    __shared__ __attribute__((aligned(16))) float part_lds[16 * 64];
+    const int b = blockIdx.x, yb = blockIdx.y, tid = threadIdx.x;
+    const int t0 = bag_tile_off[b], t1 = bag_tile_off[b + 1], nt = t1 - t0;
+    // the rows of a ds workgroup: requested before the statistics are folded
+    int row[DSP];
+    float sc[DSP], hh[DSP][4];
+    if (yb < S) tail_rows_load<DSP>(tile_map, scores, hrow, C, t0, t1, yb, S, tid, row, sc, hh);
+    // ---- fold the S partial statistics (every thread of every workgroup: the same operations in the same order)
+    const float* wb = ws + (size_t)b * TAIL_S_MAX * 8;
+    float m = -INFINITY;
+    for (int i = 0; i < S; ++i) m = fmaxf(m, wb[8 * i]);
+    float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < S; ++i) {
+        const float mw = wb[8 * i];
+        const float f = mw > -INFINITY ? expf(mw - m) : 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) sums[q] += f * wb[8 * i + 1 + q];
+    }
+    const float l = sums[0];
+    const float inv = nt > 0 && l > 0.f ? 1.0f / l : 0.f;
+    const float lse_b = nt > 0 ? m + logf(l) : -INFINITY;
+    float bfr[4], yr[4], zz[4], pp[4], dzr[4];
+    float lossacc = 0.f, dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bfr[c] = c < C ? bf[c] : 0.f;
+        yr[c] = c < C ? y[b * C + c] : 0.f;
+        zz[c] = sums[1 + c] * inv + bfr[c];
+        pp[c] = 1.0f / (1.0f + expf(-zz[c]));
+        dzr[c] = 0.f;
+    }
+    if (loss_kind == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                lossacc += -(yr[c] * fmaxf(logf(pp[c]), -100.0f) + (1.0f - yr[c]) * fmaxf(logf(1.0f - pp[c]), -100.0f));
+                dzr[c] = (pp[c] - yr[c]) * scale;
+            }
+    } else {
+        float mx = -INFINITY, se = 0.f, sy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) mx = fmaxf(mx, pp[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) se += expf(pp[c] - mx);
+        const float lse_p = mx + logf(se);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                sy += yr[c];
+                lossacc += -yr[c] * (pp[c] - lse_p);
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) dzr[c] = (expf(pp[c] - lse_p) * sy - yr[c]) * scale * pp[c] * (1.0f - pp[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dot += dzr[c] * (zz[c] - bfr[c]);
+    if (yb < S) {
+        // ---- ds of this workgroup's rows
+#pragma unroll
+        for (int k = 0; k < DSP; ++k)
+            if (row[k] >= 0) {
+                float gd = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gd += dzr[c] * hh[k][c];
+                ds[row[k]] = expf(sc[k] - m) * inv * (gd - dot);
+            }
+        for (int g8 = t0 + (DSP * S + yb) * 8 + (tid >> 5); g8 < t1; g8 += 8 * S) {
+            const int row0 = tile_map[4 * g8 + 1], nrows = tile_map[4 * g8 + 2], lr = tid & 31;
+            if (lr < nrows) {
+                const size_t r_ = (size_t)(row0 + lr);
+                float gd = 0.f;
+                for (int c = 0; c < C; ++c) gd += dzr[c] * hrow[r_ * C + c];
+                ds[r_] = expf(scores[r_] - m) * inv * (gd - dot);
+            }
+        }
+        if (yb == 0) {
+            if (tid == 0) {
+                lse[b] = lse_b;
+                cdot[b] = dot;
+                loss_sum[b] = lossacc * scale;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (tid == c && c < C) {
+                    z[b * C + c] = zz[c];
+                    p[b * C + c] = pp[c];
+                    dz[b * C + c] = dzr[c];
+                }
+            for (int j = tid; j < L; j += 256) {
+                float keep = 1.0f;
+                if (mbits != nullptr) keep = ((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f;
+                float d = 0.f;
+                for (int c = 0; c < C; ++c) d += dzr[c] * Wf[(size_t)c * L + j];
+                dM[(size_t)b * L + j] = d * keep;
+            }
+        }
+        return;
+    }
+    // ---- merge of the tile partials, columns [64 j, 64 j + 64): thread (tile group tg < 16, float4 column c4 < 16)
+    const int j0 = 64 * (yb - S), c4 = tid & 15, tg = tid >> 4;
+    const float* ml = partials + (size_t)T * L;
+    f32x4 acc = {0, 0, 0, 0};
+    int k = tg;
+    for (; k + 48 < nt; k += 64) {                 // four tiles in flight per thread
+        f32x4 v[4];
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + k + 16 * e) * L + j0 + 4 * c4);
+            w[e] = ml[2 * (t0 + k + 16 * e)];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += expf(w[e] - lse_b) * v[e];
+    }
+    for (; k < nt; k += 16)
+        acc += expf(ml[2 * (t0 + k)] - lse_b) * *reinterpret_cast<const f32x4*>(partials + (size_t)(t0 + k) * L + j0 + 4 * c4);
+    *reinterpret_cast<f32x4*>(part_lds + tg * 64 + 4 * c4) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += part_lds[q * 64 + tid];
+        const int j = j0 + tid;
+        M[(size_t)b * L + j] = v;
+        if (Mdrop != nullptr) {
+            float keep = 1.0f;
+            if (mbits != nullptr) keep = ((mbits[(size_t)b * (L >> 5) + (j >> 5)] >> (j & 31)) & 1u) ? mscale : 0.f;
+            Mdrop[(size_t)b * L + j] = v * keep;
+        }
+    }
+}
+
+extern "C" size_t mil_pool_tail_workspace_floats(int B) { return (size_t)(B > 0 ? B : 0) * TAIL_S_MAX * 8; }
+
+extern "C" int mil_pool_merge_head_ws(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
+                                      const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
+                                      float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
+                                      const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
+                                      const uint32_t* mbits, float mscale, float* Mdrop, int loss_kind, float* tail_ws,
+                                      void* stream) {
     if (!partials || !bag_tile_off || !Wf || !bf || !M || !lse || !z || !p) return MIL_EINVAL;
     if (loss_kind != MIL_LOSS_BCE && loss_kind != MIL_LOSS_CE_ON_SIGMOID) return MIL_EINVAL;
     if (y && (!loss_sum || !dz || !dM || !cdot)) return MIL_EINVAL;
@@ -782,6 +1020,20 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
     // groups walking the partials and the rows of the ds pass (config 5, 128 tiles per bag: 21 -> see DESIGN.md)
     const char* tail_env = getenv("MIL_TAIL_H");                     // "0": the long-chain form (A/B runs, equivalence test)
     const bool short_chain = C <= 4 && y && ds && hrow && !(tail_env != nullptr && tail_env[0] == '0');
+    if (short_chain && tail_ws != nullptr && T >= 64 * B && B <= 8 && (tail_env == nullptr || tail_env[0] != '1')) {
+        // a FEW long bags (>= 64 tiles = 2048 rows on average): two short launches over many workgroups per bag ("1": never).
+        // With many bags the bags themselves are the parallelism: config 5 (32 x 128 tiles) 13.9 us in one launch, 15.4 - 16.5 so.
+        int S = (T / B + 31) / 32;
+        if (S > TAIL_S_MAX) S = TAIL_S_MAX;
+        hipLaunchKernelGGL(k_tail_stats, dim3(B, S), dim3(256), 0, (hipStream_t)stream, bag_tile_off, tile_map, scores, hrow, C, S,
+                           tail_ws);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_tail_apply, dim3(B, S + L / 64), dim3(256), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf, bf,
+                           C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map, scores, hrow, ds, mbits, mscale, Mdrop,
+                           loss_kind, S, (const float*)tail_ws);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     if (short_chain) {
         if (T >= 48 * B)
             hipLaunchKernelGGL(k_pool_tail_h<1024>, dim3(B, 2), dim3(1024), 0, (hipStream_t)stream, partials, bag_tile_off, T, L, Wf, bf,
@@ -804,6 +1056,15 @@ extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_til
                            Mdrop, loss_kind);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_pool_merge_head(const float* partials, const int32_t* bag_tile_off, int T, int B, int L,
+                                   const float* Wf, const float* bf, int C, const float* y, float scale, float* M,
+                                   float* lse, float* z, float* p, float* loss_sum, float* dz, float* dM, float* cdot,
+                                   const int32_t* tile_map, const float* scores, const float* hrow, float* ds,
+                                   const uint32_t* mbits, float mscale, float* Mdrop, int loss_kind, void* stream) {
+    return mil_pool_merge_head_ws(partials, bag_tile_off, T, B, L, Wf, bf, C, y, scale, M, lse, z, p, loss_sum, dz, dM, cdot, tile_map,
+                                  scores, hrow, ds, mbits, mscale, Mdrop, loss_kind, nullptr, stream);
 }
 
 extern "C" int mil_head_fwd(const float* M, const float* Wf, const float* bf, float* z, float* p, int B, int L, int C,

@@ -134,11 +134,11 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
         if (rc != MIL_OK) return rc;
     }
     if (st & MIL_STAGE_TAIL) {
-        rc = mil_pool_merge_head(a->partials, a->bag_tile_off, a->T, a->B, a->L, a->Wf, a->bf, a->C, a->y, a->loss_scale, a->M,
-                                 a->lse, a->logits, a->prob, grads ? a->loss_bag : nullptr, grads ? a->dz : nullptr,
-                                 grads ? a->dM : nullptr, grads ? a->cdot : nullptr, use_h ? a->tile_map : nullptr,
-                                 use_h ? a->scores : nullptr, use_h ? a->hrow : nullptr, use_h ? a->ds : nullptr, mbits, mscale,
-                                 train ? a->Mdrop : nullptr, a->loss_kind, stream);
+        rc = mil_pool_merge_head_ws(a->partials, a->bag_tile_off, a->T, a->B, a->L, a->Wf, a->bf, a->C, a->y, a->loss_scale, a->M,
+                                    a->lse, a->logits, a->prob, grads ? a->loss_bag : nullptr, grads ? a->dz : nullptr,
+                                    grads ? a->dM : nullptr, grads ? a->cdot : nullptr, use_h ? a->tile_map : nullptr,
+                                    use_h ? a->scores : nullptr, use_h ? a->hrow : nullptr, use_h ? a->ds : nullptr, mbits, mscale,
+                                    train ? a->Mdrop : nullptr, a->loss_kind, a->tail_ws, stream);
         if (rc != MIL_OK) return rc;
         if (grads && !use_h) {          // no head projections: the score gradient takes a second pass over x
             rc = a->x_bf16 ? mil_attn_pool_bwd_bf16((const uint16_t*)a->x, a->scores, a->lse, a->dM, a->cdot, a->tile_map, a->T,

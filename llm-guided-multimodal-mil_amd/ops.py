@@ -149,14 +149,16 @@ def pool_merge_head(partials, layout: BagLayout, L: int, Wf, bf, y=None, scale: 
                 (torch.zeros if getattr(layout, "device_lengths", False) else torch.empty)(scores.shape[0], device=dev)
     if mbits is not None:
         out["Mdrop"] = torch.empty((B, L), device=dev)
-    rc = _lib.lib().mil_pool_merge_head(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
-                                        _p(_f32c(bf, "bf")), C, _p(y), float(scale), _p(out["M"]), _p(out["lse"]),
-                                        _p(out["logits"]), _p(out["prob"]), _p(out.get("loss_bag")), _p(out.get("dz")),
-                                        _p(out.get("dM")), _p(out.get("cdot")),
-                                        _p(layout.tile_map) if "ds" in out else None, _p(scores) if "ds" in out else None,
-                                        _p(hrow) if "ds" in out else None, _p(out.get("ds")), _p(mbits), float(mscale),
-                                        _p(out.get("Mdrop")), int(loss_kind), _stream())
-    _lib.check(rc, "mil_pool_merge_head")
+    # long bags (one ragged bag per step): the tail spreads over many workgroups through a small workspace
+    ws = torch.empty(_lib.lib().mil_pool_tail_workspace_floats(B), device=dev) if ("ds" in out and layout.T >= 64 * B and B <= 8) else None
+    rc = _lib.lib().mil_pool_merge_head_ws(_p(partials), _p(layout.bag_tile_off), layout.T, B, L, _p(_f32c(Wf, "Wf")),
+                                           _p(_f32c(bf, "bf")), C, _p(y), float(scale), _p(out["M"]), _p(out["lse"]),
+                                           _p(out["logits"]), _p(out["prob"]), _p(out.get("loss_bag")), _p(out.get("dz")),
+                                           _p(out.get("dM")), _p(out.get("cdot")),
+                                           _p(layout.tile_map) if "ds" in out else None, _p(scores) if "ds" in out else None,
+                                           _p(hrow) if "ds" in out else None, _p(out.get("ds")), _p(mbits), float(mscale),
+                                           _p(out.get("Mdrop")), int(loss_kind), _p(ws), _stream())
+    _lib.check(rc, "mil_pool_merge_head_ws")
     return out
 
 

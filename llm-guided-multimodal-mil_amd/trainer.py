@@ -186,7 +186,7 @@ class ImageOnlyTrainer:
         grads = y is not None
         st = dict(scores=self._buf("scores", R), partials=self._buf("partials", T * (L + 2)),
                   M=self._buf("M", B * L), lse=self._buf("lse", B), logits=self._buf("logits", B * C),
-                  prob=self._buf("prob", B * C))
+                  prob=self._buf("prob", B * C), tail_ws=self._buf("tail_ws", _lib.lib().mil_pool_tail_workspace_floats(B)))
         if grads:
             if b16:
                 need = _lib.lib().mil_gate_bwd_workspace_floats_bf16(R, L) if (self.bf16_grad_mfma and L % 256 == 0) else \
@@ -213,6 +213,7 @@ class ImageOnlyTrainer:
         a.exp_avg, a.exp_avg_sq, a.n_param = fp.exp_avg.data_ptr(), fp.exp_avg_sq.data_ptr(), fp.flat.numel()
         a.adam_step_dev = pv(self.step_counter)
         a.lr_dev = pv(self.lr_dev)
+        a.tail_ws = st["tail_ws"].data_ptr()
         a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale = self.betas[0], self.betas[1], self.eps, self.wd, 1.0
         self._args, self._args_key = a, key
         self._keep = (x, y, layout, dict(st), self._w16)

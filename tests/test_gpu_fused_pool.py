@@ -84,3 +84,23 @@ def test_short_chain_tail_equals_the_merge_first_tail(train_mode, B, N):
         ref = float(b[k].abs().max())
         assert d <= 3e-6 * max(1.0, ref), (k, d, ref)
     assert bool(torch.isfinite(a["grad"]).all())
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+@pytest.mark.parametrize("B,N", [(3, 5000), (1, 10016), (2, 4096), (1, 40000)])     # 40 000 rows: more tiles than 16 x 4 passes
+def test_long_bag_tail_in_two_launches_equals_the_one_launch_tail(train_mode, B, N):
+    """k_tail_stats + k_tail_apply (>= 64 tiles per bag on average: many workgroups per bag) against k_pool_tail_h (MIL_TAIL_H=1:
+    one launch, two workgroups per bag): the same numbers up to summation order."""
+    old = os.environ.pop("MIL_TAIL_H", None)
+    try:
+        a = _run(train_mode, True, B, N)
+    finally:
+        if old is not None:
+            os.environ["MIL_TAIL_H"] = old
+    b = _run_tail(train_mode, True, B, N)
+    assert torch.equal(a["scores"], b["scores"]) and torch.equal(a["partials"], b["partials"])
+    for k in ("logits", "ds", "grad", "loss"):
+        d = float((a[k] - b[k]).abs().max())
+        ref = float(b[k].abs().max())
+        assert d <= 3e-6 * max(1.0, ref), (k, d, ref)
+    assert bool(torch.isfinite(a["grad"]).all())
