@@ -57,6 +57,9 @@ int mil_dropout_keep_bits(uint32_t* bits, int rows, int cols, float p_drop, uint
                           const int32_t* offset_dev, void* stream);
 /* counter[0] += v on the stream (a device-side pass counter that a replayed hipGraph advances: dropout offsets). */
 int mil_counter_add(int32_t* counter, int v, void* stream);
+/* dst[0..n) = values_host[0..n), n <= 8, the values travelling as kernel arguments of one tiny launch (no staging copy): the
+ * per-step bag lengths of a capacity bucket (bags.DeviceBagLayout.set_lengths, segments.FusionBucket.set_lengths). */
+int mil_set_i32(int32_t* dst, const int32_t* values_host, int n, void* stream);
 /* t[row][col] = keep ? t * scale : 0, in place (dropout backward for a consumer that cannot fold the mask in). */
 int mil_dropout_apply_bits(float* t, const uint32_t* bits, int rows, int cols, float scale, void* stream);
 

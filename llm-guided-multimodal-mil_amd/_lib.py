@@ -34,6 +34,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_pool_merge_head_ws": (c_int, [_P] * 2 + [c_int, c_int, c_int, _P, _P, c_int, _P, c_float] + [_P] * 12
                                + [_P, c_float, _P, c_int, _P, _P]),
     "mil_pool_tail_workspace_floats": (c_size_t, [c_int]),
+    "mil_set_i32": (c_int, [_P, _P, c_int, _P]),
     "mil_head_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int, _P]),
     "mil_bce_fwd_bwd": (c_int, [_P] * 4 + [c_int, c_int, c_float, _P]),
     "mil_head_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),

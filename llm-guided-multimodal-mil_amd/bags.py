@@ -174,6 +174,21 @@ def bucket_rows(n: int, floor: int = 256) -> int:
         b *= 2
 
 
+def upload_lengths(dst: torch.Tensor, lengths) -> None:
+    """dst (int32, on the device) <- lengths on the current stream.  Up to 8 values go as kernel arguments of one tiny launch
+    (mil_set_i32); a copy from pageable host memory cost a blit kernel behind a ~9 us gap in front of every replayed step."""
+    n = len(lengths)
+    if n <= 8 and dst.is_cuda:
+        import ctypes
+        from . import _lib
+        arr = (ctypes.c_int32 * n)(*lengths)
+        rc = _lib.lib().mil_set_i32(ctypes.c_void_p(dst.data_ptr()), arr, n,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "mil_set_i32")
+    else:
+        dst.copy_(torch.tensor(lengths, dtype=torch.int32), non_blocking=True)
+
+
 class DeviceBagLayout:
     """Bag layout whose lengths live ON THE DEVICE: the step kernels rebuild the tile map from `bag_len_dev` every pass
     (mil_build_tile_map) and mask the rows beyond the true total, so one set of launch parameters - one captured hipGraph -
@@ -196,5 +211,5 @@ class DeviceBagLayout:
         if len(lengths) != self.B or sum(lengths) > self.R:
             raise ValueError(f"{len(lengths)} bags / {sum(lengths)} rows do not fit a layout of {self.B} bags / {self.R} rows")
         self.lengths = lengths
-        self.bag_len_dev.copy_(torch.tensor(lengths, dtype=torch.int32), non_blocking=True)
+        upload_lengths(self.bag_len_dev, lengths)
         return self

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import lifetime
+from .bags import upload_lengths
 
 POOL_KEYS_PER_TILE = 64
 ROWS_PER_BLOCK = 32
@@ -148,7 +149,7 @@ class FusionBucket:
             raise ValueError(f"FusionBucket: lengths {lengths} do not fit {self.B} bags / {self.cap} rows "
                              f"(every bag needs >= {self._min_rows} rows)")
         self.lengths = lengths
-        self.len_dev.copy_(torch.tensor(lengths, dtype=torch.int32), non_blocking=True)
+        upload_lengths(self.len_dev, lengths)
         return self
 
     def refresh(self):
