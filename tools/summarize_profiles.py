@@ -85,7 +85,7 @@ if region:
     except Exception:       # noqa: BLE001
         bl = {}
     ev = bl.get("kernels_ms", {})
-    pair = {"k_gate_fwd": "gate_fwd_with_pool_fused", "k_gate_bwd_dw": "gate_bwd_dw", "k_pool_merge_head": "merge_head_loss_ds",
+    pair = {"k_gate_fwd": "gate_fwd_with_pool_fused", "k_gate_bwd_dw": "gate_bwd_dw", "k_pool_merge_head": "merge_head_loss_ds", "k_pool_tail_h": "merge_head_loss_ds",
             "k_gate_bwd_reduce": "gate_bwd_reduce_head_adam"}
     with open(os.path.join(DST, f"{TAG}_cfg2_timed_region.csv"), "w") as o:
         o.write(f"# rocprofv3 --kernel-trace -- {WORK['cfg2']}\n")
