@@ -454,7 +454,11 @@ def config3_fusion(dev, steps=30, warmup=4):
                          "frozen tower eager + trainable part replayed",
             "roofline": {"bound": "mfma", "kernel": "step (fc_pathology + gate GEMMs)", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                         "flops_per_step": flops, "traffic": None},
+                         "flops_per_step": flops, "traffic": _pmc_traffic("cfg3_step"),
+                         "traffic_source": "profiles/pmc_traffic.json: HBM bytes of the WHOLE step (2 x FETCH_SIZE + WRITE_SIZE summed "
+                                           "over every kernel of the replayed step, separate rocprofv3 --pmc passes)"},
+            "step_hbm_ms_at_peak": (round(_pmc_traffic("cfg3_step") / (PEAK_HBM_GBS * 1e9) * 1e3, 4)
+                                    if _pmc_traffic("cfg3_step") else None),
             "parity": {"bags_checked": [0, B - 1], "max_abs_dlogit": dl, "top1_equal": top1,
                        "oracle": "fp32 oracle fused_forward (model/aggregator.py:134-209 wiring)", "tolerance": 1e-3}}
 

@@ -159,3 +159,185 @@ void k_gemm64(const float* __restrict__ A, int lda, const float* __restrict__ B,
         }
     }
 }
+
+
+// 64 x 64 tiles for products of a FEW HUNDRED rows (the frozen text tower at one bag x 10 prompts x 77 tokens = 770 rows:
+// the learnable-prompt step of the one-bag-per-GPU regime; 96 such products per step).  64 x 128 tiles make 156 workgroups of
+// 770 x 1536 and the 128 x 128 path 84 (+ split-K): 35 - 42 us for 1.2 - 1.6 GFLOP = 0.2 - 0.27 of peak.  Half-width tiles double
+// the workgroups again (312 for 770 x 1536, 416 for 770 x 2048; 32 KB of LDS: five resident per CU), and blockIdx.z splits
+// K when even that leaves CUs idle (770 x 512 with K = 2048: 104 tiles x 4 splits), the raw partial tiles going to the
+// workspace for k_splitk_reduce and its epilogue.  Same pipeline, swizzle and fragment convention as k_gemm64; wave tile
+// 32 x 32 (2 x 2 waves).
+#ifndef G64N_SETS
+#define G64N_SETS 2      /* 1 / 2 / 3 / 4 register sets measured within 7 % of each other; 2 was the best */
+#endif
+template <int BMODE>
+__global__ __launch_bounds__(256)
+void k_gemm64n(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+               int M, int N, int K, int kchunk, float* __restrict__ partial, const float* __restrict__ bias, int act,
+               const float* __restrict__ residual, int ldr, int accumulate, float* __restrict__ aux, int ldaux, int aux_mode) {
+    constexpr int ASZ = 64 * 32;
+    constexpr int BSZ = BMODE == 0 ? 64 * 32 : LG_BK * 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];       // 32 KB
+    float* as = smem;
+    float* bs = smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int nslice = (kend - kbeg) / LG_BK;
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const float* asrc[2];
+    int aoff[2];
+    const float* bsrc[2];
+    int boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = srow + 32 * i;
+        asrc[i] = A + (size_t)min(i0 + row, M - 1) * lda + 4 * sch + kbeg;
+        aoff[i] = g64_swz(row, sch);
+        if (BMODE == 0) {
+            bsrc[i] = B + (size_t)min(j0 + row, N - 1) * ldb + 4 * sch + kbeg;
+            boff[i] = g64_swz(row, sch);
+        } else {
+            const int kr = (tid >> 4) + 16 * i, c4 = tid & 15;
+            bsrc[i] = B + (size_t)(kbeg + kr) * ldb + min(j0 + 4 * c4, max(N - 4, 0));
+            boff[i] = kr * 64 + 4 * c4;
+        }
+    }
+    // G64N_SETS register sets in rotation: the loads of slice q are issued G64N_SETS slices before the slice whose MFMAs
+    // they are stored under (with mostly ONE workgroup of four waves per CU nothing else hides an L2 / Infinity Cache
+    // round trip: one set - a lead of one 16-MFMA slice, 0.43 us - left the kernel waiting 1.5 us per slice)
+    constexpr int NS = G64N_SETS;
+    f32x4 ra[NS][2], rb[NS][2];
+    auto a_load = [&](int set, int i, int k0) { ra[set][i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0); };
+    auto b_load = [&](int set, int i, int k0) {
+        rb[set][i] = *reinterpret_cast<const f32x4*>(BMODE == 0 ? bsrc[i] + k0 : bsrc[i] + (size_t)k0 * ldb);
+    };
+    auto a_store = [&](int set, int i, float* dst) { *reinterpret_cast<f32x4*>(dst + aoff[i]) = ra[set][i]; };
+    auto b_store = [&](int set, int i, float* dst) { *reinterpret_cast<f32x4*>(dst + boff[i]) = rb[set][i]; };
+
+    // (one accumulator per wave: four independent ones - MFMA jj of a k-group into accumulator jj - measured the same, so
+    // the dependent chain is not what these short launches wait for)
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a_load(0, i, 0); b_load(0, i, 0); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a_store(0, i, as); b_store(0, i, bs); }
+#pragma unroll
+    for (int q = 1; q <= NS; ++q) {
+        const int kq = min(q, nslice - 1) * LG_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a_load(q % NS, i, kq); b_load(q % NS, i, kq); }
+    }
+    __syncthreads();
+    const int arow = 32 * wi + r;
+    auto slice = [&](int s, auto set_c) {
+        constexpr int set = decltype(set_c)::value;             // = (s + 1) % NS: holds slice s + 1, then takes slice s + 1 + NS
+        const int buf = s & 1;
+        const int k2 = min(s + 1 + NS, nslice - 1) * LG_BK;
+        const float* ab = as + buf * ASZ;
+        const float* bb = bs + buf * BSZ;
+        float* an = as + (buf ^ 1) * ASZ;
+        float* bn = bs + (buf ^ 1) * BSZ;
+        f32x4 fa[2], fb[2];
+        auto frag_a = [&](int t, int q) { fa[q] = *reinterpret_cast<const f32x4*>(ab + g64_swz(arow, 2 * t + h)); };
+        auto frag_b = [&](int t, int q) {
+            if (BMODE == 0) {
+                fb[q] = *reinterpret_cast<const f32x4*>(bb + g64_swz(32 * wj + r, 2 * t + h));
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fb[q][jj] = bb[(8 * t + 4 * h + jj) * 64 + 32 * wj + r];
+            }
+        };
+        frag_a(0, 0); frag_b(0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = t & 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int g = 4 * t + jj;
+                if (g >= 2 && g < 6) {              // four staging pieces: slice s + 1 into LDS, its registers reloaded
+                    const int pc = g - 2;
+                    if (pc < 2) { a_store(set, pc, an); a_load(set, pc, k2); }
+                    else { b_store(set, pc - 2, bn); b_load(set, pc - 2, k2); }
+                }
+                if (t < 3) {
+                    if (jj == 0) frag_a(t + 1, q ^ 1);
+                    if (jj == 1) frag_b(t + 1, q ^ 1);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][jj], fb[q][jj], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    };
+    for (int s = 0; s < nslice; s += NS) {
+        slice(s, std::integral_constant<int, 1 % NS>{});
+        if (NS > 1 && s + 1 < nslice) slice(s + 1, std::integral_constant<int, 2 % NS>{});
+        if (NS > 2 && s + 2 < nslice) slice(s + 2, std::integral_constant<int, 3 % NS>{});
+        if (NS > 3 && s + 3 < nslice) slice(s + 3, std::integral_constant<int, 4 % NS>{});
+    }
+
+    const int rbase = i0 + 32 * wi;
+    const int j = j0 + 32 * wj + r;
+    if (j >= N) return;
+    if (partial != nullptr) {                       // split-K: the raw tile, epilogue in k_splitk_reduce
+        float* o = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = rbase + mfma32_row(i, h);
+            if (row < M) o[(size_t)row * N + j] = acc[i];
+        }
+        return;
+    }
+    const float bj = bias != nullptr ? bias[j] : 0.f;
+    float rv[16], pv[16], cv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rc = min(rbase + mfma32_row(i, h), M - 1);
+        rv[i] = residual != nullptr ? residual[(size_t)rc * ldr + j] : 0.f;
+        pv[i] = aux_mode == AUX_MUL_DGELU ? aux[(size_t)rc * ldaux + j] : 0.f;
+        cv[i] = accumulate ? C[(size_t)rc * ldc + j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = rbase + mfma32_row(i, h);
+        if (row >= M) continue;
+        float v = acc[i] + bj;
+        if (aux_mode == AUX_STORE_PRE) {
+            aux[(size_t)row * ldaux + j] = v;
+        } else if (aux_mode == AUX_MUL_DGELU) {
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * pv[i]));
+            v *= sg * (1.0f + 1.702f * pv[i] * (1.0f - sg));
+        }
+        if (act == ACT_TANH) v = tanhf(v);
+        else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
+        C[(size_t)row * ldc + j] = v + rv[i] + cv[i];
+    }
+}
+
+// plan for k_gemm64n: products of at most 2048 rows whose 64 x 128 tiles would not fill 1.5 rounds; S = K splits
+static bool small_tile_plan(int M, int N, int K, int a_mode, int* S_out, int* kchunk_out) {
+    if (a_mode != 0 || M > 2048 || K < 256 || (K % LG_BK) != 0 || (N & 3)) return false;
+    const long t128 = (long)((M + 63) / 64) * ((N + 127) / 128);
+    if (t128 >= 3 * MIL_NUM_CU / 2) return false;                  // k_gemm64 takes it
+    const long t = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (t < 16) return false;                                      // a handful of tiles: the split-K plan of the big tile
+    // target number of workgroups: one per CU (end to end, the learnable-prompt step of one ragged bag: 7.33 / 6.83 / 6.80 /
+    // 7.07 / 7.11 ms at 128 / 192 / 256 / 320 / 512 - a split costs its partial tiles and the fold launch)
+    static const int slots = getenv("MIL_G64N_SLOTS") ? atoi(getenv("MIL_G64N_SLOTS")) : MIL_NUM_CU;
+    int S = (int)((slots + t / 2) / t);
+    if (S > K / 256) S = K / 256;                                  // at least eight 32-deep slices per split
+    if (S < 1) S = 1;
+    int kchunk = ((K + S - 1) / S + LG_BK - 1) / LG_BK * LG_BK;
+    S = (K + kchunk - 1) / kchunk;
+    *S_out = S;
+    *kchunk_out = S > 1 ? kchunk : K;
+    return true;
+}

@@ -498,6 +498,12 @@ static bool tail_plan(int M, int N, int K, int a_mode, int* rows_main, int* S_ou
 extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int kchunk, rows_main, S_tail;
+#if !defined(LG_NO_TILE64N)
+    {
+        int S64;
+        if (small_tile_plan(M, N, K, a_mode, &S64, &kchunk)) return S64 > 1 ? (size_t)S64 * M * N : 0;
+    }
+#endif
     if (tail_plan(M, N, K, a_mode, &rows_main, &S_tail, &kchunk)) return (size_t)S_tail * (M - rows_main) * N;
     const int S = splitk_plan(M, N, K, a_mode, &kchunk);
     return S > 1 ? (size_t)S * M * N : 0;
@@ -540,6 +546,28 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
             else
                 hipLaunchKernelGGL(k_gemm64<1>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
             MIL_CHECK_LAUNCH();
+            return MIL_OK;
+        }
+    }
+#endif
+#if !defined(LG_NO_TILE64N)
+    {
+        // a few hundred rows: 64 x 64 tiles, K split over blockIdx.z when the tiles alone leave CUs idle (gemm64.h)
+        int S64, kc64;
+        if (small_tile_plan(M, N, K, a_mode, &S64, &kc64) && (S64 == 1 || (workspace != nullptr && workspace_floats >= (size_t)S64 * M * N))) {
+            const dim3 grid((N + 63) / 64, (M + 63) / 64, S64);
+            float* part = S64 > 1 ? workspace : nullptr;
+            if (b_mode == 0)
+                hipLaunchKernelGGL(k_gemm64n<0>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kc64, part, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+            else
+                hipLaunchKernelGGL(k_gemm64n<1>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, kc64, part, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+            MIL_CHECK_LAUNCH();
+            if (S64 > 1) {
+                const size_t n = (size_t)M * N;
+                hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, S64, C, ldc, M, N, bias,
+                                   act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+                MIL_CHECK_LAUNCH();
+            }
             return MIL_OK;
         }
     }

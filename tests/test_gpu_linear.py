@@ -271,3 +271,42 @@ def test_weight_gradient_of_a_tall_activation_on_the_low_valu_kernel(rows, N, K,
     refW, refb = G.T @ x.double(), G.sum(0)
     assert rel_err(dW.double(), refW) <= 2e-5
     assert rel_err(db.double(), refb) <= 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,b_mode,extras", [(770, 1536, 512, 0, "bias_tanh"), (770, 512, 2048, 0, "aux"),
+                                                 (770, 2048, 512, 1, "plain"), (770, 512, 1536, 1, "accumulate"),
+                                                 (770, 516, 2048, 1, "residual"), (2048, 512, 768, 0, "bias_tanh"),
+                                                 (1217, 2048, 512, 0, "aux"), (513, 520, 1024, 0, "residual")])
+def test_64_x_64_tiles_for_a_few_hundred_rows(M, N, K, b_mode, extras):
+    """Products of at most 2048 rows whose 64 x 128 tiles would leave CUs idle (the text tower at one bag x 10 prompts x 77 tokens)
+    take k_gemm64n: 64 x 64 tiles, K split over blockIdx.z (raw partial tiles + k_splitk_reduce's epilogue) when the tiles alone
+    do not fill the chip."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dev = torch.device("cuda")
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = A.double() @ W.double().t()
+    Ad = A.to(dev)
+    Bd = (W if b_mode == 0 else W.t().contiguous()).to(dev)
+    if extras == "bias_tanh":
+        b = torch.randn(N, generator=g)
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K, bias=b.to(dev), act=ops.ACT["tanh"])
+        ref = torch.tanh(ref + b.double())
+    elif extras == "residual":
+        res = torch.randn(M, N, generator=g)
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K, residual=res.to(dev))
+        ref = ref + res.double()
+    elif extras == "accumulate":
+        out = torch.ones(M, N, device=dev)
+        ops.gemm(Ad, 0, Bd, b_mode, M, N, K, out=out, accumulate=True)
+        ref = ref + 1
+    elif extras == "aux":
+        b = torch.randn(N, generator=g)
+        pre = torch.empty(M, N, device=dev)
+        out = ops.gemm_aux(Ad, Bd, b_mode, M, N, K, pre, 1, bias=b.to(dev), act=ops.ACT["quickgelu"])
+        p = ref + b.double()
+        assert rel_err(pre.cpu(), p.float()) <= 2e-6
+        ref = p * torch.sigmoid(1.702 * p)
+    else:
+        out = ops.gemm(Ad, 0, Bd, b_mode, M, N, K)
+    assert rel_err(out.cpu(), ref.float()) <= 2e-6

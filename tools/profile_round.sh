@@ -34,7 +34,7 @@ for w in cfg2 pool cfg5 cfg3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- ${CMD[$w]} > $OUT/stats_$w.log 2>&1
   echo "stats $w done"
 done
-for w in cfg2 pool cfg5; do
+for w in cfg2 pool cfg5 cfg3; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$w -- ${CMD[$w]} > $OUT/fetch_$w.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$w -- ${CMD[$w]} > $OUT/write_$w.log 2>&1
   echo "traffic $w done"

@@ -123,6 +123,21 @@ with open(os.path.join(DST, f"{TAG}_hbm_traffic_pmc.csv"), "w") as o:
                     per[k] += m * mult * 1024.0
         for k, b in per.items():
             traffic[f"{w}:{k}"] = b
+    # config 3: HBM bytes of the WHOLE step = every kernel's bytes over all its dispatches / the number of steps run (one
+    # fc_pathology forward launch, k_gemm_nt2, per step)
+    tot3, steps3 = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+    for name, sub, mult in (("FETCH_SIZE", "fetch_cfg3", 2.0), ("WRITE_SIZE", "write_cfg3", 1.0)):
+        for k, v in pmc(sub).items():
+            vals = v.get(name, [])
+            tot3[name] += sum(vals) * mult * 1024.0
+            if k.startswith("k_gemm_nt2"):
+                steps3[name] = len(vals)
+    if steps3["FETCH_SIZE"] and steps3["WRITE_SIZE"]:
+        rd, wr = tot3["FETCH_SIZE"] / steps3["FETCH_SIZE"], tot3["WRITE_SIZE"] / steps3["WRITE_SIZE"]
+        traffic["cfg3:step"] = rd + wr
+        o.write(f"cfg3,WHOLE STEP (all kernels / {steps3['FETCH_SIZE']} steps),FETCH_SIZE x 2 + WRITE_SIZE,,,{(rd + wr) / 2 ** 20:.1f}\n")
+        o.write(f"cfg3,WHOLE STEP read,FETCH_SIZE x 2,,,{rd / 2 ** 20:.1f}\n")
+        o.write(f"cfg3,WHOLE STEP written,WRITE_SIZE,,,{wr / 2 ** 20:.1f}\n")
 # the keys bench.py looks up
 alias = {}
 for key, b in traffic.items():
@@ -139,6 +154,8 @@ for key, b in traffic.items():
         alias["pool_4096x512"] = alias.get("pool_4096x512", 0.0) + b
     if w == "pool" and k.startswith("k_pool_merge"):
         alias["pool_4096x512"] = alias.get("pool_4096x512", 0.0) + b
+    if w == "cfg3" and k == "step":
+        alias["cfg3_step"] = b
 if alias:
     json.dump({"_source": f"profiles/{TAG}_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)", **alias},
               open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
