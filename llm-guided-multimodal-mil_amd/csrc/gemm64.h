@@ -167,7 +167,9 @@ void k_gemm64(const float* __restrict__ A, int lda, const float* __restrict__ B,
 // the workgroups again (312 for 770 x 1536, 416 for 770 x 2048; 32 KB of LDS: five resident per CU), and blockIdx.z splits
 // K when even that leaves CUs idle (770 x 512 with K = 2048: 104 tiles x 4 splits), the raw partial tiles going to the
 // workspace for k_splitk_reduce and its epilogue.  Same pipeline, swizzle and fragment convention as k_gemm64; wave tile
-// 32 x 32 (2 x 2 waves).
+// 32 x 32 (2 x 2 waves).  Measured on this kernel and left out: four independent accumulators per wave, 1 - 4 rotating
+// register sets of prefetch (within 7 % of each other), 64-deep LDS stages (half the barriers: 6.72 - 6.84 against 6.75 - 6.80 ms
+// for the learnable-prompt step) - what these launches wait for is neither the MFMA chain nor the loads nor the barrier alone.
 #ifndef G64N_SETS
 #define G64N_SETS 2      /* 1 / 2 / 3 / 4 register sets measured within 7 % of each other; 2 was the best */
 #endif

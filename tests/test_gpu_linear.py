@@ -276,7 +276,9 @@ def test_weight_gradient_of_a_tall_activation_on_the_low_valu_kernel(rows, N, K,
 @pytest.mark.parametrize("M,N,K,b_mode,extras", [(770, 1536, 512, 0, "bias_tanh"), (770, 512, 2048, 0, "aux"),
                                                  (770, 2048, 512, 1, "plain"), (770, 512, 1536, 1, "accumulate"),
                                                  (770, 516, 2048, 1, "residual"), (2048, 512, 768, 0, "bias_tanh"),
-                                                 (1217, 2048, 512, 0, "aux"), (513, 520, 1024, 0, "residual")])
+                                                 (1217, 2048, 512, 0, "aux"), (513, 520, 1024, 0, "residual"),
+                                                 (770, 1536, 352, 0, "bias_tanh"), (300, 1024, 288, 1, "plain"),
+                                                 (77, 1536, 512, 0, "aux"), (77, 512, 2048, 1, "residual")])
 def test_64_x_64_tiles_for_a_few_hundred_rows(M, N, K, b_mode, extras):
     """Products of at most 2048 rows whose 64 x 128 tiles would leave CUs idle (the text tower at one bag x 10 prompts x 77 tokens)
     take k_gemm64n: 64 x 64 tiles, K split over blockIdx.z (raw partial tiles + k_splitk_reduce's epilogue) when the tiles alone
