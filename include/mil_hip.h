@@ -373,6 +373,13 @@ int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ld
                      const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB, long strideC,
                      const float* bias, long strideBias, const float* residual, int ldr, float* workspace,
                      size_t workspace_floats, void* stream);
+/* a_mode 0 with pad_rows > 0: C has pad_rows rows, and those outside every group - the padding rows of a capacity bucket
+ * (segments.FusionBucket: bag lengths on the device) - are left holding ZERO.  One group and T H <= 96: the product's own
+ * launch writes those zeros (no fill in front of it); otherwise C is cleared first. */
+int mil_gemm_grouped_pad(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                         const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB, long strideC,
+                         const float* bias, long strideBias, const float* residual, int ldr, float* workspace,
+                         size_t workspace_floats, int pad_rows, void* stream);
 /* out[j] (+)= sum_i Y[i][j]  (bias gradients).  With a workspace of mil_colsum_workspace_floats(M, N) floats
  * a tall matrix is summed in 256-row chunks by many workgroups and folded in a second launch (fixed order). */
 size_t mil_colsum_workspace_floats(int M, int N);

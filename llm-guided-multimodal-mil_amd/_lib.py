@@ -81,6 +81,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                c_int, _P]),
     "mil_gemm_grouped": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
                                  c_long, c_long, _P, c_long, _P, c_int, _P, c_size_t, _P]),
+    "mil_gemm_grouped_pad": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
+                                 c_long, c_long, _P, c_long, _P, c_int, _P, c_size_t, c_int, _P]),
     "mil_gemm_grouped_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mil_gemm_aux": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P, c_int, c_int, _P]),

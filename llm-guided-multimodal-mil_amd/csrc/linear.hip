@@ -720,14 +720,29 @@ extern "C" size_t mil_gemm_grouped_workspace_floats(int a_mode, int G, int max_g
     return S >= 2 ? (size_t)G * S * M * N : 0;
 }
 
-extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
-                                const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB,
-                                long strideC, const float* bias, long strideBias, const float* residual, int ldr,
-                                float* workspace, size_t workspace_floats, void* stream) {
-    if (!A || !B || !C || !grp_off || G < 0 || max_group_rows < 0 || N <= 0) return MIL_EINVAL;
+// pad_rows > 0 (a_mode 0 only): C has pad_rows rows and those outside every group - the padding of a capacity bucket, whose
+// bag lengths live on the device - must read ZERO.  With one group the few-columns kernels write those zeros themselves;
+// any other case clears C first.
+extern "C" int mil_gemm_grouped_pad(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                                    const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB,
+                                    long strideC, const float* bias, long strideBias, const float* residual, int ldr,
+                                    float* workspace, size_t workspace_floats, int pad_rows, void* stream) {
+    if (!A || !B || !C || !grp_off || G < 0 || max_group_rows < 0 || N <= 0 || pad_rows < 0) return MIL_EINVAL;
+    if (pad_rows > 0 && a_mode != 0) return MIL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool skinny_nt = a_mode == 0 && b_mode == 0 && residual == nullptr && N <= 96 && (N % 32) == 0 && K > 0 && (K % LG_BK) == 0;
+    const bool skinny_nn = a_mode == 0 && b_mode == 1 && K > 0 && K <= 96 && (K % LG_BK) == 0 && (N % 128) == 0 && (bias == nullptr || strideBias == 0);
+    int pad_end = 0;
+    if (pad_rows > 0) {
+        if (G == 1 && max_group_rows >= pad_rows && (skinny_nt || skinny_nn)) {
+            pad_end = pad_rows;
+        } else {
+            hipError_t e = hipMemsetAsync(C, 0, (size_t)pad_rows * ldc * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     if (G == 0 || max_group_rows == 0) return MIL_OK;
     if ((lda & 3) || (ldb & 3)) return MIL_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     GemmGroups gg{grp_off, strideB, strideC, strideBias, a_mode == 0 ? GRP_ROWS : GRP_CONTRACT, 1};
     if (a_mode == 0) {
         // C[rows_g, :N] = A[rows_g, :K] . B_g   (b_mode 0: B_g [N, K];  b_mode 1: B_g [K, N]);  K % 32 == 0
@@ -738,16 +753,16 @@ extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float
             const bool narrow = (long)G * ((max_group_rows + 63) / 64) < MIL_NUM_CU;      // few bags: 32-row workgroups
             const dim3 gs(narrow ? (max_group_rows + 31) / 32 : (max_group_rows + 63) / 64, G);
 #define SKINNY_NT(NCTV)                                                                                                  \
-    if (narrow) hipLaunchKernelGGL((k_skinny_nt<NCTV, 1>), gs, dim3(64 * NCTV), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias); \
-    else hipLaunchKernelGGL((k_skinny_nt<NCTV, 2>), gs, dim3(128 * NCTV), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias);
+    if (narrow) hipLaunchKernelGGL((k_skinny_nt<NCTV, 1>), gs, dim3(64 * NCTV), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias, pad_end); \
+    else hipLaunchKernelGGL((k_skinny_nt<NCTV, 2>), gs, dim3(128 * NCTV), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, K, bias, strideBias, pad_end);
             if (N == 32) { SKINNY_NT(1) } else if (N == 64) { SKINNY_NT(2) } else { SKINNY_NT(3) }
 #undef SKINNY_NT
         } else if (b_mode == 1 && K <= 96 && (N % 128) == 0 && (bias == nullptr || strideBias == 0)) {
             // K = T x H: the whole contraction staged at once
             const dim3 gs(N / 128, (max_group_rows + 63) / 64, G);
-            if (K == 32) hipLaunchKernelGGL(k_skinny_nn<32>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr);
-            else if (K == 64) hipLaunchKernelGGL(k_skinny_nn<64>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr);
-            else hipLaunchKernelGGL(k_skinny_nn<96>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr);
+            if (K == 32) hipLaunchKernelGGL(k_skinny_nn<32>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr, pad_end);
+            else if (K == 64) hipLaunchKernelGGL(k_skinny_nn<64>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr, pad_end);
+            else hipLaunchKernelGGL(k_skinny_nn<96>, gs, dim3(256), 0, st, A, lda, B, ldb, strideB, C, ldc, grp_off, N, bias, residual, ldr, pad_end);
         } else if (b_mode == 0)
             hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, 0, N, K, K, bias, 0, residual, ldr, 0, (float*)nullptr, (float*)nullptr, 0, 0, gg);
         else
@@ -772,6 +787,14 @@ extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float
     }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_gemm_grouped(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                                const int32_t* grp_off, int G, int max_group_rows, int M, int N, int K, long strideB,
+                                long strideC, const float* bias, long strideBias, const float* residual, int ldr,
+                                float* workspace, size_t workspace_floats, void* stream) {
+    return mil_gemm_grouped_pad(A, lda, a_mode, B, ldb, b_mode, C, ldc, grp_off, G, max_group_rows, M, N, K, strideB, strideC, bias,
+                                strideBias, residual, ldr, workspace, workspace_floats, 0, stream);
 }
 
 extern "C" size_t mil_colsum_workspace_floats(int M, int N) {

@@ -19,7 +19,7 @@ template <int NCT, int RWT>
 __global__ __launch_bounds__(64 * RWT * NCT) void k_skinny_nt(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                                int ldb, long strideB, float* __restrict__ C, int ldc,
                                                                const int32_t* __restrict__ grp_off, int K,
-                                                               const float* __restrict__ bias, long strideBias) {
+                                                               const float* __restrict__ bias, long strideBias, int pad_end) {
     constexpr int T = 64 * RWT * NCT, P = 32 * NCT, RW = 32 * RWT;
     constexpr int NA = (RW * 8 + T - 1) / T;       // float4 pieces of the RW x 32 A slice per thread
     constexpr int NB = (P * 8) / T;                // P x 8 pieces of the B slice: 4 / RWT per thread exactly
@@ -32,7 +32,16 @@ __global__ __launch_bounds__(64 * RWT * NCT) void k_skinny_nt(const float* __res
     const int r = lane & 31, h = lane >> 5;
     const int g = blockIdx.y, goff = grp_off[g], M = grp_off[g + 1] - goff;
     const int i0 = blockIdx.x * RW;
-    if (i0 >= M) return;
+    // pad_end > 0 (ONE group in a capacity bucket, segments.FusionBucket): the rows of C behind the group, up to pad_end, are
+    // written as zeros here - they used to be a torch.zeros fill of the whole output in front of every product
+    const int zend = pad_end > 0 && g == (int)gridDim.y - 1 ? pad_end - goff : 0;      // group-relative end of the zero rows
+    if (i0 >= M) {
+        for (int idx = threadIdx.x; idx < RW * P; idx += T) {
+            const int row = i0 + idx / P;
+            if (row < zend) C[(size_t)(goff + row) * ldc + idx % P] = 0.f;
+        }
+        return;
+    }
     A += (size_t)goff * lda;
     C += (size_t)goff * ldc;
     B += (size_t)g * strideB;
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(64 * RWT * NCT) void k_skinny_nt(const float* __res
     for (int i = 0; i < 16; ++i) {
         const int row = i0 + 32 * wr + mfma32_row(i, h);
         if (row < M) C[(size_t)row * ldc + col] = acc[i] + bj;
+        else if (row < zend) C[(size_t)row * ldc + col] = 0.f;
     }
 }
 
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const float* __restrict__ A, 
                                                    long strideB, float* __restrict__ C, int ldc,
                                                    const int32_t* __restrict__ grp_off, int N,
                                                    const float* __restrict__ bias, const float* __restrict__ residual,
-                                                   int ldr) {
+                                                   int ldr, int pad_end) {
     constexpr int AS = KP + 4;                      // A image row stride (words): 100 / 68 / 36
     __shared__ __attribute__((aligned(16))) float smem[64 * AS + KP * 128];
     float* as = smem;                               // [64][AS]   k-contiguous
@@ -119,7 +129,14 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const float* __restrict__ A, 
     const int r = lane & 31, h = lane >> 5;
     const int g = blockIdx.z, goff = grp_off[g], M = grp_off[g + 1] - goff;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 128;
-    if (i0 >= M) return;
+    const int zend = pad_end > 0 && g == (int)gridDim.z - 1 ? pad_end - goff : 0;      // as k_skinny_nt
+    if (i0 >= M) {
+        for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {                       // 64 rows x 128 columns in float4
+            const int row = i0 + (idx >> 5), j = j0 + 4 * (idx & 31);
+            if (row < zend && j < N) *reinterpret_cast<f32x4*>(C + (size_t)(goff + row) * ldc + j) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     A += (size_t)goff * lda;
     C += (size_t)goff * ldc;
     if (residual != nullptr) residual += (size_t)goff * ldr;
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const float* __restrict__ A, 
         for (int i = 0; i < 16; ++i) {
             const int row = i0 + 32 * wr + mfma32_row(i, h);
             if (row < M) C[(size_t)row * ldc + j] = acc[b][i] + bj + rv[b][i];
+            else if (row < zend) C[(size_t)row * ldc + j] = 0.f;
         }
     }
 }

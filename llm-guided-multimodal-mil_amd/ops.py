@@ -1678,14 +1678,15 @@ def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int, qp=No
 
 
 # --------------------------------------------------------------------------- multi-token absorbed attention (1 < T <= 12)
-def _gg(A, a_mode, B, b_mode, grp_off, G, max_rows, M, N, K, strideB, strideC, out, bias=None, stride_bias=0, residual=None):
+def _gg(A, a_mode, B, b_mode, grp_off, G, max_rows, M, N, K, strideB, strideC, out, bias=None, stride_bias=0, residual=None,
+        pad_rows: int = 0):
     nws = _lib.lib().mil_gemm_grouped_workspace_floats(a_mode, G, max_rows, M, N) if a_mode == 1 else 0
     ws = torch.empty(nws, device=A.device, dtype=torch.float32) if nws else None
-    rc = _lib.lib().mil_gemm_grouped(_p(A), A.stride(0), a_mode, _p(B), B.stride(-2), b_mode, _p(out), out.stride(-2),
-                                     _p(grp_off), G, max_rows, M, N, K, strideB, strideC, _p(bias), stride_bias,
-                                     _p(residual), residual.stride(0) if residual is not None else 0, _p(ws), nws,
-                                     _stream())
-    _lib.check(rc, "mil_gemm_grouped")
+    rc = _lib.lib().mil_gemm_grouped_pad(_p(A), A.stride(0), a_mode, _p(B), B.stride(-2), b_mode, _p(out), out.stride(-2),
+                                         _p(grp_off), G, max_rows, M, N, K, strideB, strideC, _p(bias), stride_bias,
+                                         _p(residual), residual.stride(0) if residual is not None else 0, _p(ws), nws,
+                                         int(pad_rows), _stream())
+    _lib.check(rc, "mil_gemm_grouped_pad")
     return out
 
 
@@ -1694,15 +1695,16 @@ def _gg_nt(A, B, bias, grp_off, max_rows, zero: bool = False):
     zero: rows outside every group (the padding rows of a capacity bucket, segments.FusionBucket) must read 0, not
     whatever the allocation holds - the grouped kernels only write the rows of their groups."""
     G, N, K = B.shape
-    out = (torch.zeros if zero else torch.empty)((A.shape[0], N), device=A.device, dtype=torch.float32)
-    return _gg(A, 0, B, 0, grp_off, G, max_rows, 0, N, K, N * K, 0, out, bias, N if bias is not None else 0)
+    out = torch.empty((A.shape[0], N), device=A.device, dtype=torch.float32)
+    return _gg(A, 0, B, 0, grp_off, G, max_rows, 0, N, K, N * K, 0, out, bias, N if bias is not None else 0,
+               pad_rows=A.shape[0] if zero else 0)
 
 
 def _gg_nn(A, B, bias, residual, grp_off, max_rows, zero: bool = False):
     """C[rows_g] = A[rows_g] . B[g] + bias + residual;  A [R, K], B [G, K, N], bias [N] shared or None.  zero: as _gg_nt."""
     G, K, N = B.shape
-    out = (torch.zeros if zero else torch.empty)((A.shape[0], N), device=A.device, dtype=torch.float32)
-    return _gg(A, 0, B, 1, grp_off, G, max_rows, 0, N, K, K * N, 0, out, bias, 0, residual)
+    out = torch.empty((A.shape[0], N), device=A.device, dtype=torch.float32)
+    return _gg(A, 0, B, 1, grp_off, G, max_rows, 0, N, K, K * N, 0, out, bias, 0, residual, pad_rows=A.shape[0] if zero else 0)
 
 
 def _gg_tn(A, X, grp_off, G, max_rows):
