@@ -532,6 +532,13 @@ int mil_value_proj_bwd(const float* dO, const float* Wv, const float* pooled, in
 int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH, void* stream);
 int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int max_group_rows,
                             int TH, float* dS, void* stream);
+/* The same with a workspace of mil_grp_col_softmax_workspace_floats(G, max_group_rows, ld) floats (0: not applicable): at most 8
+ * groups of more than 2048 rows (one ragged bag per step) take a row-parallel two-launch form - partial column statistics per
+ * 256-row chunk, then every chunk folds them and rewrites its rows - instead of one workgroup per two columns. */
+size_t mil_grp_col_softmax_workspace_floats(int G, int max_group_rows, int ld);
+int mil_grp_col_softmax_ws(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH, float* ws, void* stream);
+int mil_grp_col_softmax_bwd_ws(const float* A, const float* dA, int ld, const int32_t* grp_off, int G, int max_group_rows,
+                               int TH, float* dS, float* ws, void* stream);
 int mil_row_softmax_t(float* S, int ld, int R, int T, int H, void* stream);
 int mil_row_softmax_t_bwd(const float* A, const float* dA, int ld, int R, int T, int H, float* dS, void* stream);
 

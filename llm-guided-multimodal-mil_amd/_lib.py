@@ -113,6 +113,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_value_proj_bwd": (c_int, [_P] * 3 + [c_int] * 4 + [_P] * 3 + [_P]),
     "mil_grp_col_softmax": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "mil_grp_col_softmax_bwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "mil_grp_col_softmax_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "mil_grp_col_softmax_ws": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "mil_grp_col_softmax_bwd_ws": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]),
     "mil_row_softmax_t": (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     "mil_row_softmax_t_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "mil_value_proj": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),

@@ -904,6 +904,115 @@ __global__ __launch_bounds__(1024) void k_grp_col_softmax_bwd(const float* __res
     }
 }
 
+// A FEW LONG groups (one ragged bag of ~10 000 patches per GPU and step): the forms above give a group's column to ONE
+// workgroup, two columns wide for such a group - 48 workgroups reading 8 bytes of every 384-byte row (36 us forward, 51 us
+// backward for 3.5 MB).  Row-parallel form in two launches, every row read as a whole by consecutive lanes:
+//   k_gcs_stats  grid (G, NCH): workgroup (g, ch) = rows [ch RCH, (ch + 1) RCH) of group g, thread (row lane, column):
+//                online column maximum / sum (forward) or sum of A dA (backward) -> ws[g][ch][.][ld]
+//   k_gcs_apply  grid (G, NCH): folds the NCH partials of its group (same order everywhere), then rewrites its rows.
+// ld <= 128.
+#define GCS_NCH_MAX 64
+template <bool BWD>
+__global__ __launch_bounds__(1024) void k_gcs_stats(const float* __restrict__ S, const float* __restrict__ dA, int ld,
+                                                    const int32_t* __restrict__ grp_off, int TH, int RCH,
+                                                    float* __restrict__ ws) {
+    __shared__ float red[2][32][129];
+    const int g = blockIdx.x, ch = blockIdx.y, RL = 1024 / ld;
+    const int c = threadIdx.x % ld, rl = threadIdx.x / ld;
+    const int r0 = grp_off[g], r1 = grp_off[g + 1];
+    const int a0 = r0 + ch * RCH, a1 = min(r1, a0 + RCH);
+    float m = -INFINITY, l = 0.f;
+    if (rl < RL && c < TH) {
+        if (BWD) {
+            for (int row = a0 + rl; row < a1; row += RL) l += S[(size_t)row * ld + c] * dA[(size_t)row * ld + c];
+        } else {
+            for (int row = a0 + rl; row < a1; row += RL) {
+                const float v = S[(size_t)row * ld + c];
+                if (v > m) { l = l * expf(m - v) + 1.f; m = v; }          // exp(-inf - v) = 0 on the first row
+                else l += expf(v - m);
+            }
+        }
+    }
+    if (rl < RL) { red[0][rl][c] = m; red[1][rl][c] = l; }
+    __syncthreads();
+    if (rl == 0 && c < ld) {
+        float M = -INFINITY, L = 0.f;
+        if (BWD) {
+            for (int i = 0; i < RL; ++i) L += red[1][i][c];
+        } else {
+            for (int i = 0; i < RL; ++i) M = fmaxf(M, red[0][i][c]);
+            for (int i = 0; i < RL; ++i) L += red[0][i][c] > -INFINITY ? red[1][i][c] * expf(red[0][i][c] - M) : 0.f;
+        }
+        float* o = ws + ((size_t)g * gridDim.y + ch) * 2 * ld;
+        o[c] = M;
+        o[ld + c] = L;
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(1024) void k_gcs_apply(float* __restrict__ S, const float* __restrict__ A, const float* __restrict__ dA,
+                                                    int ld, const int32_t* __restrict__ grp_off, int TH, int RCH,
+                                                    const float* __restrict__ ws) {
+    __shared__ float cm[128], cl_[128];
+    __shared__ float red[2][32][129];
+    const int g = blockIdx.x, ch = blockIdx.y, RL = 1024 / ld, NCH = gridDim.y;
+    const int c = threadIdx.x % ld, rl = threadIdx.x / ld;
+    const int r0 = grp_off[g], r1 = grp_off[g + 1];
+    const int a0 = r0 + ch * RCH, a1 = min(r1, a0 + RCH);
+    if (a0 >= a1) return;                                   // workgroup-uniform: no rows here
+    // fold the group's NCH partial statistics: row lane rl takes partials rl, rl + RL, ... (a single lane walking all of them
+    // was a chain of ~100 dependent round trips: 31 us per launch), then the lanes are folded in a fixed order
+    if (rl < RL) {
+        const float* w = ws + (size_t)g * NCH * 2 * ld;
+        float M = -INFINITY, L = 0.f;
+        for (int i = rl; i < NCH; i += RL) {
+            const float mi = w[(size_t)i * 2 * ld + c], li = w[(size_t)i * 2 * ld + ld + c];
+            if (BWD) {
+                L += li;
+            } else if (mi > -INFINITY) {
+                if (mi > M) { L = L * expf(M - mi) + li; M = mi; }
+                else L += li * expf(mi - M);
+            }
+        }
+        red[0][rl][c] = M;
+        red[1][rl][c] = L;
+    }
+    __syncthreads();
+    if (rl == 0) {
+        float M = -INFINITY, L = 0.f;
+        if (BWD) {
+            for (int i = 0; i < RL; ++i) L += red[1][i][c];
+        } else {
+            for (int i = 0; i < RL; ++i) M = fmaxf(M, red[0][i][c]);
+            for (int i = 0; i < RL; ++i) L += red[0][i][c] > -INFINITY ? red[1][i][c] * expf(red[0][i][c] - M) : 0.f;
+        }
+        cm[c] = M;
+        cl_[c] = BWD ? L : (L > 0.f ? 1.0f / L : 0.f);
+    }
+    __syncthreads();
+    if (rl >= RL) return;
+    const bool live = c < TH;
+    const float M = cm[c], L = cl_[c];
+    for (int row = a0 + rl; row < a1; row += RL) {
+        const size_t o = (size_t)row * ld + c;
+        if (BWD) S[o] = live ? A[o] * (dA[o] - L) : 0.f;
+        else S[o] = live ? expf(S[o] - M) * L : 0.f;
+    }
+}
+
+static bool gcs_plan(int G, int max_group_rows, int ld, int* nch, int* rch) {
+    if (G > 8 || max_group_rows <= 2048 || ld > 128 || ld < 32) return false;
+    int n = (max_group_rows + 255) / 256;
+    if (n > GCS_NCH_MAX) n = GCS_NCH_MAX;
+    *nch = n;
+    *rch = (max_group_rows + n - 1) / n;
+    return true;
+}
+extern "C" size_t mil_grp_col_softmax_workspace_floats(int G, int max_group_rows, int ld) {
+    int nch, rch;
+    return gcs_plan(G, max_group_rows, ld, &nch, &rch) ? (size_t)G * nch * 2 * ld : 0;
+}
+
 // Row softmax over the T tokens of each (row, head): column t H + h.  Thread = (row, h); T <= 16.  In place.
 __global__ __launch_bounds__(256) void k_row_softmax_t(float* __restrict__ S, int ld, int R, int T, int H) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1081,11 +1190,20 @@ extern "C" int mil_value_proj(const float* pooled, const float* Wv, const float*
     return mil_value_proj_pad(pooled, Wv, bv, B, H, C, E, 1, H, o, stream);
 }
 
-extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH,
-                                   void* stream) {
+extern "C" int mil_grp_col_softmax_ws(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH,
+                                      float* ws, void* stream) {
     AP_CHECK(S && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld && max_group_rows >= 0);
     if (G == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
+    int nch, rch;
+    if (ws != nullptr && gcs_plan(G, max_group_rows, ld, &nch, &rch)) {
+        hipLaunchKernelGGL(k_gcs_stats<false>, dim3(G, nch), dim3(1024), 0, st, (const float*)S, (const float*)nullptr, ld, grp_off, TH, rch, ws);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_gcs_apply<false>, dim3(G, nch), dim3(1024), 0, st, S, (const float*)nullptr, (const float*)nullptr, ld, grp_off,
+                           TH, rch, (const float*)ws);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     // narrowest row-lane count whose registers hold the longest group (wider column blocks coalesce better)
     if (max_group_rows > 8192 && max_group_rows <= 32768)
         hipLaunchKernelGGL(k_grp_col_softmax<2>, dim3(G, (ld + 1) / 2), dim3(1024), 0, st, S, ld, grp_off, TH);
@@ -1097,11 +1215,24 @@ extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int
     return MIL_OK;
 }
 
-extern "C" int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G,
-                                       int max_group_rows, int TH, float* dS, void* stream) {
+extern "C" int mil_grp_col_softmax(float* S, int ld, const int32_t* grp_off, int G, int max_group_rows, int TH,
+                                   void* stream) {
+    return mil_grp_col_softmax_ws(S, ld, grp_off, G, max_group_rows, TH, nullptr, stream);
+}
+
+extern "C" int mil_grp_col_softmax_bwd_ws(const float* A, const float* dA, int ld, const int32_t* grp_off, int G,
+                                          int max_group_rows, int TH, float* dS, float* ws, void* stream) {
     AP_CHECK(A && dA && dS && grp_off && G >= 0 && ld > 0 && TH > 0 && TH <= ld && max_group_rows >= 0);
     if (G == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
+    int nch, rch;
+    if (ws != nullptr && gcs_plan(G, max_group_rows, ld, &nch, &rch)) {
+        hipLaunchKernelGGL(k_gcs_stats<true>, dim3(G, nch), dim3(1024), 0, st, A, dA, ld, grp_off, TH, rch, ws);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_gcs_apply<true>, dim3(G, nch), dim3(1024), 0, st, dS, A, dA, ld, grp_off, TH, rch, (const float*)ws);
+        MIL_CHECK_LAUNCH();
+        return MIL_OK;
+    }
     if (max_group_rows > 4096 && max_group_rows <= 16384)
         hipLaunchKernelGGL(k_grp_col_softmax_bwd<2>, dim3(G, (ld + 1) / 2), dim3(1024), 0, st, A, dA, ld, grp_off, TH, dS);
     else if (max_group_rows > 1024 && max_group_rows <= 4096)
@@ -1110,6 +1241,11 @@ extern "C" int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, 
         hipLaunchKernelGGL(k_grp_col_softmax_bwd<32>, dim3(G, (ld + 31) / 32), dim3(1024), 0, st, A, dA, ld, grp_off, TH, dS);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_grp_col_softmax_bwd(const float* A, const float* dA, int ld, const int32_t* grp_off, int G,
+                                       int max_group_rows, int TH, float* dS, void* stream) {
+    return mil_grp_col_softmax_bwd_ws(A, dA, ld, grp_off, G, max_group_rows, TH, dS, nullptr, stream);
 }
 
 extern "C" int mil_row_softmax_t(float* S, int ld, int R, int T, int H, void* stream) {

@@ -1714,6 +1714,12 @@ def _gg_tn(A, X, grp_off, G, max_rows):
     return _gg(A, 1, X, 1, grp_off, G, max_rows, M, N, 0, 0, M * N, out)
 
 
+def _gcs_ws(G, max_rows, ld, device):
+    """Workspace of the row-parallel grouped column softmax (a few long groups), or None."""
+    n = _lib.lib().mil_grp_col_softmax_workspace_floats(G, max_rows, ld)
+    return torch.empty(n, device=device, dtype=torch.float32) if n else None
+
+
 def _seg_colsum(Y, grp_off, G, max_rows):
     N = Y.shape[1]
     out = torch.empty((G, N), device=Y.device, dtype=torch.float32)
@@ -1789,8 +1795,9 @@ class _GrpColSoftmax(torch.autograd.Function):
         A = S if (S.is_contiguous() and S.dtype == torch.float32) else _f32c(S, "S").clone()
         if A is S:
             ctx.mark_dirty(S)              # in place: the scores are the fresh output of the product that formed them
-        rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(grp_off), G, max_rows, TH, _stream())
-        _lib.check(rc, "mil_grp_col_softmax")
+        rc = _lib.lib().mil_grp_col_softmax_ws(_p(A), A.stride(0), _p(grp_off), G, max_rows, TH,
+                                               _p(_gcs_ws(G, max_rows, A.stride(0), A.device)), _stream())
+        _lib.check(rc, "mil_grp_col_softmax_ws")
         ctx.save_for_backward(A, grp_off)
         ctx.G, ctx.TH, ctx.max_rows = G, TH, max_rows
         return A
@@ -1800,9 +1807,9 @@ class _GrpColSoftmax(torch.autograd.Function):
         A, grp_off = ctx.saved_tensors
         dA = _f32c(dA, "dA")
         dS = torch.empty_like(A)
-        rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(grp_off), ctx.G, ctx.max_rows, ctx.TH, _p(dS),
-                                                _stream())
-        _lib.check(rc, "mil_grp_col_softmax_bwd")
+        rc = _lib.lib().mil_grp_col_softmax_bwd_ws(_p(A), _p(dA), A.stride(0), _p(grp_off), ctx.G, ctx.max_rows, ctx.TH, _p(dS),
+                                                   _p(_gcs_ws(ctx.G, ctx.max_rows, A.stride(0), A.device)), _stream())
+        _lib.check(rc, "mil_grp_col_softmax_bwd_ws")
         return dS, None, None, None, None
 
 
@@ -1849,8 +1856,9 @@ class _MultiTokenPoolCore(torch.autograd.Function):
         B, off, mr = segs.B, segs.k_off, segs.Tk_max
         z = getattr(segs, "device_lengths", False)                               # capacity bucket: padding rows read 0
         A = _gg_nt(kin, Qp, None, off, mr, zero=z)                               # scores [R, THp]
-        rc = _lib.lib().mil_grp_col_softmax(_p(A), A.stride(0), _p(off), B, mr, TH, _stream())
-        _lib.check(rc, "mil_grp_col_softmax")
+        rc = _lib.lib().mil_grp_col_softmax_ws(_p(A), A.stride(0), _p(off), B, mr, TH, _p(_gcs_ws(B, mr, A.stride(0), A.device)),
+                                               _stream())
+        _lib.check(rc, "mil_grp_col_softmax_ws")
         pooled = _gg_tn(A, keys, off, B, mr)                                     # [B, THp, E]
         ctx.segs, ctx.TH = segs, TH
         ctx.set_materialize_grads(False)
@@ -1869,8 +1877,9 @@ class _MultiTokenPoolCore(torch.autograd.Function):
         z = getattr(segs, "device_lengths", False)
         dA = _gg_nt(keys, dpooled, None, off, mr, zero=z)                        # dA = keys . dpooled^T
         dS = torch.zeros_like(A) if z else torch.empty_like(A)
-        rc = _lib.lib().mil_grp_col_softmax_bwd(_p(A), _p(dA), A.stride(0), _p(off), B, mr, TH, _p(dS), _stream())
-        _lib.check(rc, "mil_grp_col_softmax_bwd")
+        rc = _lib.lib().mil_grp_col_softmax_bwd_ws(_p(A), _p(dA), A.stride(0), _p(off), B, mr, TH, _p(dS),
+                                                   _p(_gcs_ws(B, mr, A.stride(0), A.device)), _stream())
+        _lib.check(rc, "mil_grp_col_softmax_bwd_ws")
         dkeys = None
         if ctx.needs_input_grad[0]:
             dkeys = _gg_nn(A, dpooled, None, acc, off, mr, zero=z)               # values path (+ what came through the alias)

@@ -142,3 +142,27 @@ def test_skinny_nt_wide_and_narrow_workgroups(G, rows, N):
     out = ops._gg_nt(A.to(DEV), B.to(DEV), bias.to(DEV), off.to(DEV), max(lens))
     ref = torch.cat([A[int(off[i]):int(off[i + 1])] @ B[i].t() + bias[i] for i in range(G)], 0)
     assert rel_err(out.cpu(), ref) <= 2e-6
+
+
+@pytest.mark.parametrize("lens,T,ld", [([5000], 3, 32), ([2600, 2100, 4000], 7, 64), ([12288], 12, 96), ([3000] * 9, 10, 96)])
+def test_column_softmax_few_long_groups_row_parallel_form(lens, T, ld):
+    """At most 8 groups of more than 2048 rows: partial column statistics per 256-row chunk, then every chunk folds them and
+    rewrites its rows (k_gcs_stats / k_gcs_apply); nine groups fall back to the one-workgroup-per-column-block form."""
+    g = torch.Generator().manual_seed(5)
+    R, G, H = sum(lens), len(lens), 8
+    TH = T * H
+    off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    S = torch.randn((R, ld), generator=g) * 3
+    go = torch.randn((R, ld), generator=g)
+    seg = [(int(off[i]), int(off[i + 1])) for i in range(G)]
+
+    def ref_col(S):
+        out = torch.zeros_like(S)
+        out[:, :TH] = torch.cat([torch.softmax(S[a:b, :TH], 0) for a, b in seg], 0)
+        return out
+
+    o_ref, (g_ref,) = _grads(ref_col, [S], go)
+    o, (gr,) = _grads(lambda s: ops._GrpColSoftmax.apply(s * 1.0, off.to(DEV), G, TH, max(lens)), [S.to(DEV)], go.to(DEV))
+    assert float((o.cpu() - o_ref).abs().max()) <= 5e-5 and rel_err(o.cpu(), o_ref) <= 5e-5
+    assert TH == ld or float(o[:, TH:].abs().max()) == 0.0
+    assert rel_err(gr.cpu(), g_ref) <= 5e-5
