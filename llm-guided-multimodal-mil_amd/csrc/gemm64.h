@@ -343,3 +343,111 @@ static bool small_tile_plan(int M, int N, int K, int a_mode, int* S_out, int* kc
     *kchunk_out = S > 1 ? kchunk : K;
     return true;
 }
+
+
+// The grouped contraction over a FEW LONG groups (one ragged bag per step: pooled vectors and the absorbed vectors'
+// gradients of the multi-token attention, C_g[M <= 128, N] = A[rows_g, :M]^T . B[rows_g, :N]).  The 128 x 128 form gives a
+// 10 000-row bag 4 column tiles x 32 row chunks = 128 workgroups of 12 slices, one per CU with nothing to overlap their
+// latencies: 43 us + 10 us of fold for 1.2 GFLOP.  Here: 64 x 64 tiles of the output, K (the group's rows) split so that
+// about three workgroups share a CU, each a handful of slices long; both operands are k-major, so their [32][64] LDS
+// images are read by consecutive lanes (conflict-free ds_read_b32).  blockIdx.z = group * S + split; the split's partial
+// tile goes to ws[(group * S + split)][M][N] for k_grouped_fold.
+__global__ __launch_bounds__(256)
+void k_gemm64tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ ws, int M, int N,
+                const int32_t* __restrict__ grp_off, int S) {
+    constexpr int TSZ = LG_BK * 64;
+    __shared__ __attribute__((aligned(16))) float smem[4 * TSZ];               // 32 KB: [2] A stages, [2] B stages
+    float* as = smem;
+    float* bs = smem + 2 * TSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.z / S, sp = blockIdx.z % S;
+    const int goff = grp_off[g], gn = grp_off[g + 1] - goff;
+    const int chunk = ((gn + S - 1) / S + LG_BK - 1) / LG_BK * LG_BK;
+    const int kbeg = min(gn, sp * chunk), kend = min(gn, kbeg + chunk);
+    const int nslice = (kend - kbeg + LG_BK - 1) / LG_BK;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    A += (size_t)goff * lda;
+    B += (size_t)goff * ldb;
+
+    const int kr = tid >> 4, c4 = tid & 15;                    // staging: k rows kr, kr + 16; 16-byte column chunk c4
+    const int acol = min(i0 + 4 * c4, max(M - 4, 0)), bcol = min(j0 + 4 * c4, max(N - 4, 0));
+    f32x4 ra[2][2], rb[2][2];
+    auto load = [&](int set, int sl) {                         // slice sl of this split; rows at / beyond kend contribute zero
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = kbeg + sl * LG_BK + kr + 16 * p;
+            const bool ok = row < kend;
+            const int rc = ok ? row : kend - 1;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)rc * lda + acol);
+            ra[set][p] = ok ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[set][p] = *reinterpret_cast<const f32x4*>(B + (size_t)rc * ldb + bcol);
+        }
+    };
+    auto store = [&](int set, float* an, float* bn) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<f32x4*>(an + (kr + 16 * p) * 64 + 4 * c4) = ra[set][p];
+            *reinterpret_cast<f32x4*>(bn + (kr + 16 * p) * 64 + 4 * c4) = rb[set][p];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (nslice > 0) {
+        load(0, 0);
+        store(0, as, bs);
+        load(1, min(1, nslice - 1));
+        load(0, min(2, nslice - 1));
+        __syncthreads();
+        auto slice = [&](int s, auto set_c) {
+            constexpr int set = decltype(set_c)::value;         // = (s + 1) & 1: holds slice s + 1, then takes slice s + 3
+            const int buf = s & 1;
+            const float* ab = as + buf * TSZ;
+            const float* bb = bs + buf * TSZ;
+            float fa[2][4], fb[2][4];
+            auto frag = [&](int t, int q) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    fa[q][jj] = ab[(8 * t + 4 * h + jj) * 64 + 32 * wi + r];
+                    fb[q][jj] = bb[(8 * t + 4 * h + jj) * 64 + 32 * wj + r];
+                }
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int q = t & 1;
+                if (t == 1) { store(set, as + (buf ^ 1) * TSZ, bs + (buf ^ 1) * TSZ); load(set, min(s + 3, nslice - 1)); }
+                if (t < 3) frag(t + 1, q ^ 1);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][jj], fb[q][jj], acc, 0, 0, 0);
+            }
+            __syncthreads();
+        };
+        for (int s = 0; s < nslice; s += 2) {
+            slice(s, std::integral_constant<int, 1>{});
+            if (s + 1 < nslice) slice(s + 1, std::integral_constant<int, 0>{});
+        }
+    }
+    float* o = ws + (size_t)blockIdx.z * M * N;
+    const int n = j0 + 32 * wj + r;
+    if (n >= N) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = i0 + 32 * wi + mfma32_row(i, h);
+        if (m < M) o[(size_t)m * N + n] = acc[i];
+    }
+}
+
+// plan of k_gemm64tn: at most 8 groups of at least 2048 rows, M <= 128; S = splits of a group's rows
+static bool tn64_plan(int G, int max_group_rows, int M, int N, int* S_out) {
+    if (G <= 0 || G > 8 || max_group_rows < 2048 || M > 128 || M < 4 || (M & 3) || (N & 3)) return false;
+    const long tiles = (long)G * ((M + 63) / 64) * ((N + 63) / 64);
+    int S = (int)((3 * MIL_NUM_CU + tiles / 2) / tiles);
+    if (S > max_group_rows / 128) S = max_group_rows / 128;       // at least four slices per split
+    if (S > 64) S = 64;
+    if (S < 2) return false;
+    *S_out = S;
+    return true;
+}

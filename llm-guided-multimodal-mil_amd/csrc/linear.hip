@@ -710,6 +710,10 @@ __global__ __launch_bounds__(256) void k_grouped_fold(const float* __restrict__ 
 
 extern "C" size_t mil_gemm_grouped_workspace_floats(int a_mode, int G, int max_group_rows, int M, int N) {
     if (a_mode != 1 || M > 128 || G <= 0) return 0;
+    {
+        int S64;
+        if (tn64_plan(G, max_group_rows, M, N, &S64)) return (size_t)G * S64 * M * N;
+    }
     const int tiles = G * ((N + 127) / 128);
     int S = (2 * MIL_NUM_CU) / (tiles > 0 ? tiles : 1);
     if (S > max_group_rows / 128) S = max_group_rows / 128;         // at least four 32-row slices per chunk
@@ -771,7 +775,17 @@ extern "C" int mil_gemm_grouped_pad(const float* A, int lda, int a_mode, const f
         // C_g[M, N] = A[rows_g, :M]^T . B[rows_g, :N]   (contraction over the group's rows)
         if (b_mode != 1 || M < 4 || (M & 3) || (N & 3) || bias || residual) return MIL_EINVAL;
         const size_t want = mil_gemm_grouped_workspace_floats(a_mode, G, max_group_rows, M, N);
-        if (workspace != nullptr && want > 0 && workspace_floats >= want && strideC == (long)M * N && ldc == N) {
+        int S64;
+        if (tn64_plan(G, max_group_rows, M, N, &S64) && workspace != nullptr && workspace_floats >= (size_t)G * S64 * M * N &&
+            strideC == (long)M * N && ldc == N && lda >= M) {
+            // a few long groups: 64 x 64 tiles, ~3 workgroups per CU (gemm64.h: k_gemm64tn), then the fold
+            hipLaunchKernelGGL(k_gemm64tn, dim3((N + 63) / 64, (M + 63) / 64, G * S64), dim3(256), 0, st, A, lda, B, ldb, workspace, M, N,
+                               grp_off, S64);
+            MIL_CHECK_LAUNCH();
+            const size_t total = (size_t)G * M * N;
+            hipLaunchKernelGGL(k_grouped_fold, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, workspace, S64,
+                               (size_t)M * N, C, total);
+        } else if (workspace != nullptr && want > 0 && workspace_floats >= want && strideC == (long)M * N && ldc == N) {
             // few output tiles per group: split each group's rows over S workgroups, fold the partial tiles afterwards
             gg.splits = (int)(want / ((size_t)G * M * N));
             const dim3 grid((N + 127) / 128, gg.splits, G);

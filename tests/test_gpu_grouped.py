@@ -166,3 +166,21 @@ def test_column_softmax_few_long_groups_row_parallel_form(lens, T, ld):
     assert float((o.cpu() - o_ref).abs().max()) <= 5e-5 and rel_err(o.cpu(), o_ref) <= 5e-5
     assert TH == ld or float(o[:, TH:].abs().max()) == 0.0
     assert rel_err(gr.cpu(), g_ref) <= 5e-5
+
+
+@pytest.mark.parametrize("lens,M,N", [([9001], 96, 512), ([2048, 3000, 2500], 32, 512), ([12288], 64, 256), ([15592], 96, 512),
+                                      ([4000, 0, 2100], 96, 512)])
+def test_grouped_contraction_of_a_few_long_groups(lens, M, N):
+    """C_g = A[rows_g]^T . X[rows_g] for at most 8 groups of >= 2048 rows: k_gemm64tn (64 x 64 tiles, ~3 workgroups per CU,
+    rows of a split beyond the group's end contribute zero) + k_grouped_fold."""
+    g = torch.Generator().manual_seed(sum(lens) + M)
+    R, G = sum(lens), len(lens)
+    off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    A = torch.randn((R, M), generator=g)
+    X = torch.randn((R, N), generator=g)
+    ref = torch.stack([A[int(off[i]):int(off[i + 1])].double().t() @ X[int(off[i]):int(off[i + 1])].double() for i in range(G)])
+    out = ops._gg_tn(A.to(DEV), X.to(DEV), off.to(DEV), G, max(lens))
+    assert out.shape == (G, M, N)
+    assert rel_err(out.cpu(), ref.float()) <= 3e-6
+    if 0 in lens:
+        assert float(out[lens.index(0)].abs().max()) == 0.0
