@@ -349,7 +349,8 @@ static bool small_tile_plan(int M, int N, int K, int a_mode, int* S_out, int* kc
 // gradients of the multi-token attention, C_g[M <= 128, N] = A[rows_g, :M]^T . B[rows_g, :N]).  The 128 x 128 form gives a
 // 10 000-row bag 4 column tiles x 32 row chunks = 128 workgroups of 12 slices, one per CU with nothing to overlap their
 // latencies: 43 us + 10 us of fold for 1.2 GFLOP.  Here: 64 x 64 tiles of the output, K (the group's rows) split so that
-// about three workgroups share a CU, each a handful of slices long; both operands are k-major, so their [32][64] LDS
+// about three workgroups share a CU, each a handful of slices long (many short groups - 32 bags x 1024 rows - the same
+// tiles with one or two splits: no rows of M padded to 128); both operands are k-major, so their [32][64] LDS
 // images are read by consecutive lanes (conflict-free ds_read_b32).  blockIdx.z = group * S + split; the split's partial
 // tile goes to ws[(group * S + split)][M][N] for k_grouped_fold.
 __global__ __launch_bounds__(256)
@@ -440,14 +441,15 @@ void k_gemm64tn(const float* __restrict__ A, int lda, const float* __restrict__ 
     }
 }
 
-// plan of k_gemm64tn: at most 8 groups of at least 2048 rows, M <= 128; S = splits of a group's rows
+// plan of k_gemm64tn: M <= 128 and groups of at least 512 rows; S = splits of a group's rows (1: straight into C, no fold)
 static bool tn64_plan(int G, int max_group_rows, int M, int N, int* S_out) {
-    if (G <= 0 || G > 8 || max_group_rows < 2048 || M > 128 || M < 4 || (M & 3) || (N & 3)) return false;
+    static const int off = getenv("MIL_TN64_OFF") ? atoi(getenv("MIL_TN64_OFF")) : 0;      // A/B switch
+    if (off || G <= 0 || max_group_rows < 512 || M > 128 || M < 4 || (M & 3) || (N & 3)) return false;
     const long tiles = (long)G * ((M + 63) / 64) * ((N + 63) / 64);
     int S = (int)((3 * MIL_NUM_CU + tiles / 2) / tiles);
     if (S > max_group_rows / 128) S = max_group_rows / 128;       // at least four slices per split
     if (S > 64) S = 64;
-    if (S < 2) return false;
+    if (S < 1) S = 1;
     *S_out = S;
     return true;
 }
