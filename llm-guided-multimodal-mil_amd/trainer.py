@@ -418,10 +418,19 @@ class ImageOnlyTrainer:
         else:
             groups += [("gate_bwd_dw", S.STAGE_GATE_BWD), ("gate_bwd_reduce_head_adam", S.STAGE_REDUCE | S.STAGE_ADAM)]
         masks = (ctypes.c_uint32 * len(groups))(*[m for _, m in groups])
-        out = (ctypes.c_float * (len(groups) + 1))()
-        rc = _lib.lib().mil_image_only_step_profile(ctypes.byref(a2), masks, len(groups), warm, iters, out, ops._stream())
-        _lib.check(rc, "mil_image_only_step_profile")
-        return {n: float(out[i]) for i, (n, _) in enumerate(groups)}, float(out[len(groups)])
+        # several short batches, per group the MEDIAN of the batch means: one stalled iteration (a 1 ms hiccup of the box
+        # inside 50 steps moved a 107 us group to 126 us once) must not reach the roofline object
+        nb = 5 if iters >= 20 else 1
+        per = max(1, iters // nb)
+        runs = []
+        for b in range(nb):
+            out = (ctypes.c_float * (len(groups) + 1))()
+            rc = _lib.lib().mil_image_only_step_profile(ctypes.byref(a2), masks, len(groups), warm if b == 0 else 1, per, out,
+                                                        ops._stream())
+            _lib.check(rc, "mil_image_only_step_profile")
+            runs.append([float(v) for v in out])
+        med = [sorted(r[i] for r in runs)[nb // 2] for i in range(len(groups) + 1)]
+        return {n: med[i] for i, (n, _) in enumerate(groups)}, med[len(groups)]
 
     # ------------------------------------------------------------------ hipGraph replay of the launch-bound part
     def capture(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
