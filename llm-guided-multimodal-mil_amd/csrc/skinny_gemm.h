@@ -65,30 +65,35 @@ __global__ __launch_bounds__(64 * RWT * NCT) void k_skinny_nt(const float* __res
         bsrc[i] = B + (size_t)col * ldb + 4 * ch;
         boff[i] = col * LG_KS + 4 * ch;
     }
-    f32x4 ra[NA], rb[NB];
-    auto load = [&](int k0) {
+    // two register sets in rotation: the loads of slice s + 3 are issued while slice s is multiplied and are stored two
+    // slices later (one set - a lead of one slice = 16 MFMAs - left every slice waiting for its HBM round trip: 2.6 us per
+    // slice at two workgroups per CU, 42 us for 64 MB)
+    f32x4 ra[2][NA], rb[2][NB];
+    auto load = [&](int set, int k0) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) if (alive[i]) ra[i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
+        for (int i = 0; i < NA; ++i) if (alive[i]) ra[set][i] = *reinterpret_cast<const f32x4*>(asrc[i] + k0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
+        for (int i = 0; i < NB; ++i) rb[set][i] = *reinterpret_cast<const f32x4*>(bsrc[i] + k0);
     };
-    auto store = [&](int buf) {
+    auto store = [&](int set, int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) if (alive[i]) *reinterpret_cast<f32x4*>(as + buf * ASZ + aoff[i]) = ra[i];
+        for (int i = 0; i < NA; ++i) if (alive[i]) *reinterpret_cast<f32x4*>(as + buf * ASZ + aoff[i]) = ra[set][i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(bs + buf * BSZ + boff[i]) = rb[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(bs + buf * BSZ + boff[i]) = rb[set][i];
     };
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int nslice = K / LG_BK;
-    load(0);
-    store(0);
+    load(0, 0);
+    store(0, 0);
+    load(1, min(1, nslice - 1) * LG_BK);
+    load(0, min(2, nslice - 1) * LG_BK);
     __syncthreads();
-    for (int s = 0; s < nslice; ++s) {
+    auto slice = [&](int s, auto set_c) {
+        constexpr int set = decltype(set_c)::value;             // = (s + 1) & 1: holds slice s + 1, then takes slice s + 3
         const int buf = s & 1;
-        if (s + 1 < nslice) load((s + 1) * LG_BK);
         const float* ap = as + buf * ASZ + (32 * wr + r) * LG_KS + 4 * h;
         const float* bp = bs + buf * BSZ + (32 * wc + r) * LG_KS + 4 * h;
         f32x4 fa[4], fb[4];
@@ -97,12 +102,17 @@ __global__ __launch_bounds__(64 * RWT * NCT) void k_skinny_nt(const float* __res
             fa[t] = *reinterpret_cast<const f32x4*>(ap + 8 * t);
             fb[t] = *reinterpret_cast<const f32x4*>(bp + 8 * t);
         }
+        if (s + 1 < nslice) store(set, buf ^ 1);
+        load(set, min(s + 3, nslice - 1) * LG_BK);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][jj], fb[t][jj], acc, 0, 0, 0);
-        if (s + 1 < nslice) store(buf ^ 1);
         __syncthreads();
+    };
+    for (int s = 0; s < nslice; s += 2) {
+        slice(s, std::integral_constant<int, 1>{});
+        if (s + 1 < nslice) slice(s + 1, std::integral_constant<int, 0>{});
     }
     const int col = 32 * wc + r;
     const float bj = bias != nullptr ? bias[(size_t)g * strideBias + col] : 0.f;
