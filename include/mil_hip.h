@@ -304,6 +304,12 @@ size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode);
 int mil_gemm(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
              int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
              int accumulate, float* workspace, size_t workspace_floats, void* stream);
+/* mil_gemm for a CAPACITY BUCKET (a_mode 0): rows_dev = device int32 with the true number of rows of A / C (<= M, the capacity the
+ * launch is sized for; the bag lengths of fusion_step.RaggedFusionStepper live on the device).  Output tiles wholly behind
+ * it are written as zeros without being computed, so the launch's time follows the true row count.  NULL = mil_gemm. */
+int mil_gemm_rows(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M, int N,
+                  int K, const float* bias, int act, const float* residual, int ldr, int accumulate, float* workspace,
+                  size_t workspace_floats, const int32_t* rows_dev, void* stream);
 
 /* Tall NT products C[M, N] = act(A[M, K] W[N, K]^T + bias), act in {0 none, 1 tanh, 2 ReLU}, on the low-VALU LDS-DMA
  * pipeline of the gate forward kernel (256 x 256 tiles, csrc/linear_nt2.hip): what mil_gemm dispatches nn.Linear layers on
@@ -342,6 +348,11 @@ size_t mil_linear_bwd_params_workspace_floats(int rows, int n_out, int k_in);
 int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows,
                           int n_out, int k_in, float* dW, int lddw, float* db, int accumulate, float* workspace,
                           size_t workspace_floats, void* stream);
+/* The same for a capacity bucket: only the first rows_dev[0] rows (device int32, <= rows) carry gradients; the tall-activation
+ * kernel spreads those over its row chunks instead of walking the padding.  NULL = mil_linear_bwd_params. */
+int mil_linear_bwd_params_rows(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows,
+                               int n_out, int k_in, float* dW, int lddw, float* db, int accumulate, float* workspace,
+                               size_t workspace_floats, const int32_t* rows_dev, void* stream);
 
 /* mil_gemm (a_mode 0) with one auxiliary [M, N] tensor touched in the epilogue:
  *   aux_mode 1: aux = the pre-activation (product + bias, before act) is stored too - QuickGELU's backward needs it;

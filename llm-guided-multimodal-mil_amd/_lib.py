@@ -71,6 +71,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_gemm_workspace_floats": (c_size_t, [c_int] * 4),
     "mil_gemm": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
                          _P, c_size_t, _P]),
+    "mil_gemm_rows": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int,
+                         _P, c_size_t, _P, _P]),
     "mil_gemm_nt2_ok": (c_int, [c_int] * 5),
     "mil_gemm_tn2_ok": (c_int, [c_int] * 6),
     "mil_gemm_tn2_splits": (c_int, [c_int] * 3),
@@ -147,6 +149,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_linear_bwd_params_workspace_floats": (c_size_t, [c_int] * 3),
     "mil_linear_bwd_params": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
                                       c_size_t, _P]),
+    "mil_linear_bwd_params_rows": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
+                                      c_size_t, _P, _P]),
 }
 
 STAGE_DROPBITS, STAGE_GATE_FWD, STAGE_POOL, STAGE_TAIL, STAGE_GATE_BWD, STAGE_REDUCE, STAGE_ADAM = 1, 2, 4, 8, 16, 32, 64

@@ -17,9 +17,19 @@ template <int BMODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_gemm64(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
               int M, int N, int K, const float* __restrict__ bias, int act, const float* __restrict__ residual, int ldr,
-              int accumulate, float* __restrict__ aux, int ldaux, int aux_mode) {
+              int accumulate, float* __restrict__ aux, int ldaux, int aux_mode, const int32_t* __restrict__ rows_dev) {
     constexpr int ASZ = 64 * 32;
     constexpr int BSZ = BMODE == 0 ? 128 * 32 : LG_BK * 128;
+    // rows_dev (a capacity bucket whose true row count lives on the device; rows from it on are padding): tiles that lie
+    // wholly in the padding write zeros and leave - the launch is sized for the capacity, its time follows the true count
+    if (rows_dev != nullptr && (int)(blockIdx.y * 64) >= __builtin_amdgcn_readfirstlane(rows_dev[0])) {
+        if (!accumulate)
+            for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+                const int row = blockIdx.y * 64 + (idx >> 5), j = blockIdx.x * 128 + 4 * (idx & 31);
+                if (row < M && j < N) *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + j) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];       // 48 KB
     float* as = smem;
     float* bs = smem + 2 * ASZ;

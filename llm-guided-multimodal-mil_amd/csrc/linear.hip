@@ -511,7 +511,8 @@ extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
 
 static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M,
                      int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
-                     float* workspace, size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream) {
+                     float* workspace, size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream,
+                     const int32_t* rows_dev = nullptr) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return MIL_EINVAL;
     if (M == 0 || N == 0) return MIL_OK;
     if ((lda & 3) || (ldb & 3) || act < 0 || act > 3) return MIL_EINVAL;
@@ -528,7 +529,7 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
         // low-VALU LDS-DMA kernel (linear_nt2.hip)
         const long tiles = (long)((M + 255) / 256) * (N / 256);
         const long rounds = (tiles + MIL_NUM_CU - 1) / MIL_NUM_CU;
-        if (tiles >= (3 * MIL_NUM_CU) / 4 && 8 * tiles >= 7 * rounds * MIL_NUM_CU)
+        if (rows_dev == nullptr && tiles >= (3 * MIL_NUM_CU) / 4 && 8 * tiles >= 7 * rounds * MIL_NUM_CU)
             return mil_gemm_nt2(A, lda, B, ldb, C, ldc, M, N, K, bias, act, stream);
     }
 #endif
@@ -539,12 +540,12 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
         // (tools/kbench_gemm64.py, kbench_gemm_k.py: 10 300 x 2048 x 512 241 -> 199 us, x 512 x 512 85 -> 65, 32 768 x 512 x 384
         // 137 -> 126, x 1536 equal), and no product of this kind needs split-K or the split last round any more.
         const long ct = (N + 127) / 128, t64 = ((M + 63) / 64) * ct;
-        if (t64 >= 3 * MIL_NUM_CU / 2 && K >= 256) {
+        if ((t64 >= 3 * MIL_NUM_CU / 2 || (rows_dev != nullptr && t64 >= MIL_NUM_CU / 2 && (N & 3) == 0)) && K >= 256) {
             const dim3 grid((unsigned)ct, (M + 63) / 64);
             if (b_mode == 0)
-                hipLaunchKernelGGL(k_gemm64<0>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+                hipLaunchKernelGGL(k_gemm64<0>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode, rows_dev);
             else
-                hipLaunchKernelGGL(k_gemm64<1>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode);
+                hipLaunchKernelGGL(k_gemm64<1>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode, rows_dev);
             MIL_CHECK_LAUNCH();
             return MIL_OK;
         }
@@ -629,6 +630,16 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
                      workspace_floats, nullptr, 0, AUX_NONE, stream);
 }
 
+// rows_dev (nullable, a_mode 0): device int32 with the TRUE number of rows of A / C (<= M; M then is the capacity the launch
+// is sized for - a bucket of fusion_step.RaggedFusionStepper).  Tiles wholly behind it write zeros instead of products.
+extern "C" int mil_gemm_rows(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
+                             int M, int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
+                             float* workspace, size_t workspace_floats, const int32_t* rows_dev, void* stream) {
+    if (rows_dev != nullptr && a_mode != 0) return MIL_EINVAL;
+    return gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
+                     workspace_floats, nullptr, 0, AUX_NONE, stream, rows_dev);
+}
+
 extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
                             int M, int N, int K, const float* bias, int act, const float* residual, int ldr,
                             int accumulate, float* workspace, size_t workspace_floats, float* aux, int ldaux, int aux_mode,
@@ -651,9 +662,14 @@ extern "C" size_t mil_linear_bwd_params_workspace_floats(int rows, int n_out, in
     return (size_t)S * n_out * k_in + (size_t)S * n_out;
 }
 
-extern "C" int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx,
-                                     int rows, int n_out, int k_in, float* dW, int lddw, float* db, int accumulate,
-                                     float* workspace, size_t workspace_floats, void* stream) {
+int mil_gemm_tn2_rows(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows, int N, int K,
+                      float* partial, float* cs_partial, const int32_t* rows_dev, void* stream);      // linear_nt2.hip
+
+// rows_dev (nullable): device int32 with the true number of rows (<= rows: the capacity of a bucket) - the rows behind it
+// carry zero gradients, and the tall-activation kernel then spreads only the true rows over its workgroups.
+extern "C" int mil_linear_bwd_params_rows(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx,
+                                          int rows, int n_out, int k_in, float* dW, int lddw, float* db, int accumulate,
+                                          float* workspace, size_t workspace_floats, const int32_t* rows_dev, void* stream) {
     if (!dY || !X || !dW || !workspace || rows <= 0 || n_out < 4 || (n_out & 3) || k_in < 4 || (k_in & 3)) return MIL_EINVAL;
     if ((lddy & 3) || (ldx & 3) || (Y != nullptr && (ldy & 3))) return MIL_EINVAL;
     if (act != ACT_NONE && act != ACT_TANH && act != ACT_RELU) return MIL_EINVAL;
@@ -666,7 +682,8 @@ extern "C" int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, 
         // tall activation, whole 128 x 128 output tiles: the low-VALU split-rows kernel (linear_nt2.hip), same partial layout
         const int S2 = mil_gemm_tn2_splits(rows, n_out, k_in);
         float* cs2 = db != nullptr ? workspace + (size_t)S2 * n_out * k_in : nullptr;
-        int rc = mil_gemm_tn2(dY, lddy, act != ACT_NONE ? Y : nullptr, ldy, act, X, ldx, rows, n_out, k_in, workspace, cs2, stream);
+        int rc = mil_gemm_tn2_rows(dY, lddy, act != ACT_NONE ? Y : nullptr, ldy, act, X, ldx, rows, n_out, k_in, workspace, cs2,
+                                   rows_dev, stream);
         if (rc != MIL_OK) return rc;
         const size_t n2 = (size_t)n_out * k_in;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, workspace, S2, dW, lddw, n_out,
@@ -693,6 +710,13 @@ extern "C" int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, 
                        (const float*)cs_part, db, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_linear_bwd_params(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx,
+                                     int rows, int n_out, int k_in, float* dW, int lddw, float* db, int accumulate,
+                                     float* workspace, size_t workspace_floats, void* stream) {
+    return mil_linear_bwd_params_rows(dY, lddy, Y, ldy, act, X, ldx, rows, n_out, k_in, dW, lddw, db, accumulate, workspace,
+                                      workspace_floats, nullptr, stream);
 }
 
 #include "skinny_gemm.h"

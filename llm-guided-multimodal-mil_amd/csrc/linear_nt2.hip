@@ -183,7 +183,14 @@ typedef unsigned int tn2_u32x4 __attribute__((ext_vector_type(4)));
 template <int ACT>
 __global__ __launch_bounds__(512) void k_gemm_tn2(const float* __restrict__ dY, int lddy, const float* __restrict__ Y, int ldy,
                                                   const float* __restrict__ X, int ldx, float* __restrict__ part,
-                                                  float* __restrict__ cs_part, int rows, int N, int K, int KC, int NJ, int NM) {
+                                                  float* __restrict__ cs_part, int rows, int N, int K, int KC, int NJ, int NM,
+                                                  const int32_t* __restrict__ rows_dev) {
+    if (rows_dev != nullptr) {
+        // a capacity bucket: only the first rows_dev[0] rows carry gradients - split THOSE evenly over the launch's row chunks
+        rows = min(rows, __builtin_amdgcn_readfirstlane(rows_dev[0]));
+        const int S = (int)gridDim.x / (NM * NJ);
+        KC = max(2 * TN2_BKR, ((rows + S - 1) / S + 2 * TN2_BKR - 1) / (2 * TN2_BKR) * (2 * TN2_BKR));
+    }
     __shared__ __attribute__((aligned(16))) float smem_all[2 * 2 * 2 * TN2_BKR * 128];
     const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     float* smem = smem_all + grp * (2 * 2 * TN2_BKR * 128);     // this K group's stages: [2][32][128] G, [2][32][128] X
@@ -383,8 +390,8 @@ extern "C" int mil_gemm_tn2_splits(int rows, int N, int K) {
     return tn2_plan(rows, N, K, &kc);
 }
 
-extern "C" int mil_gemm_tn2(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows,
-                            int N, int K, float* partial, float* cs_partial, void* stream) {
+int mil_gemm_tn2_rows(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows, int N, int K,
+                      float* partial, float* cs_partial, const int32_t* rows_dev, void* stream) {
     if (!dY || !X || !partial || !mil_gemm_tn2_ok(lddy, ldy, ldx, rows, N, K)) return MIL_EINVAL;
     if (act != NT2_ACT_NONE && act != NT2_ACT_TANH && act != NT2_ACT_RELU) return MIL_EINVAL;
     if (act != NT2_ACT_NONE && !Y) return MIL_EINVAL;
@@ -395,10 +402,14 @@ extern "C" int mil_gemm_tn2(const float* dY, int lddy, const float* Y, int ldy, 
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(S * NM * NJ);
     switch (act) {
-        case NT2_ACT_TANH: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_TANH>, grid, dim3(512), 0, st, dY, lddy, Y, ldy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM); break;
-        case NT2_ACT_RELU: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_RELU>, grid, dim3(512), 0, st, dY, lddy, Y, ldy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM); break;
-        default: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_NONE>, grid, dim3(512), 0, st, dY, lddy, Y ? Y : dY, Y ? ldy : lddy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM); break;
+        case NT2_ACT_TANH: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_TANH>, grid, dim3(512), 0, st, dY, lddy, Y, ldy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM, rows_dev); break;
+        case NT2_ACT_RELU: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_RELU>, grid, dim3(512), 0, st, dY, lddy, Y, ldy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM, rows_dev); break;
+        default: hipLaunchKernelGGL(k_gemm_tn2<NT2_ACT_NONE>, grid, dim3(512), 0, st, dY, lddy, Y ? Y : dY, Y ? ldy : lddy, X, ldx, partial, cs_partial, rows, N, K, kc, NJ, NM, rows_dev); break;
     }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+extern "C" int mil_gemm_tn2(const float* dY, int lddy, const float* Y, int ldy, int act, const float* X, int ldx, int rows,
+                            int N, int K, float* partial, float* cs_partial, void* stream) {
+    return mil_gemm_tn2_rows(dY, lddy, Y, ldy, act, X, ldx, rows, N, K, partial, cs_partial, nullptr, stream);
 }

@@ -88,8 +88,8 @@ class aggregator(nn.Module):
             self._pe = pe.to(device)
         return lifetime.note(self._pe)            # a captured graph keeps the table it saw when a larger one replaces it
 
-    def _lin_tanh(self, seq: nn.Sequential, x):
-        return ops.linear_act(x, seq[0].weight, seq[0].bias, "tanh")
+    def _lin_tanh(self, seq: nn.Sequential, x, rows_dev=None):
+        return ops.linear_act(x, seq[0].weight, seq[0].bias, "tanh", rows_dev=rows_dev)
 
     def _head(self, M):
         if self.training:
@@ -174,7 +174,7 @@ class aggregator(nn.Module):
             raise ValueError(f"bucket of {bucket.B} bags x {bucket.cap} rows x {bucket.P} token(s): got x {tuple(x.shape)}, "
                              f"text {tuple(t.shape)}")
         bucket.refresh()                                                                   # maps from len_dev, on the device
-        xi = self._lin_tanh(self.fc_pathology, x)                                          # :149
+        xi = self._lin_tanh(self.fc_pathology, x, rows_dev=bucket.rows_dev)                # :149 (tiles behind the true rows: zeros)
         point = self._lin_tanh(self.fc_CI2Pth, t.reshape(B * P, EMBED))                    # :190
         q, k = self.TwoWayTransformer_Pth.flat(xi, point, self.pe_rows(bucket.cap, xi.device), None, None,
                                                keys_tail_rows=B * P, segs=(bucket.s_tt, bucket.s_ti, bucket.s_it))
@@ -202,7 +202,7 @@ class aggregator(nn.Module):
         tflat = t.reshape(B * P, EMBED)
         tw = self.TwoWayTransformer_Both                                                      # :160,168: one module, twice
         q_ct, k_ct = tw.flat(ct_rows, self._lin_tanh(self.fc_CI2CT, tflat), self.pe_rows(D, dev), [D] * B, [P] * B)
-        xi = self._lin_tanh(self.fc_pathology, x)                                             # :141
+        xi = self._lin_tanh(self.fc_pathology, x, rows_dev=bucket.rows_dev)                   # :141
         q_p, k_p = tw.flat(xi, self._lin_tanh(self.fc_CI2Pth, tflat), self.pe_rows(bucket.cap, dev), None, None,
                            keys_tail_rows=bucket.tail_rows, segs=(bucket.s_tt, bucket.s_ti, bucket.s_it))
         x0 = ops.append_rows(k_p, torch.cat([q_ct, k_ct, q_p], 0), tail_reserved=True)        # :173 (no concat of the patches)

@@ -451,7 +451,7 @@ ACT = {"none": 0, "tanh": 1, "relu": 2, "quickgelu": 3}
 
 
 def gemm(A, a_mode: int, B, b_mode: int, M: int, N: int, K: int, out=None, bias=None, act: int = 0, residual=None,
-         accumulate: bool = False, split_k: bool = True):
+         accumulate: bool = False, split_k: bool = True, rows_dev=None):
     """C[M,N] (+)= act(A_op . B_op + bias) + residual  (include/mil_hip.h: mil_gemm)."""
     A = _f32c(A, "A")
     B = _f32c(B, "B")
@@ -462,6 +462,12 @@ def gemm(A, a_mode: int, B, b_mode: int, M: int, N: int, K: int, out=None, bias=
         nws = _lib.lib().mil_gemm_workspace_floats(M, N, K, a_mode)
         if nws:
             ws = torch.empty(nws, device=A.device, dtype=torch.float32)
+    if rows_dev is not None:       # capacity bucket: true row count on the device (include/mil_hip.h: mil_gemm_rows)
+        rc = _lib.lib().mil_gemm_rows(_p(A), A.stride(0), a_mode, _p(B), B.stride(0), b_mode, _p(out), out.stride(0), M, N, K,
+                                      _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
+                                      1 if accumulate else 0, _p(ws), nws, _p(rows_dev), _stream())
+        _lib.check(rc, "mil_gemm_rows")
+        return out
     rc = _lib.lib().mil_gemm(_p(A), A.stride(0), a_mode, _p(B), B.stride(0), b_mode, _p(out), out.stride(0), M, N, K,
                              _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
                              1 if accumulate else 0, _p(ws), nws, _stream())
@@ -483,7 +489,7 @@ def gemm_aux(A, B, b_mode: int, M: int, N: int, K: int, aux, aux_mode: int, bias
     return out
 
 
-def linear_bwd_params(dy, y, act: int, x, dW_out=None, db_out=None, want_db: bool = True):
+def linear_bwd_params(dy, y, act: int, x, dW_out=None, db_out=None, want_db: bool = True, rows_dev=None):
     """dW = (dy (.) act'(y))^T x and db = its column sums in one product launch + fold (mil_linear_bwd_params).
     y may be None for act 0.  Returns (dW [N, K], db [N] or None)."""
     rows, N = dy.shape
@@ -494,9 +500,10 @@ def linear_bwd_params(dy, y, act: int, x, dW_out=None, db_out=None, want_db: boo
         db = db_out if db_out is not None else torch.empty(N, device=dy.device, dtype=torch.float32)
     nws = _lib.lib().mil_linear_bwd_params_workspace_floats(rows, N, K)
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
-    rc = _lib.lib().mil_linear_bwd_params(_p(dy), dy.stride(0), _p(y), y.stride(0) if y is not None else 0, act, _p(x),
-                                          x.stride(0), rows, N, K, _p(dW), dW.stride(0), _p(db), 0, _p(ws), nws, _stream())
-    _lib.check(rc, "mil_linear_bwd_params")
+    rc = _lib.lib().mil_linear_bwd_params_rows(_p(dy), dy.stride(0), _p(y), y.stride(0) if y is not None else 0, act, _p(x),
+                                               x.stride(0), rows, N, K, _p(dW), dW.stride(0), _p(db), 0, _p(ws), nws,
+                                               _p(rows_dev), _stream())
+    _lib.check(rc, "mil_linear_bwd_params_rows")
     return dW, db
 
 
@@ -631,10 +638,11 @@ class _LinearAct(torch.autograd.Function):
     sam/common.py:21-26.  x [M, K], W [N, K]."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act: int, residual):
+    def forward(ctx, x, W, b, act: int, residual, rows_dev=None):
         x = _f32c(x, "x")
         W = _f32c(W, "W")
         M, K = x.shape
+        ctx.rows_dev = rows_dev             # capacity bucket: rows from rows_dev[0] on are padding (zero out, zero gradient)
         N = W.shape[0]
         res = _f32c(residual, "residual") if residual is not None else None
         pre = None
@@ -655,7 +663,7 @@ class _LinearAct(torch.autograd.Function):
             rc = _lib.lib().mil_quickgelu(_p(pre), None, _p(y), pre.numel(), _stream())
             _lib.check(rc, "mil_quickgelu")
         else:
-            y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res)
+            y = gemm(x, 0, W, 0, M, N, K, bias=b, act=act, residual=res, rows_dev=rows_dev)
         ctx.act = act
         ctx.has_b = b is not None
         ctx.b_param = b                     # only to look up its flat-gradient slot in backward
@@ -677,7 +685,7 @@ class _LinearAct(torch.autograd.Function):
                 dy = dy.clone()
             dx, dW, db = linear_mid_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                         ctx.has_b and ctx.needs_input_grad[2], W_slot, b_slot)
-            return dx, (dW if ctx.needs_input_grad[1] else None), db, None, (dy if ctx.has_res else None)
+            return dx, (dW if ctx.needs_input_grad[1] else None), db, None, (dy if ctx.has_res else None), None
         if ctx.small:
             if dy.data_ptr() % 16:
                 dy = dy.clone()
@@ -690,9 +698,9 @@ class _LinearAct(torch.autograd.Function):
                 # nothing else references that tensor object (see grad_slot)
                 dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False)
                 deferred.queue_dw(dy, y, x, W_slot.detach(), (b_slot.detach() if want_db else None), ctx.act)
-                return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None)
+                return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None), None
             dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], want_dW, want_db, W_slot, b_slot)
-            return dx, dW, db, None, (dy if ctx.has_res else None)
+            return dx, dW, db, None, (dy if ctx.has_res else None), None
         if ctx.act == ACT["quickgelu"]:
             dpre = torch.empty_like(dy)
             rc = _lib.lib().mil_quickgelu(_p(y), _p(dy), _p(dpre), dy.numel(), _stream())     # y holds the pre-activation
@@ -703,18 +711,18 @@ class _LinearAct(torch.autograd.Function):
                 # parameters only (fc_pathology: the bag features carry no gradient): act' is applied while dy is staged
                 # for the weight-gradient product, which also yields the bias gradient - no dpre tensor at all
                 dW, db = linear_bwd_params(dy, y if ctx.act else None, ctx.act, x, W_slot, b_slot,
-                                           ctx.has_b and ctx.needs_input_grad[2])
-                return None, dW, db, None, (dy if ctx.has_res else None)
+                                           ctx.has_b and ctx.needs_input_grad[2], rows_dev=ctx.rows_dev)
+                return None, dW, db, None, (dy if ctx.has_res else None), None
             dpre = act_bwd(dy, y, ctx.act)
             if fused:
                 dx = gemm(dpre, 0, W, 1, M, K, N)
                 dW, db = linear_bwd_params(dpre, None, 0, x, W_slot, b_slot, ctx.has_b and ctx.needs_input_grad[2])
-                return dx, dW, db, None, (dy if ctx.has_res else None)
+                return dx, dW, db, None, (dy if ctx.has_res else None), None
         dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
         dW = gemm(dpre, 1, x, 1, N, K, M, out=W_slot, split_k=True) if ctx.needs_input_grad[1] else None
         db = colsum(dpre, out=b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res else None
-        return dx, dW, db, None, dres
+        return dx, dW, db, None, dres, None
 
 
 def _small_dw(dy, yv, x, W, b, act: int):
@@ -856,10 +864,12 @@ def mlp_quickgelu(x, W1, b1, W2, b2, residual=None):
     return _MlpQuickGelu.apply(x, W1, b1, W2, b2, residual)
 
 
-def linear_act(x, W, b=None, act: str = "none", residual=None):
+def linear_act(x, W, b=None, act: str = "none", residual=None, rows_dev=None):
+    """rows_dev: device int32 [1] with the true row count of a capacity bucket (x has the bucket's capacity rows; the rows behind
+    the count come out as zeros and carry no gradient) - tall layers only; the few-rows kernels ignore it."""
     lead = x.shape[:-1]
     y = _LinearAct.apply(x.reshape(-1, x.shape[-1]), W, b, ACT[act],
-                         residual.reshape(-1, residual.shape[-1]) if residual is not None else None)
+                         residual.reshape(-1, residual.shape[-1]) if residual is not None else None, rows_dev)
     return y.reshape(*lead, W.shape[0])
 
 
