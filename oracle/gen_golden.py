@@ -196,6 +196,28 @@ def gen_twoway_ctmap(tw, tag, seed, T, D, hw):
     npz(tag, **arrs)
 
 
+def gen_twoway_ctbase(tw, tag, seed, N, D, hw):
+    """`--alignment_base CT` (sam/transformer.py:78-86): the CT feature map [1, 512, D, h, w] arrives as POINT embedding and
+    becomes the D query tokens (mean over (h, w), permute); image_embedding [1, N, 512] are the keys."""
+    name = "TwoWayTransformer_Pth"
+    p = syn.twoway_params(seed, name)
+    args = SimpleNamespace(alignment_base="CT", model_CT="resnetMC3_18")
+    m = tw.TwoWayTransformer(args=args, depth=2, embedding_dim=512, num_heads=8, mlp_dim=2048).eval()
+    m.load_state_dict(sub(p, name + "."))
+    ct = syn.make_ct_map(seed + 1, 1, D, hw)
+    g = torch.Generator().manual_seed(seed + 2)
+    img = torch.randn((1, N, 512), generator=g).requires_grad_(True)
+    import oracle.mil_oracle as orc
+    pe = orc.sinusoidal_pe(N, 512).unsqueeze(0)
+    q, k = m(img, pe, ct)
+    gq = torch.randn(q.shape, generator=g)
+    gk = torch.randn(k.shape, generator=g)
+    ((q * gq).sum() + (k * gk).sum()).backward()
+    arrs = dict(seed=seed, shape=np.array([N, D, hw]), queries=q[0], keys=k[0], dimage=img.grad[0])
+    pack_grads(arrs, grads_of(m, "g." + name + "."), full=False)
+    npz(tag, **arrs)
+
+
 def gen_fused_ct_pth(ab, tw, cm, tag, seed, B, N, P, D, hw, clip_layers):
     """model/aggregator.py:134-209 with modality ['CT', 'pathology'] and a PRECOMPUTED CT map in place of extractor_CT:
     both modalities go through TwoWayTransformer_Both (:160,168), the multi-modal bag is the 4-segment concat of :173."""
@@ -396,6 +418,7 @@ def main():
     gen_twoway(tw, "twoway_T1_N200", 73, 1, 200)
     gen_twoway_ctmap(tw, "twoway_ctmap_T1", 75, 1, 160, 3)
     gen_twoway_ctmap(tw, "twoway_ctmap_T10", 76, 10, 160, 2)
+    gen_twoway_ctbase(tw, "twoway_ctbase_N64", 77, 64, 20, 3)
     gen_clip(cm, "clip_text_small", 81, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, store_params=False)
     gen_clip(cm, "clip_text_vitb32", 82, width=512, layers=12, vocab=49408, heads=8, embed=512, P=2,
              store_params=False)
@@ -420,6 +443,10 @@ if __name__ == "__main__":
         gen_twoway_ctmap(_tw, "twoway_ctmap_T1", 75, 1, 160, 3)
         gen_twoway_ctmap(_tw, "twoway_ctmap_T10", 76, 10, 160, 2)
         gen_fused_ct_pth(_ab, _tw, _cm, "fused_ct_pth", 95, B=2, N=96, P=1, D=160, hw=2, clip_layers=2)
+    elif len(sys.argv) > 1 and sys.argv[1] == "ctbase":      # round 3: --alignment_base CT
+        torch.set_num_threads(8)
+        _ab, _tw, _cm = load_reference()
+        gen_twoway_ctbase(_tw, "twoway_ctbase_N64", 77, 64, 20, 3)
     elif len(sys.argv) > 1 and sys.argv[1] == "coop":        # regenerate only the learnable-context fixtures
         torch.set_num_threads(8)
         _ab, _tw, _cm = load_reference()

@@ -56,6 +56,15 @@ def test_twoway_transformer_on_a_ct_map_vs_reference(tag):
             check_grad("g." + name + "." + n, got, g, 1e-3)
 
 
+def test_alignment_base_ct_is_refused_loudly():
+    """`--alignment_base CT` (160 CT tokens as queries) is outside the built path: the module says so instead of computing something
+    else (the branch itself is pinned on the oracle side: tests/test_oracle_golden.py::test_twoway_alignment_base_ct)."""
+    m = TwoWayTransformer(args=SimpleNamespace(alignment_base="CT", model_CT="resnetMC3_18"), depth=2, embedding_dim=512,
+                          num_heads=8, mlp_dim=2048).to(DEV)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros((1, 8, 512), device=DEV), torch.zeros((1, 8, 512), device=DEV), torch.zeros((1, 512, 4, 2, 2), device=DEV))
+
+
 def _args(**kw):
     a = dict(modality=["CT", "pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
              learnablePrompt=0, alignment_base="CI", model_CT="resnetMC3_18")

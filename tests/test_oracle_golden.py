@@ -241,6 +241,33 @@ def test_twoway_on_a_ct_map(tag):
             check_grad("g." + n, got, g, 2e-4)
 
 
+def test_twoway_alignment_base_ct():
+    """`--alignment_base CT` (sam/transformer.py:78-86): the CT map's D tokens are the QUERIES (point embedding) of the two-way
+    transformer, the image tokens the keys - the oracle restatement against the reference's own forward."""
+    g = load_golden("twoway_ctbase_N64")
+    seed = int(g["seed"])
+    N, D, hw = [int(v) for v in g["shape"]]
+    name = "TwoWayTransformer_Pth"
+    p = syn.twoway_params(seed, name)
+    ct = syn.make_ct_map(seed + 1, 1, D, hw)
+    gen = torch.Generator().manual_seed(seed + 2)
+    img = torch.randn((1, N, 512), generator=gen)[0].requires_grad_(True)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+    q, k = orc.twoway_transformer(img, orc.sinusoidal_pe(N, 512), orc.ct_map_tokens(ct)[0], leaves, name)
+    gq = torch.randn((1, D, 512), generator=gen)[0]
+    gk = torch.randn((1, N, 512), generator=gen)[0]
+    ((q * gq).sum() + (k * gk).sum()).backward()
+    assert rel_err(q, g["queries"]) <= TOL and rel_err(k, g["keys"]) <= TOL
+    assert rel_err(img.grad, g["dimage"]) <= 1e-4
+    for n in p:
+        gn = float(g["g." + n + ".norm"])
+        got = leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(leaves[n])
+        if gn == 0.0:
+            assert float(got.abs().max()) <= 1e-12, n
+        else:
+            check_grad("g." + n, got, g, 2e-4)
+
+
 def test_fused_ct_and_pathology():
     """modality ['CT', 'pathology'] with a precomputed CT map: TwoWayTransformer_Both twice, 4-segment bag (aggregator.py:155-173)."""
     g = load_golden("fused_ct_pth")
