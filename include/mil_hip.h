@@ -461,6 +461,13 @@ int mil_attn_rows_bwd(const float* q, const float* k, const float* v, const floa
                       const float* lse, const int32_t* k_off, const int32_t* blk_map,
                       const int32_t* bag_blk_off, int nblk, int B, int H, int C, float* dq, float* dk, float* dv,
                       float* workspace, void* stream);
+/* The rows form's backward for ANY number of queries and keys per bag (plain per-(row, head) loops; workspace Tq * H floats):
+ * what `--alignment_base CT` needs (sam/transformer.py:78-86: 160 CT tokens as queries) - no shipped run does, so no fast
+ * kernel exists for it.  q_bag [Tq] / k_bag [Tk]: row -> bag.  Not causal. */
+int mil_attn_rows_bwd_general(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                              const float* lse, const int32_t* q_off, const int32_t* k_off, const int32_t* q_bag,
+                              const int32_t* k_bag, int Tq, int Tk, int H, int C, float* dq, float* dk, float* dv,
+                              float* workspace, void* stream);
 /* "pool" form: <= 16 queries per bag over many keys (token->image attention: an H-head attention pool over
  * the patches).  tile_map int32 [ntiles][3] = {bag, key0, nkeys <= 64}, bag_tile_off [B+1].
  * forward workspace: ntiles * 16 * (H*C + 2*H) floats; backward workspace: ntiles * 16 * H*C floats. */

@@ -100,6 +100,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_linear_small_ln_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P]),
     "mil_attn_rows_fwd": (c_int, [_P] * 6 + [c_int] * 4 + [_P, _P, _P]),
     "mil_attn_rows_bwd": (c_int, [_P] * 9 + [c_int] * 4 + [_P] * 4 + [_P]),
+    "mil_attn_rows_bwd_general": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_int] + [_P] * 5),
     "mil_attn_pool_fwd_mh": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
     "mil_attn_pool_bwd_mh": (c_int, [_P] * 9 + [c_int] * 5 + [_P] * 4 + [_P]),
     "mil_attn_seq_fwd": (c_int, [_P] * 3 + [c_int, _P] + [c_int] * 5 + [_P, _P, _P]),

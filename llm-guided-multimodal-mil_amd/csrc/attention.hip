@@ -926,6 +926,107 @@ extern "C" int mil_attn_rows_bwd(const float* q, const float* k, const float* v,
     return MIL_OK;
 }
 
+// ================================================================================ rows: GENERAL backward (any Tq, Tk per bag)
+// The shapes no shipped run needs a fast kernel for (`--alignment_base CT`, sam/transformer.py:78-86: 160 CT tokens as
+// queries over N patches, N patches over 160 tokens, self-attention over 160 tokens): plain thread-per-(row, head) loops.
+//   k_attn_gen_bwd_q   thread (query row, head): D = dO . O, then over the bag's keys  p = exp(scale q . k - lse),
+//                      ds = p (dO . v - D),  dq += scale ds k;  D goes to dws [Tq, H]
+//   k_attn_gen_bwd_kv  thread (key row, head): over the bag's queries  dv += p dO,  dk += scale ds q
+template <int C>
+__global__ __launch_bounds__(256) void k_attn_gen_bwd_q(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const float* __restrict__ o,
+                                                        const float* __restrict__ dout, const float* __restrict__ lse,
+                                                        const int32_t* __restrict__ k_off, const int32_t* __restrict__ q_bag,
+                                                        int Tq, int H, float scale, float* __restrict__ dq,
+                                                        float* __restrict__ dws) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tq * H) return;
+    const int row = idx / H, h = idx % H, I = H * C;
+    const int b = q_bag[row], kb = k_off[b], nk = k_off[b + 1] - kb;
+    float qr[C], gr[C], acc[C];
+    float D = 0.f;
+#pragma unroll
+    for (int e = 0; e < C; ++e) {
+        qr[e] = q[(size_t)row * I + h * C + e] * scale;
+        gr[e] = dout[(size_t)row * I + h * C + e];
+        D += gr[e] * o[(size_t)row * I + h * C + e];
+        acc[e] = 0.f;
+    }
+    dws[(size_t)row * H + h] = D;
+    const float ls = lse[(size_t)row * H + h];
+    for (int j = 0; j < nk; ++j) {
+        const float* kr = k + (size_t)(kb + j) * I + h * C;
+        const float* vr = v + (size_t)(kb + j) * I + h * C;
+        float sdot = 0.f, dp = 0.f;
+#pragma unroll
+        for (int e = 0; e < C; ++e) { sdot += qr[e] * kr[e]; dp += gr[e] * vr[e]; }
+        const float ds = expf(sdot - ls) * (dp - D);
+#pragma unroll
+        for (int e = 0; e < C; ++e) acc[e] += ds * kr[e];
+    }
+#pragma unroll
+    for (int e = 0; e < C; ++e) dq[(size_t)row * I + h * C + e] = acc[e] * scale;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_attn_gen_bwd_kv(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ dout,
+                                                         const float* __restrict__ lse, const float* __restrict__ dws,
+                                                         const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_bag,
+                                                         int Tk, int H, float scale, float* __restrict__ dk,
+                                                         float* __restrict__ dv) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Tk * H) return;
+    const int row = idx / H, h = idx % H, I = H * C;
+    const int b = k_bag[row], qb = q_off[b], nq = q_off[b + 1] - qb;
+    float kr[C], vr[C], ak[C], av[C];
+#pragma unroll
+    for (int e = 0; e < C; ++e) {
+        kr[e] = k[(size_t)row * I + h * C + e] * scale;
+        vr[e] = v[(size_t)row * I + h * C + e];
+        ak[e] = 0.f;
+        av[e] = 0.f;
+    }
+    for (int i = 0; i < nq; ++i) {
+        const float* qr = q + (size_t)(qb + i) * I + h * C;
+        const float* gr = dout + (size_t)(qb + i) * I + h * C;
+        float sdot = 0.f, dp = 0.f;
+#pragma unroll
+        for (int e = 0; e < C; ++e) { sdot += qr[e] * kr[e]; dp += gr[e] * vr[e]; }
+        const float p = expf(sdot - lse[(size_t)(qb + i) * H + h]);
+        const float ds = p * (dp - dws[(size_t)(qb + i) * H + h]);
+#pragma unroll
+        for (int e = 0; e < C; ++e) { av[e] += p * gr[e]; ak[e] += ds * qr[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < C; ++e) {
+        dk[(size_t)row * I + h * C + e] = ak[e] * scale;
+        dv[(size_t)row * I + h * C + e] = av[e];
+    }
+}
+
+extern "C" int mil_attn_rows_bwd_general(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                         const float* lse, const int32_t* q_off, const int32_t* k_off,
+                                         const int32_t* q_bag, const int32_t* k_bag, int Tq, int Tk, int H, int C, float* dq,
+                                         float* dk, float* dv, float* workspace, void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !q_off || !k_off || !q_bag || !k_bag || !dq || !dk || !dv || !workspace)
+        return MIL_EINVAL;
+    if ((C != 32 && C != 64) || H <= 0 || Tq < 0 || Tk < 0) return MIL_EINVAL;
+    const float scale = 1.0f / sqrtf((float)C);
+    hipStream_t st = (hipStream_t)stream;
+    if (Tq > 0) {
+        DISPATCH_C(C, hipLaunchKernelGGL((k_attn_gen_bwd_q<CC>), dim3((Tq * H + 255) / 256), dim3(256), 0, st, q, k, v, o, dout, lse,
+                                         k_off, q_bag, Tq, H, scale, dq, workspace));
+        MIL_CHECK_LAUNCH();
+    }
+    if (Tk > 0) {
+        DISPATCH_C(C, hipLaunchKernelGGL((k_attn_gen_bwd_kv<CC>), dim3((Tk * H + 255) / 256), dim3(256), 0, st, q, k, v, dout, lse,
+                                         (const float*)workspace, q_off, k_bag, Tk, H, scale, dk, dv));
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
 extern "C" int mil_attn_pool_fwd_mh(const float* q, const float* k, const float* v, const int32_t* q_off,
                                     const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int B, int Tmax,
                                     int H, int C, float* o, float* lse, float* workspace, void* stream) {

@@ -258,13 +258,15 @@ class TwoWayTransformer(nn.Module):
         point_embedding [B, T, E] -> (queries [B, T, E], keys [B, N, E]).  A 5-D image_embedding is a CT feature map
         [B, E, D, h, w] (:78-98): it becomes D tokens (mean over h, w; resnetMC3_18) or D*h*w tokens (medicalNet)."""
         if getattr(self.args, "alignment_base", "CI") == "CT":
-            # :78-86: the CT map as POINT embedding = 160 query tokens per bag.  The attention kernels built here cover what the
-            # shipped runs use - <= 16 queries per bag over any number of keys, any number of query rows over <= 16 keys, and
-            # self-attention over <= 96 tokens; 160 queries x N keys needs a general ragged attention core, which no run of the
-            # reference exercises (run_train.sh / run_test.sh: commented-out lines only).  The oracle restates the branch
-            # (tests/test_oracle_golden.py::test_twoway_alignment_base_ct, golden from the reference's own class).
-            raise NotImplementedError("alignment_base='CT' (CT tokens as queries, sam/transformer.py:78-86) is not on the built path")
-        if image_embedding.dim() == 5:
+            # :78-86: the CT map arrives as POINT embedding and its D tokens are the queries; the image side stays [B, N, E].
+            # D x 8 heads exceeds every few-token fast path: self-attention over D tokens (<= 96: the whole-sequence kernel), D
+            # queries over N keys and N queries over D keys go through the general rows kernels (mil_attn_rows_fwd /
+            # mil_attn_rows_bwd_general) - no shipped run takes this branch, so it is correct rather than fast.
+            if point_embedding.dim() == 5:
+                Bc = point_embedding.shape[0]
+                rows, Tn = ops.ct_map_tokens(point_embedding, getattr(self.args, "model_CT", "resnetMC3_18"))
+                point_embedding = rows.view(Bc, Tn, rows.shape[1])
+        elif image_embedding.dim() == 5:
             Bc = image_embedding.shape[0]
             rows, Tn = ops.ct_map_tokens(image_embedding, getattr(self.args, "model_CT", "resnetMC3_18"))
             image_embedding = rows.view(Bc, Tn, rows.shape[1])

@@ -914,6 +914,16 @@ class _AttnRows(torch.autograd.Function):
         segs, H, C = ctx.segs, ctx.H, ctx.C
         I = H * C
         do = _f32c(do, "do")
+        if (not ctx.causal) and segs.Tk_max > 16 and (segs.q_lengths != segs.k_lengths or segs.Tk_max > SEQ_MAX_TOKENS):
+            # more than 16 keys per bag outside whole-sequence self-attention (`--alignment_base CT`: 160 CT tokens as
+            # queries / keys): the general per-(row, head) loops (include/mil_hip.h: mil_attn_rows_bwd_general)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ws = torch.empty(max(1, q.shape[0]) * H, device=q.device, dtype=torch.float32)
+            rc = _lib.lib().mil_attn_rows_bwd_general(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(segs.q_off), _p(segs.k_off),
+                                                      _p(segs.q_bag), _p(segs.k_bag), q.shape[0], k.shape[0], H, C, _p(dq),
+                                                      _p(dk), _p(dv), _p(ws), _stream())
+            _lib.check(rc, "mil_attn_rows_bwd_general")
+            return dq, dk, dv, None, None, None
         if ctx.causal or segs.Tk_max > 16:
             # whole-sequence self-attention (the CLIP text blocks under learnable prompts): q, k, v share the segments
             if segs.q_lengths != segs.k_lengths or segs.Tk_max > SEQ_MAX_TOKENS:
@@ -1019,6 +1029,8 @@ class _AttnPool(torch.autograd.Function):
 
 
 def attention_pool(q, k, v, segs, H: int):
+    if segs.Tq_max > 16:          # more queries per bag than the pool form holds: the rows form (general backward)
+        return _AttnRows.apply(q, k, v, segs, H, False)
     return _AttnPool.apply(q, k, v, segs, H)
 
 

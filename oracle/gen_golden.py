@@ -419,6 +419,7 @@ def main():
     gen_twoway_ctmap(tw, "twoway_ctmap_T1", 75, 1, 160, 3)
     gen_twoway_ctmap(tw, "twoway_ctmap_T10", 76, 10, 160, 2)
     gen_twoway_ctbase(tw, "twoway_ctbase_N64", 77, 64, 20, 3)
+    gen_twoway_ctbase(tw, "twoway_ctbase_D160", 78, 200, 160, 2)
     gen_clip(cm, "clip_text_small", 81, width=64, layers=2, vocab=1000, heads=2, embed=64, P=3, store_params=False)
     gen_clip(cm, "clip_text_vitb32", 82, width=512, layers=12, vocab=49408, heads=8, embed=512, P=2,
              store_params=False)
@@ -447,6 +448,7 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         _ab, _tw, _cm = load_reference()
         gen_twoway_ctbase(_tw, "twoway_ctbase_N64", 77, 64, 20, 3)
+        gen_twoway_ctbase(_tw, "twoway_ctbase_D160", 78, 200, 160, 2)
     elif len(sys.argv) > 1 and sys.argv[1] == "coop":        # regenerate only the learnable-context fixtures
         torch.set_num_threads(8)
         _ab, _tw, _cm = load_reference()

@@ -56,13 +56,37 @@ def test_twoway_transformer_on_a_ct_map_vs_reference(tag):
             check_grad("g." + name + "." + n, got, g, 1e-3)
 
 
-def test_alignment_base_ct_is_refused_loudly():
-    """`--alignment_base CT` (160 CT tokens as queries) is outside the built path: the module says so instead of computing something
-    else (the branch itself is pinned on the oracle side: tests/test_oracle_golden.py::test_twoway_alignment_base_ct)."""
+@pytest.mark.parametrize("tag", ["twoway_ctbase_N64", "twoway_ctbase_D160"])
+def test_twoway_transformer_alignment_base_ct_vs_reference(tag):
+    """`--alignment_base CT` (sam/transformer.py:78-86): the 5-D CT map is the POINT embedding - its D tokens are the queries of
+    every attention (more than 16 per bag: the general rows kernels, mil_attn_rows_bwd_general; D = 160 also exceeds the
+    whole-sequence self-attention kernel) - against the reference's own TwoWayTransformer (oracle/gen_golden.py ctbase)."""
+    g = load_golden(tag)
+    seed = int(g["seed"])
+    N, D, hw = [int(v) for v in g["shape"]]
+    name = "TwoWayTransformer_Pth"
+    p = syn.twoway_params(seed, name)
     m = TwoWayTransformer(args=SimpleNamespace(alignment_base="CT", model_CT="resnetMC3_18"), depth=2, embedding_dim=512,
-                          num_heads=8, mlp_dim=2048).to(DEV)
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros((1, 8, 512), device=DEV), torch.zeros((1, 8, 512), device=DEV), torch.zeros((1, 512, 4, 2, 2), device=DEV))
+                          num_heads=8, mlp_dim=2048)
+    m.load_state_dict({k[len(name) + 1:]: v for k, v in p.items()})
+    m = m.to(DEV).eval()
+    ct = syn.make_ct_map(seed + 1, 1, D, hw).to(DEV)
+    gen = torch.Generator().manual_seed(seed + 2)
+    img = torch.randn((1, N, 512), generator=gen).to(DEV).requires_grad_(True)
+    q, k = m(img, orc.sinusoidal_pe(N, 512).unsqueeze(0).to(DEV), ct)
+    assert q.shape == (1, D, 512) and k.shape == (1, N, 512)
+    gq = torch.randn((1, D, 512), generator=gen).to(DEV)
+    gk = torch.randn((1, N, 512), generator=gen).to(DEV)
+    ((q * gq).sum() + (k * gk).sum()).backward()
+    assert rel_err(q[0].detach().cpu(), g["queries"]) <= 5e-5 and rel_err(k[0].detach().cpu(), g["keys"]) <= 5e-5
+    assert rel_err(img.grad[0].cpu(), g["dimage"]) <= 5e-4
+    for n, prm in m.named_parameters():
+        gn = float(g["g." + name + "." + n + ".norm"])
+        got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+        if gn == 0.0:
+            assert float(got.abs().max()) <= 1e-10, n
+        else:
+            check_grad("g." + name + "." + n, got, g, 1e-3)
 
 
 def _args(**kw):

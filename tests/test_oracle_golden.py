@@ -241,10 +241,11 @@ def test_twoway_on_a_ct_map(tag):
             check_grad("g." + n, got, g, 2e-4)
 
 
-def test_twoway_alignment_base_ct():
+@pytest.mark.parametrize("tag", ["twoway_ctbase_N64", "twoway_ctbase_D160"])
+def test_twoway_alignment_base_ct(tag):
     """`--alignment_base CT` (sam/transformer.py:78-86): the CT map's D tokens are the QUERIES (point embedding) of the two-way
     transformer, the image tokens the keys - the oracle restatement against the reference's own forward."""
-    g = load_golden("twoway_ctbase_N64")
+    g = load_golden(tag)
     seed = int(g["seed"])
     N, D, hw = [int(v) for v in g["shape"]]
     name = "TwoWayTransformer_Pth"
