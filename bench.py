@@ -58,7 +58,13 @@ def parse_args(argv=None):
                          "step, which then sits in the 256 MB Infinity Cache from one step to the next - no loader does that)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--regions", type=int, default=7,
+                    help="the timed region (exactly --steps steps between two barrier + synchronize pairs) is run this many times "
+                         "back to back; ms_per_step is the MEDIAN region, every region is listed in ms_per_step_runs")
     ap.add_argument("--bags-per-gpu", type=int, default=32)
+    ap.add_argument("--global-bags", type=int, default=0,
+                    help="strong scaling (SURVEY 8d, config 4 for W < 8): G bags in total, G / W per GPU (G % W == 0); "
+                         "default 0 = weak scaling with --bags-per-gpu bags on every GPU")
     ap.add_argument("--patches", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -71,7 +77,10 @@ def parse_args(argv=None):
                     "one all-reduce + Adam every ACCUM passes; a 'step' stays one pass over one batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 objects")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 / ragged-regime objects")
+    ap.add_argument("--no-ragged", action="store_true", help="skip configs.ragged_image / ragged_fusion / ragged_ct_pth "
+                    "(one ragged bag per step fed from the HBM-resident cohort)")
+    ap.add_argument("--only-ragged", default="", help="(tools) run just this regime object (image | fusion | ct_pth) and print it")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (default: eager; "
                     "the step is GPU-bound either way)")
     ap.add_argument("--dump", default="", help="(tests) rank 0 saves loss + flat gradient of the first step here")
@@ -463,6 +472,190 @@ def config3_fusion(dev, steps=30, warmup=4):
                        "oracle": "fp32 oracle fused_forward (model/aggregator.py:134-209 wiring)", "tolerance": 1e-3}}
 
 
+# ----------------------------------------------------------------------------------------------- the authors' regime (N=1)
+def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
+    """One ragged bag per step, N ~ U[2000, 15592] changing every step (reference run_train.sh:81: --batch_size = number of
+    GPUs; dataset.py:366-393: bags of up to 15 592 patches, a fresh 10 - 20 % patch drop every epoch), model.train().
+    kind: "image" (image-only fused step, F = 512), "fusion" (aggregator(args): pathology + one note, ViT-B/32 text embedding
+    cached per note), "ct_pth" (the authors' own run: CT + pathology, loss_point CT-Pth-Last + textCosSim).
+    Three ways of feeding the SAME replayed per-bucket graphs, each timed end to end over whole epochs of the cohort:
+      resident   cohort.DeviceCohort: bags in HBM, the epoch's drop drawn on the device, one gather launch per step
+                 (`ms_per_step`, `feed`: what train_ddp.py --hip_graph 1 runs)
+      replay     the step alone: the bag already on the device, one D2D copy into the bucket (round 3's figure)
+      host       round 3's train_ddp loop: host bag -> zero-padded [1, n, F] pageable tensor -> .to(dev) -> D2D into the bucket
+    Parity: two bags of the cohort, eval mode, fed through the cohort, against the oracle on the rows oracle/cohort.py says
+    the device drew."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from mil_amd import synthetic as syn
+    from mil_amd.cohort import DeviceCohort, keep_count
+    from oracle import cohort as oc
+    from oracle import mil_oracle as orc
+    fusion = kind != "image"
+    with_ct = kind == "ct_pth"
+    F = 768 if fusion else 512
+    steps = steps or (3 * n_bags if not fusion else 2 * n_bags)
+    rng = np.random.default_rng(0)
+    ns = [int(v) for v in rng.integers(2000, 15593, size=n_bags)]
+    keeps = [0.9 if i % 2 else 0.8 for i in range(n_bags)]            # biopsies / resections (dataset.py:374-381)
+    off = np.concatenate([[0], np.cumsum(ns)])
+    big = torch.randn((int(off[-1]), F), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    labels = syn.make_labels(3, n_bags)
+    ids = syn.make_token_ids(2, n_bags, 1)
+    co = DeviceCohort(lambda j: big[off[j]:off[j + 1]], labels, dev, ids=ids, keep=keeps, seed=1234, lengths=ns)
+    CT_SHAPE = (512, 160, 2, 2)
+    ct = syn.make_ct_map(5, 1, CT_SHAPE[1], CT_SHAPE[2]).to(dev) if with_ct else None
+
+    if not fusion:
+        from mil_amd.trainer import ImageOnlyTrainer, RaggedImageOnlyStepper
+        p = syn.image_only_params(1, L=F)
+
+        def make(train=True):
+            tr = ImageOnlyTrainer(p, dev, train_mode=train, counted=True)
+            return tr, RaggedImageOnlyStepper(tr, B=1)
+        tr, st = make()
+
+        def feed_step(st_, j):
+            k = co.lengths([j])[0]
+            slot = st_.slot(k)
+            ks = co.feed([j], slot.x, slot.layout.bag_len_dev, slot.y)
+            return st_.step(slot, ks, on_device=True)
+
+        def put_step(st_, xrows, yrow, k):
+            slot = st_.slot(k)
+            slot.x[:k].copy_(xrows, non_blocking=True)
+            slot.y.copy_(yrow, non_blocking=True)
+            return st_.step(slot, [k])
+        graphs = lambda st_: sum(s_.graph is not None for s_ in st_.slots.values())      # noqa: E731
+    else:
+        from mil_amd.fusion_step import RaggedFusionStepper
+        from mil_amd.model.utils import get_model
+        from mil_amd.optim import FlatAdam
+        args = SimpleNamespace(modality=["CT", "pathology"] if with_ct else ["pathology"], model_pathology="ABMIL", model_CI="CLIP",
+                               aggregator="ABMIL", num_classes=2, learnablePrompt=0, n_ctx=8, clinical_features=["f"] * 9,
+                               alignment_base="CI", model_CT="resnetMC3_18", clip_layers=12, cache_text=1)
+        torch.manual_seed(1234)
+        model = get_model(args).to(dev)
+        with torch.no_grad():
+            co.set_text(torch.cat([model.clinic_extractor(co.ids[i:i + 16]) for i in range(0, n_bags, 16)], 0))
+
+        def make(train=True):
+            model.train(train)
+            opt = FlatAdam([q for q in model.parameters() if q.requires_grad], lr=1e-5 if train else 0.0, weight_decay=1e-7,
+                           counted=True)
+            return opt, RaggedFusionStepper(model, opt, B=1, ct_shape=CT_SHAPE if with_ct else None,
+                                            loss_mult=3.0 if with_ct else 1.0, cossim=with_ct)
+        tr, st = make()
+
+        def feed_step(st_, j):
+            k = co.lengths([j])[0]
+            slot = st_.slot(k)
+            ks = co.feed([j], slot.x, slot.bucket.len_dev, slot.y, text_dst=slot.text)
+            if with_ct:
+                slot.ct.copy_(ct, non_blocking=True)
+            return st_.step(slot, ks, on_device=True)
+
+        def put_step(st_, xrows, yrow, k, j=0):
+            slot = st_.slot(k)
+            slot.x[:k].copy_(xrows, non_blocking=True)
+            slot.y.copy_(yrow, non_blocking=True)
+            slot.text.copy_(co.text[j:j + 1], non_blocking=True)
+            if with_ct:
+                slot.ct.copy_(ct, non_blocking=True)
+            return st_.step(slot, [k])
+        graphs = lambda st_: len(st_.gs._graphs)      # noqa: E731
+
+    def epoch_order(e):
+        return [int(v) for v in np.random.default_rng(100 + e).permutation(n_bags)]
+
+    # ---- resident cohort, end to end: draw per epoch + feed per step + replay
+    done, e = 0, 0
+    while done < n_bags:                              # one warm epoch: every bucket captured
+        co.draw_epoch(e)
+        for j in epoch_order(e):
+            feed_step(st, j)
+            done += 1
+        e += 1
+    torch.cuda.synchronize()
+    t0, done = time.perf_counter(), 0
+    while done < steps:
+        co.draw_epoch(e)
+        for j in epoch_order(e):
+            if done >= steps:
+                break
+            feed_step(st, j)
+            done += 1
+        e += 1
+    torch.cuda.synchronize()
+    ms_res = (time.perf_counter() - t0) / steps * 1e3
+    n_graphs = graphs(st)
+    # ---- the step alone (device-resident bag, one D2D copy): comparable with round 3's 0.149 / 1.07 / 1.8 ms
+    seq = [epoch_order(e + 1)[i % n_bags] for i in range(steps)]
+    ylab = co.labels
+    for j in seq[:8]:
+        put_step(st, big[off[j]:off[j] + co.k_train[j]], ylab[j:j + 1], co.k_train[j], *([j] if fusion else []))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in seq:
+        put_step(st, big[off[j]:off[j] + co.k_train[j]], ylab[j:j + 1], co.k_train[j], *([j] if fusion else []))
+    torch.cuda.synchronize()
+    ms_replay = (time.perf_counter() - t0) / steps * 1e3
+    # ---- round 3's loop: the bag comes from pageable host memory every step
+    host_bags = {j: big[off[j]:off[j] + co.k_train[j]].cpu() for j in seq[:host_steps]}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in seq[:host_steps]:
+        xb = torch.zeros((1, co.k_train[j], F))        # collate_bags' zero-pad to [B, maxN, F] (dataset.py:386-391)
+        xb[0] = host_bags[j]
+        xd = xb.to(dev, non_blocking=True)              # pageable: the copy is synchronous
+        put_step(st, xd[0], labels[j:j + 1].to(dev, non_blocking=True), co.k_train[j], *([j] if fusion else []))
+    torch.cuda.synchronize()
+    ms_host = (time.perf_counter() - t0) / host_steps * 1e3
+    del host_bags
+    # ---- parity: eval mode, two bags fed through the cohort vs the oracle on the rows the numpy restatement selects
+    tr_e, st_e = make(train=False)
+    if fusion:
+        sd = {k_: v_.detach().cpu() for k_, v_ in model.state_dict().items()}
+    co.draw_epoch(10 ** 6)
+    dl, top1 = 0.0, True
+    for j in (0, n_bags - 1):
+        out = feed_step(st_e, j)
+        rows = oc.patch_drop_select(ns[j], keep_count(ns[j], keeps[j]), j, co.seed, 10 ** 6)
+        xb = big[off[j]:off[j + 1]].cpu()[rows]
+        with torch.no_grad():
+            if not fusion:
+                o = orc.image_only_forward(xb, p)
+                z, pr = tr_e.last["logits"].cpu(), out[1].cpu()
+            elif with_ct:
+                o = orc.fused_forward_ct_pth(ct[0].cpu(), xb, ids[j], sd)
+                z, pr = out[2].cpu(), out[1].cpu()
+            else:
+                o = orc.fused_forward(xb, ids[j], sd)
+                z, pr = out[2].cpu(), out[1].cpu()
+        dl = max(dl, float((z - o["logits"]).abs().max()))
+        top1 = top1 and bool(torch.equal(pr.argmax(-1), o["prob"].argmax(-1)))
+    mean_k = float(np.mean(co.k_train))
+    bytes_step = mean_k * F * 4
+    work = {"image": f"image-only fused step (fwd + BCE + bwd + Adam), F = {F}",
+            "fusion": "aggregator(args): fc_pathology + cached ViT-B/32 note embedding + TwoWay fusion + ABMIL + head, fwd + BCE + bwd + Adam",
+            "ct_pth": "aggregator(args), modality [CT, pathology], CT feature map [512, 160, 2, 2] as input, loss_point CT-Pth-Last "
+                      "+ textCosSim (run_train.sh:81), fwd + loss + bwd + Adam"}[kind]
+    res = {"workload": f"1 ragged bag per step, {n_bags}-bag cohort N ~ U[2000, 15592] (mean {np.mean(ns):.0f}, kept {mean_k:.0f} "
+                       f"after the per-epoch 10/20 % drop) x {F}, model.train(); {work}",
+           "ms_per_step": round(ms_res, 4), "bags_per_s": round(1e3 / ms_res, 1), "steps": steps, "graphs": n_graphs,
+           "feed": "HBM-resident cohort: per-epoch patch drop drawn on the device (mil_patch_drop_select), one gather launch per "
+                   "step into the bucket (mil_cohort_feed)",
+           "replay_only_ms_per_step": round(ms_replay, 4), "feed_overhead": round(ms_res / ms_replay - 1.0, 4),
+           "from_host_pageable_ms_per_step": round(ms_host, 4),
+           "from_host_note": f"{host_steps} steps of round 3's loop: zero-padded pageable host bag -> .to(dev) -> D2D into the bucket",
+           "feed_bytes_per_step": int(2 * bytes_step), "feed_bytes_note": "gather: kept rows read once from the cohort + written once to the bucket",
+           "parity": {"bags_checked": [0, n_bags - 1], "max_abs_dlogit": dl, "top1_equal": top1, "tolerance": 1e-3,
+                      "oracle": "eval mode; oracle forward on the rows oracle/cohort.py selects for the same (seed, epoch, bag)"}}
+    del co, big
+    return res
+
+
 # ----------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
     import torch
@@ -472,6 +665,7 @@ def run_rank(args):
     from mil_amd.bags import BagLayout
     from mil_amd.trainer import ImageOnlyTrainer
 
+    strict_fail = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -501,6 +695,11 @@ def run_rank(args):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, {args.gpus} expected")
 
     B, N, L, C = args.bags_per_gpu, args.patches, args.dim, 2
+    strong = args.global_bags > 0
+    if strong:
+        if args.global_bags % world:
+            raise SystemExit(f"bench.py: --global-bags {args.global_bags} is not a multiple of the {world} ranks")
+        B = args.global_bags // world
     params = syn.image_only_params(1234, L=L)
     tr = ImageOnlyTrainer(params, dev, world_size=world, train_mode=bool(args.train_mode), accum=args.accum)
     nb = max(1, args.batches) if not args.graph else 1       # a captured step replays its static buffers
@@ -547,16 +746,22 @@ def run_rank(args):
     # left waiting in the barrier - the launcher must notice, stop them and return non-zero
     if os.environ.get("MIL_BENCH_FAIL_RANK") == str(rank):
         os._exit(3)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY --steps steps between a barrier + synchronize on both sides - and that region --regions times back to back: at
+    # the driver's flags one region is 20 steps = 5 ms, where a single 0.3 ms host hiccup moves the figure by 6 % (round 3's
+    # driver run read 8 % below every other run of the same command); the median region is what the line reports
+    regions = []
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        regions.append(time.perf_counter() - t0)
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(regions, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # per region: the slowest rank
+        regions = [float(v) for v in t.tolist()]
+    elapsed = sorted(regions)[len(regions) // 2]
     loss = float(tr.loss_sum.item())
 
     rccl = None
@@ -588,9 +793,15 @@ def run_rank(args):
         line = {
             "metric": "bags/sec fwd+bwd, N=1024 patches D=512", "value": round(value, 1), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "ms_per_step_runs": [round(r / args.steps * 1e3, 4) for r in regions],
+            "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+            "timing": f"median of {len(regions)} timed regions of exactly {args.steps} steps each (barrier + synchronize on both "
+                      "sides, max over ranks per region)",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
             "config": {"workload": f"{B} bags/GPU x {N} patches x {L} dims, image-only gated-attention MIL "
-                                   f"fwd+BCE+bwd+allreduce+Adam (BASELINE config 2; x{world} GPUs = {world * B} bags)",
+                                   f"fwd+BCE+bwd+allreduce+Adam (BASELINE config 2; x{world} GPUs = {world * B} bags"
+                                   + (", strong scaling: the global batch is fixed - SURVEY 8d's config-4 reading" if strong else "") + ")",
                        "bags_per_gpu": B, "patches": N, "dim": L, "global_bags": world * B,
                        "parallelism": f"dp{world}", "loss": round(loss, 6), "mode": mode, "accum": args.accum,
                        "batches_cycled": nb,
@@ -608,7 +819,8 @@ def run_rank(args):
         if not args.no_breakdown:
             # each launch group of the step, timed INSIDE the running step (HIP events between the groups, on the stream the
             # kernels are launched on; mil_image_only_step_profile) - the figure rocprofv3's kernel trace of the step reports
-            kb, ev_step = tr.time_step_groups(x, lay, y, 50)
+            rot = list(zip(xs, ys)) if nb > 1 else None       # the same rotation as the timed loop
+            kb, ev_step = tr.time_step_groups(x, lay, y, 50, rot=rot)
             kb_alone = kernel_breakdown(tr, x, lay, y)
             names = {"gate_fwd_with_pool_fused": "k_gate_fwd2<train, pool pass in the epilogue>", "gate_fwd": "k_gate_fwd2",
                      "gate_bwd_dw": "k_gate_bwd_dw2", "gate_bwd_dw_reduce_head": "k_gate_bwd_dw_bf16 (+ fold)", "gate_bwd_dw_reduce_head_adam": "k_gate_bwd_dw_bf16 (+ fold with Adam)"}
@@ -623,10 +835,19 @@ def run_rank(args):
                                 if (B, N, L, args.dtype) == (32, 1024, 512, "f32") else None,
                                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, bytes per launch)",
                                 "flops_per_launch": flops[dom], "ms_per_launch": round(kb[dom], 4),
-                                "timing": "HIP events inside the running step, 50 steps right after the timed region"}
+                                "timing": "HIP events inside the running step, 50 steps right after the timed region, rotating "
+                                          f"through the same {nb} batch(es) as the timed loop"}
             line["kernels_ms"] = {k: round(v, 4) for k, v in kb.items()}
             line["kernels_ms_sum"] = round(sum(kb.values()), 4)
             line["kernels_ms_event_step"] = round(ev_step, 4)
+            # the step as the events see it (its launches + the event gaps) against the host-timed median: they describe the
+            # same loop on the same batches, so more than 5 % apart means one of the two measurements is off
+            diff = abs(ev_step - ms_step) / ms_step
+            line["consistency"] = {"ms_per_step": round(ms_step, 4), "kernels_ms_event_step": round(ev_step, 4),
+                                   "kernels_ms_sum": round(sum(kb.values()), 4), "rel_diff": round(diff, 4), "ok": diff <= 0.05}
+            if diff > 0.05:
+                print(f"bench.py: WARNING - the host-timed step ({ms_step:.4f} ms) and the event-timed step ({ev_step:.4f} ms) "
+                      f"differ by {diff:.1%} (> 5 %): the roofline objects do not describe the headline", file=sys.stderr)
             line["kernels_ms_standalone"] = {k: round(v, 4) for k, v in kb_alone.items()}
             line["kernels_ms_note"] = ("kernels_ms: launch groups of the step as it runs (world size 1: keep bits drawn by the "
                                        "forward launch, pool partial pass in its epilogue, Adam inside the reduce launch); "
@@ -637,7 +858,7 @@ def run_rank(args):
                 # the 4 R L D flop count does not contain, so the MFMA fraction of the bare products is reported beside it
                 from mil_amd.trainer import ImageOnlyTrainer
                 tr_e = ImageOnlyTrainer(params, dev, train_mode=False)
-                kbe, _ = tr_e.time_step_groups(x, lay, y, 30)
+                kbe, _ = tr_e.time_step_groups(x, lay, y, 30, rot=rot)
                 line["roofline_eval_mode"] = {
                     "bound": "mfma", "kernel": names[dom], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "achieved": round(flops[dom] / (kbe[dom] * 1e-3) / 1e12, 2),
@@ -648,7 +869,11 @@ def run_rank(args):
                 line["roofline_pool"] = pool_roofline(dev)
         if world == 1 and not args.no_configs and args.dtype == "f32":
             cfgs = {}
-            for name, fn in (("cfg5", config5_bf16), ("cfg3", config3_fusion)):
+            jobs = [("cfg5", config5_bf16), ("cfg3", config3_fusion)]
+            if not args.no_ragged:
+                jobs += [("ragged_image", lambda d: ragged_regime(d, "image")), ("ragged_fusion", lambda d: ragged_regime(d, "fusion")),
+                         ("ragged_ct_pth", lambda d: ragged_regime(d, "ct_pth"))]
+            for name, fn in jobs:
                 try:
                     cfgs[name] = fn(dev)
                 except Exception as e:      # noqa: BLE001  (the headline line must still be printed)
@@ -658,13 +883,23 @@ def run_rank(args):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(N, L)
         print(json.dumps(line), flush=True)
+        if os.environ.get("MIL_BENCH_STRICT") == "1" and not line.get("consistency", {}).get("ok", True):
+            strict_fail = True
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if strict_fail:
+        raise SystemExit(3)
 
 
 def main():
     args = parse_args()
+    if args.only_ragged:
+        import torch
+        import mil_amd  # noqa: F401
+        torch.cuda.set_device(0)
+        print(json.dumps(ragged_regime(torch.device("cuda", 0), args.only_ragged)), flush=True)
+        return
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -40,7 +40,7 @@ extern "C" {
 #define MIL_SMALL_ROWS 64  /* most rows the token-side mil_linear_small_* entry points accept */
 
 /* Library/ABI version, for the host mirror's load-time check. */
-int mil_abi_version(void);   /* 5 */
+int mil_abi_version(void);   /* 6 */
 
 /* ---- dropout keep bits (train mode) -------------------------------------------------------
  * model.train() upstream drops the bag rows with p = 0.5 BEFORE the gate and pools the dropped rows
@@ -62,6 +62,49 @@ int mil_counter_add(int32_t* counter, int v, void* stream);
 int mil_set_i32(int32_t* dst, const int32_t* values_host, int n, void* stream);
 /* t[row][col] = keep ? t * scale : 0, in place (dropout backward for a consumer that cannot fold the mask in). */
 int mil_dropout_apply_bits(float* t, const uint32_t* bits, int rows, int cols, float scale, void* stream);
+
+/* ---- HBM-resident cohort: per-epoch patch drop + per-step feed (csrc/cohort.hip) -----------------
+ * Replaces the reference's host-side input pipeline for the pathology bags: dataset.py:366-393 (np.load of one
+ * `<patient>.npy` [n, 768] per item, `sorted(random.sample(range(n), int(n * keep)))` with keep = 0.9 / 0.8, zero-pad) and
+ * train_ddp.py:193,274-293 (DataLoader workers, pinned memory, `.cuda(non_blocking=True)`).  The cohort lives in ONE flat
+ * device buffer `cohort [total_rows, L]`, bag j owning rows [row_off[j], row_off[j+1]).
+ *
+ * mil_patch_drop_select: one launch per epoch for ALL nbags bags.  sel[out_off[j] + i], i < keep[j], = the cohort rows
+ * (absolute row numbers) of a uniformly random keep[j]-subset of bag j's rows in ASCENDING order - the rows holding the
+ * keep[j] smallest 32-bit keys, ties by row number, key of row i of bag j = word (i & 3) of
+ * Philox4x32-10(counter = (i >> 2, j, epoch_lo, epoch_hi), key = seed ^ 0x70617463685F6472).  keep[j] == n_j copies the
+ * identity (no drop).  row_off [nbags + 1], keep [nbags], out_off [nbags + 1] are device int32 arrays.  bag0: the tables
+ * describe bags bag0 .. bag0 + nbags - 1 of the cohort (j in the counter = bag0 + table slot), so a bag streamed from the host
+ * alone (cohort.HostFeed) draws the subset it would draw as part of the resident cohort. */
+int mil_patch_drop_select(const int32_t* row_off, const int32_t* keep, const int32_t* out_off, int nbags, int bag0,
+                          uint64_t seed, uint64_t epoch, int32_t* sel, void* stream);
+
+#define MIL_FEED_MAX_BAGS 8
+#define MIL_FEED_MAX_AUX 4
+/* One step's bags, by value (a HOST struct: everything in it is known on the host without a sync - keep counts follow
+ * from the bag lengths).  The nb bags land back to back in dst from row dst_row0; bag b contributes rows[b] rows:
+ * cohort rows sel[sel_off[b] + i] when `sel` is given, else src_row0[b] + i (no drop).  The same launch writes
+ * len_dev[dst_bag0 + b] = rows[b] and, for each of the naux side tables (labels [nbags, C] fp32, token ids [nbags, P, 77]
+ * int64, cached text embeddings [nbags, P, 512] fp32, ...), copies the aux_words[a] 4-byte words of table row bag_id[b] to
+ * row dst_bag0 + b of aux_dst[a]. */
+typedef struct mil_cohort_feed_desc {
+    uint32_t struct_bytes;          /* sizeof(mil_cohort_feed_desc) */
+    int32_t nb;                     /* 1 .. MIL_FEED_MAX_BAGS */
+    int32_t L;                      /* row width in floats, L % 4 == 0 */
+    int32_t dst_row0, dst_bag0;     /* first output row / first output bag slot */
+    int32_t naux;                   /* 0 .. MIL_FEED_MAX_AUX */
+    int32_t sel_off[MIL_FEED_MAX_BAGS];
+    int32_t src_row0[MIL_FEED_MAX_BAGS];
+    int32_t rows[MIL_FEED_MAX_BAGS];
+    int32_t bag_id[MIL_FEED_MAX_BAGS];
+    int32_t aux_words[MIL_FEED_MAX_AUX];
+    const void* aux_table[MIL_FEED_MAX_AUX];
+    void* aux_dst[MIL_FEED_MAX_AUX];
+} mil_cohort_feed_desc;
+/* dst [>= dst_row0 + sum rows, L] - typically the static input buffer of a capacity bucket; rows behind the bags are left
+ * as they are (every consumer masks them by the device-side lengths).  len_dev nullable. */
+int mil_cohort_feed(const float* cohort, const int32_t* sel, const mil_cohort_feed_desc* d, float* dst, int32_t* len_dev,
+                    void* stream);
 
 /* ---- tile map ---------------------------------------------------------------------------
  * The attention-pool kernels split every bag into tiles of MIL_POOL_TILE rows.
@@ -771,6 +814,11 @@ int mil_build_fusion_segs_tail(const int32_t* len_dev, int B, int nseg, const in
  * event.  Synchronises the stream.  The step really executes (parameters move on when MIL_STAGE_ADAM is in a group). */
 int mil_image_only_step_profile(const mil_image_only_step* a, const uint32_t* groups, int ngroups, int warm, int iters,
                                 float* ms_out, void* stream);
+/* The same with the input batch ROTATING: iteration i runs on (xs[i % nrot], ys[i % nrot]) (host arrays of nrot <= 64 device
+ * pointers, every batch of the descriptor's shape) - the cache regime of a loop that cycles through several resident
+ * batches (bench.py --batches); one batch alone stays in the Infinity Cache from step to step.  nrot == 0: as above. */
+int mil_image_only_step_profile_rot(const mil_image_only_step* a, const void* const* xs, const float* const* ys, int nrot,
+                                    const uint32_t* groups, int ngroups, int warm, int iters, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mil_hip.h")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/mil_hip.h one to one
@@ -60,6 +60,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_image_only_step_run": (c_int, [_P, _P]),
     "mil_image_only_step_time": (c_int, [_P, c_uint32, c_int, c_int, _P, _P]),
     "mil_image_only_step_profile": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "mil_image_only_step_profile_rot": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "mil_patch_drop_select": (c_int, [_P, _P, _P, c_int, c_int, c_uint64, c_uint64, _P, _P]),
+    "mil_cohort_feed": (c_int, [_P, _P, _P, _P, _P, _P]),
     "mil_cast_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "mil_gate_scores_fwd_bf16": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, _P, c_float, _P]),
     "mil_attn_pool_partial_bf16": (c_int, [_P] * 3 + [c_int, c_int, _P, _P, c_float, _P]),
@@ -168,6 +171,15 @@ class SmallDwDesc(ctypes.Structure):
 
 
 SMALL_DW_MAX = 32
+FEED_MAX_BAGS, FEED_MAX_AUX = 8, 4
+
+
+class CohortFeedDesc(ctypes.Structure):
+    """Mirror of mil_cohort_feed_desc (include/mil_hip.h); layout checked against the header by tests/test_abi.py."""
+    _fields_ = [("struct_bytes", c_uint32), ("nb", c_int32), ("L", c_int32), ("dst_row0", c_int32), ("dst_bag0", c_int32),
+                ("naux", c_int32), ("sel_off", c_int32 * FEED_MAX_BAGS), ("src_row0", c_int32 * FEED_MAX_BAGS),
+                ("rows", c_int32 * FEED_MAX_BAGS), ("bag_id", c_int32 * FEED_MAX_BAGS), ("aux_words", c_int32 * FEED_MAX_AUX),
+                ("aux_table", c_void_p * FEED_MAX_AUX), ("aux_dst", c_void_p * FEED_MAX_AUX)]
 
 
 class ImageOnlyStep(ctypes.Structure):

@@ -213,3 +213,12 @@ class DeviceBagLayout:
         self.lengths = lengths
         upload_lengths(self.bag_len_dev, lengths)
         return self
+
+    def note_lengths(self, lengths):
+        """The lengths are ALREADY in bag_len_dev (cohort.DeviceCohort.feed wrote them in its gather launch): host
+        bookkeeping only, no upload."""
+        lengths = [int(v) for v in lengths]
+        if len(lengths) != self.B or sum(lengths) > self.R:
+            raise ValueError(f"{len(lengths)} bags / {sum(lengths)} rows do not fit a layout of {self.B} bags / {self.R} rows")
+        self.lengths = lengths
+        return self

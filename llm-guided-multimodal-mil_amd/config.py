@@ -69,6 +69,12 @@ def create_arg_parser(argv=None):
     p.add_argument("--path_data_pathology", type=str, default="", help="directory of <patientid>.npy bags (dataset.py:367)")
     p.add_argument("--index_json", type=str, default="", help="cohort index; default <path_data_pathology>/index.json")
     p.add_argument("--augmentation", type=int, default=1, help="train-time patch drop (dataset.py:374-381)")
+    p.add_argument("--resident_cohort", type=int, default=1,
+                   help="with --hip_graph 1: load every bag ONCE into HBM (cohort.DeviceCohort), draw the per-epoch patch drop "
+                        "on the device and feed each step by one gather launch; 0 = the host pipeline per step (np.load, "
+                        "random.sample drop, zero-pad, pageable copy).  Falls back to 0 by itself when the cohort does not fit")
+    p.add_argument("--patch_keep", type=float, default=1.0, help="synthetic cohorts: keep fraction of the per-epoch patch drop "
+                   "(on-disk cohorts use the reference's 0.9 / 0.8 per bag kind)")
     # ---- synthetic data (no hospital data offline)
     p.add_argument("--synthetic", default=[1024, 768, 64], type=arg_as_list,
                    help="[patches per bag, patch feature dim, bags in the synthetic cohort]")

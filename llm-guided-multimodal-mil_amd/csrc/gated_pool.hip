@@ -1521,7 +1521,7 @@ static inline int split_plan(int R, int L, int* KC_out) {
     return (R + kc - 1) / kc;
 }
 
-extern "C" int mil_abi_version(void) { return 5; }
+extern "C" int mil_abi_version(void) { return 6; }
 
 // Small batches (the authors train with ONE bag per GPU: R = 1 000 - 15 000 rows): 128-row tiles would leave most CUs
 // idle (8 workgroups for 1024 patches, each walking all of K: the kernel takes its full ~100 us for 1/32 of the

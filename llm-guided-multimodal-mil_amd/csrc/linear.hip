@@ -512,7 +512,7 @@ extern "C" size_t mil_gemm_workspace_floats(int M, int N, int K, int a_mode) {
 static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc, int M,
                      int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
                      float* workspace, size_t workspace_floats, float* aux, int ldaux, int aux_mode, void* stream,
-                     const int32_t* rows_dev = nullptr) {
+                     const int32_t* rows_dev = nullptr, int* rows_honoured = nullptr) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return MIL_EINVAL;
     if (M == 0 || N == 0) return MIL_OK;
     if ((lda & 3) || (ldb & 3) || act < 0 || act > 3) return MIL_EINVAL;
@@ -547,6 +547,7 @@ static int gemm_impl(const float* A, int lda, int a_mode, const float* B, int ld
             else
                 hipLaunchKernelGGL(k_gemm64<1>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, aux, ldaux, aux_mode, rows_dev);
             MIL_CHECK_LAUNCH();
+            if (rows_honoured != nullptr) *rows_honoured = 1;
             return MIL_OK;
         }
     }
@@ -630,14 +631,40 @@ extern "C" int mil_gemm(const float* A, int lda, int a_mode, const float* B, int
                      workspace_floats, nullptr, 0, AUX_NONE, stream);
 }
 
+// C rows [64 * ceil(rows_dev / 64), M) <- 0: what k_gemm64 writes for the tiles wholly behind the true row count, for the
+// dispatches that do not read rows_dev themselves (small-tile plan, split-K, the 128-row kernel: ADVICE r3 - their padding
+// rows held act(stale x W + b), harmless today, garbage for any future reader of those rows).
+__global__ __launch_bounds__(256) void k_zero_rows_from(float* __restrict__ C, int ldc, int M, int N, const int32_t* __restrict__ rows_dev) {
+    const int first = (__builtin_amdgcn_readfirstlane(rows_dev[0]) + 63) & ~63;
+    const int row0 = blockIdx.x * 64;
+    if (row0 < first) return;
+    const int n4 = N >> 2;
+    for (int idx = threadIdx.x; idx < 64 * n4; idx += 256) {
+        const int row = row0 + idx / n4, j = 4 * (idx % n4);
+        if (row < M) *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + j) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (N & 3)
+        for (int idx = threadIdx.x; idx < 64 * (N & 3); idx += 256) {
+            const int row = row0 + idx / (N & 3), j = (N & ~3) + idx % (N & 3);
+            if (row < M) C[(size_t)row * ldc + j] = 0.f;
+        }
+}
+
 // rows_dev (nullable, a_mode 0): device int32 with the TRUE number of rows of A / C (<= M; M then is the capacity the launch
-// is sized for - a bucket of fusion_step.RaggedFusionStepper).  Tiles wholly behind it write zeros instead of products.
+// is sized for - a bucket of fusion_step.RaggedFusionStepper).  Rows from 64 * ceil(rows_dev / 64) on are ZERO on return
+// (accumulate == 0) whichever kernel the shape dispatches to; rows between rows_dev and that boundary are unspecified.
 extern "C" int mil_gemm_rows(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,
                              int M, int N, int K, const float* bias, int act, const float* residual, int ldr, int accumulate,
                              float* workspace, size_t workspace_floats, const int32_t* rows_dev, void* stream) {
     if (rows_dev != nullptr && a_mode != 0) return MIL_EINVAL;
-    return gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
-                     workspace_floats, nullptr, 0, AUX_NONE, stream, rows_dev);
+    int honoured = 0;
+    const int rc = gemm_impl(A, lda, a_mode, B, ldb, b_mode, C, ldc, M, N, K, bias, act, residual, ldr, accumulate, workspace,
+                             workspace_floats, nullptr, 0, AUX_NONE, stream, rows_dev, &honoured);
+    if (rc != MIL_OK || rows_dev == nullptr || honoured || accumulate || M <= 0 || N <= 0) return rc;
+    if ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return MIL_EINVAL;
+    hipLaunchKernelGGL(k_zero_rows_from, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, C, ldc, M, N, rows_dev);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
 }
 
 extern "C" int mil_gemm_aux(const float* A, int lda, int a_mode, const float* B, int ldb, int b_mode, float* C, int ldc,

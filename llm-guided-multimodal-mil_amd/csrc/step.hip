@@ -268,20 +268,29 @@ extern "C" int mil_image_only_step_time(const mil_image_only_step* a, uint32_t s
 // and not as a stand-alone repetition of one kernel.  groups[i] is the stage mask of group i (run in order, each as
 // one mil_image_only_step_run call; MIL_STAGE_POOL_FUSED and friends ride along as given); ms_out[i] = average
 // duration of group i, ms_out[ngroups] = average of first-event -> last-event (the step with its event gaps).
-extern "C" int mil_image_only_step_profile(const mil_image_only_step* a, const uint32_t* groups, int ngroups, int warm,
-                                           int iters, float* ms_out, void* stream) {
+// nrot > 0: iteration i runs on batch (xs[i % nrot], ys[i % nrot]) - the same rotation as the caller's timed loop, so the
+// groups are timed in the cache regime the headline step runs in (one resident batch stays in the Infinity Cache).
+extern "C" int mil_image_only_step_profile_rot(const mil_image_only_step* a, const void* const* xs, const float* const* ys,
+                                               int nrot, const uint32_t* groups, int ngroups, int warm, int iters,
+                                               float* ms_out, void* stream) {
     if (!a || !groups || !ms_out || ngroups <= 0 || ngroups > 16 || iters <= 0 || iters > 256 || warm < 0) return MIL_EINVAL;
+    if (nrot < 0 || nrot > 64 || (nrot > 0 && (!xs || !ys))) return MIL_EINVAL;
+    for (int i = 0; i < nrot; ++i)
+        if (!xs[i] || !ys[i]) return MIL_EINVAL;
     mil_image_only_step s = *a;
     hipStream_t st = (hipStream_t)stream;
     const int per = ngroups + 1, nev = per * iters;
     hipEvent_t* ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * (size_t)nev);
     if (!ev) return MIL_EINVAL;
-    int made = 0, rc = MIL_OK;
+    int made = 0, rc = MIL_OK, turn = 0;
     for (; made < nev; ++made)
         if (hipEventCreate(&ev[made]) != hipSuccess) { rc = MIL_EINVAL; break; }
-    for (int i = 0; i < warm && rc == MIL_OK; ++i)
+    for (int i = 0; i < warm && rc == MIL_OK; ++i, ++turn) {
+        if (nrot > 0) { s.x = xs[turn % nrot]; s.y = ys[turn % nrot]; }
         for (int g = 0; g < ngroups && rc == MIL_OK; ++g) { s.stages = groups[g]; rc = mil_image_only_step_run(&s, stream); }
-    for (int i = 0; i < iters && rc == MIL_OK; ++i) {
+    }
+    for (int i = 0; i < iters && rc == MIL_OK; ++i, ++turn) {
+        if (nrot > 0) { s.x = xs[turn % nrot]; s.y = ys[turn % nrot]; }
         (void)hipEventRecord(ev[i * per], st);
         for (int g = 0; g < ngroups && rc == MIL_OK; ++g) {
             s.stages = groups[g];
@@ -303,4 +312,9 @@ extern "C" int mil_image_only_step_profile(const mil_image_only_step* a, const u
     for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
     free(ev);
     return rc;
+}
+
+extern "C" int mil_image_only_step_profile(const mil_image_only_step* a, const uint32_t* groups, int ngroups, int warm,
+                                           int iters, float* ms_out, void* stream) {
+    return mil_image_only_step_profile_rot(a, nullptr, nullptr, 0, groups, ngroups, warm, iters, ms_out, stream);
 }

@@ -11,7 +11,8 @@ from . import synthetic as syn
 
 class SyntheticBags(Dataset):
     def __init__(self, n_bags: int, patches: int, feat_dim: int, prompts: int = 1, num_classes: int = 2,
-                 seed: int = 1234, ragged: bool = False):
+                 seed: int = 1234, ragged: bool = False, keep: float = 1.0):
+        self.keep = float(keep)              # per-epoch patch drop of a resident cohort (cohort.DeviceCohort.from_dataset)
         self.n, self.patches, self.feat_dim, self.prompts, self.C, self.seed = n_bags, patches, feat_dim, prompts, num_classes, seed
         g = torch.Generator().manual_seed(seed)
         lo = max(1, patches // 2)
@@ -45,7 +46,8 @@ def load_cohort(args, mode: str, prompts: int):
         return ds, int(first.shape[1])
     n_patch, feat, n_bags = [int(v) for v in args.synthetic]
     seed = args.seed + (0 if mode == "train" else 1)
-    return SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, seed, args.ragged), feat
+    return SyntheticBags(n_bags, n_patch, feat, prompts, args.num_classes, seed, args.ragged,
+                         keep=float(getattr(args, "patch_keep", 1.0)) if mode == "train" else 1.0), feat
 
 
 def collate_bags(items):

@@ -115,10 +115,11 @@ class RaggedFusionStepper:
             loss = loss + ops.cosine_embedding_loss(toks[0].squeeze(1), toks[1].squeeze(1))
         return loss, prob, m.last_logits
 
-    def step(self, slot, lengths: Sequence[int]):
+    def step(self, slot, lengths: Sequence[int], on_device: bool = False):
         """One training step on the bags packed in slot.x (bag b at rows [sum(lengths[:b]), +lengths[b])).  Returns
-        (loss, prob, logits) - static tensors of the bucket's graph once it replays."""
-        slot.bucket.set_lengths(lengths)
+        (loss, prob, logits) - static tensors of the bucket's graph once it replays.  on_device: the lengths already sit in
+        slot.bucket.len_dev (the cohort's feed launch wrote them)."""
+        slot.bucket.set_lengths(lengths, on_device=on_device)
         body = lambda: self._body(slot)      # noqa: E731
         if not self.use_graph:
             self.eager_only += 1
@@ -190,8 +191,8 @@ class RaggedFusionInference:
         return prob
 
     @torch.no_grad()
-    def forward(self, slot, lengths: Sequence[int]):
-        slot.bucket.set_lengths(lengths)
+    def forward(self, slot, lengths: Sequence[int], on_device: bool = False):
+        slot.bucket.set_lengths(lengths, on_device=on_device)
         ent = self._graphs.get(slot.cap)
         if ent is None:
             n = self._seen[slot.cap] = self._seen.get(slot.cap, 0) + 1

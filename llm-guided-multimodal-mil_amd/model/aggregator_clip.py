@@ -24,7 +24,17 @@ class aggregator(nn.Module):
 
     def forward(self, x_list: List[torch.Tensor], lengths=None):
         M = self.extractor_pathology(x_list[0], lengths)
-        h = F.dropout(M, 0.25, True) if self.training else M
+        h = M
+        if self.training and M.shape[1] % 32 == 0:
+            # Dropout(.25) in front of the head (aggregator_clip.py / aggregator.py:129) from the SAME stream as the fused
+            # route: Philox keep words keyed like ABMIL.flat_head_loss's (module seed ^ golden ratio, the pass counter the
+            # patch mask of this forward has just advanced), not torch's generator (two training-mode streams)
+            ab = self.extractor_pathology
+            self.last_mbits = ops.dropout_keep_bits(M.shape[0], M.shape[1], ops.M_DROP_P, ab._drop_seed ^ 0x9E3779B97F4A7C15,
+                                                    0, M.device, offset_dev=ab._drop_ctr)
+            h = ops.dropout_bits(M, self.last_mbits, ops.M_DROP_SCALE)
+        elif self.training:
+            h = F.dropout(M, 0.25, True)
         p, z = ops.head_sigmoid(h, self.fc[1].weight, self.fc[1].bias)
         self.last_logits = z
         return M, p

@@ -67,6 +67,27 @@ def dropout_apply_bits(t, bits, scale: float):
     return t
 
 
+class _DropoutBits(torch.autograd.Function):
+    """y = keep ? t / (1 - p) : 0 through a packed keep-bit tensor; the backward reads the same bits."""
+
+    @staticmethod
+    def forward(ctx, t, bits, scale: float):
+        ctx.save_for_backward(bits)
+        ctx.scale = scale
+        return dropout_apply_bits(t.detach().clone().contiguous(), bits, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (bits,) = ctx.saved_tensors
+        return dropout_apply_bits(dy.detach().clone().contiguous(), bits, ctx.scale), None, None
+
+
+def dropout_bits(t, bits, scale: float):
+    """Differentiable form of dropout_apply_bits (out of place): the head's Dropout(.25) of the autograd route draws the same
+    Philox keep words as the fused tail (csrc/dropout.hip) instead of torch's generator."""
+    return _DropoutBits.apply(t, bits, scale)
+
+
 def gate_scores_fwd(x, Wv, bv, Wu, bu, w, b, save_gates: bool = True, xbits=None, xscale: float = 1.0):
     """scores [R], gates [R, 384] (or None).  ABMIL.py:52-54.  xbits: keep bits of the patch dropout (train mode)."""
     x = _f32c(x, "x")

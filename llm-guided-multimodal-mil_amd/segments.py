@@ -125,7 +125,7 @@ class FusionBucket:
         self._tail_host = (ctypes.c_int32 * len(self.tail))(*self.tail)
         # the ABMIL pool's score gradient: real rows are written by the fused tail, padding rows zeroed by refresh()
         self.ds = torch.zeros(cap + B * tail_rows, device=device, dtype=torch.float32)
-        self.lengths = None
+        self.lengths = self._uploaded = None
         tok = AttnSegs.make([P] * B, [P] * B, device)
         self.s_tt = tok
         ones = [P] * B
@@ -142,14 +142,21 @@ class FusionBucket:
         self._lib = _lib
         self._min_rows = _lib.lib().mil_layernorm_bagrow_rows_per_block(cap) if B > 1 else 1
 
-    def set_lengths(self, lengths):
-        """Upload this step's true patch counts (a tiny async copy); the maps follow on the device at refresh()."""
+    def fits(self, lengths) -> bool:
+        """Side-effect-free: can this bucket's kernels take these bags (count, capacity, shortest bag)?"""
         lengths = [int(v) for v in lengths]
-        if len(lengths) != self.B or sum(lengths) > self.cap or min(lengths) < self._min_rows:
+        return len(lengths) == self.B and sum(lengths) <= self.cap and min(lengths) >= self._min_rows
+
+    def set_lengths(self, lengths, on_device: bool = False):
+        """Upload this step's true patch counts (one tiny launch; skipped when the same lengths are already there or when
+        `on_device` says the feed launch wrote them - cohort.DeviceCohort.feed); the maps follow on the device at refresh()."""
+        lengths = [int(v) for v in lengths]
+        if not self.fits(lengths):
             raise ValueError(f"FusionBucket: lengths {lengths} do not fit {self.B} bags / {self.cap} rows "
                              f"(every bag needs >= {self._min_rows} rows)")
-        self.lengths = lengths
-        upload_lengths(self.len_dev, lengths)
+        if not on_device and lengths != self._uploaded:
+            upload_lengths(self.len_dev, lengths)
+        self.lengths = self._uploaded = lengths
         return self
 
     def refresh(self):

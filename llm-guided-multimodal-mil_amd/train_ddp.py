@@ -170,8 +170,38 @@ def main_worker(local_rank: int, nprocs: int, args):
             optimizer.load_state_dict(ck["optimizer"])
             args.start_epoch = ck["epoch"]
 
+    # ---- the input side.  With a bucketed stepper the cohort lives in HBM (cohort.DeviceCohort): loaded once, the
+    # per-epoch patch drop drawn on the device, every step fed by ONE gather launch into the bucket's static buffers -
+    # instead of the reference's per-step np.load + random.sample + pad + H2D copy (dataset.py:366-393, train_ddp.py:274-293)
+    cohort = None
+    any_stepper = (stepper if fused else fstepper)
+    if any_stepper is not None and getattr(args, "resident_cohort", 1):
+        from .cohort import DeviceCohort
+        lens_all = ([int(v) for v in data.lengths] if hasattr(data, "lengths") else None)
+        if lens_all is None:
+            import numpy as _np
+            lens_all = [int(_np.load(os.path.join(data.root, k + ".npy"), mmap_mode="r").shape[0]) for k in data.keys]
+        if DeviceCohort.fits(DeviceCohort.bytes_needed(lens_all, args.patch_dim), dev):
+            cohort = DeviceCohort.from_dataset(data, dev, seed=args.seed, augmentation=bool(getattr(args, "augmentation", 1)))
+            if not fused and not fstepper.tower_inside:
+                # --cache_text 1: every note's frozen-tower embedding once, as a device table the feed launch reads
+                with torch.no_grad():
+                    cohort.set_text(torch.cat([model.clinic_extractor(cohort.ids[i:i + 32]) for i in range(0, cohort.nb, 32)], 0))
+            print(f"cohort resident in HBM: {cohort.nb} bags, {cohort.x.shape[0]} rows x {cohort.F}, "
+                  f"{cohort.x.numel() * 4 / 2 ** 30:.2f} GiB")
+        else:
+            print("cohort does not fit the device next to the working set: host pipeline per step")
+    ct_pool = None
+    if not fused and fstepper is not None and "CT" in args.modality:
+        # synthetic stand-in for the CT encoder's output (aggregator.py:139-140): a small device-resident pool drawn ONCE
+        # (it was a 1.3 MB host tensor built inside the training loop every step)
+        g_ct = torch.Generator(device=dev).manual_seed(args.seed + 7919)
+        ct_pool = torch.randn((16,) + CT_SHAPE, device=dev, generator=g_ct)
+
     for epoch in range(args.start_epoch, args.n_epochs):
         idx = shard_indices(len(data), world, rank, epoch)                               # sampler.set_epoch(epoch)
+        if cohort is not None:
+            cohort.draw_epoch(epoch, augment=True)                                       # one launch: this epoch's patch drop
         lr = scheduled_lr(lr0, epoch, args.n_epochs, args.schedule, args.cos)
         losses, accs, bt = AverageMeter("Loss", ":.4e"), AverageMeter("Acc", ":6.3f"), AverageMeter("Time", ":6.3f")
         steps = min(args.iter_per_epoch, len(idx) // per_gpu)
@@ -179,7 +209,40 @@ def main_worker(local_rank: int, nprocs: int, args):
         model.train()
         end = time.time()
         for it in range(steps):
-            batch = collate_bags([data[j] for j in idx[it * per_gpu:(it + 1) * per_gpu]])
+            take = idx[it * per_gpu:(it + 1) * per_gpu]
+            if cohort is not None:
+                ks = cohort.lengths(take)
+                if fused:
+                    tr.lr = lr
+                    slot = stepper.slot(sum(ks))
+                    cohort.feed(take, slot.x, slot.layout.bag_len_dev, slot.y)
+                    loss, prob = stepper.step(slot, ks, on_device=True)
+                    y, nb_ = slot.y, len(take)
+                else:
+                    for g in optimizer.param_groups:
+                        g["lr"] = lr
+                    slot = fstepper.slot(sum(ks))
+                    if slot.bucket.fits(ks):
+                        if fstepper.tower_inside:
+                            cohort.feed(take, slot.x, slot.bucket.len_dev, slot.y, ids_dst=slot.ids)
+                        else:
+                            cohort.feed(take, slot.x, slot.bucket.len_dev, slot.y, text_dst=slot.text)
+                        if slot.ct is not None:
+                            for b_, j_ in enumerate(take):
+                                slot.ct[b_].copy_(ct_pool[int(j_) % ct_pool.shape[0]], non_blocking=True)
+                        loss, prob, _ = fstepper.step(slot, ks, on_device=True)
+                        y, nb_ = slot.y, len(take)
+                    else:
+                        slot = None
+                if slot is not None:
+                    if it % 10 == 0 or it == steps - 1:
+                        losses.update(float(loss.detach()), nb_)
+                        accs.update(float(calculate_accuracy(prob.detach(), y)), nb_)
+                        bt.update(time.time() - end)
+                        progress.display(it)
+                    end = time.time()
+                    continue
+            batch = collate_bags([data[j] for j in take])
             x = batch["pathology"].to(dev, non_blocking=True)
             y = batch["label"].to(dev, non_blocking=True)
             if fused:
@@ -202,9 +265,7 @@ def main_worker(local_rank: int, nprocs: int, args):
                 slot = None
                 if fstepper is not None and len(lengths) == per_gpu:
                     slot = fstepper.slot(sum(lengths))
-                    try:
-                        slot.bucket.set_lengths(lengths)
-                    except ValueError:                       # a bag too short for the bucket's kernels: exact-shape step
+                    if not slot.bucket.fits(lengths):        # a bag too short for the bucket's kernels: exact-shape step
                         slot = None
                 if slot is not None:
                     r0 = 0
@@ -213,9 +274,8 @@ def main_worker(local_rank: int, nprocs: int, args):
                         r0 += n
                     slot.y.copy_(y, non_blocking=True)
                     if slot.ct is not None:
-                        from . import synthetic as syn
-                        slot.ct.copy_(syn.make_ct_map(args.seed + 7919 * epoch + it, x.shape[0], CT_SHAPE[1], CT_SHAPE[2]),
-                                      non_blocking=True)
+                        for b_, j_ in enumerate(take):
+                            slot.ct[b_].copy_(ct_pool[int(j_) % ct_pool.shape[0]], non_blocking=True)
                     if fstepper.tower_inside:
                         slot.ids.copy_(batch["CI"], non_blocking=True)                    # the text tower runs inside the step
                     else:

@@ -386,12 +386,14 @@ class ImageOnlyTrainer:
         out["adam"] = float(ms.value)
         return out
 
-    def time_step_groups(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor, iters: int = 50, warm: int = 5):
+    def time_step_groups(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor, iters: int = 50, warm: int = 5, rot=None):
         """HIP-event duration (ms) of each launch group INSIDE the running step (mil_image_only_step_profile): the whole
         step is executed `iters` times with an event between its groups, so each kernel is timed after its predecessor, on
         the cache state the step leaves - the figure a rocprofv3 kernel trace of the step reports.  Adam runs on scratch
         copies of the parameters and moments (same launch, the trainer's state stays put).  Returns ({group: ms}, step_ms);
-        step_ms is first-to-last event, i.e. the step plus its event gaps."""
+        step_ms is first-to-last event, i.e. the step plus its event gaps.  rot: list of (x, y) batches of this shape the
+        iterations rotate through - the cache regime of a loop over several resident batches (a single batch
+        stays in the Infinity Cache from step to step, which is not what the headline loop runs in)."""
         a = self._fill(x, layout, y, None)
         self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)          # state every stage reads exists
         fp = self.fp
@@ -423,11 +425,18 @@ class ImageOnlyTrainer:
         nb = 5 if iters >= 20 else 1
         per = max(1, iters // nb)
         runs = []
+        nrot = len(rot) if rot else 0
+        for xr, yr in (rot or []):
+            if xr.shape != x.shape or xr.dtype != x.dtype or yr.shape != y.shape or not xr.is_contiguous():
+                raise _lib.MilHipError("time_step_groups: every rotated batch must have the shape of the first")
+        xs_arr = (ctypes.c_void_p * max(1, nrot))(*[t[0].data_ptr() for t in (rot or [])])
+        ys_arr = (ctypes.c_void_p * max(1, nrot))(*[t[1].data_ptr() for t in (rot or [])])
         for b in range(nb):
             out = (ctypes.c_float * (len(groups) + 1))()
-            rc = _lib.lib().mil_image_only_step_profile(ctypes.byref(a2), masks, len(groups), warm if b == 0 else 1, per, out,
-                                                        ops._stream())
-            _lib.check(rc, "mil_image_only_step_profile")
+            rc = _lib.lib().mil_image_only_step_profile_rot(ctypes.byref(a2), xs_arr if nrot else None, ys_arr if nrot else None,
+                                                            nrot, masks, len(groups), warm if b == 0 else 1, per, out,
+                                                            ops._stream())
+            _lib.check(rc, "mil_image_only_step_profile_rot")
             runs.append([float(v) for v in out])
         med = [sorted(r[i] for r in runs)[nb // 2] for i in range(len(groups) + 1)]
         return {n: med[i] for i, (n, _) in enumerate(groups)}, med[len(groups)]
@@ -509,9 +518,13 @@ class RaggedImageOnlyStepper:
             s = self.slots[cap] = self.Slot(cap, self.B, L, C, self.tr.device)
         return s
 
-    def step(self, slot: "RaggedImageOnlyStepper.Slot", lengths):
+    def step(self, slot: "RaggedImageOnlyStepper.Slot", lengths, on_device: bool = False):
+        """on_device: the lengths already sit in slot.layout.bag_len_dev (the cohort's feed launch wrote them)."""
         tr = self.tr
-        slot.layout.set_lengths(lengths)
+        if on_device:
+            slot.layout.note_lengths(lengths)
+        else:
+            slot.layout.set_lengths(lengths)
         slot.visits += 1
         if slot.graph is None and self.use_graph and slot.visits >= 2:
             tr.capture(slot.x, slot.layout, slot.y)                # warm-up pass + capture (two optimizer-free passes)

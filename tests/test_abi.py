@@ -52,7 +52,8 @@ def test_tile_map_ragged():
         assert (tm[bto[b]:bto[b + 1], 0] == b).all()
 
 
-@pytest.mark.parametrize("cname,pyname", [("mil_image_only_step", "ImageOnlyStep"), ("mil_small_dw_desc", "SmallDwDesc")])
+@pytest.mark.parametrize("cname,pyname", [("mil_image_only_step", "ImageOnlyStep"), ("mil_small_dw_desc", "SmallDwDesc"),
+                                          ("mil_cohort_feed_desc", "CohortFeedDesc")])
 def test_struct_layouts_match_the_header(tmp_path, cname, pyname):
     """The ctypes mirrors of the C structs (the one-call step, the grouped weight-gradient descriptor) against the C compiler's
     view of include/mil_hip.h."""

@@ -60,6 +60,32 @@ def test_ranks_rehearsal_equals_the_single_process_step(tmp_path, W):
     assert rel_err(got["grad"], tr.fp.grad.cpu()) <= 1e-5
 
 
+def test_strong_scaling_rehearsal_keeps_the_global_batch(tmp_path):
+    """`--global-bags G` (config 4 for W < 8 keeps the 256-bag global batch, 256 / W per GPU): two ranks of G / 2
+    bags each reproduce the one-process gradient on the same G bags; the line says `"scaling": "strong"` and lists every
+    timed region."""
+    dump = str(tmp_path / "g.pt")
+    small = [a_ for a_ in SMALL if a_ not in ("--bags-per-gpu", "4")]
+    line = bench("--gpus", "2", *small, "--global-bags", "8", "--regions", "3", "--train-mode", "0", "--dump", dump,
+                 env={"MIL_BENCH_REHEARSAL": "1"})
+    assert line["scaling"] == "strong" and line["config"]["global_bags"] == 8 and line["config"]["bags_per_gpu"] == 4
+    assert len(line["ms_per_step_runs"]) == 3
+    assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert line["ms_per_step"] == sorted(line["ms_per_step_runs"])[1]                    # the median region
+    got = torch.load(dump, weights_only=True)
+    dev = torch.device("cuda")
+    B, N, L = 4, 128, 512
+    x = torch.cat([syn.make_bags(4321 + r, B, N, L).reshape(B * N, L) for r in range(2)], 0).to(dev)
+    y = torch.cat([syn.make_labels(99 + r, B, 2) for r in range(2)], 0).to(dev)
+    tr = ImageOnlyTrainer(syn.image_only_params(1234, L=L), dev)
+    tr.forward(x, BagLayout.uniform(8, N, dev), y)
+    tr.backward()
+    assert abs(float(tr.loss_sum.item()) - got["loss"]) <= 1e-6
+    assert rel_err(got["grad"], tr.fp.grad.cpu()) <= 1e-5
+    r = bench("--gpus", "2", *small, "--global-bags", "7", env={"MIL_BENCH_REHEARSAL": "1"}, expect_ok=False)
+    assert r.returncode != 0 and "multiple" in (r.stderr + r.stdout)
+
+
 def test_more_ranks_than_gpus_is_refused_not_downgraded():
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a one-GPU box")

@@ -164,3 +164,37 @@ def test_bf16_train_mode_step_matches_oracle_on_the_same_masks(lengths, L, grad_
         tr.train_step(x16, lay, y.to(DEV))
     torch.cuda.synchronize()
     assert bool(torch.isfinite(tr.fp.flat).all())
+
+
+def test_image_only_module_in_train_mode_draws_philox_masks_for_patches_and_head():
+    """model/aggregator_clip.py in `model.train()`: BOTH dropouts come from the module's Philox stream (the head
+    used torch's generator while the fused route drew keep words), the masks are outputs, and logits + gradients equal the
+    oracle on exactly those masks."""
+    from types import SimpleNamespace
+    from mil_amd.model.utils_clip import get_model
+    L, lengths = 512, [128, 128, 128]
+    torch.manual_seed(3)
+    m = get_model(SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", num_classes=2, patch_dim=L)).to(DEV).train()
+    bags = [torch.randn((n, L), generator=torch.Generator().manual_seed(70 + i)) for i, n in enumerate(lengths)]
+    pad = torch.stack(bags, 0)
+    y = syn.make_labels(5, 3)
+    _, prob = m([pad.to(DEV)])
+    loss = torch.nn.BCELoss()(prob, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ab = m.extractor_pathology
+    p = {k.replace("extractor_pathology.", "aggregator."): v.detach().cpu() for k, v in m.state_dict().items()}
+    rl, rz, rp, rg = _masked_oracle(bags, y, p, ab.last_xbits, m.last_mbits, L)
+    # the head's words are the fused tail's: key = module seed ^ golden ratio, stream position = the pass counter
+    want = P.keep_bits(3, L, 0.25, (ab._drop_seed ^ 0x9E3779B97F4A7C15) & (2 ** 64 - 1), int(ab._drop_ctr.item()))
+    assert np.array_equal(_u32(m.last_mbits), want)
+    assert float((m.last_logits.detach().cpu() - rz).abs().max()) <= 2e-5
+    assert abs(float(loss.item()) - float(rl)) <= 2e-6
+    for k, v in m.named_parameters():
+        ko = k.replace("extractor_pathology.", "aggregator.")
+        if ko.endswith("attention_weights.bias"):
+            continue
+        assert rel_err(v.grad.cpu(), rg[ko]) <= 2e-4, k
+    b1 = m.last_mbits.clone()
+    m([pad.to(DEV)])
+    assert not torch.equal(b1, m.last_mbits)                       # a fresh head mask every pass
