@@ -80,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / config 5 / ragged-regime objects")
     ap.add_argument("--no-ragged", action="store_true", help="skip configs.ragged_image / ragged_fusion / ragged_ct_pth "
                     "(one ragged bag per step fed from the HBM-resident cohort)")
+    ap.add_argument("--no-rccl-floor", action="store_true", help="skip the rccl_floor object (two child runs at world size 1 with "
+                    "the RCCL all-reduce forced into the step)")
     ap.add_argument("--only-ragged", default="", help="(tools) run just this regime object (image | fusion | ct_pth) and print it")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (default: eager; "
                     "the step is GPU-bound either way)")
@@ -333,8 +335,10 @@ def config5_bf16(dev, steps=60, warmup=5):
     kb_alone = tr.time_pieces(x, lay, y, 20)
     flops = 4.0 * R * L * D_GATE
     # in-step groups: the weight gradient's launch pair (+ head parameter gradients) is one entry point on this path
-    dom = max(("gate_fwd", "gate_bwd_dw_reduce_head_adam"), key=lambda k: kb[k])
-    hbm = R * L * 2 / (kb["gate_fwd"] * 1e-3) / 1e9
+    # round 4: the deep forward carries the pool partial pass in its epilogue (group "gate_fwd_with_pool_fused")
+    fwd_key = "gate_fwd_with_pool_fused" if "gate_fwd_with_pool_fused" in kb else "gate_fwd"
+    dom = max((fwd_key, "gate_bwd_dw_reduce_head_adam"), key=lambda k: kb[k])
+    hbm = R * L * 2 / (kb[fwd_key] * 1e-3) / 1e9
     # the same step in model.train() mode (in-kernel dropout through the keep-bit tensors): THIS is what the object is
     # quoted on, like the headline; the eval-mode step and its launch groups - the ones the roofline objects
     # below are computed from - stand beside it
@@ -357,11 +361,12 @@ def config5_bf16(dev, steps=60, warmup=5):
             "kernels_ms_train_mode": {k: round(v, 4) for k, v in kb_train.items()},
             "roofline_note": "roofline / roofline_step / kernels_ms below: the eval-mode step (eval_mode_ms_per_step)",
             "step_algorithmic_bytes": 2 * R * L * 2, "step_hbm_frac": round(2 * R * L * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "roofline": {"bound": "mfma", "kernel": "k_gate_fwd_bf16_deep" if dom == "gate_fwd" else "k_gate_bwd_dw_bf16 (+ its fold)",
+            "roofline": {"bound": "mfma", "kernel": ("k_gate_fwd_bf16_deep" + (" (+ pool pass in its epilogue)" if fwd_key != "gate_fwd" else ""))
+                         if dom == fwd_key else "k_gate_bwd_dw_bf16 (+ its fold)",
                          "achieved": round(flops / (kb[dom] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(flops / (kb[dom] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                          "flops_per_launch": flops, "ms_per_launch": round(kb[dom], 4), "timing": "HIP events inside the running step",
-                         "traffic": _pmc_traffic("cfg5_" + ("gate_fwd" if dom == "gate_fwd" else "gate_bwd_dw")),
+                         "traffic": _pmc_traffic("cfg5_" + ("gate_fwd" if dom == fwd_key else "gate_bwd_dw")),
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, bytes per launch)"},
             "roofline_step": {"bound": "mfma", "achieved": round(2 * flops / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(2 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -472,6 +477,35 @@ def config3_fusion(dev, steps=30, warmup=4):
                        "oracle": "fp32 oracle fused_forward (model/aggregator.py:134-209 wiring)", "tolerance": 1e-3}}
 
 
+# ----------------------------------------------------------------------------------------------- multi-GPU floors at N = 1
+def rccl_floor(args):
+    """What the N > 1 step costs before any link is involved: this same workload at world size 1 with the step's RCCL
+    all-reduce forced in (MIL_FORCE_COLLECTIVES=1) - once with the collective issued eagerly between the fold and the Adam
+    launch (today's N > 1 path) and once with [fold -> all_reduce -> Adam] captured in the step's hipGraph
+    (MIL_GRAPH_COLLECTIVE=1).  Each is a child process (a process group cannot be added to a rank that has already run); a
+    child that fails reports its error instead of a number."""
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--regions", "5", "--prime", str(args.prime), "--batches", str(args.batches), "--train-mode", str(args.train_mode),
+            "--no-configs", "--no-cpu-baseline", "--no-breakdown"]
+    for name, extra in (("eager_collective", {}), ("graph_collective", {"MIL_GRAPH_COLLECTIVE": "1"})):
+        env = dict(os.environ, MIL_FORCE_COLLECTIVES="1", MASTER_PORT=str(_free_port()), **extra)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=300)
+            ln = json.loads(r.stdout.strip().splitlines()[-1])
+            out[name] = {"ms_per_step": ln["ms_per_step"], "ms_per_step_runs": ln["ms_per_step_runs"],
+                         "allreduce_us": ln["rccl"]["allreduce_us"], "allreduce_bytes": ln["rccl"]["allreduce_bytes"],
+                         "launch": ln["config"]["launch"]}
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    out["note"] = ("world size 1, RCCL all-reduce of the step's 0.79 MB buffer forced into every step: the fixed cost of the N > 1 "
+                   "path (split fold / Adam launches + one collective call) beside the headline step, which folds Adam into the "
+                   "fold launch; the first SCALE run adds the xGMI hops on top of these")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- the authors' regime (N=1)
 def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
     """One ragged bag per step, N ~ U[2000, 15592] changing every step (reference run_train.sh:81: --batch_size = number of
@@ -512,7 +546,7 @@ def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
         p = syn.image_only_params(1, L=F)
 
         def make(train=True):
-            tr = ImageOnlyTrainer(p, dev, train_mode=train, counted=True)
+            tr = ImageOnlyTrainer(p, dev, train_mode=train, counted=True, lr=1e-5 if train else 0.0)    # parity pass: weights stay put
             return tr, RaggedImageOnlyStepper(tr, B=1)
         tr, st = make()
 
@@ -612,7 +646,33 @@ def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
         put_step(st, xd[0], labels[j:j + 1].to(dev, non_blocking=True), co.k_train[j], *([j] if fusion else []))
     torch.cuda.synchronize()
     ms_host = (time.perf_counter() - t0) / host_steps * 1e3
-    del host_bags
+    # ---- the fallback for a cohort that does not fit HBM (cohort.HostFeed): a background thread fills two pinned staging
+    # buffers with the UN-dropped bag, the copy runs on its own stream, drop + placement on the device as above
+    from mil_amd.cohort import HostFeed
+    full_host = {j: big[off[j]:off[j + 1]].cpu().numpy() for j in set(seq[:host_steps + 1])}
+    hf = HostFeed(lambda j: full_host[j], ns, F, labels, dev, ids=ids, keep=keeps, seed=co.seed)
+
+    def hf_step(j, nxt):
+        k = co.k_train[j]
+        slot = st.slot(k)
+        ldev = slot.bucket.len_dev if fusion else slot.layout.bag_len_dev
+        hf.next(slot.x, ldev, slot.y, epoch=e)
+        if nxt is not None:
+            hf.prefetch(nxt)                             # loads while this step runs
+        if fusion:
+            slot.text.copy_(co.text[j:j + 1], non_blocking=True)
+            if with_ct:
+                slot.ct.copy_(ct, non_blocking=True)
+        return st.step(slot, [k], on_device=True)
+    hf.prefetch(seq[0])
+    hf_step(seq[0], seq[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1, host_steps + 1):
+        hf_step(seq[i], seq[i + 1] if i < host_steps else None)
+    torch.cuda.synchronize()
+    ms_pinned = (time.perf_counter() - t0) / host_steps * 1e3
+    del host_bags, full_host, hf
     # ---- parity: eval mode, two bags fed through the cohort vs the oracle on the rows the numpy restatement selects
     tr_e, st_e = make(train=False)
     if fusion:
@@ -649,6 +709,9 @@ def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
            "replay_only_ms_per_step": round(ms_replay, 4), "feed_overhead": round(ms_res / ms_replay - 1.0, 4),
            "from_host_pageable_ms_per_step": round(ms_host, 4),
            "from_host_note": f"{host_steps} steps of round 3's loop: zero-padded pageable host bag -> .to(dev) -> D2D into the bucket",
+           "from_host_pinned_prefetch_ms_per_step": round(ms_pinned, 4),
+           "from_host_pinned_note": "cohort.HostFeed, the fallback when the cohort does not fit: un-dropped bag from host RAM through "
+                                    "two pinned buffers (background thread) + copy stream, drop and placement on the device",
            "feed_bytes_per_step": int(2 * bytes_step), "feed_bytes_note": "gather: kept rows read once from the cohort + written once to the bucket",
            "parity": {"bags_checked": [0, n_bags - 1], "max_abs_dlogit": dl, "top1_equal": top1, "tolerance": 1e-3,
                       "oracle": "eval mode; oracle forward on the rows oracle/cohort.py selects for the same (seed, epoch, bag)"}}
@@ -701,7 +764,11 @@ def run_rank(args):
             raise SystemExit(f"bench.py: --global-bags {args.global_bags} is not a multiple of the {world} ranks")
         B = args.global_bags // world
     params = syn.image_only_params(1234, L=L)
-    tr = ImageOnlyTrainer(params, dev, world_size=world, train_mode=bool(args.train_mode), accum=args.accum)
+    # MIL_GRAPH_COLLECTIVE=1 (world size > 1 or forced collectives): the step - all-reduce included - replays from one hipGraph
+    # per resident batch, [forward .. fold -> all_reduce -> Adam] as one captured segment (trainer.capture)
+    graph_coll = use_dist and os.environ.get("MIL_GRAPH_COLLECTIVE") == "1" and args.accum == 1 and not rehearsal
+    tr = ImageOnlyTrainer(params, dev, world_size=world, train_mode=bool(args.train_mode), accum=args.accum,
+                          counted=bool(graph_coll))
     nb = max(1, args.batches) if not args.graph else 1       # a captured step replays its static buffers
     xs = [syn.make_bags(4321 + rank + 1000 * i, B, N, L).reshape(B * N, L).to(dev) for i in range(nb)]   # resident in HBM before timing
     if args.dtype == "bf16":
@@ -725,7 +792,29 @@ def run_rank(args):
             torch.save({"grad": tr.fp.grad.detach().cpu().clone(), "loss": float(tr.loss_sum.item())}, args.dump)
         tr.reset_dropout_stream()
 
-    if not args.graph:
+    launch_kind = "eager" if not args.graph else "hipGraph(fwd+bwd)+eager(allreduce,adam)"
+    graphs = None
+    if graph_coll and not args.graph:
+        try:
+            graphs = []
+            for i in range(nb):
+                tr.capture(xs[i], lay, ys[i], collective_in_graph=True)
+                graphs.append(tr._graph)
+            if not all(g["collective"] for g in graphs):
+                graphs = None
+        except Exception as e:      # noqa: BLE001  (capability probe: RCCL / torch may refuse the capture)
+            print(f"bench.py: collective-in-graph capture refused ({type(e).__name__}: {e}); eager collective", file=sys.stderr)
+            graphs = None
+    if graphs is not None:
+        turn = [0]
+        launch_kind = "hipGraph(fwd+bwd+allreduce+adam), one per resident batch"
+
+        def step():
+            i = turn[0] % nb
+            turn[0] += 1
+            tr._graph = graphs[i]
+            return tr.replay_step()
+    elif not args.graph:
         turn = [0]
 
         def step():
@@ -805,7 +894,7 @@ def run_rank(args):
                        "bags_per_gpu": B, "patches": N, "dim": L, "global_bags": world * B,
                        "parallelism": f"dp{world}", "loss": round(loss, 6), "mode": mode, "accum": args.accum,
                        "batches_cycled": nb,
-                       "launch": "eager" if not args.graph else "hipGraph(fwd+bwd)+eager(allreduce,adam)"},
+                       "launch": launch_kind},
         }
         if rccl is not None:
             line["rccl"] = rccl
@@ -867,6 +956,8 @@ def run_rank(args):
                 del tr_e
             if world == 1 and args.dtype == "f32":
                 line["roofline_pool"] = pool_roofline(dev)
+        if world == 1 and not use_dist and not args.no_breakdown and not args.no_rccl_floor and args.dtype == "f32":
+            line["rccl_floor"] = rccl_floor(args)
         if world == 1 and not args.no_configs and args.dtype == "f32":
             cfgs = {}
             jobs = [("cfg5", config5_bf16), ("cfg3", config3_fusion)]

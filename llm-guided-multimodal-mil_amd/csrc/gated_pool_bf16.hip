@@ -288,14 +288,34 @@ __device__ __forceinline__ void dma16_raw(const void* gptr, unsigned lds_byte_ad
 // three-group ring (12 KB) - so no ordinary load enters the kernel's hand-counted vmcnt accounting (the piece is the
 // oldest operation of its slice: that slice's wait becomes vmcnt(8), and by the next slice's vmcnt(7) it has landed);
 // the A fragments are masked after their LDS read (keep_bf16x8), the 1 / (1 - p) multiplies the finished pre-activation.
-template <int GMODE, bool DROP>      // saved gates: 0 none, 1 fp32 [R, 384], 2 bf16 [R, 384] (branch-free epilogue per mode)
+//
+// PQ > 0 (= L / 512; round 4): the attention-pool PARTIAL PASS of the workgroup's eight 32-row tiles runs in the epilogue,
+// as k_gate_fwd2<.., PQ> does for fp32.  Wave w takes tile w (rows 32 w .. 32 w + 31 of the workgroup) once the 256 scores
+// are final and plays k_pool_partial_bf16's four waves one after the other - virtual wave v = rows v, v + 4, ..., the same
+// per-element accumulation order, the same 16-value reduction for the head-projection by-product, the four partial sums
+// folded in the same order - so partials / hrow equal the stand-alone kernel's bit for bit.  The rows come back from the
+// Infinity Cache (the main loop streamed the workgroup's 512 KB moments ago; one round of the grid is 128 MiB of the 256):
+// the stand-alone pass's 257 MiB HBM read and its launch are gone.  Virtual wave 0's rows are requested between the two row
+// halves of the activation epilogue (the first half's 96 accumulator registers are free by then), every further virtual
+// wave's rows while its predecessor is being accumulated.  Only for batches whose tiles are all full and aligned.
+struct GateFwdPool16 {
+    const int32_t* tile_map;    // [T][4] = {bag, row0, nrows, 0}
+    float* partials;            // [T][L] then [T][2]
+    int T;
+    const float* Wf;            // [2][L] head rows (C == 2)
+    float* hrow;                // [R][2]
+    const uint32_t* mbits;      // [B][L/32] keep words of the head's dropout (train mode), else NULL
+    float mscale;
+};
+
+template <int GMODE, bool DROP, int PQ = 0>      // saved gates: 0 none, 1 fp32 [R, 384], 2 bf16 [R, 384] (branch-free epilogue per mode)
 __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restrict__ x, const u16* __restrict__ Wv,
                                                             const float* __restrict__ bv, const u16* __restrict__ Wu,
                                                             const float* __restrict__ bu, const float* __restrict__ wvec,
                                                             const float* __restrict__ battn, float* __restrict__ scores,
                                                             float* __restrict__ gates, int R, int L,
                                                             u16* __restrict__ gates16, const uint32_t* __restrict__ xbits,
-                                                            float xscale) {
+                                                            float xscale, GateFwdPool16 pool = GateFwdPool16{}) {
     __shared__ __attribute__((aligned(16))) u16 smem[HC_NX * HC_XS + HC_NW * HC_WS];      // 64 + 72 KB
     __shared__ __attribute__((aligned(16))) uint32_t mring[DROP ? 3 * HC_TM * 4 : 4];    // keep words [3 groups][256 rows][4 slices]
     u16* xring = smem;
@@ -488,8 +508,29 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
 #endif
     float* sred = reinterpret_cast<float*>(smem) + 8 * (32 * 192) / 2;       // [2][256], behind the eight gate tiles
     u16* tile_lds = smem + wave * (32 * 192);                               // this wave's [32][192] bf16 tile (12 KB)
+    // fused pool pass: this wave's tile, its row registers and the loader.  Buffer q2 holds the 512-column block q2 of the
+    // eight rows of ONE virtual wave (32 registers); it is refilled with the next virtual wave's rows as soon as the current
+    // ones are accumulated, so every load has the other block's arithmetic to land under
+    constexpr int PNQ = PQ > 0 ? PQ : 1;
+    constexpr int PROWS = PQ > 0 ? MIL_POOL_TILE / 4 : 1;
+    const int ptrow0 = row0 + 32 * wave_u;                                   // wave-uniform
+    const bool plive = PQ > 0 && ptrow0 < R;                                 // R % 32 == 0 (host): a tile is whole or absent
+    u16x8 pv[PNQ][PROWS];
+    unsigned pmw[PNQ][PROWS];
+    auto pool_load = [&](int q2, int vw) {                                   // q2 compile-time, vw wave-uniform
+#pragma unroll
+        for (int i = 0; i < PROWS; ++i) {
+            const int row = ptrow0 + vw + 4 * i;
+            pv[q2][i] = *reinterpret_cast<const u16x8*>(x + (size_t)row * L + 8 * lane + 512 * q2);
+            if (DROP) pmw[q2][i] = xbits[(size_t)row * (L >> 5) + (lane >> 2) + 16 * q2];
+        }
+    };
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+        if (PQ > 0 && q == 1 && plive) {                       // under the second half of the activation epilogue
+#pragma unroll
+            for (int q2 = 0; q2 < PNQ; ++q2) pool_load(q2, 0);
+        }
         float part[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) part[i] = 0.f;
@@ -534,9 +575,98 @@ __global__ __launch_bounds__(512) void k_gate_fwd_bf16_deep(const u16* __restric
         }
     }
     __syncthreads();
+    float* sc_lds = sred + 2 * HC_TM;                  // [256] final scores (fused pool pass)
     if (tid < HC_TM) {
         const int gr = row0 + tid;
-        if (gr < R) scores[gr] = sred[tid] + sred[HC_TM + tid] + battn[0];
+        const float sc = sred[tid] + sred[HC_TM + tid] + battn[0];
+        if (gr < R) scores[gr] = sc;
+        if (PQ > 0) sc_lds[tid] = gr < R ? sc : -INFINITY;
+    }
+    if (PQ > 0) {
+        __syncthreads();
+        // tile weights, as wave 0 of k_pool_partial_bf16 forms them
+        const float s_ = lane < 32 ? sc_lds[32 * wave_u + lane] : -INFINITY;
+        const float m_ = wave_allmax(s_);
+        const float p_ = lane < 32 ? expf(s_ - m_) : 0.f;
+        const float l_ = wave_allsum(p_);
+        if (plive) {
+            const int t = ptrow0 >> 5;
+            const int bag_ = pool.tile_map[4 * t];
+            // head rows as this tile's bag sees them (k_pool_partial_bf16's head_row), one 512-column block at a time
+            auto head_rows = [&](int q2, float (*wf)[8]) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(pool.Wf + (size_t)c * L + 512 * q2 + 8 * lane);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(pool.Wf + (size_t)c * L + 512 * q2 + 8 * lane + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { wf[c][e] = DROP ? w0[e] * xscale : w0[e]; wf[c][4 + e] = DROP ? w1[e] * xscale : w1[e]; }
+                    if (DROP) {
+                        const unsigned mm = pool.mbits[(size_t)bag_ * (L >> 5) + 16 * q2 + (lane >> 2)] >> (8 * (lane & 3));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) wf[c][e] = ((mm >> e) & 1u) ? wf[c][e] * pool.mscale : 0.f;
+                    }
+                }
+            };
+            float tot[PNQ][8];
+#pragma unroll
+            for (int q2 = 0; q2 < PNQ; ++q2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tot[q2][e] = 0.f;
+#pragma unroll 1
+            for (int vw = 0; vw < 4; ++vw) {
+                float d16[16];
+#pragma unroll
+                for (int q2 = 0; q2 < PNQ; ++q2) {
+                    float wf[2][8];
+                    head_rows(q2, wf);
+                    if (DROP) {
+#pragma unroll
+                        for (int i = 0; i < PROWS; ++i) pv[q2][i] = keep_bf16x8_b(pv[q2][i], pmw[q2][i] >> (8 * (lane & 3)));
+                    }
+                    float pacc[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pacc[e] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < PROWS; ++i) {
+                        const float pl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_), vw + 4 * i));
+                        const float p = DROP ? pl * xscale : pl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pacc[e] += p * bf16_to_f32(pv[q2][i][e]);
+                    }
+                    // by-product: d16[2 i + c] = sum over the row's columns, block q2 = 0 first (the stand-alone kernel's order)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int i = 0; i < PROWS; ++i) {
+                            float d = q2 == 0 ? 0.f : d16[2 * i + c];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d += bf16_to_f32(pv[q2][i][e]) * wf[c][e];
+                            d16[2 * i + c] = d;
+                        }
+                    // this block's registers are free: the next virtual wave's rows of the same block
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (vw + 1 < 4) pool_load(q2, vw + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the four virtual waves' sums in the stand-alone kernel's fold order: ((a0 + a1) + a2) + a3
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tot[q2][e] += pacc[e];
+                }
+                const float toth = wave_reduce16(d16, lane);
+                const int k = wave_reduce16_index(lane), rr = vw + 4 * (k >> 1);
+                if ((lane & 3) == 0) pool.hrow[(size_t)(ptrow0 + rr) * 2 + (k & 1)] = toth;
+            }
+            float* out = pool.partials + (size_t)t * L;
+#pragma unroll
+            for (int q2 = 0; q2 < PNQ; ++q2) {
+                *reinterpret_cast<f32x4*>(out + 512 * q2 + 8 * lane) = f32x4{tot[q2][0], tot[q2][1], tot[q2][2], tot[q2][3]};
+                *reinterpret_cast<f32x4*>(out + 512 * q2 + 8 * lane + 4) = f32x4{tot[q2][4], tot[q2][5], tot[q2][6], tot[q2][7]};
+            }
+            if (lane == 0) {
+                float* ml = pool.partials + (size_t)pool.T * L + 2 * t;
+                ml[0] = m_;
+                ml[1] = l_;
+            }
+        }
     }
 #if defined(HC_STAMP)
     if (tid == 0 && GMODE == 2) {      // diagnostic build: (loop cycles, loop 100 MHz ticks, epilogue cycles, start tick) per workgroup
@@ -555,7 +685,11 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
                                                            float* __restrict__ partials, int L,
                                                            const float* __restrict__ Wf, int C, float* __restrict__ hrow,
                                                            const uint32_t* __restrict__ xbits, float xscale,
-                                                           const uint32_t* __restrict__ mbits, float mscale) {
+                                                           const uint32_t* __restrict__ mbits, float mscale, int rev) {
+    // rev: tiles are taken LAST FIRST.  At config 5 x (256 MiB) is as large as the Infinity Cache: the gate forward has just
+    // streamed it front to back, so its tail is what the cache still holds - a pass that starts at the front again evicts
+    // every line just before reaching it (LRU under a cyclic sweep), one that starts at the back is served from the cache
+    // until it runs past what survived, and leaves the FRONT of x behind for the weight gradient, which starts there.
     // train mode: xbits [R][L/32] keep bits of the patch dropout - the DROPPED x is what gets pooled (ABMIL.py:49,59):
     // dropped elements are zeroed right after the load, the 1/(1-p) goes into the tile weights; mbits [B][L/32] = the
     // head's Dropout(.25) folded into the head rows of the by-product (as k_pool_partial)
@@ -563,7 +697,7 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
     __shared__ float ml_lds[2];
     __shared__ __attribute__((aligned(16))) float red[3 * NQ * 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
+    const int t = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
     // the tile's rows are requested FIRST: they depend on nothing, and their trip from HBM then runs under the softmax of
     // the tile's scores (wave 0) and the barrier behind it
@@ -929,6 +1063,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
         }
+        // (round 4: __syncthreads() here compiles to s_waitcnt lgkmcnt(0) + s_barrier on gfx950 - it does NOT drain vmcnt, so the
+        // prefetched loads of slice sl + 2 stay in flight across it; a hand-written LDS-only barrier produced the same code)
         __syncthreads();
     }
 
@@ -1009,6 +1145,30 @@ extern "C" int mil_gate_scores_fwd_bf16(const uint16_t* x, const uint16_t* Wv, c
     return MIL_OK;
 }
 
+// Gate forward of the bf16 step with the pool partial pass in its epilogue (csrc/step.hip, MIL_STAGE_POOL_FUSED): *fused = 1
+// when the deep kernel with PQ took it, else the plain forward ran and the caller launches the stand-alone pass.
+int gate_fwd_bf16_with_pool(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu, const float* bu,
+                            const float* w, const float* b, float* scores, uint16_t* gates16, int R, int L, const uint32_t* xbits,
+                            float xscale, const int32_t* tile_map, int T, float* partials, const float* Wf, float* hrow,
+                            const uint32_t* mbits, float mscale, int* fused, void* stream) {
+    *fused = 0;
+    const bool ok = x && gates16 && tile_map && partials && Wf && hrow && (L == 512 || L == 1024) && R >= HC_TM * MIL_NUM_CU &&
+                    (R % 32) == 0 && (long)T * MIL_POOL_TILE == R && ((xbits != nullptr) == (mbits != nullptr));
+    if (!ok)
+        return mil_gate_scores_fwd_bf16(x, Wv, bv, Wu, bu, w, b, scores, nullptr, R, L, MIL_GATE_D, gates16, xbits, xscale, stream);
+    if (!Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
+    const GateFwdPool16 pool{tile_map, partials, T, Wf, hrow, mbits, mbits ? mscale : 1.0f};
+    const dim3 grid((R + HC_TM - 1) / HC_TM);
+    const hipStream_t st_ = (hipStream_t)stream;
+#define HCP_LAUNCH(D, Q) hipLaunchKernelGGL((k_gate_fwd_bf16_deep<2, D, Q>), grid, dim3(512), 0, st_, x, Wv, bv, Wu, bu, w, b, scores, (float*)nullptr, R, L, gates16, xbits, xbits ? xscale : 1.0f, pool)
+    if (xbits) { if (L == 512) HCP_LAUNCH(true, 1); else HCP_LAUNCH(true, 2); }
+    else { if (L == 512) HCP_LAUNCH(false, 1); else HCP_LAUNCH(false, 2); }
+#undef HCP_LAUNCH
+    MIL_CHECK_LAUNCH();
+    *fused = 1;
+    return MIL_OK;
+}
+
 // eval / train instantiations: the eval kernels carry no trace of the keep-bit handling (templated, not branched: the
 // branched form cost the eval-mode pool pass 16 us at config 5)
 static void launch_pool_partial_bf16(const uint16_t* x, const float* scores, const int32_t* tile_map, int T, int L,
@@ -1016,8 +1176,13 @@ static void launch_pool_partial_bf16(const uint16_t* x, const float* scores, con
                                      const uint32_t* mbits, float mscale, hipStream_t st) {
     const bool drop = xbits != nullptr || mbits != nullptr;
     const float xs = xbits ? xscale : 1.0f, ms = mbits ? mscale : 1.0f;
-    const bool nt = (size_t)T * MIL_POOL_TILE * L * sizeof(uint16_t) > MIL_STREAM_BYTES;
-#define POOL16(NQ_, D_, N_) hipLaunchKernelGGL((k_pool_partial_bf16<NQ_, D_, N_>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, (D_) ? xs : 1.0f, mbits, (D_) ? ms : 1.0f)
+    const size_t xbytes = (size_t)T * MIL_POOL_TILE * L * sizeof(uint16_t);
+    // x between one and two Infinity Caches large: back to front (see the kernel), with ordinary loads - the pass is meant
+    // to hit the cache and to leave the front of x there; larger still: a pure stream, nontemporal
+    static const int rev_env = [] { const char* e = getenv("MIL_POOL_REV"); return e ? atoi(e) : -1; }();
+    const int rev = rev_env >= 0 ? rev_env : (xbytes > MIL_STREAM_BYTES && xbytes <= ((size_t)512 << 20) ? 1 : 0);
+    const bool nt = xbytes > MIL_STREAM_BYTES && !rev;
+#define POOL16(NQ_, D_, N_) hipLaunchKernelGGL((k_pool_partial_bf16<NQ_, D_, N_>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, (D_) ? xs : 1.0f, mbits, (D_) ? ms : 1.0f, rev)
     if (L == 512) {
         if (drop) { if (nt) POOL16(1, true, true); else POOL16(1, true, false); }
         else { if (nt) POOL16(1, false, true); else POOL16(1, false, false); }

@@ -39,6 +39,12 @@ int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const fl
                               int step, const int* step_dev, float lr, const float* lr_dev, float beta1, float beta2, float eps,
                               float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream);
 
+// gated_pool_bf16.hip: bf16 gate forward with the pool partial pass in its epilogue when the batch allows
+int gate_fwd_bf16_with_pool(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu, const float* bu,
+                            const float* w, const float* b, float* scores, uint16_t* gates16, int R, int L, const uint32_t* xbits,
+                            float xscale, const int32_t* tile_map, int T, float* partials, const float* Wf, float* hrow,
+                            const uint32_t* mbits, float mscale, int* fused, void* stream);
+
 // dropout.hip: both keep-bit tensors of a step in one launch
 int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
                            const int32_t* offset_dev, void* stream);
@@ -63,6 +69,16 @@ static int step_check(const mil_image_only_step* a) {
 static bool fuse_pool_enabled() {
     const char* e = getenv("MIL_FUSE_POOL");
     return e == nullptr || e[0] != '0';
+}
+
+// bf16 step: the pool pass in the deep forward's epilogue (round 4).  Measured at config 5 on one box (tools/cfg5_quick.py):
+// eval mode 0.3464 ms fused vs 0.3456 stand-alone - a tie, with 257 MiB less HBM traffic and one launch fewer; train mode
+// 0.504 vs 0.415 ms - the keep-word handling of eight rows per unit pushes the 256-register forward into scratch.  So:
+// eval on, train off; MIL_FUSE_POOL16=1 / 0 forces it either way.
+static bool fuse_pool16_enabled(bool train) {
+    const char* e = getenv("MIL_FUSE_POOL16");
+    if (e != nullptr) return e[0] != '0';
+    return !train;
 }
 
 extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* stream) {
@@ -95,7 +111,13 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     if (st & MIL_STAGE_GATE_FWD) {
         float* gates = grads ? a->gates : nullptr;
         const bool g16 = a->x_bf16 && a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16 != nullptr;
-        if (a->x_bf16)
+        if (a->x_bf16 && g16 && grads && (st & MIL_STAGE_POOL) && (st & MIL_STAGE_POOL_FUSED) && use_h && a->C == 2 &&
+            fuse_pool_enabled() && fuse_pool16_enabled(train))
+            // forward + pool partial pass in one launch (falls back inside when the shape does not allow it)
+            rc = gate_fwd_bf16_with_pool((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores, a->gates16,
+                                         a->R, a->L, xbits, xscale, a->tile_map, a->T, a->partials, a->Wf, a->hrow, mbits, mscale,
+                                         &pool_fused, stream);
+        else if (a->x_bf16)
             rc = mil_gate_scores_fwd_bf16((const uint16_t*)a->x, a->Wv16, a->bv, a->Wu16, a->bu, a->w, a->b, a->scores,
                                           g16 ? nullptr : gates, a->R, a->L, MIL_GATE_D, (grads && g16) ? a->gates16 : nullptr,
                                           xbits, xscale, stream);

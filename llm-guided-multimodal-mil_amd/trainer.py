@@ -403,7 +403,12 @@ class ImageOnlyTrainer:
         a2.adam_step_dev, a2.lr_dev, a2.adam_step, a2.lr, a2.accumulate = None, None, 1, self.lr, 0
         S = _lib
         fwd = S.STAGE_TILEMAP | S.STAGE_DROPBITS | S.STAGE_GATE_FWD
-        fused_pool = (not a.x_bf16) and getattr(layout, "aligned32", False)
+        # bf16: the deep forward carries the pool pass when the batch fills the chip with 256-row workgroups (csrc/step.hip
+        # falls back to two launches inside the group otherwise - the label then names what was asked for)
+        fused_pool = getattr(layout, "aligned32", False) and (not a.x_bf16 or (a.L in (512, 1024) and a.R >= 256 * 256
+                                                                               and bool(a.gates16) and a.C == 2
+                                                                               and os.environ.get("MIL_FUSE_POOL", "1") != "0"
+                                                                               and os.environ.get("MIL_FUSE_POOL16", "0" if a.train else "1") != "0"))
         groups = []
         if fused_pool:
             groups.append(("gate_fwd_with_pool_fused", fwd | S.STAGE_POOL | S.STAGE_POOL_FUSED))
@@ -442,12 +447,17 @@ class ImageOnlyTrainer:
         return {n: med[i] for i, (n, _) in enumerate(groups)}, med[len(groups)]
 
     # ------------------------------------------------------------------ hipGraph replay of the launch-bound part
-    def capture(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor):
+    def capture(self, x: torch.Tensor, layout: BagLayout, y: torch.Tensor, collective_in_graph: Optional[bool] = None):
         """Capture forward+backward (static buffers) into one hipGraph.  ``x`` and ``y`` become the static input
         buffers: copy new bags into them, then call ``replay_step()``.  With counted=True the Adam launch (device step
         counter) is inside the graph as well when no all-reduce is needed.  The graph entry keeps references to every
         tensor its launches point at (layout, workspace, bf16 shadows), so later growth of the trainer's buffers or
-        eviction from BagLayout's cache cannot free memory a replay reads."""
+        eviction from BagLayout's cache cannot free memory a replay reads.
+
+        collective_in_graph (default: MIL_GRAPH_COLLECTIVE=1, counted trainers only): at world size > 1 the captured segment
+        is [forward .. fold -> all_reduce -> Adam] - the step's one RCCL collective becomes a node of the graph instead of
+        an eager call between two launches, so no host round trip and no eager stream hand-over sits on the exposed
+        fold -> collective -> update path.  Returns self; `self._graph["collective"]` says which form was captured."""
         if self.accum != 1:
             # the micro-batch index (dropout stream position) and the accumulate flag are launch arguments frozen at capture
             raise _lib.MilHipError("ImageOnlyTrainer.capture: gradient accumulation (accum > 1) cannot be replayed from one graph")
@@ -455,17 +465,29 @@ class ImageOnlyTrainer:
         if a.train and self.step_counter is None:
             raise _lib.MilHipError("ImageOnlyTrainer.capture in train mode needs counted=True: the dropout stream position "
                                    "must live on the device, or every replay would draw the same mask")
-        in_graph_adam = self.step_counter is not None and not (self.world > 1 or self.force_collectives) and self.accum == 1
+        collective = self.world > 1 or self.force_collectives
+        if collective_in_graph is None:
+            collective_in_graph = os.environ.get("MIL_GRAPH_COLLECTIVE") == "1"
+        collective_in_graph = bool(collective_in_graph) and collective and self.step_counter is not None and self.accum == 1
+        in_graph_adam = self.step_counter is not None and self.accum == 1 and (not collective or collective_in_graph)
         stages = _lib.STAGE_ALL if in_graph_adam else _lib.STAGE_ALL & ~_lib.STAGE_ADAM
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)
+            if collective_in_graph:
+                self.reduce_only()          # RCCL sets its communicator up on first use: never inside a capture
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._run(a, stages)
-        self._graph = dict(graph=graph, keep=(self._keep, dict(self._ws)), args=a, adam=in_graph_adam, last=dict(self.last))
+            if collective_in_graph:
+                self._run(a, _lib.STAGE_ALL & ~_lib.STAGE_ADAM)
+                self.reduce_only()
+                self._run(a, _lib.STAGE_ADAM)
+            else:
+                self._run(a, stages)
+        self._graph = dict(graph=graph, keep=(self._keep, dict(self._ws)), args=a, adam=in_graph_adam, last=dict(self.last),
+                           collective=collective_in_graph)
         return self
 
     def replay_step(self):

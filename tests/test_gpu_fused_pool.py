@@ -14,14 +14,17 @@ from mil_amd.trainer import ImageOnlyTrainer
 pytestmark = pytest.mark.gpu
 
 
-def _run(train_mode, fuse, B, N, L=512):
+def _run(train_mode, fuse, B, N, L=512, bf16=False):
     dev = torch.device("cuda")
     old = os.environ.get("MIL_FUSE_POOL")
     os.environ["MIL_FUSE_POOL"] = "1" if fuse else "0"
+    os.environ["MIL_FUSE_POOL16"] = "1" if fuse else "0"        # bf16: the fused form is the default in eval mode only
     try:
         p = syn.image_only_params(1234, L=L)
         tr = ImageOnlyTrainer(p, dev, train_mode=train_mode)
         x = syn.make_bags(4321, B, N, L).reshape(B * N, L).to(dev)
+        if bf16:
+            x = x.to(torch.bfloat16)
         y = syn.make_labels(99, B).to(dev)
         lay = BagLayout.uniform(B, N, dev)
         tr.forward(x, lay, y)
@@ -36,6 +39,7 @@ def _run(train_mode, fuse, B, N, L=512):
             out["xbits"] = tr.last["xbits"].clone()
         return out
     finally:
+        os.environ.pop("MIL_FUSE_POOL16", None)
         if old is None:
             os.environ.pop("MIL_FUSE_POOL", None)
         else:
@@ -103,4 +107,23 @@ def test_long_bag_tail_in_two_launches_equals_the_one_launch_tail(train_mode, B,
         d = float((a[k] - b[k]).abs().max())
         ref = float(b[k].abs().max())
         assert d <= 3e-6 * max(1.0, ref), (k, d, ref)
+    assert bool(torch.isfinite(a["grad"]).all())
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+@pytest.mark.parametrize("B,N,L", [(32, 4096, 1024), (17, 4096, 512), (33, 2016, 1024)])
+def test_bf16_fused_pool_pass_equals_the_stand_alone_launch(train_mode, B, N, L):
+    """Round 4: the bf16 deep forward (k_gate_fwd_bf16_deep<2, .., PQ>) with the pool partial pass in its epilogue - one wave
+    per 32-row tile playing k_pool_partial_bf16's four waves in turn - against the stand-alone pass (MIL_FUSE_POOL=0).
+    32 x 4096 x 1024 is BASELINE config 5; 17 x 4096 x 512 the one-block form; 33 x 2016 = 66 528 rows = 259.9 workgroups of
+    256 rows: the last one has seven live tiles."""
+    a = _run(train_mode, True, B, N, L, bf16=True)
+    b = _run(train_mode, False, B, N, L, bf16=True)
+    assert torch.equal(a["scores"], b["scores"])
+    if train_mode:
+        assert torch.equal(a["xbits"], b["xbits"]) and torch.equal(a["mbits"], b["mbits"])
+    for k in ("partials", "hrow", "logits", "ds", "grad", "loss"):
+        d = float((a[k] - b[k]).abs().max())
+        ref = float(b[k].abs().max())
+        assert d <= 2e-6 * max(1.0, ref), (k, d, ref)
     assert bool(torch.isfinite(a["grad"]).all())
