@@ -682,6 +682,16 @@ int mil_adam_step_counted_noinc(float* param, const float* grad, float* exp_avg,
 int mil_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int32_t* step_counter,
                       const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                       int inc, void* stream);
+#define MIL_ADAM_MAX_SEGS 8
+/* mil_adam_step_dev over nseg <= MIL_ADAM_MAX_SEGS contiguous ranges [seg_begin[i], seg_end[i]) (HOST arrays of element
+ * offsets into the flat buffers, begins 16-byte aligned) in ONE launch, the step counter advanced by that same launch
+ * (inc != 0): optim.FlatAdam's update of the live parameter ranges - torch.optim.Adam skips parameters without a gradient
+ * (train_ddp.py:115-118) - was one launch per range plus a one-thread increment.  done_counter: device int32 [1], zero before
+ * the first launch; the launch leaves it zero. */
+int mil_adam_step_dev_segs(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const size_t* seg_begin,
+                           const size_t* seg_end, int nseg, int32_t* step_counter, const float* lr_dev,
+                           int32_t* done_counter, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                           int inc, void* stream);
 
 /* torch.optim.SGD step without momentum (train_ddp.py:103-108: the optimizer of the learnable-prompt runs) over a
  * flat fp32 buffer: g = grad_scale * grad + weight_decay * param;  param -= lr * g.  Both buffers 16-byte aligned. */

@@ -146,6 +146,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_adam_step_counted": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
     "mil_adam_step_counted_noinc": (c_int, [_P] * 4 + [c_size_t, _P] + [c_float] * 6 + [_P]),
     "mil_adam_step_dev": (c_int, [_P] * 4 + [c_size_t, _P, _P] + [c_float] * 5 + [c_int, _P]),
+    "mil_adam_step_dev_segs": (c_int, [_P] * 4 + [_P, _P, c_int, _P, _P, _P] + [c_float] * 5 + [c_int, _P]),
     "mil_sgd_step": (c_int, [_P, _P, c_size_t] + [c_float] * 3 + [_P]),
     "mil_linear_mid_fwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "mil_linear_mid_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int,

@@ -685,11 +685,10 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
                                                            float* __restrict__ partials, int L,
                                                            const float* __restrict__ Wf, int C, float* __restrict__ hrow,
                                                            const uint32_t* __restrict__ xbits, float xscale,
-                                                           const uint32_t* __restrict__ mbits, float mscale, int rev) {
-    // rev: tiles are taken LAST FIRST.  At config 5 x (256 MiB) is as large as the Infinity Cache: the gate forward has just
-    // streamed it front to back, so its tail is what the cache still holds - a pass that starts at the front again evicts
-    // every line just before reaching it (LRU under a cyclic sweep), one that starts at the back is served from the cache
-    // until it runs past what survived, and leaves the FRONT of x behind for the weight gradient, which starts there.
+                                                           const uint32_t* __restrict__ mbits, float mscale) {
+    // (Round 4, measured and dropped: taking the tiles LAST FIRST so that a cache-sized x - 256 MiB at config 5, just streamed
+    // front to back by the gate forward - is met where the Infinity Cache still holds it: 58.8 us against 51.0 us for the
+    // front-to-back nontemporal sweep, and the tail launch behind it 18.9 against 14.2 us.)
     // train mode: xbits [R][L/32] keep bits of the patch dropout - the DROPPED x is what gets pooled (ABMIL.py:49,59):
     // dropped elements are zeroed right after the load, the 1/(1-p) goes into the tile weights; mbits [B][L/32] = the
     // head's Dropout(.25) folded into the head rows of the by-product (as k_pool_partial)
@@ -697,7 +696,7 @@ __global__ __launch_bounds__(256) void k_pool_partial_bf16(const u16* __restrict
     __shared__ float ml_lds[2];
     __shared__ __attribute__((aligned(16))) float red[3 * NQ * 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int t = blockIdx.x;
     const int row0 = tile_map[4 * t + 1], nrows = tile_map[4 * t + 2];
     // the tile's rows are requested FIRST: they depend on nothing, and their trip from HBM then runs under the softmax of
     // the tile's scores (wave 0) and the barrier behind it
@@ -923,6 +922,9 @@ __device__ __forceinline__ ushort4 pack_bf16x4(const f32x4 v) {
 //     (the bf16 MFMA hides VALU and LDS-write issue, unlike the f32 one).
 // Round 1 ran 2 x 256 threads per CU on 32-row slices: 200 us + reduce at config 5.
 #define WB_BKR 64
+#if !defined(WB_SETS)
+#define WB_SETS 1      // register sets of the staging prefetch; 2 = loads two slices ahead: measured, no change (see the kernel)
+#endif
 template <bool DROP>      // DROP: train mode, x read through the keep bits (templated: the eval kernel is the one tuned above)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gate_bwd_dw_bf16(const u16* __restrict__ x, const u16* __restrict__ gates,
                                                           const float* __restrict__ ds, const float* __restrict__ wvec,
@@ -954,36 +956,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int xrow = tid >> 5, xc = tid & 31;
     const int arow = tid >> 4, ad4 = tid & 15;
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
-    u16x8 rx[8];
-    ushort4 hv[4], hu[4];
-    float rds[4], rmask[4];
+    // WB_SETS register sets: slice q lives in set q % WB_SETS, its global loads are issued WB_SETS slices before its staging
+    // parts need them.  Round 4 tested the hypothesis that the kernel sits at "one memory latency per 64-row slice" (1.7 us per
+    // slice against 0.43 us of MFMA time) because with one set every load has exactly one slice time to land: with two sets
+    // (234 VGPRs + 128 AGPRs, no spills, bit-identical results) the weight gradient of config 5 takes 168.7 us against
+    // 169 - 172 us - no change.  It is not load latency; what the lone wave of a SIMD cannot hide is the ISSUE of its own
+    // staging work (~240 VALU + 16 LDS writes + 20 loads per slice next to 32 MFMAs), as the ablations of round 2 said.
+    u16x8 rx[WB_SETS][8];
+    ushort4 hv[WB_SETS][4], hu[WB_SETS][4];
+    float rds[WB_SETS][4], rmask[WB_SETS][4];
     f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
     float acc_ds = 0.f;
 
-    unsigned rxm[DROP ? 8 : 1];
-    auto xload = [&](int i, int rs) {
+    unsigned rxm[WB_SETS][DROP ? 8 : 1];
+    auto xload = [&](int z, int i, int rs) {
         const int gr = min(rs + xrow + 8 * i, rend - 1);
-        rx[i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
-        if (DROP) rxm[i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
+        rx[z][i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
+        if (DROP) rxm[z][i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
     };
-    auto xwrite = [&](int i, int buf) {
+    auto xwrite = [&](int z, int i, int buf) {
         // columns 0..127 -> panel 0, 128..255 -> panel 1 (each panel is its own 160-stride image)
         u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
-        *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8_b(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
+        *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8_b(rx[z][i], rxm[z][i] >> (8 * (xc & 3))) : rx[z][i];
     };
-    auto aload = [&](int i, int rs, bool live) {
+    auto aload = [&](int z, int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
         const int gc = min(gr, rend - 1);
         const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
-        hv[i] = *reinterpret_cast<const ushort4*>(gp);
-        hu[i] = *reinterpret_cast<const ushort4*>(gp + 192);
-        rds[i] = ds[gc];
-        rmask[i] = (live && gr < rend) ? 1.f : 0.f;
+        hv[z][i] = *reinterpret_cast<const ushort4*>(gp);
+        hu[z][i] = *reinterpret_cast<const ushort4*>(gp + 192);
+        rds[z][i] = ds[gc];
+        rmask[z][i] = (live && gr < rend) ? 1.f : 0.f;
     };
-    auto awrite = [&](int i, int buf) {
-        const f32x4 v = {bf16_to_f32(hv[i].x), bf16_to_f32(hv[i].y), bf16_to_f32(hv[i].z), bf16_to_f32(hv[i].w)};
-        const f32x4 u = {bf16_to_f32(hu[i].x), bf16_to_f32(hu[i].y), bf16_to_f32(hu[i].z), bf16_to_f32(hu[i].w)};
-        const float dsv = rds[i] * rmask[i];
+    auto awrite = [&](int z, int i, int buf) {
+        const f32x4 v = {bf16_to_f32(hv[z][i].x), bf16_to_f32(hv[z][i].y), bf16_to_f32(hv[z][i].z), bf16_to_f32(hv[z][i].w)};
+        const f32x4 u = {bf16_to_f32(hu[z][i].x), bf16_to_f32(hu[z][i].y), bf16_to_f32(hu[z][i].z), bf16_to_f32(hu[z][i].w)};
+        const float dsv = rds[z][i] * rmask[z][i];
         const f32x4 a = (dsv * w4) * u;
         const f32x4 t = a * v;
         const f32x4 pv = a - t * v;               // ds w U (1 - V^2)
@@ -1005,29 +1013,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+    // slice q of the chunk: rows rbeg + 64 q ..; beyond the last slice the x rows are clamped and the dPre rows masked to zero
+    auto slice_rows = [&](int q) { return rbeg + min(q, max(nslice - 1, 0)) * WB_BKR; };
+    auto load_all = [&](int z, int q) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xload(z, i, slice_rows(q));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aload(z, i, slice_rows(q), q < nslice);
+    };
     if (nslice > 0) {
+        load_all(0, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xload(i, rbeg);
+        for (int i = 0; i < 8; ++i) xwrite(0, i, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) aload(i, rbeg, true);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xwrite(i, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) awrite(i, 0);
-        const int rs1 = rbeg + min(1, nslice - 1) * WB_BKR;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xload(i, rs1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) aload(i, rs1, nslice > 1);
+        for (int i = 0; i < 4; ++i) awrite(0, i, 0);
+        // slice 1 -> set 1 % WB_SETS, slice 2 -> set 2 % WB_SETS (one set: slice 1 only, as before)
+        load_all(1 % WB_SETS, 1);
+        if (WB_SETS > 1) load_all(0, 2);
     }
     __syncthreads();
     // fragment column offsets inside an image: wave tile + 16-lane group + 4 p
     const int acol = 64 * wi + 16 * tg + 4 * tp;                 // + 32 a
     const int bcol = 16 * tg + 4 * tp;                           // + 32 b inside panel wj
-    for (int sl = 0; sl < nslice; ++sl) {
+    // one slice: multiply stage `buf` (slice sl) while slice sl + 1 goes from register set ZW to the other stage and that
+    // set is reloaded with slice sl + 1 + WB_SETS
+    auto do_slice = [&](int sl, auto zw_c) {
+        constexpr int ZW = decltype(zw_c)::value;
         const int buf = sl & 1;
-        const bool live2 = sl + 2 < nslice;
-        const int rs2 = rbeg + min(sl + 2, nslice - 1) * WB_BKR;
+        const int qn = sl + 1 + WB_SETS;                         // the slice the freed registers are reloaded with
+        const bool liven = qn < nslice;
+        const int rsn = slice_rows(qn);
         const u16* ai = ab + buf * ASZ;
         const u16* bi = xb + buf * BSZ + wj * ASZ;
         u16x8 fa[2][2], fb[2][4];                                // [register set][tile]
@@ -1040,8 +1055,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         // twelve staging parts of the next slice, three per k-step
         auto stage = [&](int p) {
-            if (p < 8) { xwrite(p, buf ^ 1); xload(p, rs2); }
-            else { awrite(p - 8, buf ^ 1); aload(p - 8, rs2, live2); }
+            if (p < 8) { xwrite(ZW, p, buf ^ 1); xload(ZW, p, rsn); }
+            else { awrite(ZW, p - 8, buf ^ 1); aload(ZW, p - 8, rsn, liven); }
         };
         frags(0, 0);
 #pragma unroll
@@ -1064,8 +1079,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
         }
         // (round 4: __syncthreads() here compiles to s_waitcnt lgkmcnt(0) + s_barrier on gfx950 - it does NOT drain vmcnt, so the
-        // prefetched loads of slice sl + 2 stay in flight across it; a hand-written LDS-only barrier produced the same code)
+        // prefetched loads stay in flight across it; a hand-written LDS-only barrier produced the same code)
         __syncthreads();
+    };
+    {
+        using Z0 = std::integral_constant<int, 0>;
+        using Z1 = std::integral_constant<int, 1 % WB_SETS>;
+        int sl = 0;
+        for (; sl + 1 < nslice; sl += 2) {                       // slice sl + 1 sits in set (sl + 1) % WB_SETS
+            do_slice(sl, Z1{});
+            do_slice(sl + 1, Z0{});
+        }
+        if (sl < nslice) do_slice(sl, Z1{});
     }
 
     // partial tile -> part[s][128m + 64wi + 32a + row][j0 + 128wj + 32b + r]
@@ -1176,13 +1201,8 @@ static void launch_pool_partial_bf16(const uint16_t* x, const float* scores, con
                                      const uint32_t* mbits, float mscale, hipStream_t st) {
     const bool drop = xbits != nullptr || mbits != nullptr;
     const float xs = xbits ? xscale : 1.0f, ms = mbits ? mscale : 1.0f;
-    const size_t xbytes = (size_t)T * MIL_POOL_TILE * L * sizeof(uint16_t);
-    // x between one and two Infinity Caches large: back to front (see the kernel), with ordinary loads - the pass is meant
-    // to hit the cache and to leave the front of x there; larger still: a pure stream, nontemporal
-    static const int rev_env = [] { const char* e = getenv("MIL_POOL_REV"); return e ? atoi(e) : -1; }();
-    const int rev = rev_env >= 0 ? rev_env : (xbytes > MIL_STREAM_BYTES && xbytes <= ((size_t)512 << 20) ? 1 : 0);
-    const bool nt = xbytes > MIL_STREAM_BYTES && !rev;
-#define POOL16(NQ_, D_, N_) hipLaunchKernelGGL((k_pool_partial_bf16<NQ_, D_, N_>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, (D_) ? xs : 1.0f, mbits, (D_) ? ms : 1.0f, rev)
+    const bool nt = (size_t)T * MIL_POOL_TILE * L * sizeof(uint16_t) > MIL_STREAM_BYTES;
+#define POOL16(NQ_, D_, N_) hipLaunchKernelGGL((k_pool_partial_bf16<NQ_, D_, N_>), dim3(T), dim3(256), 0, st, x, scores, tile_map, partials, L, Wf, C, hrow, xbits, (D_) ? xs : 1.0f, mbits, (D_) ? ms : 1.0f)
     if (L == 512) {
         if (drop) { if (nt) POOL16(1, true, true); else POOL16(1, true, false); }
         else { if (nt) POOL16(1, false, true); else POOL16(1, false, false); }

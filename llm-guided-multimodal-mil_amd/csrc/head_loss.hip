@@ -187,6 +187,75 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const f
     }
 }
 __global__ void k_step_inc(int* step_dev) { *step_dev += 1; }
+
+// Adam over up to MIL_ADAM_MAX_SEGS contiguous ranges of one flat buffer AND the advance of the device step counter in ONE
+// launch (optim.FlatAdam: parameters that received no gradient are skipped, as torch.optim.Adam skips them, so the live part
+// of the buffer is a few ranges - three launches plus a one-thread increment per fusion step before).  Every workgroup reads
+// the step number when it starts; the counter may only move once all of them have, so each workgroup signs off on `done`
+// when it ends and the last one advances the step and clears `done` for the next launch (replay-safe: no host reset).
+struct AdamSegs {
+    int nseg;
+    unsigned blk_end[MIL_ADAM_MAX_SEGS];      // exclusive prefix of workgroups per range
+    unsigned long long begin[MIL_ADAM_MAX_SEGS], end[MIL_ADAM_MAX_SEGS];
+};
+__global__ __launch_bounds__(256) void k_adam_segs(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, const AdamSegs sg, float b1,
+                                                   float b2, float eps, float wd, float gscale, int* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev, int* __restrict__ done, int inc) {
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+        const double st = (double)(__hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1);
+        bc[0] = (float)(1.0 - pow((double)b1, st));
+        bc[1] = (float)sqrt(1.0 - pow((double)b2, st));
+    }
+    __syncthreads();
+    const float lr_bc1 = *lr_dev / bc[0], bc2_sqrt = bc[1];
+    int sI = 0;
+    while (sI + 1 < sg.nseg && blockIdx.x >= sg.blk_end[sI]) ++sI;
+    const unsigned b0 = sI == 0 ? 0u : sg.blk_end[sI - 1];
+    constexpr int AD_U = 4;
+    const size_t base = (size_t)sg.begin[sI] + (size_t)(blockIdx.x - b0) * (256 * 4 * AD_U), n = (size_t)sg.end[sI];
+    if (base + 256 * 4 * AD_U <= n) {
+        f32x4 p4[AD_U], g4[AD_U], m4[AD_U], v4[AD_U];
+#pragma unroll
+        for (int u = 0; u < AD_U; ++u) {
+            const size_t i = base + ((size_t)u * 256 + threadIdx.x) * 4;
+            p4[u] = *reinterpret_cast<const f32x4*>(param + i);
+            g4[u] = *reinterpret_cast<const f32x4*>(grad + i);
+            m4[u] = *reinterpret_cast<const f32x4*>(m + i);
+            v4[u] = *reinterpret_cast<const f32x4*>(v + i);
+        }
+#pragma unroll
+        for (int u = 0; u < AD_U; ++u) {
+            const size_t i = base + ((size_t)u * 256 + threadIdx.x) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = p4[u][e], me = m4[u][e], ve = v4[u][e];
+                adam_one(pe, g4[u][e], me, ve, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt);
+                p4[u][e] = pe; m4[u][e] = me; v4[u][e] = ve;
+            }
+            *reinterpret_cast<f32x4*>(param + i) = p4[u];
+            *reinterpret_cast<f32x4*>(m + i) = m4[u];
+            *reinterpret_cast<f32x4*>(v + i) = v4[u];
+        }
+    } else {
+        for (size_t j = base + threadIdx.x; j < n; j += 256) {
+            float pe = param[j], me = m[j], ve = v[j];
+            adam_one(pe, grad[j], me, ve, lr_bc1, b1, b2, eps, wd, gscale, bc2_sqrt);
+            param[j] = pe; m[j] = me; v[j] = ve;
+        }
+    }
+    if (inc) {
+        __syncthreads();                         // thread 0 read the step long ago; nothing else of this workgroup needs it
+        if (threadIdx.x == 0) {
+            const int prev = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == (int)gridDim.x - 1) {    // every workgroup has started (and read the step): advance it
+                __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(step_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
 __global__ void k_counter_add(int* ctr, int v) { *ctr += v; }
 // Up to 8 int32 values handed over AS KERNEL ARGUMENTS (the per-step bag lengths of a capacity bucket: a 4-byte
 // hipMemcpyAsync from pageable memory showed up as a 4.7 us blit kernel behind an 8.7 us gap in front of every replay).
@@ -1209,6 +1278,37 @@ extern "C" int mil_adam_step_dev(float* param, const float* grad, float* exp_avg
         hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step_counter);
         MIL_CHECK_LAUNCH();
     }
+    return MIL_OK;
+}
+
+extern "C" int mil_adam_step_dev_segs(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const size_t* seg_begin,
+                                      const size_t* seg_end, int nseg, int32_t* step_counter, const float* lr_dev,
+                                      int32_t* done_counter, float beta1, float beta2, float eps, float weight_decay,
+                                      float grad_scale, int inc, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter || !lr_dev || !done_counter || !seg_begin || !seg_end)
+        return MIL_EINVAL;
+    if (nseg < 1 || nseg > MIL_ADAM_MAX_SEGS) return MIL_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return MIL_EINVAL;
+    AdamSegs sg;
+    sg.nseg = nseg;
+    unsigned blocks = 0;
+    for (int i = 0; i < MIL_ADAM_MAX_SEGS; ++i) { sg.blk_end[i] = 0; sg.begin[i] = sg.end[i] = 0; }
+    for (int i = 0; i < nseg; ++i) {
+        if (seg_end[i] < seg_begin[i] || (seg_begin[i] & 3)) return MIL_EINVAL;
+        blocks += (unsigned)((seg_end[i] - seg_begin[i] + 4095) / 4096);
+        sg.blk_end[i] = blocks;
+        sg.begin[i] = seg_begin[i];
+        sg.end[i] = seg_end[i];
+    }
+    if (blocks == 0) {
+        if (inc) { hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter); MIL_CHECK_LAUNCH(); }
+        return MIL_OK;
+    }
+    hipLaunchKernelGGL(k_adam_segs, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, sg, beta1,
+                       beta2, eps, weight_decay, grad_scale, step_counter, lr_dev, done_counter, inc);
+    MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 

@@ -92,8 +92,8 @@ def one_token_ok(attn: "Attention", s_ti: AttnSegs, pe_table) -> bool:
 
 
 class _LN(nn.LayerNorm):
-    def forward(self, x, tail_rows: int = 0):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps, tail_rows)
+    def forward(self, x, tail_rows: int = 0, into_tail_of=None):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, tail_rows, into_tail_of)
 
 
 class TwoWayAttentionBlock(nn.Module):
@@ -251,7 +251,9 @@ class TwoWayTransformer(nn.Module):
             out, keys = self.final_attn_token_to_image.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=queries)
         else:
             out = self.final_attn_token_to_image.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=queries)
-        return self.norm_final_attn(out), keys
+        # the returned text tokens are the rows the multi-modal bag appends behind the patch tokens (model/aggregator.py:192):
+        # when exactly that many rows were reserved behind `keys`, the last LayerNorm writes them there (no copy launch)
+        return self.norm_final_attn(out, into_tail_of=keys if keys_tail_rows == out.shape[0] else None), keys
 
     def forward(self, image_embedding, image_pe, point_embedding):
         """Reference signature (sam/transformer.py:58-63): image_embedding [B, N, E], image_pe [B or 1, N, E],

@@ -323,6 +323,18 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, step_counter, lr_dev, betas=
     _lib.check(rc, "mil_adam_step_dev")
 
 
+def adam_step_dev_segs(param, grad, exp_avg, exp_avg_sq, segs, step_counter, lr_dev, done_counter, betas=(0.9, 0.999),
+                       eps: float = 1e-8, weight_decay: float = 1e-7, grad_scale: float = 1.0, inc: bool = True):
+    """Adam over the ranges `segs` = [(begin, end), ...] of the flat buffers + the step-counter advance, one launch."""
+    import ctypes
+    n = len(segs)
+    b = (ctypes.c_size_t * n)(*[int(a_) for a_, _ in segs])
+    e = (ctypes.c_size_t * n)(*[int(b_) for _, b_ in segs])
+    rc = _lib.lib().mil_adam_step_dev_segs(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), b, e, n, _p(step_counter), _p(lr_dev),
+                                           _p(done_counter), betas[0], betas[1], eps, weight_decay, grad_scale, int(inc), _stream())
+    _lib.check(rc, "mil_adam_step_dev_segs")
+
+
 def sgd_step(param, grad, lr: float = 1e-3, weight_decay: float = 1e-7, grad_scale: float = 1.0):
     """torch.optim.SGD (no momentum, L2 weight decay) over a flat buffer, in place."""
     rc = _lib.lib().mil_sgd_step(_p(param), _p(grad), param.numel(), lr, weight_decay, grad_scale, _stream())
@@ -1055,13 +1067,30 @@ def attention_pool(q, k, v, segs, H: int):
     return _AttnPool.apply(q, k, v, segs, H)
 
 
+def _tail_view(base, rows: int):
+    """The `rows` rows reserved BEHIND `base` in its storage (layer_norm(..., tail_rows=rows) allocated them), or None."""
+    if base is None or base.dim() != 2 or not base.is_contiguous() or base.storage_offset() != 0 or base.dtype != torch.float32:
+        return None
+    R, E = base.shape
+    st = base.untyped_storage()
+    if st.nbytes() != (R + rows) * E * 4:
+        return None
+    return torch.empty(0, device=base.device, dtype=torch.float32).set_(st, R * E, (rows, E), (E, 1))
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, tail_rows: int = 0):
+    def forward(ctx, x, gamma, beta, eps: float, tail_rows: int = 0, into_tail_of=None):
         x = _f32c(x, "x")
         rows, E = x.shape
         # tail_rows > 0: allocate room for that many more rows behind the result (see append_rows)
-        y = torch.empty((rows + tail_rows, E), device=x.device, dtype=torch.float32)[:rows] if tail_rows else torch.empty_like(x)
+        y = torch.empty((rows + tail_rows, E), device=x.device, dtype=torch.float32)[:rows] if tail_rows else None
+        if y is None and into_tail_of is not None:
+            # the result IS the block another tensor reserved behind itself (the text tokens of the multi-modal bag,
+            # model/aggregator.py:192): written in place there, append_rows then has nothing to copy
+            y = _tail_view(into_tail_of.detach(), rows) if into_tail_of.shape[1] == E else None
+        if y is None:
+            y = torch.empty_like(x)
         stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
         sh = _lib.shim()
         if sh is not None:
@@ -1079,7 +1108,7 @@ class _LayerNorm(torch.autograd.Function):
         x, gamma, stats = ctx.saved_tensors
         dx, dg, db = _layer_norm_bwd(x, gamma, stats, dy, None, ctx.needs_input_grad[1] or ctx.needs_input_grad[2],
                                      ctx.beta_param)
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 def _layer_norm_bwd(x, gamma, stats, dy, dres, want_params: bool, beta=None):
@@ -1193,9 +1222,9 @@ def layer_norm_bag_row(x, o, segs, gamma, beta, eps: float = 1e-5, tail_rows: in
     return _LayerNormBagRow.apply(x, o, gamma, beta, eps, segs, tail_rows)
 
 
-def layer_norm(x, gamma, beta, eps: float = 1e-5, tail_rows: int = 0):
+def layer_norm(x, gamma, beta, eps: float = 1e-5, tail_rows: int = 0, into_tail_of=None):
     lead = x.shape[:-1]
-    return _LayerNorm.apply(x.reshape(-1, x.shape[-1]), gamma, beta, eps, tail_rows).reshape(*lead, x.shape[-1])
+    return _LayerNorm.apply(x.reshape(-1, x.shape[-1]), gamma, beta, eps, tail_rows, into_tail_of).reshape(*lead, x.shape[-1])
 
 
 class _AppendRows(torch.autograd.Function):
@@ -1214,7 +1243,8 @@ class _AppendRows(torch.autograd.Function):
         if (tail_reserved and base.is_contiguous() and base.storage_offset() == 0 and base.dtype == torch.float32
                 and st.nbytes() == (R + T) * E * 4):
             big = torch.empty(0, device=base.device, dtype=torch.float32).set_(st, 0, (R + T, E), (E, 1))
-            big[R:].copy_(extra)
+            if not (extra.is_contiguous() and extra.dtype == torch.float32 and extra.data_ptr() == base.data_ptr() + R * E * 4):
+                big[R:].copy_(extra)          # (else: the producer already wrote them there - layer_norm(into_tail_of=base))
             return big
         return torch.cat([base, extra], 0)
 

@@ -66,6 +66,7 @@ class FlatAdam:
         # (utils.py:232-241 writes param_groups[0]["lr"] every epoch); sync_lr() pushes a changed value before a replay
         self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32) if (counted and self.needs_moments) else None
         self._lr_on_dev = float(lr)
+        self._done = torch.zeros(1, device=dev, dtype=torch.int32) if counted else None     # sign-off word of the one-launch update
 
     def zero_grad(self, set_to_none: bool = True):
         """Gradients are dropped (autograd then hands over fresh tensors without an accumulate kernel)."""
@@ -149,9 +150,14 @@ class FlatAdam:
         segs = self._segments()
         if self.counted:
             self.sync_lr()
-            for i, (a, b) in enumerate(segs):
-                ops.adam_step_dev(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.step_counter,
-                                  self.lr_dev, g["betas"], g["eps"], g["weight_decay"], scale, inc=(i == len(segs) - 1))
+            if len(segs) <= 8:
+                # every live range and the step-counter advance in ONE launch (three Adam launches + an increment before)
+                ops.adam_step_dev_segs(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_counter, self.lr_dev,
+                                       self._done, g["betas"], g["eps"], g["weight_decay"], scale)
+            else:
+                for i, (a, b) in enumerate(segs):
+                    ops.adam_step_dev(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.step_counter,
+                                      self.lr_dev, g["betas"], g["eps"], g["weight_decay"], scale, inc=(i == len(segs) - 1))
         else:
             self.step_count += 1
             for a, b in segs:

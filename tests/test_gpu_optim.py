@@ -162,3 +162,36 @@ def test_deferred_grouped_weight_gradients_equal_the_per_layer_ones(monkeypatch)
     assert slot1 and slot0
     for a, b in zip(g1, g0):
         assert torch.equal(a, b)
+
+
+def test_one_launch_multi_range_adam_equals_the_per_range_launches():
+    """mil_adam_step_dev_segs (round 4: every live range of the flat buffer and the step-counter advance in one launch) against
+    one mil_adam_step_dev launch per range: bit-identical parameters and moments over several steps, counter advanced once
+    per step, sign-off word back at zero (what a hipGraph replay needs)."""
+    from mil_amd import ops
+    dev = torch.device("cuda")
+    n = 3 * 4096 * 40 + 1236
+    g = torch.Generator().manual_seed(5)
+    base = [torch.randn(n, generator=g).to(dev) for _ in range(2)]
+    segs = [(0, 5000), (8192, 8192 + 4096 * 7), (40000, 40000), (50000, n)]           # short tail, whole blocks, empty, long
+    lr_dev = torch.full((1,), 1e-3, device=dev)
+
+    def run(one_launch):
+        p, m, v = base[0].clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        ctr, done = torch.zeros(1, device=dev, dtype=torch.int32), torch.zeros(1, device=dev, dtype=torch.int32)
+        for step in range(4):
+            grad = base[1] * (1.0 + 0.1 * step)
+            if one_launch:
+                ops.adam_step_dev_segs(p, grad, m, v, segs, ctr, lr_dev, done, grad_scale=0.5)
+            else:
+                live = [(a, b) for a, b in segs if b > a]
+                for i, (a, b) in enumerate(live):
+                    ops.adam_step_dev(p[a:b], grad[a:b], m[a:b], v[a:b], ctr, lr_dev, grad_scale=0.5, inc=(i == len(live) - 1))
+        torch.cuda.synchronize()
+        return p, m, v, int(ctr.item()), int(done.item())
+
+    pa, ma, va, ca, da = run(True)
+    pb, mb, vb, cb, _ = run(False)
+    assert ca == cb == 4 and da == 0
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert torch.equal(pa[5000:8192], base[0][5000:8192])                             # outside every range: untouched
