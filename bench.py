@@ -460,6 +460,19 @@ def config3_fusion(dev, steps=30, warmup=4):
     # algorithmic flops of the trainable path per step: fc_pathology fwd + dW (2 x 2*R*768*512),
     # ABMIL gate fwd + dW + dx (3 x 4*R*512*192); the absorbed one-token attention sites are HBM-bound streams
     flops = 2 * 2.0 * R * 768 * 512 + 3 * 4.0 * R * 512 * D_GATE
+    # algorithmic HBM bytes of the step: every [R, E] stream once per pass that must produce or consume it (SURVEY 8d's
+    # per-pass counting; E = 512 floats = 2 KiB per row, the raw features 768)
+    row = 512 * 4
+    n_par = sum(p_.numel() for p_ in model.parameters() if p_.requires_grad)
+    alg_bytes = (R * (768 + 512) * 4                              # fc_pathology forward: x in, xi out
+                 + 2 * (R * row + 2 * R * row)                    # per block: absorbed pool over the keys; LayerNorm(keys + row) in / out
+                 + R * row                                        # final token -> image pool
+                 + R * row + R * 384 * 4 + R * row                # gate forward (x0 in, gates out) + pool pass
+                 + (R * row + R * 384 * 4) + (R * 384 * 4 + R * row)      # gate dW (x0, gates in); gate dx (gates in, dx out)
+                 + 3 * (R * row + 3 * R * row)                    # absorbed pool backward x 3: dots (keys), apply (keys, dkeys in, dkeys out)
+                 + 2 * (3 * R * row)                              # LayerNorm-with-bag-row backward x 2: x, dy in, dx out
+                 + R * (512 + 512 + 768) * 4                      # fc_pathology parameter backward: dy, y (tanh'), x
+                 + n_par * 28)                                    # Adam: p, m, v in and out + g in
     return {"workload": f"{B} bags x {N} x 768 + one 77-token note per bag, aggregator(args) fwd+BCE+bwd+Adam "
                         "(BASELINE config 3; text embeddings of the frozen ViT-B/32 tower cached per note)",
             "ms_per_step": round(ms, 4), "bags_per_s": round(B / (ms * 1e-3), 1), "dtype": "f32", "launch": "hipGraph",
@@ -473,6 +486,10 @@ def config3_fusion(dev, steps=30, warmup=4):
                                            "over every kernel of the replayed step, separate rocprofv3 --pmc passes)"},
             "step_hbm_ms_at_peak": (round(_pmc_traffic("cfg3_step") / (PEAK_HBM_GBS * 1e9) * 1e3, 4)
                                     if _pmc_traffic("cfg3_step") else None),
+            "step_algorithmic_bytes": int(alg_bytes),
+            "traffic_over_algorithmic": (round(_pmc_traffic("cfg3_step") / alg_bytes, 3) if _pmc_traffic("cfg3_step") else None),
+            "step_algorithmic_note": "every [32768, 512] / [32768, 768] stream once per pass that produces or consumes it + Adam's "
+                                     "28 B per trainable parameter",
             "parity": {"bags_checked": [0, B - 1], "max_abs_dlogit": dl, "top1_equal": top1,
                        "oracle": "fp32 oracle fused_forward (model/aggregator.py:134-209 wiring)", "tolerance": 1e-3}}
 

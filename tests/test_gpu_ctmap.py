@@ -89,6 +89,39 @@ def test_twoway_transformer_alignment_base_ct_vs_reference(tag):
             check_grad("g." + name + "." + n, got, g, 1e-3)
 
 
+def test_alignment_base_ct_at_a_realistic_bag_length_vs_the_oracle():
+    """the general rows kernels (a thread per (row, head) looping over the other side) were pinned at N <= 200 only.
+    4096 patches x 160 CT-token queries: long softmax sums (expf(s - lse) over 4096 keys), 160 x 4096 dependent iterations
+    in the key / value backward - forward and the image gradient against the oracle's TwoWayTransformer restatement, inside a
+    bounded run time (the kernels are correct-not-fast: no shipped run takes --alignment_base CT)."""
+    import time
+    seed, N, D, hw = 91, 4096, 160, 2
+    name = "TwoWayTransformer_Pth"
+    p = syn.twoway_params(seed, name)
+    m = TwoWayTransformer(args=SimpleNamespace(alignment_base="CT", model_CT="resnetMC3_18"), depth=2, embedding_dim=512,
+                          num_heads=8, mlp_dim=2048)
+    m.load_state_dict({k[len(name) + 1:]: v for k, v in p.items()})
+    m = m.to(DEV).eval()
+    ct = syn.make_ct_map(seed + 1, 1, D, hw)
+    gen = torch.Generator().manual_seed(seed + 2)
+    img_c = torch.randn((N, 512), generator=gen)
+    gq = torch.randn((D, 512), generator=gen)
+    gk = torch.randn((N, 512), generator=gen)
+    img = img_c.unsqueeze(0).to(DEV).requires_grad_(True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    q, k = m(img, orc.sinusoidal_pe(N, 512).unsqueeze(0).to(DEV), ct.to(DEV))
+    ((q[0] * gq.to(DEV)).sum() + (k[0] * gk.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    took = time.time() - t0
+    leaf = img_c.clone().requires_grad_(True)
+    qo, ko = orc.twoway_transformer(leaf, orc.sinusoidal_pe(N, 512), orc.ct_map_tokens(ct)[0], p, name)
+    ((qo * gq).sum() + (ko * gk).sum()).backward()
+    assert rel_err(q[0].detach().cpu(), qo.detach()) <= 5e-5 and rel_err(k[0].detach().cpu(), ko.detach()) <= 5e-5
+    assert rel_err(img.grad[0].cpu(), leaf.grad) <= 5e-4
+    assert took < 20.0, took                              # measured: a fraction of a second; guards against a spill / timeout regression
+
+
 def _args(**kw):
     a = dict(modality=["CT", "pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL", num_classes=2,
              learnablePrompt=0, alignment_base="CI", model_CT="resnetMC3_18")
