@@ -666,7 +666,7 @@ def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
     # ---- the fallback for a cohort that does not fit HBM (cohort.HostFeed): a background thread fills two pinned staging
     # buffers with the UN-dropped bag, the copy runs on its own stream, drop + placement on the device as above
     from mil_amd.cohort import HostFeed
-    full_host = {j: big[off[j]:off[j + 1]].cpu().numpy() for j in set(seq[:host_steps + 1])}
+    full_host = {j: big[off[j]:off[j + 1]].cpu().pin_memory() for j in set(seq[:host_steps + 1])}     # the cohort in PINNED host RAM
     hf = HostFeed(lambda j: full_host[j], ns, F, labels, dev, ids=ids, keep=keeps, seed=co.seed)
 
     def hf_step(j, nxt):
@@ -727,8 +727,9 @@ def ragged_regime(dev, kind, n_bags=64, steps=None, host_steps=24):
            "from_host_pageable_ms_per_step": round(ms_host, 4),
            "from_host_note": f"{host_steps} steps of round 3's loop: zero-padded pageable host bag -> .to(dev) -> D2D into the bucket",
            "from_host_pinned_prefetch_ms_per_step": round(ms_pinned, 4),
-           "from_host_pinned_note": "cohort.HostFeed, the fallback when the cohort does not fit: un-dropped bag from host RAM through "
-                                    "two pinned buffers (background thread) + copy stream, drop and placement on the device",
+           "from_host_pinned_note": "cohort.HostFeed, the fallback when the cohort does not fit HBM: the cohort in pinned host memory, "
+                                    "the un-dropped bag of the NEXT step copied H2D on a copy stream into a device double buffer "
+                                    "while this step runs, drop and placement on the device (PCIe-bound: ~45 MB per bag)",
            "feed_bytes_per_step": int(2 * bytes_step), "feed_bytes_note": "gather: kept rows read once from the cohort + written once to the bucket",
            "parity": {"bags_checked": [0, n_bags - 1], "max_abs_dlogit": dl, "top1_equal": top1, "tolerance": 1e-3,
                       "oracle": "eval mode; oracle forward on the rows oracle/cohort.py selects for the same (seed, epoch, bag)"}}

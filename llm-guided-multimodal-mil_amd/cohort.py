@@ -175,11 +175,13 @@ class DeviceCohort:
 
 class HostFeed:
     """Fallback when the cohort does not fit the device: the reference's pipeline shape (train_ddp.py:193: worker + pinned
-    memory + non-blocking copy) without its per-step costs.  A background thread loads bag t+1 (np.load, un-dropped) into one
-    of two PINNED staging buffers while step t runs; `next()` issues the H2D copy on a copy stream into one of two device
-    staging buffers and makes the compute stream wait for it by an event; the patch drop and the placement into the bucket
-    then run on the device exactly as for the resident cohort (mil_patch_drop_select on one bag + mil_cohort_feed), so the
-    step sees the same rows either way."""
+    memory + non-blocking copy) without its per-step costs.  A background thread fetches bag t+1 (un-dropped) while step t
+    runs: a bag that `load` returns as a PINNED host tensor (the cohort kept in pinned host memory: the intended form - an H2D
+    copy of a 45 MB bag takes ~1 ms, the time of a fusion step, and overlaps it) is copied from where it lies; anything else
+    (np.load from disk, pageable arrays) goes through one of two pinned staging buffers first, and then the host memcpy sets
+    the pace.  `next()` issues the H2D copy on a copy stream into one of two device staging buffers and makes the compute
+    stream wait for it by an event; the patch drop and the placement into the bucket then run on the device exactly as for the
+    resident cohort (mil_patch_drop_select on one bag + mil_cohort_feed), so the step sees the same rows either way."""
 
     def __init__(self, load, lengths: Sequence[int], F: int, labels: torch.Tensor, device, ids: Optional[torch.Tensor] = None,
                  keep: Optional[Sequence[float]] = None, seed: int = 1234):
@@ -206,7 +208,19 @@ class HostFeed:
     def _load_into(self, j: int, s: int):
         a = self.load(j)
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-        self.pinned[s][:self.n[j]].copy_(t)
+        if t.is_pinned() and t.is_contiguous() and t.dtype == torch.float32:
+            src = t                                     # already pinned: the H2D copy reads it where it lies
+        else:
+            self.pinned[s][:self.n[j]].copy_(t)
+            src = self.pinned[s]
+        # the H2D copy is issued HERE, from the worker, on the copy stream: it runs while the compute stream is busy with the
+        # current step; next() only makes the compute stream wait for its event
+        n = self.n[j]
+        with torch.cuda.stream(self.copy_stream):
+            if self._used[s]:
+                self.copy_stream.wait_event(self.consumed[s])       # the feed launch that last read stage[s]
+            self.stage[s][:n].copy_(src[:n], non_blocking=True)
+            self.copied[s].record(self.copy_stream)
 
     def prefetch(self, j: int):
         """Start loading bag j on the background thread (host side only; returns at once)."""
@@ -225,11 +239,6 @@ class HostFeed:
         self._thread.join()
         n = self.n[j]
         cur = torch.cuda.current_stream()
-        with torch.cuda.stream(self.copy_stream):
-            if self._used[s]:
-                self.copy_stream.wait_event(self.consumed[s])       # the feed launch that last read stage[s]
-            self.stage[s][:n].copy_(self.pinned[s][:n], non_blocking=True)
-            self.copied[s].record(self.copy_stream)
         cur.wait_event(self.copied[s])
         k = self.k_train[j] if epoch is not None else n
         stream = ctypes.c_void_p(cur.cuda_stream)

@@ -41,8 +41,33 @@ def test(args):
         # one forward is ~70 short launches: replay it from a hipGraph per capacity bucket (fusion_step.RaggedFusionInference)
         from .fusion_step import RaggedFusionInference
         inf = RaggedFusionInference(model, B=1, P=prompts, in_dim=args.patch_dim, ct_shape=CT_SHAPE if with_ct else None)
+    cohort = None
+    if inf is not None and getattr(args, "resident_cohort", 1):
+        # the evaluation cohort resident in HBM too (cohort.DeviceCohort, no patch drop at test time: dataset.py:374 is
+        # train-only): one feed launch per bag instead of np.load + pageable copy
+        from .cohort import DeviceCohort
+        lens_all = ([int(v) for v in data.lengths] if hasattr(data, "lengths") else None)
+        if lens_all is None:
+            import numpy as _np
+            lens_all = [int(_np.load(os.path.join(data.root, k + ".npy"), mmap_mode="r").shape[0]) for k in data.keys]
+        if DeviceCohort.fits(DeviceCohort.bytes_needed(lens_all, args.patch_dim), dev):
+            cohort = DeviceCohort.from_dataset(data, dev, seed=args.seed, augmentation=False)
+            cohort.draw_epoch(0, augment=False)
     with torch.no_grad():
         for i in range(len(data)):                                     # batch_size = 1 (test_ddp.py:73)
+            if cohort is not None and not with_ct:
+                n = cohort.n[i]
+                slot = inf.slot(n)
+                if slot.bucket.fits([n]):
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    ks = cohort.feed([i], slot.x, slot.bucket.len_dev, ids_dst=slot.ids)
+                    out = inf.forward(slot, ks, on_device=True)
+                    torch.cuda.synchronize()
+                    times.append(time.time() - t0)
+                    preds.append(float(out[0, 1]))
+                    labels.append(int(cohort.labels[i].argmax()))
+                    continue
             b = collate_bags([data[i]])
             x = b["pathology"].to(dev)
             ct = None
