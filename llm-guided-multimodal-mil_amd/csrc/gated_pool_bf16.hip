@@ -1134,6 +1134,191 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 
+
+// Round 4: the same product on EIGHT waves (two per SIMD) and a 128 (gi) x 512 (j) tile, 32-row slices.  What bounds the
+// four-wave kernel above is neither HBM nor load latency (two-set prefetch: no change) nor the matrix pipe (MFMA-busy 0.29) but
+// the lone in-order wave of a SIMD: every LDS / memory wait of its staging work and every fragment-read latency is exposed,
+// the measured slice takes 2 900 cycles for 1 024 cycles of MFMAs.  Here a SIMD carries two waves that cover each other's
+// stalls (the forward's structure), each wave keeps the 2 x 4 tile (128 accumulators, 0.75 fragment reads per MFMA), and the
+// doubled j width halves the gate re-reads (2 j tiles instead of 4) and the dPre arithmetic per flop of a workgroup:
+// per 32-row slice a thread stages 4 x 16 bytes of x and ONE (V, U) float4 pair.  Price: 3 x 2 output tiles -> 42 row chunks
+// instead of 21, i.e. twice the split-K partials (66 MB at config 5) for the fold to read.
+#define W8_BKR 32
+template <bool DROP>
+__global__ __launch_bounds__(512) void k_gate_bwd_dw_bf16_w8(const u16* __restrict__ x, const u16* __restrict__ gates,
+                                                             const float* __restrict__ ds, const float* __restrict__ wvec,
+                                                             float* __restrict__ part, float* __restrict__ pbias, int R, int L,
+                                                             int KC, int NJ, const uint32_t* __restrict__ xbits) {
+    constexpr int ASZ = W8_BKR * WB_S, BSZ = 4 * ASZ;            // per stage: A image [32][160], B image 4 panels of [32][160]
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * (ASZ + BSZ)];      // 100 KB
+    u16* ab = smem;
+    u16* xb = smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 2, wj = wave & 3;
+    const int h = lane >> 5;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int jt = bid % NJ, m = (bid / NJ) % 3, s = bid / (3 * NJ);
+    const int j0 = jt * 512;
+    const int rbeg = s * KC, rend = min(R, rbeg + KC);
+    const int nslice = (rend - rbeg + W8_BKR - 1) / W8_BKR;
+
+    // staging maps: x: 32 rows x 512 cols bf16 = 2048 16-byte chunks, 4 per thread: row (tid >> 6) + 8 i, chunk tid & 63
+    //               gates: row tid >> 4 (0 .. 31), d = 64 m + 4 (tid & 15): one (V, U) quad pair per thread and slice
+    const int xrow = tid >> 6, xc = tid & 63;
+    const int arow = tid >> 4, ad4 = tid & 15;
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wvec + 64 * m + 4 * ad4);
+    u16x8 rx[4];
+    unsigned rxm[DROP ? 4 : 1];
+    ushort4 hv, hu;
+    float rds, rmask;
+    f32x4 acc_bv = {0, 0, 0, 0}, acc_bu = {0, 0, 0, 0}, acc_w = {0, 0, 0, 0};
+    float acc_ds = 0.f;
+    auto slice_rows = [&](int q) { return rbeg + min(q, max(nslice - 1, 0)) * W8_BKR; };
+    auto xload = [&](int i, int rs) {
+        const int gr = min(rs + xrow + 8 * i, rend - 1);
+        rx[i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
+        if (DROP) rxm[i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
+    };
+    auto xwrite = [&](int i, int buf) {          // columns 128 p .. 128 p + 127 -> panel p (each panel its own 160-stride image)
+        u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
+        *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8_b(rx[i], rxm[i] >> (8 * (xc & 3))) : rx[i];
+    };
+    auto aload = [&](int rs, bool live) {
+        const int gr = rs + arow;
+        const int gc = min(gr, rend - 1);
+        const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
+        hv = *reinterpret_cast<const ushort4*>(gp);
+        hu = *reinterpret_cast<const ushort4*>(gp + 192);
+        rds = ds[gc];
+        rmask = (live && gr < rend) ? 1.f : 0.f;
+    };
+    auto awrite = [&](int buf) {
+        const f32x4 v = {bf16_to_f32(hv.x), bf16_to_f32(hv.y), bf16_to_f32(hv.z), bf16_to_f32(hv.w)};
+        const f32x4 u = {bf16_to_f32(hu.x), bf16_to_f32(hu.y), bf16_to_f32(hu.z), bf16_to_f32(hu.w)};
+        const float dsv = rds * rmask;
+        const f32x4 a = (dsv * w4) * u;
+        const f32x4 t = a * v;
+        const f32x4 pv = a - t * v;               // ds w U (1 - V^2)
+        const f32x4 pu = t - t * u;               // ds w V U (1 - U)
+        u16* dst = ab + buf * ASZ + arow * WB_S + 4 * ad4;
+        *reinterpret_cast<ushort4*>(dst) = pack_bf16x4(pv);
+        *reinterpret_cast<ushort4*>(dst + 64) = pack_bf16x4(pu);
+        acc_bv += pv;
+        acc_bu += pu;
+        acc_w += (dsv * v) * u;
+        if (ad4 == 0) acc_ds += dsv;
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    if (nslice > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xload(i, slice_rows(0));
+        aload(slice_rows(0), true);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xwrite(i, 0);
+        awrite(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xload(i, slice_rows(1));
+        aload(slice_rows(1), nslice > 1);
+    }
+    __syncthreads();
+    const int acol = 64 * wi + 16 * tg + 4 * tp;                 // + 32 a
+    const int bcol = 16 * tg + 4 * tp;                           // + 32 b inside panel wj
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int buf = sl & 1;
+        const bool live2 = sl + 2 < nslice;
+        const int rs2 = slice_rows(sl + 2);
+        const u16* ai = ab + buf * ASZ;
+        const u16* bi = xb + buf * BSZ + wj * ASZ;
+        u16x8 fa[2][2], fb[2][4];                                // [register set][tile]
+        auto frags = [&](int ks, int q) {
+            const int row = 16 * ks + 8 * h + tq;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[q][a] = tr_frag(ai, row, acol + 32 * a);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[q][b] = tr_frag(bi, row, bcol + 32 * b);
+        };
+        // five staging parts of the next slice (four x chunks, one gate pair) between the sixteen MFMAs of this one
+        auto stage = [&](int p) {
+            if (p < 4) { xwrite(p, buf ^ 1); xload(p, rs2); }
+            else { awrite(buf ^ 1); aload(rs2, live2); }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < W8_BKR / 16; ++ks) {
+            const int q = ks & 1;
+            if (ks + 1 < W8_BKR / 16) frags(ks + 1, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[q][a]),
+                                                                        __builtin_bit_cast(bf16x8, fb[q][b]), acc[a][b], 0, 0, 0);
+                    const int g = a * 4 + b;
+                    const int p = ks == 0 ? (g == 1 ? 0 : g == 3 ? 1 : g == 5 ? 2 : -1) : (g == 1 ? 3 : g == 3 ? 4 : -1);
+                    if (p >= 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage(p);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    // partial tile -> part[s][128m + 64wi + 32a + row][j0 + 128wj + 32b + r]
+    const int r = lane & 31;
+    float* pt = part + ((size_t)s * HB_NG + 128 * m + 64 * wi) * L + j0 + 128 * wj + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pt[(size_t)(32 * a + mfma32_row(i, h)) * L + 32 * b] = acc[a][b][i];
+
+    if (jt == 0) {
+        float* redf = reinterpret_cast<float*>(smem);   // [32 row groups][3][64]
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            redf[(arow * 3 + 0) * 64 + 4 * ad4 + e] = acc_bv[e];
+            redf[(arow * 3 + 1) * 64 + 4 * ad4 + e] = acc_bu[e];
+            redf[(arow * 3 + 2) * 64 + 4 * ad4 + e] = acc_w[e];
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid / 64, d = tid % 64;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) v += redf[(g * 3 + which) * 64 + d];
+            pbias[((size_t)s * 4 + which) * 192 + 64 * m + d] = v;
+        }
+        if (m == 0) {
+            __syncthreads();
+            redf[tid] = acc_ds;
+            __syncthreads();
+            if (tid == 0) {
+                float v = 0.f;
+                for (int g = 0; g < 512; g += 16) v += redf[g];
+                pbias[((size_t)s * 4 + 3) * 192] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- host entry points
 extern "C" int mil_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
     if (!src || !dst) return MIL_EINVAL;
@@ -1259,10 +1444,59 @@ static inline int split_plan_bf16(int R, int L, int* KC_out) {
     return (R + kc - 1) / kc;
 }
 
+// eight-wave kernel (128 x 512 tiles; L a multiple of 512): OPT-IN, MIL_DW16_W8=1.  Measured at config 5 on one box
+// (tools/cfg5_quick.py, weight gradient + fold): eval 177.4 us against 170.9 us for the four-wave kernel, train 194.8 against
+// 201.6 us - a tie, although every thread stages half as much and two waves per SIMD cover each other's stalls.  What the
+// two kernels share is the wave tile (2 x 4: 0.75 transposing fragment reads per MFMA) - i.e. the LDS traffic per flop; that,
+// not issue, latency or HBM, is what binds them (96 KB of ds_read_b64_tr_b16 + 48 KB of staging writes per 4.2 MFLOP).
+static inline bool dw16_use_w8(int R, int L) {
+    const char* e = getenv("MIL_DW16_W8");               // read per call: the A/B tests toggle it inside one process
+    (void)R;
+    return (L % 512) == 0 && e != nullptr && atoi(e) != 0;
+}
+static inline int split_plan_bf16_w8(int R, int L, int* KC_out) {
+    const int NJ = L / 512;
+    int smax = MIL_NUM_CU / (3 * NJ);
+    if (smax < 1) smax = 1;
+    int kc = ((R + smax - 1) / smax + 63) / 64 * 64;
+    if (kc < 64) kc = 64;
+    *KC_out = kc;
+    return (R + kc - 1) / kc;
+}
+// weight-gradient launch of either form; returns the number of row chunks S (partials part[S][384][L], pbias[S][4][192])
+static int launch_gate_bwd_dw16(const uint16_t* x, const uint16_t* gates, const float* ds, const float* w, float* workspace,
+                                size_t workspace_floats, int R, int L, const uint32_t* xbits, hipStream_t st, int* S_out,
+                                float** pbias_out) {
+    int kc;
+    const bool w8 = dw16_use_w8(R, L);
+    const int S = w8 ? split_plan_bf16_w8(R, L, &kc) : split_plan_bf16(R, L, &kc);
+    const size_t need = (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
+    if (workspace_floats < need) return MIL_ENOSPC;
+    float* part = workspace;
+    float* pbias = workspace + (size_t)S * HB_NG * L;
+    if (w8) {
+        const int NJ = L / 512;
+        if (xbits != nullptr)
+            hipLaunchKernelGGL(k_gate_bwd_dw_bf16_w8<true>, dim3(S * 3 * NJ), dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+        else
+            hipLaunchKernelGGL(k_gate_bwd_dw_bf16_w8<false>, dim3(S * 3 * NJ), dim3(512), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    } else {
+        const int NJ = L / 256;
+        if (xbits != nullptr)
+            hipLaunchKernelGGL(k_gate_bwd_dw_bf16<true>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+        else
+            hipLaunchKernelGGL(k_gate_bwd_dw_bf16<false>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    }
+    *S_out = S;
+    *pbias_out = pbias;
+    return MIL_OK;
+}
+
 extern "C" size_t mil_gate_bwd_workspace_floats_bf16(int R, int L) {
     if (R <= 0 || L <= 0 || (L % 256) != 0) return 0;
     int kc;
-    const int S = split_plan_bf16(R, L, &kc);
+    int S = split_plan_bf16(R, L, &kc);
+    if ((L % 512) == 0) S = max(S, split_plan_bf16_w8(R, L, &kc));      // either kernel may run (dw16_use_w8)
     return (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
 }
 
@@ -1298,18 +1532,12 @@ int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const fl
         ad = AdamFuse{param_flat, grad_flat, exp_avg, exp_avg_sq, (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
                       (float)sqrt(bc2), step_dev, lr, lr_dev};
     }
-    int kc;
-    const int S = split_plan_bf16(R, L, &kc);
-    const size_t need = (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
-    if (workspace_floats < need) return MIL_ENOSPC;
-    float* part = workspace;
-    float* pbias = workspace + (size_t)S * HB_NG * L;
-    const int NJ = L / 256;
     hipStream_t st = (hipStream_t)stream;
-    if (xbits != nullptr)
-        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<true>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
-    else
-        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<false>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    int S;
+    float* pbias;
+    float* part = workspace;
+    const int rc_dw = launch_gate_bwd_dw16(x, gates, ds, w, workspace, workspace_floats, R, L, xbits, st, &S, &pbias);
+    if (rc_dw != MIL_OK) return rc_dw;
     MIL_CHECK_LAUNCH();
     const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     const int nred = (nthreads + 255) / 256, nhead = C * ((L + 63) / 64) + 1;
@@ -1326,18 +1554,12 @@ extern "C" int mil_gate_bwd_params_bf16(const uint16_t* x, const uint16_t* gates
                                         const uint32_t* xbits, float xscale, void* stream) {
     if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % 256) != 0 || R <= 0) return MIL_EINVAL;
-    int kc;
-    const int S = split_plan_bf16(R, L, &kc);
-    const size_t need = (size_t)S * HB_NG * L + (size_t)S * 4 * 192;
-    if (workspace_floats < need) return MIL_ENOSPC;
-    float* part = workspace;
-    float* pbias = workspace + (size_t)S * HB_NG * L;
-    const int NJ = L / 256;
     hipStream_t st = (hipStream_t)stream;
-    if (xbits != nullptr)
-        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<true>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
-    else
-        hipLaunchKernelGGL(k_gate_bwd_dw_bf16<false>, dim3(S * 3 * NJ), dim3(256), 0, st, x, gates, ds, w, part, pbias, R, L, kc, NJ, xbits);
+    int S;
+    float* pbias;
+    float* part = workspace;
+    const int rc_dw = launch_gate_bwd_dw16(x, gates, ds, w, workspace, workspace_floats, R, L, xbits, st, &S, &pbias);
+    if (rc_dw != MIL_OK) return rc_dw;
     MIL_CHECK_LAUNCH();
     const int nthreads = HB_NG * (L / 4) + GR_NB * (3 * 192 + 1);
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3((nthreads + 255) / 256), dim3(256), 0, st, part, pbias, S, S, L, dWv, dbv, dWu,

@@ -19,7 +19,7 @@ class CLIP(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.args = args
-        self.model = CLIPText(512, 77, int(getattr(args, "clip_vocab", 49408)), int(getattr(args, "clip_width", 512)),
+        self.model = CLIPText(int(getattr(args, "clip_embed", 512)), 77, int(getattr(args, "clip_vocab", 49408)), int(getattr(args, "clip_width", 512)),
                               int(getattr(args, "clip_heads", 8)), int(getattr(args, "clip_layers", 12)))
         for p in self.model.parameters():
             p.requires_grad_(False)

@@ -128,3 +128,33 @@ def test_fused_bf16_tail_equals_the_separate_launches_bit_for_bit():
     for k in a._w16:
         assert torch.equal(a._w16[k].view(torch.int16), b._w16[k].view(torch.int16)), k
         assert torch.equal(a._w16[k], a.fp.p(k).to(torch.bfloat16)), k          # the shadow IS the rounded master
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+@pytest.mark.parametrize("lengths,L", [([9000, 7000, 424], 1024), ([16384], 512), ([5000, 3211], 1024)])
+def test_eight_wave_weight_gradient_equals_the_four_wave_kernel(lengths, L, train_mode, monkeypatch):
+    """Round 4: k_gate_bwd_dw_bf16_w8 (eight waves, 128 x 512 tiles, 32-row slices; MIL_DW16_W8=1) against the four-wave kernel
+    (MIL_DW16_W8=0) on the same step: same bf16-rounded dPre and x, same fp32 accumulation, another split of the rows over
+    workgroups - gradients agree to summation order (1e-5 rel), and both satisfy the oracle bar.  Row counts with partial
+    last slices / chunks (16 424 = 513.25 slices of 32; 8 211 rows), one and two j tiles."""
+    p = syn.image_only_params(5, L=L)
+    dev = torch.device(DEV)
+    x16 = torch.randn((sum(lengths), L), generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16)
+    y = syn.make_labels(4, len(lengths)).to(DEV)
+    lay = BagLayout.make(lengths, dev)
+    out = {}
+    for w8 in ("0", "1"):
+        monkeypatch.setenv("MIL_DW16_W8", w8)
+        tr = ImageOnlyTrainer(p, dev, lr=1e-3, train_mode=train_mode, seed=11)
+        tr.forward(x16, lay, y)
+        tr.backward()
+        torch.cuda.synchronize()
+        out[w8] = tr.fp.grad.clone()
+        assert bool(torch.isfinite(out[w8]).all())
+    from mil_amd.trainer import PARAM_ORDER
+    for k in PARAM_ORDER:
+        a = out["1"][tr.fp.offsets[k]:tr.fp.offsets[k] + tr.fp.p(k).numel()]
+        b = out["0"][tr.fp.offsets[k]:tr.fp.offsets[k] + tr.fp.p(k).numel()]
+        if k.endswith("attention_weights.bias"):
+            continue
+        assert rel_err(a.cpu(), b.cpu()) <= 1e-5, (k, rel_err(a.cpu(), b.cpu()))

@@ -22,9 +22,7 @@ def test_learnable_prompts_vs_golden(tag):
     seed = int(g["seed"])
     p = syn.clip_text_params(seed, width=width, layers=layers, vocab=vocab, embed=embed)
     args = SimpleNamespace(learnablePrompt=1, n_ctx=n_ctx, clinical_features=["f"] * (P - 1), clip_vocab=vocab,
-                           clip_width=width, clip_heads=heads, clip_layers=layers)
-    if embed != 512:
-        pytest.skip("the wrapper builds a 512-d joint space; the reduced fixture is covered by the oracle test")
+                           clip_width=width, clip_heads=heads, clip_layers=layers, clip_embed=embed)
     m = CLIP(args)
     m.model.load_state_dict({k[len("clinic_extractor.model."):]: v for k, v in p.items()}, strict=False)
     gen = torch.Generator().manual_seed(seed + 2)
