@@ -71,14 +71,15 @@ static bool fuse_pool_enabled() {
     return e == nullptr || e[0] != '0';
 }
 
-// bf16 step: the pool pass in the deep forward's epilogue (round 4).  Measured at config 5 on one box (tools/cfg5_quick.py):
-// eval mode 0.3464 ms fused vs 0.3456 stand-alone - a tie, with 257 MiB less HBM traffic and one launch fewer; train mode
-// 0.504 vs 0.415 ms - the keep-word handling of eight rows per unit pushes the 256-register forward into scratch.  So:
-// eval on, train off; MIL_FUSE_POOL16=1 / 0 forces it either way.
+// bf16 step: the pool pass in the deep forward's epilogue (round 4) is OPT-IN (MIL_FUSE_POOL16=1).  Measured at config 5
+// on one box (tools/cfg5_quick.py): eval mode 0.3464 ms fused vs 0.3456 stand-alone - a tie; train mode 0.504 vs 0.415 ms - the
+// keep-word handling of eight rows per unit pushes the 256-register forward into scratch.  The re-read is served by the
+// Infinity Cache, but FETCH_SIZE counts those requests like HBM ones (profiles/r04_hbm_traffic_pmc.csv: 605 + 118 MiB for the
+// fused launch against 327 + 98 and 257 + 17 for the two separate ones), so no traffic saving can be shown either.
 static bool fuse_pool16_enabled(bool train) {
     const char* e = getenv("MIL_FUSE_POOL16");
-    if (e != nullptr) return e[0] != '0';
-    return !train;
+    (void)train;
+    return e != nullptr && e[0] != '0';
 }
 
 extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* stream) {

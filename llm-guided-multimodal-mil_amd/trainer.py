@@ -408,7 +408,7 @@ class ImageOnlyTrainer:
         fused_pool = getattr(layout, "aligned32", False) and (not a.x_bf16 or (a.L in (512, 1024) and a.R >= 256 * 256
                                                                                and bool(a.gates16) and a.C == 2
                                                                                and os.environ.get("MIL_FUSE_POOL", "1") != "0"
-                                                                               and os.environ.get("MIL_FUSE_POOL16", "0" if a.train else "1") != "0"))
+                                                                               and os.environ.get("MIL_FUSE_POOL16", "0") != "0"))
         groups = []
         if fused_pool:
             groups.append(("gate_fwd_with_pool_fused", fwd | S.STAGE_POOL | S.STAGE_POOL_FUSED))

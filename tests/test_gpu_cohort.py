@@ -188,3 +188,33 @@ def test_full_size_cohort_properties():
         ks = co.feed([j], x)
         want = big.index_select(0, co.sel[co.sel_off[j]:co.sel_off[j + 1]].long())
         assert torch.equal(x[:ks[0]], want)
+
+
+def test_cohort_edge_cases_empty_and_tiny_bags_and_rejected_arguments():
+    """Edge cases the reference's loader meets: a bag whose keep count rounds to zero (int(1 * 0.9) = 0), an empty bag, bags
+    of 1 - 5 rows; and the feed's argument checks (destination too small, wrong width, missing side table)."""
+    ns = [1, 0, 2, 5, 64]
+    keeps = [0.9, 0.9, 0.8, 0.8, 1.0]
+    g = torch.Generator().manual_seed(2)
+    bags = [torch.randn((n, 32), generator=g) for n in ns]
+    co = DeviceCohort(bags, syn.make_labels(1, len(ns)), DEV, keep=keeps, seed=3)
+    assert co.k_train == [0, 0, 1, 4, 64]
+    co.draw_epoch(7)
+    torch.cuda.synchronize()
+    want = oc.select_epoch(np.asarray(co.row_off), co.k_train, co.seed, 7)
+    assert np.array_equal(co.sel.cpu().numpy()[:co.sel_off[-1]], want)
+    x = torch.full((128, 32), -1.0, device=DEV)
+    ld = torch.full((5,), -1, device=DEV, dtype=torch.int32)
+    ks = co.feed([0, 1, 2, 3, 4], x, ld)
+    torch.cuda.synchronize()
+    assert ks == [0, 0, 1, 4, 64] and ld.cpu().tolist() == ks
+    flat = torch.cat(bags, 0)
+    assert torch.equal(x[:69].cpu(), flat[want]) and bool((x[69:] == -1.0).all())
+    with pytest.raises(ValueError):
+        co.feed([4, 4, 4], torch.zeros((100, 32), device=DEV))           # 192 rows do not fit
+    with pytest.raises(ValueError):
+        co.feed([4], torch.zeros((128, 64), device=DEV))                 # wrong row width
+    with pytest.raises(ValueError):
+        co.feed([4], x, ids_dst=torch.zeros((1, 1, 77), device=DEV, dtype=torch.int64))      # the cohort holds no ids
+    with pytest.raises(ValueError):
+        DeviceCohort([torch.randn(4, 30)], syn.make_labels(1, 1), DEV)   # width not a multiple of 4 floats

@@ -1,7 +1,11 @@
 """One ragged bag per step (the authors' regime, run_train.sh:81 + dataset.py:366-393): bags with N ~ U[2000, 15592] patches,
 lengths on the device, one hipGraph per capacity bucket.  Prints ms/step for the bucketed-graph path and for the exact-length
 eager path.  Default: the image-only fused step; --fusion: aggregator(args) with one clinical note per bag (the paper's model;
-frozen ViT-B/32 text embedding cached per note, as training does)."""
+frozen ViT-B/32 text embedding cached per note, as training does).
+
+--from-host / --resident (round 4): the same regime with the INPUT SIDE in the measurement - bench.ragged_regime: the cohort
+resident in HBM with the per-epoch patch drop drawn on the device and one feed launch per step (what train_ddp.py --hip_graph 1
+runs), beside the step alone, round 3's pageable host loop and the pinned double-buffered fallback (one JSON object)."""
 import json, os, sys, time
 from types import SimpleNamespace
 import numpy as np
@@ -13,6 +17,11 @@ from mil_amd.bags import BagLayout
 from mil_amd.trainer import ImageOnlyTrainer, RaggedImageOnlyStepper
 
 dev = torch.device("cuda")
+if "--from-host" in sys.argv or "--resident" in sys.argv:
+    import bench
+    kind = "ct_pth" if "--ct" in sys.argv else ("fusion" if "--fusion" in sys.argv else "image")
+    print(json.dumps(bench.ragged_regime(dev, kind)))
+    sys.exit(0)
 fusion = "--fusion" in sys.argv
 steps = 300 if not fusion else 150
 rng = np.random.default_rng(0)

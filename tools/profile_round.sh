@@ -12,11 +12,15 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_round
-rm -rf "$OUT"; mkdir -p "$OUT"
+# PART=A: the profiled runs (kernel traces + PMC passes); PART=B: the un-profiled bench.py lines; PART=C: the tools/ lines;
+# unset: all (a gpurun call is limited to 20 minutes - run the parts as separate calls)
+PART=${PART:-ABC}
+if [[ "$PART" == *A* ]]; then rm -rf "$OUT"; fi
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --no-configs --no-cpu-baseline --no-breakdown"
 declare -A CMD
-CMD[cfg2]="$BENCH --steps 200 --warmup 10"      # the bench's own priming (--prime 300): the chip at its steady clock
+CMD[cfg2]="$BENCH --regions 3 --steps 200 --warmup 10"      # the bench's own priming (--prime 300): the chip at its steady clock
 CMD[pool]="python3 $ROOT/tools/prof_pool.py"
 CMD[cfg5]="python3 $ROOT/tools/prof_stage.py --bf16"           # STEPS=60 below: the last 30 steps are the steady state
 CMD[cfg3]="python3 $ROOT/tools/bench_fusion.py --graph --steps 20 --warmup 3"
@@ -30,6 +34,7 @@ if [ "${QUICK:-0}" = "1" ]; then
   exit 0
 fi
 export STEPS=60
+if [[ "$PART" == *A* ]]; then
 for w in cfg2 pool cfg5 cfg3; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- ${CMD[$w]} > $OUT/stats_$w.log 2>&1
   echo "stats $w done"
@@ -43,15 +48,22 @@ for w in cfg2 cfg5; do
   timeout -k 10 300 rocprofv3 --pmc $MFMA --output-format csv -d $OUT/mfma_$w -- ${CMD[$w]} > $OUT/mfma_$w.log 2>&1
   echo "mfma $w done"
 done
+find $OUT -name "*agent_info*" -delete
+fi
+if [[ "$PART" == *B* ]]; then
 python3 $ROOT/bench.py --steps 200 --warmup 20 > $OUT/bench_line.json 2> $OUT/bench_line.err
 echo "bench done"
-python3 $ROOT/bench.py --steps 200 --warmup 20 --train-mode 0 --no-configs --no-cpu-baseline > $OUT/bench_eval_line.json 2>/dev/null
+python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2>/dev/null      # the driver's flags
+python3 $ROOT/bench.py --steps 200 --warmup 20 --train-mode 0 --no-configs --no-cpu-baseline --no-rccl-floor > $OUT/bench_eval_line.json 2>/dev/null
+MIL_FORCE_COLLECTIVES=1 python3 $ROOT/bench.py --gpus 1 --no-configs --no-cpu-baseline --no-rccl-floor > $OUT/bench_rccl1_line.json 2>/dev/null
+echo "part B done"
+fi
+if [[ "$PART" != *C* ]]; then exit 0; fi
 python3 $ROOT/tools/bench_ragged.py > $OUT/ragged_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion > $OUT/ragged_fusion_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion --prompts10 > $OUT/ragged_fusion_p10_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion --coop > $OUT/ragged_fusion_coop_line.json 2>/dev/null
 python3 $ROOT/tools/bench_ragged.py --fusion --ct > $OUT/ragged_fusion_ct_line.json 2>/dev/null
-MIL_FORCE_COLLECTIVES=1 python3 $ROOT/bench.py --gpus 1 --no-configs --no-cpu-baseline > $OUT/bench_rccl1_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --steps 50 --warmup 5 > $OUT/fusion_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --graph --prompts 10 --steps 20 --warmup 3 > $OUT/p10_line.json 2>/dev/null
 python3 $ROOT/tools/bench_fusion.py --coop --steps 10 --warmup 3 > $OUT/coop_line.json 2>/dev/null

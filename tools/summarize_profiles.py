@@ -5,9 +5,9 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 CFG2_STEPS, CFG2_WARMUP = 200, 10
-WORK = {"cfg2": f"python3 bench.py --no-configs --no-cpu-baseline --no-breakdown --steps {CFG2_STEPS} --warmup {CFG2_WARMUP}   "
+WORK = {"cfg2": f"python3 bench.py --no-configs --no-cpu-baseline --no-breakdown --regions 3 --steps {CFG2_STEPS} --warmup {CFG2_WARMUP}   "
                 "(32 bags x 1024 x 512 fp32, train-mode step, default --prime 300; kernels of the step only)",
         "pool": "python3 tools/prof_pool.py   (attention-pool stage alone, 64 bags x 4096 x 512 fp32 = 512 MiB of x)",
         "cfg5": "python3 tools/prof_stage.py --bf16   (32 bags x 4096 x 1024, bf16 storage, 12 steps)",
@@ -192,8 +192,42 @@ def steady_stats(w, last, out_name):
 
 
 steady_stats("cfg5", 30, f"{TAG}_cfg5_steady.csv")
+
+
+def replayed_step_stats(w, marker, steps, out_name):
+    """cfg3: per-kernel launches and time of ONE REPLAYED step - the dispatches between consecutive launches of
+    `marker` (one per step) over the last `steps` steps of the trace, i.e. the hipGraph replays of the timed loop only; the
+    whole-run stats file also averages the eager warm-up / capture passes (more launches per step, torch fills and copies)."""
+    f = sorted(glob.glob(os.path.join(SRC, "stats_" + w, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    if not f:
+        return
+    rows = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f[0]))]
+    rows.sort(key=lambda r: r[1])
+    idx = [i for i, r in enumerate(rows) if r[0].startswith(marker)]
+    if len(idx) < steps + 1:
+        return
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    use = list(zip(idx[-steps - 1:-1], idx[-steps:]))
+    for a, b in use:
+        for n, s0, e0 in rows[a:b]:
+            agg[n][0] += 1
+            agg[n][1] += (e0 - s0) / 1e3
+    n = len(use)
+    span = (rows[use[-1][1]][1] - rows[use[0][0]][1]) / 1e3 / n
+    with open(os.path.join(DST, out_name), "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace -- {WORK[w]}\n# ONE replayed step: dispatches between consecutive {marker} launches, "
+                f"averaged over the last {n} steps (the timed hipGraph replays; eager warm-up / capture passes excluded)\n")
+        o.write(f"# launches per step {sum(v[0] for v in agg.values()) / n:.1f}, kernel time per step {sum(v[1] for v in agg.values()) / n:.1f} us, "
+                f"step span {span:.1f} us (under the profiler)\n")
+        o.write("kernel,launches_per_step,us_per_step,avg_us\n")
+        for name, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"{name},{c / n:.2f},{t / n:.2f},{t / c:.2f}\n")
+
+
+replayed_step_stats("cfg3", "k_gemm_nt2", 15, f"{TAG}_cfg3_replayed_step.csv")
 lines = {}
-for key, fn in (("bench", "bench_line.json"), ("bench_eval_mode", "bench_eval_line.json"), ("ragged_one_bag", "ragged_line.json"),
+for key, fn in (("bench", "bench_line.json"), ("bench_driver_flags", "bench_driver_line.json"), ("bench_eval_mode", "bench_eval_line.json"),
+                ("ragged_one_bag", "ragged_line.json"),
                 ("ragged_fusion", "ragged_fusion_line.json"), ("ragged_fusion_10_prompts", "ragged_fusion_p10_line.json"),
                 ("ragged_fusion_learnable_prompts", "ragged_fusion_coop_line.json"),
                 ("ragged_fusion_ct_plus_pathology", "ragged_fusion_ct_line.json"),
