@@ -971,24 +971,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned rxm[WB_SETS][DROP ? 8 : 1];
     auto xload = [&](int z, int i, int rs) {
         const int gr = min(rs + xrow + 8 * i, rend - 1);
+#if !defined(WB_ABL_NOX)       // ablation builds (tools/build_variants.sh + tools/kbench_dw16.py): times only, results meaningless
         rx[z][i] = *reinterpret_cast<const u16x8*>(x + (size_t)gr * L + j0 + 8 * xc);
+#else
+        asm volatile("" : "+v"(rx[z][i]) : "v"(gr));
+#endif
         if (DROP) rxm[z][i] = xbits[(size_t)gr * (L >> 5) + ((j0 + 8 * xc) >> 5)];
     };
     auto xwrite = [&](int z, int i, int buf) {
         // columns 0..127 -> panel 0, 128..255 -> panel 1 (each panel is its own 160-stride image)
         u16* dst = xb + buf * BSZ + (xc >> 4) * ASZ + (xrow + 8 * i) * WB_S + 8 * (xc & 15);
+#if !defined(WB_ABL_NOXW)
         *reinterpret_cast<u16x8*>(dst) = DROP ? keep_bf16x8_b(rx[z][i], rxm[z][i] >> (8 * (xc & 3))) : rx[z][i];
+#else
+        asm volatile("" ::"v"(rx[z][i]), "v"(dst));
+#endif
     };
     auto aload = [&](int z, int i, int rs, bool live) {
         const int gr = rs + arow + 16 * i;
         const int gc = min(gr, rend - 1);
         const u16* gp = gates + (size_t)gc * HB_NG + 64 * m + 4 * ad4;
+#if !defined(WB_ABL_NOG)
         hv[z][i] = *reinterpret_cast<const ushort4*>(gp);
         hu[z][i] = *reinterpret_cast<const ushort4*>(gp + 192);
         rds[z][i] = ds[gc];
+#else
+        asm volatile("" : "+v"(hv[z][i]), "+v"(hu[z][i]), "+v"(rds[z][i]) : "v"(gp));
+#endif
         rmask[z][i] = (live && gr < rend) ? 1.f : 0.f;
     };
     auto awrite = [&](int z, int i, int buf) {
+#if defined(WB_ABL_NOAW)
+        asm volatile("" ::"v"(hv[z][i]), "v"(hu[z][i]), "v"(rds[z][i]), "v"(buf));
+        return;
+#endif
         const f32x4 v = {bf16_to_f32(hv[z][i].x), bf16_to_f32(hv[z][i].y), bf16_to_f32(hv[z][i].z), bf16_to_f32(hv[z][i].w)};
         const f32x4 u = {bf16_to_f32(hu[z][i].x), bf16_to_f32(hu[z][i].y), bf16_to_f32(hu[z][i].z), bf16_to_f32(hu[z][i].w)};
         const float dsv = rds[z][i] * rmask[z][i];
@@ -1048,10 +1064,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         u16x8 fa[2][2], fb[2][4];                                // [register set][tile]
         auto frags = [&](int ks, int q) {
             const int row = 16 * ks + 8 * h + tq;
+#if !defined(WB_ABL_NOFRAG)
 #pragma unroll
             for (int a = 0; a < 2; ++a) fa[q][a] = tr_frag(ai, row, acol + 32 * a);
 #pragma unroll
             for (int b = 0; b < 4; ++b) fb[q][b] = tr_frag(bi, row, bcol + 32 * b);
+#else
+#pragma unroll
+            for (int a = 0; a < 2; ++a) asm volatile("" : "+v"(fa[q][a]) : "v"(row), "v"(ai));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(fb[q][b]) : "v"(bi));
+#endif
         };
         // twelve staging parts of the next slice, three per k-step
         auto stage = [&](int p) {
@@ -1068,8 +1091,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
+#if !defined(WB_ABL_NOMFMA)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[q][a]),
                                                                         __builtin_bit_cast(bf16x8, fb[q][b]), acc[a][b], 0, 0, 0);
+#else
+                    asm volatile("" : "+v"(acc[a][b]) : "v"(fa[q][a]), "v"(fb[q][b]));
+#endif
                     const int g = a * 4 + b;                     // 8 MFMAs per k-step: a staging part behind #1, #3, #5
                     if (g == 1 || g == 3 || g == 5) {
                         __builtin_amdgcn_sched_barrier(0);
