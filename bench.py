@@ -795,11 +795,19 @@ def run_rank(args):
     x, y = xs[0], ys[0]
     lay = BagLayout.uniform(B, N, dev)
 
+    done_ev = torch.cuda.Event()
+
     def barrier():
+        # synchronize on both sides of the rank barrier.  The wait itself polls an event recorded behind the last launch (the
+        # blocking wait of hipDeviceSynchronize wakes tens of microseconds after the GPU has finished - 1 % of a 20-step region);
+        # torch.cuda.synchronize() then returns at once and keeps the contract's semantics
+        done_ev.record()
+        while not done_ev.query():
+            pass
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     if args.dump:
         tr.forward(x, lay, y)

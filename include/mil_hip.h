@@ -17,6 +17,25 @@
  *  - bags are concatenated along the row axis: x is [R, L] row-major and bag b owns rows
  *    [bag_off[b], bag_off[b+1]).  One softmax per bag (the reference runs one bag per
  *    forward: model/dim1/ABMIL.py:48,57; test_ddp.py:73).
+ *
+ * What a binding needs (the CORE - 12 entries), and what the rest is
+ *  - the image-only model (BASELINE configs 1 / 2 / 4 / 5): `mil_image_only_step_run` (one call per training step: the struct
+ *    at the end of this file) + `mil_gate_bwd_workspace_floats[_bf16]`, `mil_pool_tail_workspace_floats`; for bf16 storage
+ *    also `mil_cast_bf16`.
+ *  - the input side: `mil_patch_drop_select` (once per epoch), `mil_cohort_feed` (once per step), `mil_set_i32`.
+ *  - the fusion model through autograd: one forward + one backward entry per layer family - `mil_gemm` /
+ *    `mil_linear_bwd_params` (every nn.Linear), `mil_layernorm_fwd` / `_bwd_res`, `mil_absorbed_pool_value_fwd` /
+ *    `mil_absorbed_pool_bwd` (token -> image attention with one text token per bag), `mil_adam_step_dev_segs`.
+ *  Everything else is a VARIANT of one of these for a shape or a regime, named by suffix:
+ *    `_rows`      capacity-bucket form: the true row count is a device int32 (one ragged bag per step, length on the device)
+ *    `_h`, `_head`, `_adam`, `_ws`   the neighbouring stage fused into the launch (head projections, head gradients, Adam, a
+ *                 workspace for long bags)
+ *    `_bf16`, `_x16`   bf16 storage of x / gates
+ *    `_small_`, `_mid_`, `_grouped`, `_nt2` / `_tn2`, `_aux`, `_split`   the same product for <= 64 rows, 65 - 1024 rows, per-bag
+ *                 groups, whole rounds of 256 x 256 tiles, an extra epilogue operand, split-bf16 operands
+ *    `_pad`       operands / outputs in the grouped products' padded layout
+ *    `_counted`, `_dev`, `_segs`   Adam with the step number / learning rate in device memory (hipGraph replay), several ranges
+ *    `_time`, `_profile[_rot]`     measurement helpers of the one-call step
  */
 #ifndef MIL_HIP_H
 #define MIL_HIP_H
