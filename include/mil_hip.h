@@ -799,6 +799,9 @@ typedef struct mil_image_only_step {
     const float* lr_dev;            /* nullable, needs adam_step_dev: [1] learning rate read on the device instead of `lr`, so a
                                      * captured step follows the schedule of utils.py:232-241 without re-capture */
     float* tail_ws;                 /* nullable: mil_pool_tail_workspace_floats(B) floats for MIL_STAGE_TAIL (long bags) */
+    int32_t* done_dev;              /* nullable, with adam_step_dev: [1] sign-off word, zero before the first step and left zero by
+                                     * every step - the fold launch that applies Adam then advances adam_step_dev itself (its last
+                                     * workgroup to read the step number does it) instead of a one-thread launch behind it */
 } mil_image_only_step;
 
 int mil_image_only_step_run(const mil_image_only_step* a, void* stream);

@@ -201,7 +201,7 @@ class ImageOnlyStep(ctypes.Structure):
         + [(n, _P) for n in ("param_flat", "grad_flat", "exp_avg", "exp_avg_sq")]
         + [("n_param", c_uint64), ("adam_step", c_int32), ("adam_step_dev", _P)]
         + [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "grad_scale")]
-        + [("lr_dev", _P), ("tail_ws", _P)])
+        + [("lr_dev", _P), ("tail_ws", _P), ("done_dev", _P)])
 
 
 _lib = None

@@ -2150,7 +2150,7 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
                                    float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                                    float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
                                    float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
-                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream, int* done = nullptr);
 
 // mil_gate_bwd_reduce_head with Adam applied by the threads that produce the final gradients (world size 1: nothing sits
 // between the gradient and the update): param_flat / exp_avg / exp_avg_sq are indexed like grad_flat, in which dWv .. dbf all
@@ -2166,14 +2166,14 @@ extern "C" int mil_gate_bwd_reduce_head_adam(const float* workspace, int R, int 
                                           lr, nullptr, beta1, beta2, eps, weight_decay, grad_scale, stream);
 }
 
-// step_dev != NULL: the update's number is (*step_dev + 1), read on the device (hipGraph replay); the caller increments
-// the counter afterwards.  Internal (step.hip).
+// step_dev != NULL: the update's number is (*step_dev + 1), read on the device (hipGraph replay); the counter is advanced by
+// this launch itself when `done` (a zeroed sign-off word) is given, else by the caller afterwards.  Internal (step.hip).
 int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
                                    float* dw, float* db, int accumulate, float xscale, const float* dz, const float* M,
                                    float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                                    float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
                                    float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
-                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream, int* done) {
     if (!workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db || !dz || !M || !dWf || !dbf) return MIL_EINVAL;
     if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || (step_dev == nullptr && step < 1)) return MIL_EINVAL;
     if (step_dev != nullptr) step = 1;
@@ -2196,7 +2196,7 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     // the kernel forms the same single-precision quotient k_adam forms (lr / (float)bc1): the two routes stay bit-identical
     const AdamFuse ad{param_flat, grad_flat, exp_avg, exp_avg_sq, (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
-                      (float)sqrt(bc2), step_dev, lr, lr_dev};
+                      (float)sqrt(bc2), step_dev, lr, lr_dev, step_dev ? done : nullptr};
     hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(nred + nhead), dim3(256), 0, (hipStream_t)stream, workspace,
                        workspace + (size_t)S * GF_NG * L, S, use_dw2(R, L) ? S * (L / 128) : S, L, dWv, dbv, dWu, dbu, dw, db,
                        accumulate, xscale, nred, head, ad);

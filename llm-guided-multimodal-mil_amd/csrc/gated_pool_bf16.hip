@@ -1538,7 +1538,7 @@ int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const fl
                               const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                               float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg, float* exp_avg_sq,
                               int step, const int* step_dev, float lr, const float* lr_dev, float beta1, float beta2, float eps,
-                              float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream) {
+                              float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream, int* done) {
     if (!x || !gates || !ds || !w || !workspace || !dWv || !dbv || !dWu || !dbu || !dw || !db) return MIL_EINVAL;
     if (!dz || !M || !dWf || !dbf || B <= 0 || C <= 0 || C > 32 || (loss_bag && !loss_out)) return MIL_EINVAL;
     if (L <= 0 || (L % 256) != 0 || R <= 0) return MIL_EINVAL;
@@ -1557,7 +1557,7 @@ int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const fl
         const double bc1 = 1.0 - pow((double)beta1, (double)step);
         const double bc2 = 1.0 - pow((double)beta2, (double)step);
         ad = AdamFuse{param_flat, grad_flat, exp_avg, exp_avg_sq, (float)bc1, beta1, beta2, eps, weight_decay, grad_scale,
-                      (float)sqrt(bc2), step_dev, lr, lr_dev};
+                      (float)sqrt(bc2), step_dev, lr, lr_dev, step_dev ? done : nullptr};
     }
     hipStream_t st = (hipStream_t)stream;
     int S;

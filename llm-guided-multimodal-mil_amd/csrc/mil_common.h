@@ -186,6 +186,8 @@ struct AdamFuse {
     const int* step_dev;      // or NULL.  Device counter of the steps ALREADY taken (a step replayed from a hipGraph): the
     float lr;                 // kernel forms the bias corrections from it instead of taking them from the host
     const float* lr_dev;      // or NULL.  Learning rate in device memory (a schedule changes it between replays of one graph)
+    int* done;                // or NULL.  With step_dev: sign-off word (zero between launches) - the LAST workgroup of the grid to
+                              // resolve advances *step_dev itself, so the step needs no one-thread increment launch behind it
 };
 // lr / bc1 and sqrt(bc2) of this launch (k_adam's expressions).  With a device step counter every workgroup derives the two
 // bias corrections itself; with lr_dev the learning rate is read from device memory, so a captured graph follows the schedule.
@@ -202,6 +204,14 @@ __device__ __forceinline__ AdamFuse adam_fuse_resolve(const AdamFuse& ad, float*
         __syncthreads();
         bc1 = bcs[0];
         r.bc2_sqrt = bcs[1];
+        if (ad.done != nullptr && threadIdx.x == 0) {
+            // every workgroup reads the step number before it signs off; the counter moves once all of them have
+            const int prev = __hip_atomic_fetch_add(ad.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == (int)(gridDim.x * gridDim.y * gridDim.z) - 1) {
+                __hip_atomic_store(ad.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(const_cast<int*>(ad.step_dev), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     const float lr = ad.lr_dev != nullptr ? *ad.lr_dev : ad.lr;
     r.lr_bc1 = lr / bc1;

@@ -27,7 +27,7 @@ int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* 
                                    float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                                    float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg,
                                    float* exp_avg_sq, int step, const int* step_dev, float lr, const float* lr_dev, float beta1,
-                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+                                   float beta2, float eps, float weight_decay, float grad_scale, void* stream, int* done);
 
 // gated_pool_bf16.hip: bf16-MFMA weight gradient whose fold launch carries the head gradients, the loss and (param_flat != NULL)
 // Adam + the refresh of the bf16 weight shadows
@@ -37,7 +37,7 @@ int gate_bwd_params_bf16_tail(const uint16_t* x, const uint16_t* gates, const fl
                               const float* M, float* dWf, float* dbf, int B, int C, const float* loss_bag, float* loss_out,
                               float* param_flat, const float* grad_flat, size_t n_param, float* exp_avg, float* exp_avg_sq,
                               int step, const int* step_dev, float lr, const float* lr_dev, float beta1, float beta2, float eps,
-                              float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream);
+                              float weight_decay, float grad_scale, uint16_t* Wv16, uint16_t* Wu16, void* stream, int* done);
 
 // gated_pool_bf16.hip: bf16 gate forward with the pool partial pass in its epilogue when the batch allows
 int gate_fwd_bf16_with_pool(const uint16_t* x, const uint16_t* Wv, const float* bv, const uint16_t* Wu, const float* bu,
@@ -190,8 +190,9 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                                            adam_in_reduce ? a->param_flat : nullptr, a->grad_flat, (size_t)a->n_param, a->exp_avg,
                                            a->exp_avg_sq, a->adam_step, a->adam_step_dev, a->lr, a->lr_dev, a->beta1, a->beta2,
                                            a->eps, a->weight_decay, a->grad_scale, const_cast<uint16_t*>(a->Wv16),
-                                           const_cast<uint16_t*>(a->Wu16), stream);
-            if (rc == MIL_OK && adam_in_reduce && a->adam_step_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
+                                           const_cast<uint16_t*>(a->Wu16), stream, a->done_dev);
+            // (with done_dev the fold launch advances the counter itself: its last workgroup to read the step number does it)
+            if (rc == MIL_OK && adam_in_reduce && a->adam_step_dev && !a->done_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
             if (rc != MIL_OK) return rc;
         } else if (st & (MIL_STAGE_GATE_BWD | MIL_STAGE_REDUCE)) {
             if (a->bf16_grad_mfma && (a->L % 256) == 0 && a->gates16)
@@ -225,9 +226,10 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
                                                     a->accumulate, xscale, a->dz, Mhead, a->dWf, a->dbf, a->B, a->C, a->loss_bag,
                                                     a->loss_out, a->param_flat, a->grad_flat, (size_t)a->n_param, a->exp_avg,
                                                     a->exp_avg_sq, a->adam_step, a->adam_step_dev, a->lr, a->lr_dev, a->beta1,
-                                                    a->beta2, a->eps, a->weight_decay, a->grad_scale, stream);
-                // the device counter moves on after the update, as mil_adam_step_counted does
-                if (rc == MIL_OK && a->adam_step_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
+                                                    a->beta2, a->eps, a->weight_decay, a->grad_scale, stream, a->done_dev);
+                // the device counter moves on after the update, as mil_adam_step_counted does - by the fold launch itself when
+                // the caller gave it a sign-off word (done_dev), by a one-thread launch otherwise
+                if (rc == MIL_OK && a->adam_step_dev && !a->done_dev) rc = mil_counter_add(a->adam_step_dev, 1, stream);
             }
             else
                 rc = mil_gate_bwd_reduce_head(a->dw_ws, a->R, a->L, a->dWv, a->dbv, a->dWu, a->dbu, a->dw, a->db, a->accumulate,

@@ -110,6 +110,8 @@ class ImageOnlyTrainer:
         # ... and so does the learning rate: train_ddp.py sets `tr.lr = scheduled_lr(...)` every epoch (utils.py:232-241),
         # a captured step reads it from this word instead of a by-value kernel argument frozen at capture time
         self.lr_dev = torch.full((1,), float(lr), device=device, dtype=torch.float32) if counted else None
+        # sign-off word of the fold launch that applies Adam: its last workgroup advances the step counter (no increment launch)
+        self.done_dev = torch.zeros(1, device=device, dtype=torch.int32) if counted else None
         self._lr_on_dev = float(lr)
         self._ws: Dict[str, torch.Tensor] = {}   # grow-only per-step state (scores, gates, partials, ...)
         self._args: Optional[_lib.ImageOnlyStep] = None
@@ -213,6 +215,7 @@ class ImageOnlyTrainer:
         a.exp_avg, a.exp_avg_sq, a.n_param = fp.exp_avg.data_ptr(), fp.exp_avg_sq.data_ptr(), fp.flat.numel()
         a.adam_step_dev = pv(self.step_counter)
         a.lr_dev = pv(self.lr_dev)
+        a.done_dev = pv(self.done_dev)
         a.tail_ws = st["tail_ws"].data_ptr()
         a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale = self.betas[0], self.betas[1], self.eps, self.wd, 1.0
         self._args, self._args_key = a, key
