@@ -587,6 +587,24 @@ int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, c
                           const float* pooled, const int32_t* k_off, const int32_t* tile_map,
                           const int32_t* bag_tile_off, int ntiles, int n_keys, int B, int H, int C, int E,
                           const float* dkeys_acc, float* dkeys, float* dQp, float* workspace, void* stream);
+/* Round 4 - LayerNorm(x + o[bag]) (the block's image->token attention with one text token per bag:
+ * model/sam/transformer.py:303-309, every patch receives the same row o[bag]) fused with the NEXT attention site's absorbed
+ * pool (:291-295 of the next block, or :113-118): the pool's forward kernel makes the keys it reads (y [rows, E] + stats
+ * [rows, 2] = mean, rstd), and in the backward the pool's rank-16 update of dkeys is added by the LayerNorm backward to the
+ * gradient it loads - [N, 512] passes saved per pair: 1 forward, 4 backward.  tile_map: the 64-key tile map of the keys
+ * (padding tiles of a capacity bucket -> zero rows of y / dx).  x, y, dx, dy_acc [rows, E]; o, d_o [B, E]; dy_acc (nullable)
+ * = the gradient y receives from its other consumer.  E = 512, H = 8, C in {32, 64}.
+ * workspaces (floats): forward ntiles H (E + 2); backward ntiles H E + 16 n_keys + 3 ntiles E. */
+int mil_lnbr_absorbed_pool_value_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps,
+                                     const float* pe, const float* Qp, const int32_t* k_off, const int32_t* tile_map,
+                                     const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E, const float* Wv,
+                                     const float* bv, float* y, float* stats, float* pooled, float* lse, float* o_attn,
+                                     float* workspace, void* stream);
+int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* stats, const float* y,
+                               const float* pe, const float* Qp, const float* lse, const float* dpooled, const float* pooled,
+                               const int32_t* k_off, const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles,
+                               int n_keys, int B, int H, int C, int E, const float* dy_acc, float* dx, float* d_o,
+                               float* dgamma, float* dbeta, float* dQp, float* workspace, void* stream);
 int mil_value_proj(const float* pooled, const float* Wv, const float* bv, int B, int H, int C, int E, float* o,
                    void* stream);
 /* pooled in the grouped layout [B / T, THp, E] (mil_absorb_query_pad's; the multi-token pool's result as it stands). */

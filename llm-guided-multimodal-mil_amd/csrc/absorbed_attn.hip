@@ -143,10 +143,27 @@ __global__ void k_absorb_query_bwd_w(const float* __restrict__ qp, const float* 
 //   2. thread (row, head) pairs form the tile maxima, the 64 x 8 probabilities (one exponential each) and their sums
 //      through LDS; then each wave accumulates its 16 register-resident rows with plain FMAs - no re-scaling - and the
 //      four waves' accumulators (same reference maximum) are summed through LDS.
+//
+// LN = true (round 4): the keys are not read but MADE here - keys_n = LayerNorm(x_n + o[bag]) of the image->token attention
+// of the block in front (model/sam/transformer.py:303-309 with one text token per bag: every patch receives the same row
+// o[bag], see ops.layer_norm_bag_row) - written to `y` (+ mean / rstd to `stats`) on their way into the registers the pool
+// reads them from: the LayerNorm launch and the pool's own read of its 64 MB output are gone.  Same arithmetic, in the same
+// order, as k_layernorm_fwd512.  Padding tiles of a capacity bucket (nkeys < 0) write zero rows (finite: later passes read
+// whole buckets).
+struct LnbrFwd {
+    const float* x;
+    const float* o;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float* y;
+    float* stats;
+};
+template <bool LN>
 __global__ __launch_bounds__(256, 2) void k_apool_partial(const float* __restrict__ keys, const float* __restrict__ pe,
                                                        const float* __restrict__ Qp, const int32_t* __restrict__ k_off,
                                                        const int32_t* __restrict__ tile_map, float scale,
-                                                       float* __restrict__ pacc, float* __restrict__ pml) {
+                                                       float* __restrict__ pacc, float* __restrict__ pml, LnbrFwd ln) {
     constexpr int E = 512, NQ = 2, RW = AP_TILE / 4;
     __shared__ __attribute__((aligned(16))) float red[3 * AP_H * E];
     __shared__ __attribute__((aligned(16))) float s_lds[AP_TILE][AP_H];      // scores, then probabilities
@@ -156,11 +173,53 @@ __global__ __launch_bounds__(256, 2) void k_apool_partial(const float* __restric
     const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
     const int pos0 = key0 - k_off[b];
     f32x4 kv[RW][NQ];
+    if (LN) {
+        if (nkeys <= 0) {
+            for (int rr = wave; rr < -nkeys; rr += 4) {
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int rr = max(min(wave + 4 * i, nkeys - 1), 0);              // rows past the tile end: clamped, weight 0 below
+                for (int q = 0; q < NQ; ++q)
+                    *reinterpret_cast<f32x4*>(ln.y + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = f32x4{0, 0, 0, 0};
+                if (lane == 0) { ln.stats[2 * (size_t)(key0 + rr)] = 0.f; ln.stats[2 * (size_t)(key0 + rr) + 1] = 0.f; }
+            }
+            return;                                                       // no bag reads this tile's partial
+        }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) kv[i][q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
+        for (int i = 0; i < RW; ++i) {
+            const int rr = min(wave + 4 * i, nkeys - 1);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) kv[i][q] = *reinterpret_cast<const f32x4*>(ln.x + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
+        }
+        f32x4 ov[NQ], gm[NQ], bt[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            ov[q] = *reinterpret_cast<const f32x4*>(ln.o + (size_t)b * E + 256 * q + 4 * lane);
+            gm[q] = *reinterpret_cast<const f32x4*>(ln.gamma + 256 * q + 4 * lane);
+            bt[q] = *reinterpret_cast<const f32x4*>(ln.beta + 256 * q + 4 * lane);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const f32x4 v0 = kv[i][0] + ov[0], v1 = kv[i][1] + ov[1];
+            const f32x4 t = v0 + v1;
+            const float mean = wave_allsum((t[0] + t[1]) + (t[2] + t[3])) / E;
+            const f32x4 d0 = v0 - mean, d1 = v1 - mean;
+            const f32x4 sq = d0 * d0 + d1 * d1;
+            const float rstd = 1.0f / sqrtf(wave_allsum((sq[0] + sq[1]) + (sq[2] + sq[3])) / E + ln.eps);
+            kv[i][0] = d0 * rstd * gm[0] + bt[0];
+            kv[i][1] = d1 * rstd * gm[1] + bt[1];
+            if (wave + 4 * i < nkeys) {                                    // wave-uniform
+                const size_t row = (size_t)(key0 + wave + 4 * i);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(ln.y + row * E + 256 * q + 4 * lane) = kv[i][q];
+                if (lane == 0) { ln.stats[2 * row] = mean; ln.stats[2 * row + 1] = rstd; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int rr = max(min(wave + 4 * i, nkeys - 1), 0);          // rows past the tile end: clamped, weight 0 below
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) kv[i][q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane);
+        }
     }
     {
         f32x4 qv[AP_H][NQ];
@@ -426,6 +485,9 @@ __global__ __launch_bounds__(256) void k_apool_dots(const float* __restrict__ ke
 
 // dkeys_n = sum_h (a_h dpooled_h + ds_h Qp_h);  per-tile partial of dQp_h = sum_n ds_h kin_n.  Column-parallel: lane l
 // owns columns 4l..4l+3 and 256+4l..+3, the four waves split the tile's rows; a_h / ds_h come from k_apool_dots.
+// DK = false (round 4): only the per-tile partial of dQp - the rank-16 update of dkeys is left to the reader of dkeys
+// (k_lnbr_bwd_r16 adds it to the gradient it loads), so neither dkeys_acc is read nor dkeys written here.
+template <bool DK>
 __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict__ keys, const float* __restrict__ pe,
                                                          const float* __restrict__ Qp, const float* __restrict__ dpooled,
                                                          const float* __restrict__ ad, const int32_t* __restrict__ k_off,
@@ -444,11 +506,37 @@ __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict
     for (int h = 0; h < AP_H; ++h)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            qv[h][q] = *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
-            dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            if (DK) {
+                qv[h][q] = *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+                dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            }
             dq[h][q] = f32x4{0, 0, 0, 0};
         }
-    if (nkeys < 0) {
+    if (!DK) {
+        // rows of the tile four at a time per wave: 8 + 8 16-byte loads in flight per lane
+        for (int r0 = wave; r0 < nkeys; r0 += 16) {
+            f32x4 kin[4][NQ];
+            float ds[4][AP_H];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = min(r0 + 4 * u, nkeys - 1);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    kin[u][q] = *reinterpret_cast<const f32x4*>(keys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) +
+                                *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rr) * E + 256 * q + 4 * lane);
+                const float* adr = ad + (size_t)(key0 + rr) * 16 + 8;      // wave-uniform: scalar loads
+#pragma unroll
+                for (int h = 0; h < AP_H; ++h) ds[u][h] = r0 + 4 * u < nkeys ? adr[h] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) dq[h][q] += ds[u][h] * kin[u][q];
+        }
+    }
+    if (DK && nkeys < 0) {
         // padding tile of a capacity bucket (mil_build_fusion_segs): rows key0 .. key0 - nkeys - 1 lie beyond every bag; their
         // gradient is exactly zero and is written here, so the caller need not clear dkeys
         for (int rr = wave; rr < -nkeys; rr += 4)
@@ -456,7 +544,7 @@ __global__ __launch_bounds__(256) void k_apool_bwd_apply(const float* __restrict
             for (int q = 0; q < NQ; ++q)
                 *reinterpret_cast<f32x4*>(dkeys + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = f32x4{0, 0, 0, 0};
     }
-    for (int rr = wave; rr < nkeys; rr += 4) {
+    for (int rr = wave; DK && rr < nkeys; rr += 4) {
         const float* adr = ad + (size_t)(key0 + rr) * 16;          // wave-uniform: scalar loads
         float a[AP_H], ds[AP_H];
 #pragma unroll
@@ -526,6 +614,161 @@ __global__ __launch_bounds__(1024) void k_apool_bwd_merge(const float* __restric
 #pragma unroll
         for (int u = 1; u < 8; ++u) acc += *reinterpret_cast<const f32x4*>(&red[u][4 * j4]);
         *reinterpret_cast<f32x4*>(dQp + ((size_t)b * AP_H + h) * E + 4 * j4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm(x + o[bag]) backward
+// with the pool's rank-16 update folded into the gradient it loads (round 4).  The keys the pool read were y = LN(x + o[bag])
+// (k_apool_partial<true>); their gradient is
+//     dy_n = dy_acc_n (the other consumer of y)  +  sum_h (a_h[n] dpooled_h + ds_h[n] Qp_h)       (k_apool_bwd_apply<true>'s sum)
+// and this kernel is its only reader - so the sum is formed HERE, per row, in the registers that feed the LayerNorm backward,
+// instead of being written to and read back from a [N, 512] tensor (one read of dy_acc + one write of dkeys + one read by
+// the LayerNorm backward: 3 x 64 MB per site at 32 x 1024 keys).  One workgroup per 64-key tile of the pool's tile map (a
+// tile lies inside one bag: no second-bag slot as in k_layernorm_bagrow_bwd), wave w rows w, w + 4, ..; lane l owns columns
+// 4l..4l+3 and 256+4l..; the bag's 16 vectors [dpooled | Qp] stay in 128 registers.  Per-tile partials
+// part[g][3][E] = {dgamma, dbeta, do}; padding tiles (nkeys < 0) write the zero gradient of their rows.
+__global__ __launch_bounds__(256, 2) void k_lnbr_bwd_r16(const float* __restrict__ x, const float* __restrict__ o,
+                                                         const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                         const float* __restrict__ dy_acc, const float* __restrict__ ad,
+                                                         const float* __restrict__ Qp, const float* __restrict__ dpooled,
+                                                         const int32_t* __restrict__ tile_map, float* __restrict__ dx,
+                                                         float* __restrict__ part) {
+    constexpr int E = 512, NQ = 2;
+    __shared__ __attribute__((aligned(16))) float red[3][3][E];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x;
+    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
+    if (nkeys <= 0) {
+        for (int rr = wave; rr < -nkeys; rr += 4)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                *reinterpret_cast<f32x4*>(dx + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = f32x4{0, 0, 0, 0};
+        return;
+    }
+    f32x4 qv[AP_H][NQ], dp[AP_H][NQ], gm[NQ], ov[NQ], dg[NQ], db[NQ], d0[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            qv[h][q] = *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+            dp[h][q] = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + h) * E + 256 * q + 4 * lane);
+        }
+        gm[q] = *reinterpret_cast<const f32x4*>(gamma + 256 * q + 4 * lane);
+        ov[q] = *reinterpret_cast<const f32x4*>(o + (size_t)b * E + 256 * q + 4 * lane);
+        dg[q] = db[q] = d0[q] = f32x4{0, 0, 0, 0};
+    }
+    f32x4 xn[NQ], dn[NQ];                                             // next row's loads, in flight under this row's arithmetic
+    auto issue = [&](int rr) {
+        const int rc = min(rr, nkeys - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            xn[q] = *reinterpret_cast<const f32x4*>(x + (size_t)(key0 + rc) * E + 256 * q + 4 * lane);
+            dn[q] = dy_acc != nullptr ? *reinterpret_cast<const f32x4*>(dy_acc + (size_t)(key0 + rc) * E + 256 * q + 4 * lane)
+                                      : f32x4{0, 0, 0, 0};
+        }
+    };
+    issue(wave);
+    for (int rr = wave; rr < nkeys; rr += 4) {
+        const size_t row = (size_t)(key0 + rr);
+        const float* adr = ad + row * 16;                              // wave-uniform: scalar loads
+        float a[AP_H], ds[AP_H];
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) { a[h] = adr[h]; ds[h] = adr[8 + h]; }
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        f32x4 xc[NQ], d[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { xc[q] = xn[q]; d[q] = dn[q]; }
+        issue(rr + 4);
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) d[q] += a[h] * dp[h][q] + ds[h] * qv[h][q];
+        f32x4 xh[NQ], gg[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            xh[q] = (xc[q] + ov[q] - mean) * rstd;
+            gg[q] = d[q] * gm[q];
+            dg[q] += d[q] * xh[q];
+            db[q] += d[q];
+        }
+        const f32x4 t1 = gg[0] + gg[1], t2 = gg[0] * xh[0] + gg[1] * xh[1];
+        const float s1 = wave_allsum((t1[0] + t1[1]) + (t1[2] + t1[3])) / E;
+        const float s2 = wave_allsum((t2[0] + t2[1]) + (t2[2] + t2[3])) / E;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 v = rstd * (gg[q] - s1 - xh[q] * s2);
+            *reinterpret_cast<f32x4*>(dx + row * E + 256 * q + 4 * lane) = v;
+            d0[q] += v;
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            *reinterpret_cast<f32x4*>(&red[wave - 1][0][256 * q + 4 * lane]) = dg[q];
+            *reinterpret_cast<f32x4*>(&red[wave - 1][1][256 * q + 4 * lane]) = db[q];
+            *reinterpret_cast<f32x4*>(&red[wave - 1][2][256 * q + 4 * lane]) = d0[q];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                dg[q] += *reinterpret_cast<const f32x4*>(&red[w][0][256 * q + 4 * lane]);
+                db[q] += *reinterpret_cast<const f32x4*>(&red[w][1][256 * q + 4 * lane]);
+                d0[q] += *reinterpret_cast<const f32x4*>(&red[w][2][256 * q + 4 * lane]);
+            }
+            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 0) * E + 256 * q + 4 * lane) = dg[q];
+            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 1) * E + 256 * q + 4 * lane) = db[q];
+            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 2) * E + 256 * q + 4 * lane) = d0[q];
+        }
+    }
+}
+
+// Fold of the per-tile partials of k_lnbr_bwd_r16 and of k_apool_bwd_apply in ONE launch, 1024 threads = 8 groups x 128 column
+// threads (16-byte columns), every sum in a fixed order:
+//   workgroups [0, 2):              dgamma / dbeta = sum over the real tiles [0, bag_tile_off[B])
+//   workgroups [2, 2 + B):          do[bag]        = sum over the bag's tiles
+//   workgroups [2 + B, 2 + B + BH): dQp[bag][h]    = sum over the bag's tiles            (k_apool_bwd_merge's sum)
+__global__ __launch_bounds__(1024) void k_lnbr_apool_fold(const float* __restrict__ part, const float* __restrict__ pdq,
+                                                          const int32_t* __restrict__ bag_tile_off, int B,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ d_o, float* __restrict__ dQp) {
+    constexpr int E = 512;
+    __shared__ __attribute__((aligned(16))) float red[8][E];
+    const int j4 = threadIdx.x & 127, q = threadIdx.x >> 7, blk = blockIdx.x;
+    const float* src;
+    size_t stride;
+    int g0, g1;
+    float* dst;
+    if (blk < 2) {
+        src = part + (size_t)blk * E; stride = (size_t)3 * E; g0 = 0; g1 = bag_tile_off[B]; dst = blk == 0 ? dgamma : dbeta;
+    } else if (blk < 2 + B) {
+        const int bag = blk - 2;
+        src = part + (size_t)2 * E; stride = (size_t)3 * E; g0 = bag_tile_off[bag]; g1 = bag_tile_off[bag + 1]; dst = d_o + (size_t)bag * E;
+    } else {
+        const int bh = blk - 2 - B, bag = bh / AP_H, h = bh % AP_H;
+        src = pdq + (size_t)h * E; stride = (size_t)AP_H * E; g0 = bag_tile_off[bag]; g1 = bag_tile_off[bag + 1];
+        dst = dQp + (size_t)bh * E;
+    }
+    f32x4 acc = {0, 0, 0, 0};
+    int g = g0 + q;
+    for (; g + 24 < g1; g += 32) {
+        f32x4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(g + 8 * u) * stride + 4 * j4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += t[u];
+    }
+    for (; g < g1; g += 8) acc += *reinterpret_cast<const f32x4*>(src + (size_t)g * stride + 4 * j4);
+    *reinterpret_cast<f32x4*>(&red[q][4 * j4]) = acc;
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int u = 1; u < 8; ++u) acc += *reinterpret_cast<const f32x4*>(&red[u][4 * j4]);
+        *reinterpret_cast<f32x4*>(dst + 4 * j4) = acc;
     }
 }
 
@@ -1110,7 +1353,8 @@ extern "C" int mil_absorbed_pool_fwd(const float* keys, const float* pe, const f
     float* pml = workspace + (size_t)ntiles * AP_H * E;
     const float scale = 1.0f / sqrtf((float)C);
     if (ntiles > 0) {
-        hipLaunchKernelGGL(k_apool_partial, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml);
+        hipLaunchKernelGGL(k_apool_partial<false>, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml,
+                           LnbrFwd{});
         MIL_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_apool_merge, dim3(B, AP_H), dim3(E / 4), 0, st, pacc, pml, bag_tile_off, E, pooled, lse);
@@ -1132,7 +1376,8 @@ extern "C" int mil_absorbed_pool_value_fwd(const float* keys, const float* pe, c
     float* pml = workspace + (size_t)ntiles * AP_H * E;
     const float scale = 1.0f / sqrtf((float)C);
     if (ntiles > 0) {
-        hipLaunchKernelGGL(k_apool_partial, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml);
+        hipLaunchKernelGGL(k_apool_partial<false>, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, k_off, tile_map, scale, pacc, pml,
+                           LnbrFwd{});
         MIL_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_apool_merge_value, dim3(B, AP_H), dim3(1024), 0, st, pacc, pml, bag_tile_off, E, pooled, lse, Wv, bv, C, o);
@@ -1166,11 +1411,70 @@ extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const f
         hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, pooled, k_off, tile_map,
                            scale, ad);
         MIL_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_apool_bwd_apply, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, dpooled, ad, k_off, tile_map,
+        hipLaunchKernelGGL(k_apool_bwd_apply<true>, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, dpooled, ad, k_off, tile_map,
                            dkeys_acc, dkeys, pdq);
         MIL_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_apool_bwd_merge, dim3(B, AP_H), dim3(1024), 0, st, pdq, bag_tile_off, E, dQp);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// LayerNorm(x + o[bag]) + the next attention site's absorbed pool + value projection, forward: y [rows, E] (the keys, every
+// row the tile map covers - padding rows zero), stats [rows, 2], pooled, lse, o_attn.  workspace: ntiles H (E + 2) floats.
+extern "C" int mil_lnbr_absorbed_pool_value_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps,
+                                                const float* pe, const float* Qp, const int32_t* k_off, const int32_t* tile_map,
+                                                const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E,
+                                                const float* Wv, const float* bv, float* y, float* stats, float* pooled,
+                                                float* lse, float* o_attn, float* workspace, void* stream) {
+    AP_CHECK(x && o && gamma && beta && pe && Qp && k_off && tile_map && bag_tile_off && Wv && bv && y && stats && pooled && lse);
+    AP_CHECK(o_attn && workspace && H == AP_H && E == 512 && (C == 32 || C == 64) && B >= 0 && ntiles >= 0 && eps > 0.f);
+    if (B == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* pacc = workspace;
+    float* pml = workspace + (size_t)ntiles * AP_H * E;
+    const float scale = 1.0f / sqrtf((float)C);
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_apool_partial<true>, dim3(ntiles), dim3(256), 0, st, (const float*)nullptr, pe, Qp, k_off, tile_map, scale,
+                           pacc, pml, LnbrFwd{x, o, gamma, beta, eps, y, stats});
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_apool_merge_value, dim3(B, AP_H), dim3(1024), 0, st, pacc, pml, bag_tile_off, E, pooled, lse, Wv, bv, C,
+                       o_attn);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// Its backward (dpooled from mil_value_proj_bwd): dx [rows, E], do [B, E], dgamma, dbeta [E], dQp [B, H, E].  y = the keys the
+// forward wrote; dy_acc (nullable) = the gradient y receives from its other consumer.  Four launches: per-row dots, per-tile
+// dQp partials, the LayerNorm backward with the pool's rank-16 update folded into its load, one fold of all partials.
+// workspace: ntiles H E + 16 n_keys + 3 ntiles E floats.
+extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* stats, const float* y,
+                                          const float* pe, const float* Qp, const float* lse, const float* dpooled,
+                                          const float* pooled, const int32_t* k_off, const int32_t* tile_map,
+                                          const int32_t* bag_tile_off, int ntiles, int n_keys, int B, int H, int C, int E,
+                                          const float* dy_acc, float* dx, float* d_o, float* dgamma, float* dbeta, float* dQp,
+                                          float* workspace, void* stream) {
+    AP_CHECK(x && o && gamma && stats && y && pe && Qp && lse && dpooled && pooled && k_off && tile_map && bag_tile_off);
+    AP_CHECK(dx && d_o && dgamma && dbeta && dQp && workspace && H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0 && n_keys >= 0);
+    if (B == 0) return MIL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / sqrtf((float)C);
+    float* pdq = workspace;                                    // [ntiles][H][E]
+    float* ad = pdq + (size_t)ntiles * AP_H * E;               // [n_keys][16]
+    float* part = ad + (size_t)16 * n_keys;                    // [ntiles][3][E]
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, y, pe, Qp, lse, dpooled, pooled, k_off, tile_map, scale, ad);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_apool_bwd_apply<false>, dim3(ntiles), dim3(256), 0, st, y, pe, Qp, dpooled, (const float*)ad, k_off,
+                           tile_map, (const float*)nullptr, (float*)nullptr, pdq);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_lnbr_bwd_r16, dim3(ntiles), dim3(256), 0, st, x, o, gamma, stats, dy_acc, (const float*)ad, Qp, dpooled,
+                           tile_map, dx, part);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_lnbr_apool_fold, dim3(2 + B + B * AP_H), dim3(1024), 0, st, (const float*)part, (const float*)pdq, bag_tile_off,
+                       B, dgamma, dbeta, d_o, dQp);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -7,6 +7,7 @@ so state_dicts interchange; the arithmetic runs on the HIP library: projections 
 over the patches of a bag) or the "rows" kernel (patches over the few text tokens), LayerNorm and the
 positional add as streaming kernels.  Internally every tensor is flat [rows, E] with per-bag segments,
 so a batch of ragged bags is one launch sequence (the reference runs one bag per forward)."""
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -111,12 +112,16 @@ class TwoWayAttentionBlock(nn.Module):
         self.skip_first_layer_pe = skip_first_layer_pe
 
     def flat(self, queries, keys, query_pe, keys_pe_fn, s_tt: AttnSegs, s_ti: AttnSegs, s_it: AttnSegs, pe_table=None,
-             keys_tail_rows: int = 0):
+             keys_tail_rows: int = 0, pending=None, defer: bool = False):
         """One block on flat rows (sam/transformer.py:278-309).  keys_pe_fn(keys) = keys + key_pe.  With pe_table
         given and exactly one text token per bag, both cross attentions take their one-token forms and keys + pe is
-        never materialised."""
+        never materialised.  pending / defer (one-token fused route only, see TwoWayTransformer.flat): the block's last
+        LayerNorm(keys + row) is left to the next attention site's pool kernel - `defer` returns (queries, keys, (row, norm4))
+        with the norm still owed, `pending` is such a pair owed on the incoming keys."""
         if self._one_token_fused_ok(queries, s_tt, s_ti, s_it, pe_table):
-            return self._flat_one_token_fused(queries, keys, query_pe, s_ti, s_it, pe_table, keys_tail_rows)
+            return self._flat_one_token_fused(queries, keys, query_pe, s_ti, s_it, pe_table, keys_tail_rows, pending, defer)
+        if pending is not None or defer:
+            raise ValueError("pending / defer are only defined on the one-token fused route")
         if s_tt.Tk_max == 1 and min(s_tt.k_lengths, default=1) == 1:
             # One text token per bag: self-attention over a single key returns that key's value whatever q and k
             # are (softmax of one score = 1), so :282-287 reduce to out_proj(v_proj(queries)) and q_proj / k_proj
@@ -177,7 +182,8 @@ class TwoWayAttentionBlock(nn.Module):
                 and self.mlp.act == "relu" and self.mlp.lin1.weight.shape[1] == 512 and self.mlp.lin2.weight.shape[0] == 512
                 and i2t.v_proj.weight.shape[1] == 512 and all(n.eps == self.norm1.eps for n in (self.norm2, self.norm3)))
 
-    def _flat_one_token_fused(self, queries, keys, query_pe, s_ti, s_it, pe_table, keys_tail_rows):
+    def _flat_one_token_fused(self, queries, keys, query_pe, s_ti, s_it, pe_table, keys_tail_rows, pending=None,
+                              defer: bool = False):
         """The block for ONE text token per bag (the reference's `CI_prompt_version='single'`) with the token stream in three
         fused links P -> LayerNorm -> C (ops.lin_ln_lin: the norm rides in the operand load of the layer behind it, its
         backward in the operand load of the layer in front of it, gradient sums of two-consumer tensors inside the kernels):
@@ -192,13 +198,21 @@ class TwoWayAttentionBlock(nn.Module):
         vp = ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias)
         qp, q1 = ops.lin_ln_lin(vp, a.out_proj.weight, a.out_proj.bias, None if self.skip_first_layer_pe else queries,
                                 self.norm1.weight, self.norm1.bias, eps, query_pe, t2i.q_proj.weight, t2i.q_proj.bias)
-        o, keys = ops.one_token_attention(None, keys, pe_table, s_ti, t2i.q_proj.weight, t2i.q_proj.bias, t2i.k_proj.weight,
-                                          t2i.v_proj.weight, t2i.v_proj.bias, t2i.num_heads, qp=qp)
+        if pending is not None:
+            # the LayerNorm(keys + row) the block in front left to this pool (its kernel makes the keys it reads)
+            prow, pn = pending
+            o, keys = ops.lnbr_one_token_attention(keys, prow, pn.weight, pn.bias, pn.eps, pe_table, s_ti, t2i.k_proj.weight,
+                                                   t2i.v_proj.weight, t2i.v_proj.bias, t2i.num_heads, qp)
+        else:
+            o, keys = ops.one_token_attention(None, keys, pe_table, s_ti, t2i.q_proj.weight, t2i.q_proj.bias, t2i.k_proj.weight,
+                                              t2i.v_proj.weight, t2i.v_proj.bias, t2i.num_heads, qp=qp)
         h, q2 = ops.lin_ln_lin(o, t2i.out_proj.weight, t2i.out_proj.bias, q1, self.norm2.weight, self.norm2.bias, eps, None,
                                mlp.lin1.weight, mlp.lin1.bias, "relu")
         vp3, q3 = ops.lin_ln_lin(h, mlp.lin2.weight, mlp.lin2.bias, q2, self.norm3.weight, self.norm3.bias, eps, None,
                                  i2t.v_proj.weight, i2t.v_proj.bias)
         row = ops.linear_act(vp3, i2t.out_proj.weight, i2t.out_proj.bias)
+        if defer:
+            return q3, keys, (row, self.norm4)
         keys = ops.layer_norm_bag_row(keys, row, s_it, self.norm4.weight, self.norm4.bias, self.norm4.eps, keys_tail_rows)
         return q3, keys
 
@@ -241,11 +255,31 @@ class TwoWayTransformer(nn.Module):
             s_it = AttnSegs.make(n_lengths, t_lengths, dev)
         keys_pe = lambda kk: ops.add_pe(kk, pe_table, s_ti.k_bag, s_ti.k_off)      # noqa: E731
         queries, keys = point, image
+        # One text token per bag: LayerNorm(keys + row), the last op of a block, is left to the pool kernel of the NEXT
+        # attention site over those keys (ops.lnbr_one_token_attention) wherever both sides take their one-token forms.
+        fuse = os.environ.get("MIL_FUSE_LNBR", "1") != "0"
+        fa = self.final_attn_token_to_image
+        pending = None
         for li, layer in enumerate(self.layers):
-            queries, keys = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it, pe_table,
-                                       keys_tail_rows if li == len(self.layers) - 1 else 0)
+            last = li == len(self.layers) - 1
+            nxt = fa if last else self.layers[li + 1].cross_attn_token_to_image
+            defer = (fuse and layer._one_token_fused_ok(queries, s_tt, s_ti, s_it, pe_table)
+                     and (one_token_ok(fa, s_ti, pe_table) if last
+                          else self.layers[li + 1]._one_token_fused_ok(queries, s_tt, s_ti, s_it, pe_table))
+                     and ops.lnbr_one_token_ok(keys, None, layer.norm4.weight, layer.norm4.bias, nxt.k_proj.weight,
+                                               nxt.v_proj.weight, nxt.v_proj.bias, nxt.num_heads))
+            out = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it, pe_table, keys_tail_rows if last else 0,
+                             pending=pending, defer=defer)
+            queries, keys, pending = out if defer else (out[0], out[1], None)
         q = queries + point                                                      # :114-118
-        if one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
+        if pending is not None:
+            prow, pn = pending
+            _zero_grad_params(fa.k_proj.bias)
+            qp = ops.linear_act(q, fa.q_proj.weight, fa.q_proj.bias)
+            o, keys = ops.lnbr_one_token_attention(keys, prow, pn.weight, pn.bias, pn.eps, pe_table, s_ti, fa.k_proj.weight,
+                                                   fa.v_proj.weight, fa.v_proj.bias, fa.num_heads, qp, keys_tail_rows)
+            out = ops.linear_act(o, fa.out_proj.weight, fa.out_proj.bias, "none", residual=queries)
+        elif one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
             out, keys = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
         elif ops.multi_token_ok(self.embedding_dim, self.num_heads, s_ti.q_lengths):
             out, keys = self.final_attn_token_to_image.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=queries)

@@ -1734,6 +1734,86 @@ class _AbsorbedPoolValue(torch.autograd.Function):
         return dkeys, None, dQp, dWv, dbv, None, None
 
 
+class _LnbrAbsorbedPoolValue(torch.autograd.Function):
+    """keys = LayerNorm(x + row[bag]) (the image->token attention of the block in front, one text token per bag:
+    _LayerNormBagRow) followed by _AbsorbedPoolValue on those keys, as ONE node (mil_lnbr_absorbed_pool_value_fwd / _bwd): the
+    pool's forward kernel makes the keys it reads, and the pool's rank-16 update of dkeys is added by the LayerNorm backward
+    to the gradient it loads.  Returns (o [B, H C], keys [rows, E]); the keys' other consumer's gradient arrives at this node
+    (dkeys) and is folded in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, row, gamma, beta, eps: float, pe, Qp, Wv, bv, segs, C: int, tail_rows: int):
+        x, row, pe, Qp, Wv = _f32c(x, "x"), _f32c(row, "row"), _f32c(pe, "pe"), _f32c(Qp, "Qp"), _f32c(Wv, "Wv")
+        B, H, E = Qp.shape
+        rows = x.shape[0]
+        y = torch.empty((rows + tail_rows, E), device=x.device, dtype=torch.float32)[:rows] if tail_rows else torch.empty_like(x)
+        if not getattr(segs, "pad_tiles", False) and getattr(segs, "device_lengths", False):
+            y.zero_()                                   # rows no tile covers must still hold finite values
+        stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        pooled = torch.empty_like(Qp)
+        lse = torch.empty((B, H), device=x.device, dtype=torch.float32)
+        o = torch.empty((B, Wv.shape[0]), device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(1, segs.ntiles) * H * (E + 2), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_lnbr_absorbed_pool_value_fwd(_p(x), _p(row), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
+                                                         float(eps), _p(pe), _p(Qp), _p(segs.k_off), _p(segs.tile_map),
+                                                         _p(segs.bag_tile_off), segs.ntiles, B, H, C, E, _p(Wv),
+                                                         _p(_f32c(bv, "bv")), _p(y), _p(stats), _p(pooled), _p(lse), _p(o),
+                                                         _p(ws), _stream())
+        _lib.check(rc, "mil_lnbr_absorbed_pool_value_fwd")
+        ctx.segs, ctx.C, ctx.bv_param, ctx.beta_param = segs, C, bv, beta
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, row, gamma, stats, y, pe, Qp, pooled, lse, Wv)
+        return o, y
+
+    @staticmethod
+    def backward(ctx, do, dy_pass):
+        x, row, gamma, stats, y, pe, Qp, pooled, lse, Wv = ctx.saved_tensors
+        segs, C = ctx.segs, ctx.C
+        B, H, E = Qp.shape
+        rows = x.shape[0]
+        dWv = dbv = None
+        if do is None:
+            dpooled = torch.zeros_like(pooled)          # the attention output has no reader: LayerNorm backward alone
+        else:
+            dpooled, dWv, dbv = _value_proj_bwd(_f32c(do, "do"), Wv, ctx.bv_param, pooled)
+        acc = _f32c(dy_pass, "dkeys") if dy_pass is not None else None
+        dx = torch.empty_like(x)
+        if not getattr(segs, "pad_tiles", False) and getattr(segs, "device_lengths", False):
+            dx.zero_()
+        d_row = torch.empty_like(row)
+        dg = grad_slot(gamma)
+        if dg is None:
+            dg = torch.empty(E, device=x.device, dtype=torch.float32)
+        db = grad_slot(ctx.beta_param)
+        if db is None:
+            db = torch.empty(E, device=x.device, dtype=torch.float32)
+        dQp = torch.empty_like(Qp)
+        nt = max(1, segs.ntiles)
+        ws = torch.empty(nt * H * E + 16 * rows + 3 * nt * E, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_lnbr_absorbed_pool_bwd(_p(x), _p(row), _p(gamma), _p(stats), _p(y), _p(pe), _p(Qp), _p(lse),
+                                                   _p(dpooled), _p(pooled), _p(segs.k_off), _p(segs.tile_map),
+                                                   _p(segs.bag_tile_off), segs.ntiles, rows, B, H, C, E, _p(acc), _p(dx),
+                                                   _p(d_row), _p(dg), _p(db), _p(dQp), _p(ws), _stream())
+        _lib.check(rc, "mil_lnbr_absorbed_pool_bwd")
+        return dx, d_row, dg, db, None, None, dQp, dWv, dbv, None, None, None
+
+
+def lnbr_one_token_ok(x, row, gamma, beta, Wk, Wv, bv, H: int) -> bool:
+    """Shapes / trainability the fused LayerNorm(x + row) -> one-token attention node is built for."""
+    return (x.dim() == 2 and x.shape[1] == 512 and x.shape[0] > 64 and H == 8 and Wk.shape[1] == 512
+            and Wk.shape[0] // H in (32, 64)
+            and (not torch.is_grad_enabled()
+                 or (gamma.requires_grad and beta.requires_grad and Wv.requires_grad and bv.requires_grad)))
+
+
+def lnbr_one_token_attention(x, row, gamma, beta, eps, pe, segs, Wk, Wv, bv, H: int, qp, tail_rows: int = 0):
+    """keys = LayerNorm(x + row[bag]); token->image attention (projections absorbed) of ONE text token per bag over those
+    keys.  qp [B, H C]: the projected query.  Returns (attention output [B, H C] before out_proj, keys [rows, E])."""
+    C = Wk.shape[0] // H
+    Qp = _AbsorbQuery.apply(qp, Wk, H)
+    return _LnbrAbsorbedPoolValue.apply(x, row, gamma, beta, eps, pe, Qp, Wv, bv, segs, C, tail_rows)
+
+
 def one_token_attention(q_tok, keys, pe, segs, Wq, bq, Wk, Wv, bv, H: int, qp=None):
     """Token->image attention core for ONE text token per bag, projections absorbed (csrc/absorbed_attn.hip).
     q_tok [B, E] (query + its pe), keys [R, E] WITHOUT positional encoding, pe [>= max N, E].  Returns the
