@@ -727,48 +727,50 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_bwd_r16(const float* __restrict
     }
 }
 
-// Fold of the per-tile partials of k_lnbr_bwd_r16 and of k_apool_bwd_apply in ONE launch, 1024 threads = 8 groups x 128 column
-// threads (16-byte columns), every sum in a fixed order:
-//   workgroups [0, 2):              dgamma / dbeta = sum over the real tiles [0, bag_tile_off[B])
-//   workgroups [2, 2 + B):          do[bag]        = sum over the bag's tiles
-//   workgroups [2 + B, 2 + B + BH): dQp[bag][h]    = sum over the bag's tiles            (k_apool_bwd_merge's sum)
+// Fold of the per-tile partials of k_lnbr_bwd_r16 and of k_apool_bwd_apply in ONE launch; every sum in a fixed order.  A job =
+// one output vector of E floats; it is split over 4 workgroups (128 columns each) of 1024 threads = 32 tile groups x 32 column
+// threads (16-byte columns), group q sums the tiles g0 + q, g0 + q + 32, ... four loads in flight - the walk over the tiles
+// is pure latency: one workgroup per vector and 8 groups took 11 us for the 512 tiles of dgamma, this form 16 trips of 4.
+//   jobs [0, 2):              dgamma / dbeta = sum over the real tiles [0, bag_tile_off[B])
+//   jobs [2, 2 + B):          do[bag]        = sum over the bag's tiles
+//   jobs [2 + B, 2 + B + BH): dQp[bag][h]    = sum over the bag's tiles            (k_apool_bwd_merge's sum)
 __global__ __launch_bounds__(1024) void k_lnbr_apool_fold(const float* __restrict__ part, const float* __restrict__ pdq,
                                                           const int32_t* __restrict__ bag_tile_off, int B,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ d_o, float* __restrict__ dQp) {
     constexpr int E = 512;
-    __shared__ __attribute__((aligned(16))) float red[8][E];
-    const int j4 = threadIdx.x & 127, q = threadIdx.x >> 7, blk = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) float red[32][128];
+    const int j4 = threadIdx.x & 31, q = threadIdx.x >> 5, job = blockIdx.x >> 2, c0 = (blockIdx.x & 3) * 128 + 4 * j4;
     const float* src;
     size_t stride;
     int g0, g1;
     float* dst;
-    if (blk < 2) {
-        src = part + (size_t)blk * E; stride = (size_t)3 * E; g0 = 0; g1 = bag_tile_off[B]; dst = blk == 0 ? dgamma : dbeta;
-    } else if (blk < 2 + B) {
-        const int bag = blk - 2;
+    if (job < 2) {
+        src = part + (size_t)job * E; stride = (size_t)3 * E; g0 = 0; g1 = bag_tile_off[B]; dst = job == 0 ? dgamma : dbeta;
+    } else if (job < 2 + B) {
+        const int bag = job - 2;
         src = part + (size_t)2 * E; stride = (size_t)3 * E; g0 = bag_tile_off[bag]; g1 = bag_tile_off[bag + 1]; dst = d_o + (size_t)bag * E;
     } else {
-        const int bh = blk - 2 - B, bag = bh / AP_H, h = bh % AP_H;
+        const int bh = job - 2 - B, bag = bh / AP_H, h = bh % AP_H;
         src = pdq + (size_t)h * E; stride = (size_t)AP_H * E; g0 = bag_tile_off[bag]; g1 = bag_tile_off[bag + 1];
         dst = dQp + (size_t)bh * E;
     }
     f32x4 acc = {0, 0, 0, 0};
     int g = g0 + q;
-    for (; g + 24 < g1; g += 32) {
+    for (; g + 96 < g1; g += 128) {
         f32x4 t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(g + 8 * u) * stride + 4 * j4);
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(g + 32 * u) * stride + c0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc += t[u];
     }
-    for (; g < g1; g += 8) acc += *reinterpret_cast<const f32x4*>(src + (size_t)g * stride + 4 * j4);
+    for (; g < g1; g += 32) acc += *reinterpret_cast<const f32x4*>(src + (size_t)g * stride + c0);
     *reinterpret_cast<f32x4*>(&red[q][4 * j4]) = acc;
     __syncthreads();
     if (q == 0) {
 #pragma unroll
-        for (int u = 1; u < 8; ++u) acc += *reinterpret_cast<const f32x4*>(&red[u][4 * j4]);
-        *reinterpret_cast<f32x4*>(dst + 4 * j4) = acc;
+        for (int u = 1; u < 32; ++u) acc += *reinterpret_cast<const f32x4*>(&red[u][4 * j4]);
+        *reinterpret_cast<f32x4*>(dst + c0) = acc;
     }
 }
 
@@ -1473,7 +1475,7 @@ extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const 
                            tile_map, dx, part);
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_lnbr_apool_fold, dim3(2 + B + B * AP_H), dim3(1024), 0, st, (const float*)part, (const float*)pdq, bag_tile_off,
+    hipLaunchKernelGGL(k_lnbr_apool_fold, dim3(4 * (2 + B + B * AP_H)), dim3(1024), 0, st, (const float*)part, (const float*)pdq, bag_tile_off,
                        B, dgamma, dbeta, d_o, dQp);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
