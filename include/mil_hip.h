@@ -600,7 +600,7 @@ int mil_lnbr_absorbed_pool_value_fwd(const float* x, const float* o, const float
                                      const int32_t* bag_tile_off, int ntiles, int B, int H, int C, int E, const float* Wv,
                                      const float* bv, float* y, float* stats, float* pooled, float* lse, float* o_attn,
                                      float* workspace, void* stream);
-int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* stats, const float* y,
+int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* beta, const float* stats, const float* y,
                                const float* pe, const float* Qp, const float* lse, const float* dpooled, const float* pooled,
                                const int32_t* k_off, const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles,
                                int n_keys, int B, int H, int C, int E, const float* dy_acc, float* dx, float* d_o,

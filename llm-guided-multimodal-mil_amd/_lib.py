@@ -116,7 +116,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_absorbed_pool_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 3 + [_P]),
     "mil_absorbed_pool_bwd": (c_int, [_P] * 9 + [c_int] * 6 + [_P] * 4 + [_P]),
     "mil_lnbr_absorbed_pool_value_fwd": (c_int, [_P] * 4 + [c_float] + [_P] * 5 + [c_int] * 5 + [_P] * 8 + [_P]),
-    "mil_lnbr_absorbed_pool_bwd": (c_int, [_P] * 13 + [c_int] * 6 + [_P] * 7 + [_P]),
+    "mil_lnbr_absorbed_pool_bwd": (c_int, [_P] * 14 + [c_int] * 6 + [_P] * 7 + [_P]),
     "mil_absorbed_pool_value_fwd": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 6 + [_P]),
     "mil_value_proj_bwd": (c_int, [_P] * 3 + [c_int] * 4 + [_P] * 3 + [_P]),
     "mil_grp_col_softmax": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),

@@ -15,6 +15,8 @@
 //   k_apool_dots / _bwd_apply per row: recompute a_h[n] (MFMA dots); dkeys, and per-tile partial of dQp
 //   k_value_proj / _bwd       o[b][hc + c'] = Wv[hc + c'] . pooled[b][h] + bv
 #include "mil_common.h"
+#include <cstdlib>
+#include <cstring>
 
 #define AP_H 8
 #define AP_TILE 64
@@ -719,6 +721,204 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_bwd_r16(const float* __restrict
                 dg[q] += *reinterpret_cast<const f32x4*>(&red[w][0][256 * q + 4 * lane]);
                 db[q] += *reinterpret_cast<const f32x4*>(&red[w][1][256 * q + 4 * lane]);
                 d0[q] += *reinterpret_cast<const f32x4*>(&red[w][2][256 * q + 4 * lane]);
+            }
+            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 0) * E + 256 * q + 4 * lane) = dg[q];
+            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 1) * E + 256 * q + 4 * lane) = db[q];
+            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 2) * E + 256 * q + 4 * lane) = d0[q];
+        }
+    }
+}
+
+// The whole backward of the pair in ONE pass over the rows (round 4): everything k_apool_dots, k_apool_bwd_apply<false> and
+// k_lnbr_bwd_r16 do for a key row is row-local once the row sits in registers - the keys y_n = xhat_n gamma + beta are
+// RECOMPUTED from x (the LayerNorm backward needs xhat_n anyway), the 16 dot products of the row (scores against the eight
+// absorbed queries, dpooled_h . y_n) are per-lane partial sums + one 16-value transposing wave reduction, the softmax
+// weights a_h and t_h = a_h (da_h - cdot_h) come back to every lane through 16 v_readlane, then the rank-16 update, the dQp
+// partial and the LayerNorm backward run on the same registers.  Reads x + dy_acc (+ pe from L2), writes dx: 3 x 64 MB per
+// site where the three kernels moved 5 (and the round-3 form 7).  The bag's 16 vectors [scale Qp | dpooled] live in LDS
+// (32 KB, 16-byte reads, conflict-free; 64 KB per row and wave = 14 us of LDS time per site next to 37 us of HBM time); the
+// same 32 KB fold the four waves' dQp partials afterwards.
+__global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __restrict__ x, const float* __restrict__ o,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ stats, const float* __restrict__ dy_acc,
+                                                               const float* __restrict__ pe, const float* __restrict__ Qp,
+                                                               const float* __restrict__ dpooled, const float* __restrict__ pooled,
+                                                               const float* __restrict__ lse, const int32_t* __restrict__ k_off,
+                                                               const int32_t* __restrict__ tile_map, float scale,
+                                                               float* __restrict__ dx, float* __restrict__ part,
+                                                               float* __restrict__ pdq) {
+    constexpr int E = 512, NQ = 2;
+    __shared__ __attribute__((aligned(16))) float V[16 * E];          // [scale Qp_h | dpooled_h]; afterwards the dQp fold
+    __shared__ __attribute__((aligned(16))) float red3[3][3][E];
+    __shared__ float cd_lds[AP_H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x;
+    const int b = tile_map[3 * g], key0 = tile_map[3 * g + 1], nkeys = tile_map[3 * g + 2];
+    if (nkeys <= 0) {
+        for (int rr = wave; rr < -nkeys; rr += 4)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                *reinterpret_cast<f32x4*>(dx + (size_t)(key0 + rr) * E + 256 * q + 4 * lane) = f32x4{0, 0, 0, 0};
+        return;
+    }
+    const int pos0 = key0 - k_off[b];
+    f32x4 xn[NQ], dn[NQ], pn[NQ];                                     // next row's loads, in flight under this row's arithmetic
+    auto issue = [&](int rr) {
+        const int rc = min(rr, nkeys - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            xn[q] = *reinterpret_cast<const f32x4*>(x + (size_t)(key0 + rc) * E + 256 * q + 4 * lane);
+            dn[q] = dy_acc != nullptr ? *reinterpret_cast<const f32x4*>(dy_acc + (size_t)(key0 + rc) * E + 256 * q + 4 * lane)
+                                      : f32x4{0, 0, 0, 0};
+            pn[q] = *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rc) * E + 256 * q + 4 * lane);
+        }
+    };
+    issue(wave);
+    {
+        // the bag's 16 vectors -> LDS, cdot_h = dpooled_h . pooled_h (32 lanes per head, as k_apool_dots)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 256 + tid, row = idx >> 7, c4 = idx & 127;
+            f32x4 v;
+            if (row < AP_H) v = scale * *reinterpret_cast<const f32x4*>(Qp + ((size_t)b * AP_H + row) * E + 4 * c4);
+            else v = *reinterpret_cast<const f32x4*>(dpooled + ((size_t)b * AP_H + row - AP_H) * E + 4 * c4);
+            *reinterpret_cast<f32x4*>(V + row * E + 4 * c4) = v;
+        }
+        const int hh = tid >> 5, pt = tid & 31;
+        const float* dpv = dpooled + ((size_t)b * AP_H + hh) * E + 16 * pt;
+        const float* pv = pooled + ((size_t)b * AP_H + hh) * E + 16 * pt;
+        float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(dpv + 4 * u), b4 = *reinterpret_cast<const f32x4*>(pv + 4 * u);
+            v += (a4[0] * b4[0] + a4[1] * b4[1]) + (a4[2] * b4[2] + a4[3] * b4[3]);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (pt == 0) cd_lds[hh] = v;
+    }
+    f32x4 gm[NQ], bt[NQ], ov[NQ], dg[NQ], db[NQ], d0[NQ], dq[AP_H][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        gm[q] = *reinterpret_cast<const f32x4*>(gamma + 256 * q + 4 * lane);
+        bt[q] = *reinterpret_cast<const f32x4*>(beta + 256 * q + 4 * lane);
+        ov[q] = *reinterpret_cast<const f32x4*>(o + (size_t)b * E + 256 * q + 4 * lane);
+        dg[q] = db[q] = d0[q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) dq[h][q] = f32x4{0, 0, 0, 0};
+    }
+    __syncthreads();
+    // wave_reduce16 leaves value index k(l) = 8 b5 + 4 b4 + 2 b3 + b2 on lane l: lanes < 32 the score of head hl, lanes >= 32
+    // dpooled_hl . y of the same head
+    const int hl = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const float lse_l = lse[b * AP_H + hl], cd_l = cd_lds[hl];
+    const float* Vl = V + 4 * lane;
+    for (int rr = wave; rr < nkeys; rr += 4) {
+        const size_t row = (size_t)(key0 + rr);
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        f32x4 xh[NQ], y[NQ], kin[NQ], d[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            xh[q] = (xn[q] + ov[q] - mean) * rstd;
+            y[q] = xh[q] * gm[q] + bt[q];
+            kin[q] = y[q] + pn[q];
+            d[q] = dn[q];
+        }
+        issue(rr + 4);
+        float p[16];
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(Vl + h * E), q1 = *reinterpret_cast<const f32x4*>(Vl + h * E + 256);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(Vl + (AP_H + h) * E), e1 = *reinterpret_cast<const f32x4*>(Vl + (AP_H + h) * E + 256);
+            const f32x4 t = kin[0] * q0 + kin[1] * q1, u = y[0] * e0 + y[1] * e1;
+            p[h] = (t[0] + t[1]) + (t[2] + t[3]);
+            p[AP_H + h] = (u[0] + u[1]) + (u[2] + u[3]);
+        }
+        const float r = wave_reduce16(p, lane);
+        const float av = __expf(r - lse_l);                                    // lanes < 32: a_hl
+        const float hi = lane < 32 ? 0.f : r;
+        const float da = swap32_add(hi, hi);                                    // lanes < 32: da_hl (from lane + 32)
+        const float tv = av * (da - cd_l);
+        float ah[AP_H], th[AP_H];
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            const int src = ((h >> 2) & 1) * 16 + ((h >> 1) & 1) * 8 + (h & 1) * 4;
+            ah[h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), src));
+            th[h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), src));
+        }
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(Vl + h * E), q1 = *reinterpret_cast<const f32x4*>(Vl + h * E + 256);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(Vl + (AP_H + h) * E), e1 = *reinterpret_cast<const f32x4*>(Vl + (AP_H + h) * E + 256);
+            d[0] += ah[h] * e0 + th[h] * q0;
+            d[1] += ah[h] * e1 + th[h] * q1;
+            dq[h][0] += th[h] * kin[0];
+            dq[h][1] += th[h] * kin[1];
+        }
+        f32x4 gg[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            gg[q] = d[q] * gm[q];
+            dg[q] += d[q] * xh[q];
+            db[q] += d[q];
+        }
+        const f32x4 t1 = gg[0] + gg[1], t2 = gg[0] * xh[0] + gg[1] * xh[1];
+        const float s1 = wave_allsum((t1[0] + t1[1]) + (t1[2] + t1[3])) / E;
+        const float s2 = wave_allsum((t2[0] + t2[1]) + (t2[2] + t2[3])) / E;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 v = rstd * (gg[q] - s1 - xh[q] * s2);
+            *reinterpret_cast<f32x4*>(dx + row * E + 256 * q + 4 * lane) = v;
+            d0[q] += v;
+        }
+    }
+    // fold of the four waves: dgamma / dbeta / do through red3; dQp through the 32 KB of V in two rounds (3, 2 -> 1, 0; 1 -> 0)
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            *reinterpret_cast<f32x4*>(&red3[wave - 1][0][256 * q + 4 * lane]) = dg[q];
+            *reinterpret_cast<f32x4*>(&red3[wave - 1][1][256 * q + 4 * lane]) = db[q];
+            *reinterpret_cast<f32x4*>(&red3[wave - 1][2][256 * q + 4 * lane]) = d0[q];
+        }
+    }
+    __syncthreads();                                                       // every wave is done with V
+    if (wave >= 2) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(V + ((wave - 2) * AP_H + h) * E + 256 * q + 4 * lane) = dq[h][q];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dq[h][q] += *reinterpret_cast<const f32x4*>(V + (wave * AP_H + h) * E + 256 * q + 4 * lane);
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(V + h * E + 256 * q + 4 * lane) = dq[h][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int h = 0; h < AP_H; ++h)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 v = dq[h][q] + *reinterpret_cast<const f32x4*>(V + h * E + 256 * q + 4 * lane);
+                *reinterpret_cast<f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v * scale;
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                dg[q] += *reinterpret_cast<const f32x4*>(&red3[w][0][256 * q + 4 * lane]);
+                db[q] += *reinterpret_cast<const f32x4*>(&red3[w][1][256 * q + 4 * lane]);
+                d0[q] += *reinterpret_cast<const f32x4*>(&red3[w][2][256 * q + 4 * lane]);
             }
             *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 0) * E + 256 * q + 4 * lane) = dg[q];
             *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 1) * E + 256 * q + 4 * lane) = db[q];
@@ -1448,16 +1648,22 @@ extern "C" int mil_lnbr_absorbed_pool_value_fwd(const float* x, const float* o, 
 }
 
 // Its backward (dpooled from mil_value_proj_bwd): dx [rows, E], do [B, E], dgamma, dbeta [E], dQp [B, H, E].  y = the keys the
-// forward wrote; dy_acc (nullable) = the gradient y receives from its other consumer.  Four launches: per-row dots, per-tile
-// dQp partials, the LayerNorm backward with the pool's rank-16 update folded into its load, one fold of all partials.
+// forward wrote; dy_acc (nullable) = the gradient y receives from its other consumer.  Two launches: k_lnbr_apool_bwd_one +
+// one fold of all partials (MIL_LNBR_BWD=r16: the three-kernel form it replaces - per-row dots, per-tile dQp partials, the
+// LayerNorm backward with the pool's rank-16 update folded into its load - kept as the cross-check of the tests).
 // workspace: ntiles H E + 16 n_keys + 3 ntiles E floats.
-extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* stats, const float* y,
+static bool lnbr_bwd_one_pass() {
+    const char* e = getenv("MIL_LNBR_BWD");            // read per call (a call is a capture-time event under a hipGraph)
+    return e == nullptr || strcmp(e, "r16") != 0;
+}
+
+extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* beta, const float* stats, const float* y,
                                           const float* pe, const float* Qp, const float* lse, const float* dpooled,
                                           const float* pooled, const int32_t* k_off, const int32_t* tile_map,
                                           const int32_t* bag_tile_off, int ntiles, int n_keys, int B, int H, int C, int E,
                                           const float* dy_acc, float* dx, float* d_o, float* dgamma, float* dbeta, float* dQp,
                                           float* workspace, void* stream) {
-    AP_CHECK(x && o && gamma && stats && y && pe && Qp && lse && dpooled && pooled && k_off && tile_map && bag_tile_off);
+    AP_CHECK(x && o && gamma && beta && stats && y && pe && Qp && lse && dpooled && pooled && k_off && tile_map && bag_tile_off);
     AP_CHECK(dx && d_o && dgamma && dbeta && dQp && workspace && H == AP_H && E == 512 && C > 0 && B >= 0 && ntiles >= 0 && n_keys >= 0);
     if (B == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1465,7 +1671,11 @@ extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const 
     float* pdq = workspace;                                    // [ntiles][H][E]
     float* ad = pdq + (size_t)ntiles * AP_H * E;               // [n_keys][16]
     float* part = ad + (size_t)16 * n_keys;                    // [ntiles][3][E]
-    if (ntiles > 0) {
+    if (ntiles > 0 && lnbr_bwd_one_pass()) {
+        hipLaunchKernelGGL(k_lnbr_apool_bwd_one, dim3(ntiles), dim3(256), 0, st, x, o, gamma, beta, stats, dy_acc, pe, Qp, dpooled, pooled,
+                           lse, k_off, tile_map, scale, dx, part, pdq);
+        MIL_CHECK_LAUNCH();
+    } else if (ntiles > 0) {
         hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, y, pe, Qp, lse, dpooled, pooled, k_off, tile_map, scale, ad);
         MIL_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_apool_bwd_apply<false>, dim3(ntiles), dim3(256), 0, st, y, pe, Qp, dpooled, (const float*)ad, k_off,

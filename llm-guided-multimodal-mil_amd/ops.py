@@ -1762,12 +1762,12 @@ class _LnbrAbsorbedPoolValue(torch.autograd.Function):
         _lib.check(rc, "mil_lnbr_absorbed_pool_value_fwd")
         ctx.segs, ctx.C, ctx.bv_param, ctx.beta_param = segs, C, bv, beta
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x, row, gamma, stats, y, pe, Qp, pooled, lse, Wv)
+        ctx.save_for_backward(x, row, gamma, stats, y, pe, Qp, pooled, lse, Wv, beta)
         return o, y
 
     @staticmethod
     def backward(ctx, do, dy_pass):
-        x, row, gamma, stats, y, pe, Qp, pooled, lse, Wv = ctx.saved_tensors
+        x, row, gamma, stats, y, pe, Qp, pooled, lse, Wv, beta = ctx.saved_tensors
         segs, C = ctx.segs, ctx.C
         B, H, E = Qp.shape
         rows = x.shape[0]
@@ -1790,7 +1790,7 @@ class _LnbrAbsorbedPoolValue(torch.autograd.Function):
         dQp = torch.empty_like(Qp)
         nt = max(1, segs.ntiles)
         ws = torch.empty(nt * H * E + 16 * rows + 3 * nt * E, device=x.device, dtype=torch.float32)
-        rc = _lib.lib().mil_lnbr_absorbed_pool_bwd(_p(x), _p(row), _p(gamma), _p(stats), _p(y), _p(pe), _p(Qp), _p(lse),
+        rc = _lib.lib().mil_lnbr_absorbed_pool_bwd(_p(x), _p(row), _p(gamma), _p(beta), _p(stats), _p(y), _p(pe), _p(Qp), _p(lse),
                                                    _p(dpooled), _p(pooled), _p(segs.k_off), _p(segs.tile_map),
                                                    _p(segs.bag_tile_off), segs.ntiles, rows, B, H, C, E, _p(acc), _p(dx),
                                                    _p(d_row), _p(dg), _p(db), _p(dQp), _p(ws), _stream())

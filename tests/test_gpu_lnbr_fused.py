@@ -58,6 +58,20 @@ def test_fused_node_matches_the_two_nodes(lengths, C):
         assert rel_err(g1[name], g0[name]) <= 2e-5, (name, rel_err(g1[name], g0[name]))
 
 
+def test_three_kernel_backward_matches_the_one_pass_backward(monkeypatch):
+    """MIL_LNBR_BWD=r16: per-row dots + dQp partials + LayerNorm backward with the rank-16 update in its load, the form the
+    one-pass kernel (default) replaced."""
+    lengths, C = [300, 77, 512, 129], 32
+    t, pe, do, dy = _inputs(lengths, C, seed=21)
+    B = len(lengths)
+    s_ti = AttnSegs.make([1] * B, lengths, torch.device(DEV))
+    _, _, g1 = _run(True, t, pe, do, dy, s_ti, None)
+    monkeypatch.setenv("MIL_LNBR_BWD", "r16")
+    _, _, g0 = _run(True, t, pe, do, dy, s_ti, None)
+    for name in g0:
+        assert rel_err(g1[name], g0[name]) <= 1e-5, (name, rel_err(g1[name], g0[name]))
+
+
 def test_fused_node_matches_torch_on_materialised_tensors():
     lengths, C = [200, 333, 64], 32
     t, pe, do, dy = _inputs(lengths, C, seed=5)
