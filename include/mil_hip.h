@@ -474,6 +474,23 @@ int mil_linear_small_fwd(const float* x, int ldx, const float* W, int ldw, const
 int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* x, int ldx,
                          const float* W, int ldw, float* dx, int lddx, float* dW, int lddw, float* db, int M, int N,
                          int K, void* stream);
+/* Round 4 - the token-side layers take the SUMS autograd would form with elementwise launches as operands:
+ *   mil_linear_small_fwd_add   y = act((x + x2) W^T + b) (+ residual); xin [M, K] contiguous receives x + x2 for the weight
+ *                              gradient (x2 / xin: both or neither) - `queries + query_pe` in front of a q_proj
+ *                              (sam/transformer.py:114-118) without the add launch;
+ *   mil_linear_small_bwd_sum   mil_linear_small_bwd on dy + dy2 + dy3 + dy4 (the gradients several consumers sent to the
+ *                              layer's output; extras [M, N] contiguous, nullable); dysum [M, N] (nullable, needs dx)
+ *                              receives the sum for a weight gradient formed later (mil_linear_small_dw_grouped);
+ *   mil_linear_small_ln_bwd3   mil_linear_small_ln_bwd with a third addend g3. */
+int mil_linear_small_fwd_add(const float* x, int ldx, const float* x2, int ldx2, float* xin, const float* W, int ldw,
+                             const float* bias, int act, const float* residual, int ldr, float* y, int ldy, int M, int N,
+                             int K, void* stream);
+int mil_linear_small_bwd_sum(const float* dy, int lddy, const float* dy2, const float* dy3, const float* dy4, float* dysum,
+                             const float* y_or_pre, int ldyv, int act, const float* x, int ldx, const float* W, int ldw,
+                             float* dx, int lddx, float* dW, int lddw, float* db, int M, int N, int K, void* stream);
+int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3, const float* u,
+                             int ldu, const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,
+                             float* du, float* dgamma, float* dbeta, int M, int K, void* stream);
 
 /* LayerNorm folded into its neighbours on the token stream (P -> LayerNorm -> C, sam/transformer.py:287-300; E = 512):
  *   mil_linear_small_ln_fwd   C's forward with the norm applied while its operand is staged:

@@ -97,6 +97,12 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_linear_small_fwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "mil_linear_small_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P,
                                      c_int, c_int, c_int, _P]),
+    "mil_linear_small_fwd_add": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int,
+                                         c_int, _P]),
+    "mil_linear_small_bwd_sum": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P,
+                                         c_int, _P, c_int, c_int, c_int, _P]),
+    "mil_linear_small_ln_bwd3": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P,
+                                         c_int, c_int, _P]),
     "mil_linear_small_dw_grouped": (c_int, [_P, c_int, _P]),
     "mil_linear_small_ln_fwd": (c_int, [_P, c_int, _P, _P, c_float, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P,
                                         c_int, c_int, _P]),

@@ -763,8 +763,10 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
         return;
     }
     const int pos0 = key0 - k_off[b];
-    f32x4 xn[NQ], dn[NQ], pn[NQ];                                     // next row's loads, in flight under this row's arithmetic
-    auto issue = [&](int rr) {
+    // two rows of loads in flight per wave (buffers A, B: rows rr and rr + 4), each re-issued for the row 8 further on as soon
+    // as its values are consumed: one row of arithmetic (~1500 cycles per wave, two waves per SIMD) does not cover HBM latency
+    f32x4 xa[NQ], da_[NQ], pa[NQ], xb[NQ], db_[NQ], pb[NQ];
+    auto issue = [&](int rr, f32x4 (&xn)[NQ], f32x4 (&dn)[NQ], f32x4 (&pn)[NQ]) {
         const int rc = min(rr, nkeys - 1);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -774,7 +776,8 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
             pn[q] = *reinterpret_cast<const f32x4*>(pe + (size_t)(pos0 + rc) * E + 256 * q + 4 * lane);
         }
     };
-    issue(wave);
+    issue(wave, xa, da_, pa);
+    issue(wave + 4, xb, db_, pb);
     {
         // the bag's 16 vectors -> LDS, cdot_h = dpooled_h . pooled_h (32 lanes per head, as k_apool_dots)
 #pragma unroll
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
     const int hl = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
     const float lse_l = lse[b * AP_H + hl], cd_l = cd_lds[hl];
     const float* Vl = V + 4 * lane;
-    for (int rr = wave; rr < nkeys; rr += 4) {
+    auto one_row = [&](int rr, f32x4 (&xn)[NQ], f32x4 (&dn)[NQ], f32x4 (&pn)[NQ]) {
         const size_t row = (size_t)(key0 + rr);
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
         f32x4 xh[NQ], y[NQ], kin[NQ], d[NQ];
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
             kin[q] = y[q] + pn[q];
             d[q] = dn[q];
         }
-        issue(rr + 4);
+        issue(rr + 8, xn, dn, pn);
         float p[16];
 #pragma unroll
         for (int h = 0; h < AP_H; ++h) {
@@ -872,6 +875,10 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
             *reinterpret_cast<f32x4*>(dx + row * E + 256 * q + 4 * lane) = v;
             d0[q] += v;
         }
+    };
+    for (int rr = wave; rr < nkeys; rr += 8) {
+        one_row(rr, xa, da_, pa);
+        if (rr + 4 < nkeys) one_row(rr + 4, xb, db_, pb);
     }
     // fold of the four waves: dgamma / dbeta / do through red3; dQp through the 32 KB of V in two rounds (3, 2 -> 1, 0; 1 -> 0)
     if (wave > 0) {

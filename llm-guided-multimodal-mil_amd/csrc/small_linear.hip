@@ -71,11 +71,15 @@ __device__ __forceinline__ void sl_fold_store(float (*red)[4][64], const f32x4 a
 // stride 516 floats: the 16 lanes of a fragment read hit 64 different banks) and the waves split the chunk's 16-k blocks.
 #define SL_KCH 512
 #define SL_LS (SL_KCH + 4)
+// x2 / xin (round 4, both or neither): the layer's input is x + x2 (queries + their positional embedding,
+// sam/transformer.py:114) - added while the operand is staged, and written once (column tile 0) to xin [M, K] for the weight
+// gradient: the elementwise add launch in front of the layer is gone.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_small_fwd(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, int act,
                                                        const float* __restrict__ residual, int ldr,
-                                                       float* __restrict__ y, int ldy, int M, int N, int K) {
+                                                       float* __restrict__ y, int ldy, int M, int N, int K,
+                                                       const float* __restrict__ x2, int ldx2, float* __restrict__ xin) {
     __shared__ float red[NW][4][64];
     __shared__ __attribute__((aligned(16))) float opx[16 * SL_LS], opw[16 * SL_LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,6 +93,10 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd(const float* __restrict__
             const int idx = tid + i * NT, row = idx >> 7, kk = k0 + 4 * (idx & 127);
             if (kk < K) {
                 rx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)min(m0 + row, M - 1) * ldx + kk);
+                if (x2 != nullptr) {
+                    rx[i] += *reinterpret_cast<const f32x4*>(x2 + (size_t)min(m0 + row, M - 1) * ldx2 + kk);
+                    if (blockIdx.x == 0 && m0 + row < M) *reinterpret_cast<f32x4*>(xin + (size_t)(m0 + row) * K + kk) = rx[i];
+                }
                 rw[i] = *reinterpret_cast<const f32x4*>(W + (size_t)min(n0 + row, N - 1) * ldw + kk);
             } else {
                 rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -120,12 +128,24 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd(const float* __restrict__
     sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, bias, act, residual, ldr, y, ldy);
 }
 
-template <int NW>
+// The gradient of a layer's output that SEVERAL consumers wrote (round 4): dy + dy2 + dy3 + dy4 (each [M, N] contiguous,
+// nullable) summed while the operand is staged - autograd's elementwise add launches between the token-side layers are gone
+// (ops.fan_out) - and written once to dysum [M, N] (nullable) for the deferred weight-gradient launch.
+// EX = true: the extras are loaded UNCONDITIONALLY (a missing one points at dy with weight 0) - a branch per addend made
+// every staged load wait for the one before it (+1.5 us per launch, measured on the launches that have no extras at all).
+struct SmallDyExtra {
+    const float* dy2;
+    const float* dy3;
+    const float* dy4;
+    float w2, w3, w4;
+    float* dysum;
+};
+template <int NW, bool EX>
 __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__ dy, int lddy, const float* __restrict__ yv,
                                                        int ldyv, int act, const float* __restrict__ x, int ldx,
                                                        const float* __restrict__ W, int ldw, float* __restrict__ dx,
                                                        int lddx, float* __restrict__ dW, int lddw, float* __restrict__ db,
-                                                       int M, int N, int K, int nW, int nKt) {
+                                                       int M, int N, int K, int nW, int nKt, SmallDyExtra ex) {
     __shared__ float red[NW][4][64];
     __shared__ __attribute__((aligned(16))) float opa[16 * SL_LS];       // dx role: dpre of the tile's 16 rows, one n chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,6 +169,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
                 const int m = 2 * (s0 + u) + h;
                 const int mm = min(m, M - 1);
                 float g = dy[(size_t)mm * lddy + nc];
+                if (EX)
+                    g += ex.w2 * ex.dy2[(size_t)mm * N + nc] + ex.w3 * ex.dy3[(size_t)mm * N + nc] + ex.w4 * ex.dy4[(size_t)mm * N + nc];
                 if (act != SL_NONE) g = sl_dact(g, yv[(size_t)mm * ldyv + nc], act);
                 fa[u] = m < M ? g : 0.f;
                 fb[u] = m < M ? x[(size_t)mm * ldx + kc] : 0.f;
@@ -192,6 +214,12 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
             const int mrow = min(m0 + row, M - 1);
             if (nn < N) {
                 rg[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)mrow * lddy + nn);
+                if (EX) {
+                    const f32x4 e2 = *reinterpret_cast<const f32x4*>(ex.dy2 + (size_t)mrow * N + nn);
+                    const f32x4 e3 = *reinterpret_cast<const f32x4*>(ex.dy3 + (size_t)mrow * N + nn);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(ex.dy4 + (size_t)mrow * N + nn);
+                    rg[i] += ex.w2 * e2 + ex.w3 * e3 + ex.w4 * e4;
+                }
                 if (act != SL_NONE) ry[i] = *reinterpret_cast<const f32x4*>(yv + (size_t)mrow * ldyv + nn);
             } else {
                 rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -206,6 +234,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
         for (int i = 0; i < LPT; ++i) {
             const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
             f32x4 g = rg[i];
+            if (EX && ex.dysum != nullptr && k0 == 0 && m0 + row < M && n0c + 4 * c < N)
+                *reinterpret_cast<f32x4*>(ex.dysum + (size_t)(m0 + row) * N + n0c + 4 * c) = g;      // the summed dy, before act'
             if (act != SL_NONE) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) g[jj] = sl_dact(g[jj], ry[i][jj], act);
@@ -326,7 +356,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd_ln(const float* __restric
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restrict__ g1, int ldg1, const float* __restrict__ g2,
-                                                          int ldg2, const float* __restrict__ u, int ldu,
+                                                          int ldg2, const float* __restrict__ g3, int ldg3, float w2, float w3,
+                                                          const float* __restrict__ u, int ldu,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ W, int ldw, float* __restrict__ dx,
                                                           int lddx, float* __restrict__ du, float* __restrict__ dgamma,
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
             for (int e = 0; e < 8; ++e) {
                 const int m = min(mb + 4 * e, M - 1);
                 gv[e] = g1[(size_t)m * ldg1 + c];
-                if (g2 != nullptr) gv[e] += g2[(size_t)m * ldg2 + c];
+                gv[e] += w2 * g2[(size_t)m * ldg2 + c] + w3 * g3[(size_t)m * ldg3 + c];
                 uv[e] = u[(size_t)m * ldu + c];
                 mu[e] = stats[2 * m];
                 rs[e] = stats[2 * m + 1];
@@ -381,7 +412,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
         for (int j = 0; j < 4; ++j) {
             const int c = 4 * p + 128 * j;
             f32x4 g = *reinterpret_cast<const f32x4*>(g1 + (size_t)grow * ldg1 + c);
-            if (g2 != nullptr) g += *reinterpret_cast<const f32x4*>(g2 + (size_t)grow * ldg2 + c);
+            g += w2 * *reinterpret_cast<const f32x4*>(g2 + (size_t)grow * ldg2 + c) +
+                 w3 * *reinterpret_cast<const f32x4*>(g3 + (size_t)grow * ldg3 + c);
             xh[j] = (*reinterpret_cast<const f32x4*>(u + (size_t)grow * ldu + c) - mean) * rstd;
             gg[j] = g * *reinterpret_cast<const f32x4*>(gamma + c);
             const f32x4 t = gg[j] * xh[j];
@@ -488,28 +520,46 @@ __global__ __launch_bounds__(512) void k_small_dw_grouped(const SmallDwBatch bat
 
 static inline bool sl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int mil_linear_small_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias, int act,
-                                    const float* residual, int ldr, float* y, int ldy, int M, int N, int K,
-                                    void* stream) {
+// y = act((x + x2) W^T + b) (+ residual); xin [M, K] contiguous = x + x2 (written for the weight gradient).  x2 == NULL:
+// mil_linear_small_fwd.
+extern "C" int mil_linear_small_fwd_add(const float* x, int ldx, const float* x2, int ldx2, float* xin, const float* W, int ldw,
+                                        const float* bias, int act, const float* residual, int ldr, float* y, int ldy, int M,
+                                        int N, int K, void* stream) {
     if (!x || !W || !y || M <= 0 || M > MIL_SMALL_ROWS || N <= 0 || K <= 0) return MIL_EINVAL;
     if ((K & 15) || (ldx & 3) || (ldw & 3) || act < 0 || act > 4) return MIL_EINVAL;
     if (!sl_aligned16(x) || !sl_aligned16(W)) return MIL_EINVAL;
+    if ((x2 != nullptr) != (xin != nullptr)) return MIL_EINVAL;
+    if (x2 && ((ldx2 & 3) || !sl_aligned16(x2) || !sl_aligned16(xin))) return MIL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((N + 15) / 16, (M + 15) / 16);
     if (K >= 1024)
         hipLaunchKernelGGL((k_small_fwd<SL_WAVES_DEEP>), grid, dim3(64 * SL_WAVES_DEEP), 0, st, x, ldx, W, ldw, bias, act,
-                           residual, ldr, y, ldy, M, N, K);
+                           residual, ldr, y, ldy, M, N, K, x2, ldx2, xin);
     else
         hipLaunchKernelGGL((k_small_fwd<SL_WAVES>), grid, dim3(64 * SL_WAVES), 0, st, x, ldx, W, ldw, bias, act, residual,
-                           ldr, y, ldy, M, N, K);
+                           ldr, y, ldy, M, N, K, x2, ldx2, xin);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
+extern "C" int mil_linear_small_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias, int act,
+                                    const float* residual, int ldr, float* y, int ldy, int M, int N, int K,
+                                    void* stream) {
+    return mil_linear_small_fwd_add(x, ldx, nullptr, 0, nullptr, W, ldw, bias, act, residual, ldr, y, ldy, M, N, K, stream);
+}
 
-extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* x,
-                                    int ldx, const float* W, int ldw, float* dx, int lddx, float* dW, int lddw,
-                                    float* db, int M, int N, int K, void* stream) {
+// mil_linear_small_bwd on the gradient dy + dy2 + dy3 + dy4 (extras [M, N] contiguous, nullable); dysum [M, N] (nullable;
+// needs dx): the sum, for a weight gradient formed later.
+extern "C" int mil_linear_small_bwd_sum(const float* dy, int lddy, const float* dy2, const float* dy3, const float* dy4,
+                                        float* dysum, const float* y_or_pre, int ldyv, int act, const float* x, int ldx,
+                                        const float* W, int ldw, float* dx, int lddx, float* dW, int lddw, float* db, int M,
+                                        int N, int K, void* stream) {
     if (!dy || M <= 0 || M > MIL_SMALL_ROWS || N <= 0 || K <= 0 || act < 0 || act > 4) return MIL_EINVAL;
+    if (dysum && !dx) return MIL_EINVAL;
+    if ((dy2 && !sl_aligned16(dy2)) || (dy3 && !sl_aligned16(dy3)) || (dy4 && !sl_aligned16(dy4)) || (dysum && !sl_aligned16(dysum)))
+        return MIL_EINVAL;
+    const bool has_ex = dy2 || dy3 || dy4 || dysum;
+    const SmallDyExtra ex{dy2 ? dy2 : dy, dy3 ? dy3 : dy, dy4 ? dy4 : dy, dy2 ? 1.f : 0.f, dy3 ? 1.f : 0.f, dy4 ? 1.f : 0.f, dysum};
+    if (has_ex && lddy != N) return MIL_EINVAL;               // the stand-in pointers are read with the extras' stride
     if (act != SL_NONE && !y_or_pre) return MIL_EINVAL;
     if ((dW || db) && !x) return MIL_EINVAL;
     if (dx && !W) return MIL_EINVAL;
@@ -522,14 +572,29 @@ extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or
     if (nW + nX == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(nW + nX);
-    if (dx != nullptr && N >= 1024)
-        hipLaunchKernelGGL((k_small_bwd<SL_WAVES_DEEP>), grid, dim3(64 * SL_WAVES_DEEP), 0, st, dy, lddy, y_or_pre, ldyv, act,
-                           x, ldx, W, ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt);
-    else
-        hipLaunchKernelGGL((k_small_bwd<SL_WAVES>), grid, dim3(64 * SL_WAVES), 0, st, dy, lddy, y_or_pre, ldyv, act, x, ldx, W,
-                           ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt);
+    if (dx != nullptr && N >= 1024) {
+        if (has_ex)
+            hipLaunchKernelGGL((k_small_bwd<SL_WAVES_DEEP, true>), grid, dim3(64 * SL_WAVES_DEEP), 0, st, dy, lddy, y_or_pre, ldyv,
+                               act, x, ldx, W, ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt, ex);
+        else
+            hipLaunchKernelGGL((k_small_bwd<SL_WAVES_DEEP, false>), grid, dim3(64 * SL_WAVES_DEEP), 0, st, dy, lddy, y_or_pre, ldyv,
+                               act, x, ldx, W, ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt, ex);
+    } else {
+        if (has_ex)
+            hipLaunchKernelGGL((k_small_bwd<SL_WAVES, true>), grid, dim3(64 * SL_WAVES), 0, st, dy, lddy, y_or_pre, ldyv, act, x, ldx,
+                               W, ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt, ex);
+        else
+            hipLaunchKernelGGL((k_small_bwd<SL_WAVES, false>), grid, dim3(64 * SL_WAVES), 0, st, dy, lddy, y_or_pre, ldyv, act, x, ldx,
+                               W, ldw, dx, lddx, dW, lddw, db, M, N, K, nW, nKt, ex);
+    }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* x,
+                                    int ldx, const float* W, int ldw, float* dx, int lddx, float* dW, int lddw,
+                                    float* db, int M, int N, int K, void* stream) {
+    return mil_linear_small_bwd_sum(dy, lddy, nullptr, nullptr, nullptr, nullptr, y_or_pre, ldyv, act, x, ldx, W, ldw, dx, lddx,
+                                    dW, lddw, db, M, N, K, stream);
 }
 
 extern "C" int mil_linear_small_dw_grouped(const mil_small_dw_desc* descs, int n, void* stream) {
@@ -576,10 +641,12 @@ extern "C" int mil_linear_small_ln_fwd(const float* u, int ldu, const float* gam
 // Input gradient of the layer P that FEEDS a LayerNorm, with the norm's backward applied on the way in (k_small_bwd_ln):
 // g1 (+ g2) [M, 512] = gradient at the norm's output, u = P's output (the norm's input), stats from the forward;
 // dx [M, K] = du W (W = P's weight [512, K]; NULL: du only), du [M, 512] (nullable), dgamma / dbeta [512] (both or neither).
-extern "C" int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* u, int ldu,
-                                       const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,
-                                       float* du, float* dgamma, float* dbeta, int M, int K, void* stream) {
+extern "C" int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3,
+                                        const float* u, int ldu, const float* stats, const float* gamma, const float* W,
+                                        int ldw, float* dx, int lddx, float* du, float* dgamma, float* dbeta, int M, int K,
+                                        void* stream) {
     if (!g1 || !u || !stats || !gamma || M <= 0 || M > MIL_SMALL_ROWS) return MIL_EINVAL;
+    if (g3 && ((ldg3 & 3) || !sl_aligned16(g3))) return MIL_EINVAL;
     if ((dx != nullptr) && (!W || K <= 0)) return MIL_EINVAL;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return MIL_EINVAL;
     if ((ldg1 & 3) || (g2 && (ldg2 & 3)) || (ldu & 3) || !sl_aligned16(g1) || (g2 && !sl_aligned16(g2)) || !sl_aligned16(u) ||
@@ -588,7 +655,14 @@ extern "C" int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g
     const int kt = dx ? (K + 15) / 16 : 1;
     const int nX = kt * ((M + 15) / 16);
     hipLaunchKernelGGL((k_small_bwd_ln<SL_WAVES>), dim3(nX + (dgamma ? 4 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
-                       g2, ldg2, u, ldu, stats, gamma, W, ldw, dx, lddx, du, dgamma, dbeta, M, dx ? K : 16, nX);
+                       g2 ? g2 : g1, g2 ? ldg2 : ldg1, g3 ? g3 : g1, g3 ? ldg3 : ldg1, g2 ? 1.f : 0.f, g3 ? 1.f : 0.f, u, ldu, stats, gamma,
+                       W, ldw, dx, lddx, du, dgamma, dbeta, M, dx ? K : 16, nX);      // a missing addend: g1 again, weight 0 (no branch)
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+extern "C" int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* u, int ldu,
+                                       const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,
+                                       float* du, float* dgamma, float* dbeta, int M, int K, void* stream) {
+    return mil_linear_small_ln_bwd3(g1, ldg1, g2, ldg2, nullptr, 0, u, ldu, stats, gamma, W, ldw, dx, lddx, du, dgamma, dbeta, M,
+                                    K, stream);
 }

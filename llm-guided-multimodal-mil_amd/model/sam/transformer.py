@@ -41,7 +41,7 @@ class Attention(nn.Module):
         o = core(qp, kp, vp, segs, self.num_heads)
         return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual)
 
-    def one_token(self, q, keys, pe_table, segs: AttnSegs, residual=None):
+    def one_token(self, q, keys, pe_table, segs: AttnSegs, residual=None, qp=None):
         """Token->image attention when every bag has ONE text token: the K / V projections over the patches are
         absorbed into H query vectors and H pooled key vectors (ops.one_token_attention) - an HBM-bound pass over
         the keys instead of two [N, E] x [E, I] GEMMs.  keys come WITHOUT positional encoding (added on the fly).
@@ -49,7 +49,7 @@ class Attention(nn.Module):
         gradient is folded inside the pool's backward."""
         _zero_grad_params(self.k_proj.bias)
         o, keys_pass = ops.one_token_attention(q, keys, pe_table, segs, self.q_proj.weight, self.q_proj.bias,
-                                               self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads)
+                                               self.k_proj.weight, self.v_proj.weight, self.v_proj.bias, self.num_heads, qp=qp)
         return ops.linear_act(o, self.out_proj.weight, self.out_proj.bias, "none", residual=residual), keys_pass
 
     def multi_token_pool(self, q, keys, kin, segs: AttnSegs, residual=None):
@@ -195,8 +195,10 @@ class TwoWayAttentionBlock(nn.Module):
         _zero_grad_params(a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, t2i.k_proj.bias,
                           i2t.q_proj.weight, i2t.q_proj.bias, i2t.k_proj.weight, i2t.k_proj.bias)
         eps = self.norm1.eps
-        vp = ops.linear_act(queries, a.v_proj.weight, a.v_proj.bias)
-        qp, q1 = ops.lin_ln_lin(vp, a.out_proj.weight, a.out_proj.bias, None if self.skip_first_layer_pe else queries,
+        # two consumers of the incoming queries: their gradients meet in the producer's backward kernel (ops.fan_out)
+        qa, qb = (queries, None) if self.skip_first_layer_pe else ops.fan_out(queries, 2)
+        vp = ops.linear_act(qa, a.v_proj.weight, a.v_proj.bias)
+        qp, q1 = ops.lin_ln_lin(vp, a.out_proj.weight, a.out_proj.bias, qb,
                                 self.norm1.weight, self.norm1.bias, eps, query_pe, t2i.q_proj.weight, t2i.q_proj.bias)
         if pending is not None:
             # the LayerNorm(keys + row) the block in front left to this pool (its kernel makes the keys it reads)
@@ -254,7 +256,9 @@ class TwoWayTransformer(nn.Module):
             s_ti = AttnSegs.make(t_lengths, n_lengths, dev)
             s_it = AttnSegs.make(n_lengths, t_lengths, dev)
         keys_pe = lambda kk: ops.add_pe(kk, pe_table, s_ti.k_bag, s_ti.k_off)      # noqa: E731
-        queries, keys = point, image
+        # `point` feeds the first block's queries, every block's query_pe and the final attention: one handle each
+        pa = ops.fan_out(point, len(self.layers) + 2)
+        queries, keys = pa[0], image
         # One text token per bag: LayerNorm(keys + row), the last op of a block, is left to the pool kernel of the NEXT
         # attention site over those keys (ops.lnbr_one_token_attention) wherever both sides take their one-token forms.
         fuse = os.environ.get("MIL_FUSE_LNBR", "1") != "0"
@@ -268,23 +272,27 @@ class TwoWayTransformer(nn.Module):
                           else self.layers[li + 1]._one_token_fused_ok(queries, s_tt, s_ti, s_it, pe_table))
                      and ops.lnbr_one_token_ok(keys, None, layer.norm4.weight, layer.norm4.bias, nxt.k_proj.weight,
                                                nxt.v_proj.weight, nxt.v_proj.bias, nxt.num_heads))
-            out = layer.flat(queries, keys, point, keys_pe, s_tt, s_ti, s_it, pe_table, keys_tail_rows if last else 0,
+            out = layer.flat(queries, keys, pa[1 + li], keys_pe, s_tt, s_ti, s_it, pe_table, keys_tail_rows if last else 0,
                              pending=pending, defer=defer)
             queries, keys, pending = out if defer else (out[0], out[1], None)
-        q = queries + point                                                      # :114-118
-        if pending is not None:
-            prow, pn = pending
-            _zero_grad_params(fa.k_proj.bias)
-            qp = ops.linear_act(q, fa.q_proj.weight, fa.q_proj.bias)
-            o, keys = ops.lnbr_one_token_attention(keys, prow, pn.weight, pn.bias, pn.eps, pe_table, s_ti, fa.k_proj.weight,
-                                                   fa.v_proj.weight, fa.v_proj.bias, fa.num_heads, qp, keys_tail_rows)
-            out = ops.linear_act(o, fa.out_proj.weight, fa.out_proj.bias, "none", residual=queries)
-        elif one_token_ok(self.final_attn_token_to_image, s_ti, pe_table):
-            out, keys = self.final_attn_token_to_image.one_token(q, keys, pe_table, s_ti, residual=queries)
+        qf, qr = ops.fan_out(queries, 2)                                         # :114-118: q = queries + point; residual
+        if pending is not None or one_token_ok(fa, s_ti, pe_table):
+            # q_proj(queries + point): the sum is formed while the projection stages its operand
+            qp = ops.linear_act(qf, fa.q_proj.weight, fa.q_proj.bias, x2=pa[-1])
+            if pending is not None:
+                prow, pn = pending
+                _zero_grad_params(fa.k_proj.bias)
+                o, keys = ops.lnbr_one_token_attention(keys, prow, pn.weight, pn.bias, pn.eps, pe_table, s_ti, fa.k_proj.weight,
+                                                       fa.v_proj.weight, fa.v_proj.bias, fa.num_heads, qp, keys_tail_rows)
+                out = ops.linear_act(o, fa.out_proj.weight, fa.out_proj.bias, "none", residual=qr)
+            else:
+                out, keys = fa.one_token(None, keys, pe_table, s_ti, residual=qr, qp=qp)
         elif ops.multi_token_ok(self.embedding_dim, self.num_heads, s_ti.q_lengths):
-            out, keys = self.final_attn_token_to_image.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=queries)
+            q = qf + pa[-1]
+            out, keys = fa.multi_token_pool(q, keys, keys_pe(keys), s_ti, residual=qr)
         else:
-            out = self.final_attn_token_to_image.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=queries)
+            q = qf + pa[-1]
+            out = fa.flat(q, keys_pe(keys), keys, s_ti, "pool", residual=qr)
         # the returned text tokens are the rows the multi-modal bag appends behind the patch tokens (model/aggregator.py:192):
         # when exactly that many rows were reserved behind `keys`, the last LayerNorm writes them there (no copy launch)
         return self.norm_final_attn(out, into_tail_of=keys if keys_tail_rows == out.shape[0] else None), keys

@@ -609,11 +609,19 @@ def _stream_int() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def linear_small_fwd(x, W, b, act: int, residual=None):
-    """Token-side nn.Linear (M <= 64 rows) in one launch (include/mil_hip.h: mil_linear_small_fwd)."""
+def linear_small_fwd(x, W, b, act: int, residual=None, x2=None):
+    """Token-side nn.Linear (M <= 64 rows) in one launch (include/mil_hip.h: mil_linear_small_fwd).  x2: a second addend of
+    the input (mil_linear_small_fwd_add) - returns (y, x + x2)."""
     M, K = x.shape
     N = W.shape[0]
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    if x2 is not None:
+        xin = torch.empty((M, K), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mil_linear_small_fwd_add(_p(x), x.stride(0), _p(x2), x2.stride(0), _p(xin), _p(W), W.stride(0), _p(b), act,
+                                                 _p(residual), residual.stride(0) if residual is not None else 0, _p(y),
+                                                 y.stride(0), M, N, K, _stream())
+        _lib.check(rc, "mil_linear_small_fwd_add")
+        return y, xin
     sh = _lib.shim()
     if sh is not None:          # same C entry through the torch cpp_extension binding (csrc/torch_shim.cpp)
         sh.linear_small_fwd(x, W, b, act, residual, y, _stream_int())
@@ -647,14 +655,23 @@ def grad_slot(param):
     return slot.detach()
 
 
-def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool, dW_out=None, db_out=None):
-    """dx, dW, db of that layer in one launch (mil_linear_small_bwd)."""
+def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool, want_db: bool, dW_out=None, db_out=None,
+                     extras=(), dysum=None):
+    """dx, dW, db of that layer in one launch (mil_linear_small_bwd).  extras: up to three more addends of dy (the gradients
+    other consumers of the layer's output sent: _FanOut), summed while the operand is staged; dysum [M, N]: receives the sum."""
     M, K = x.shape
     N = W.shape[0]
     dx = torch.empty((M, K), device=x.device, dtype=torch.float32) if want_dx else None
     dW = (dW_out if dW_out is not None else torch.empty((N, K), device=x.device, dtype=torch.float32)) if want_dW else None
     db = (db_out if db_out is not None else torch.empty(N, device=x.device, dtype=torch.float32)) if want_db else None
     yv = y_or_pre if act != 0 else None
+    if extras or dysum is not None:
+        e = list(extras) + [None] * (3 - len(extras))
+        rc = _lib.lib().mil_linear_small_bwd_sum(_p(dy), dy.stride(0), _p(e[0]), _p(e[1]), _p(e[2]), _p(dysum), _p(yv),
+                                                 yv.stride(0) if yv is not None else 0, act, _p(x), x.stride(0), _p(W),
+                                                 W.stride(0), _p(dx), K, _p(dW), K, _p(db), M, N, K, _stream())
+        _lib.check(rc, "mil_linear_small_bwd_sum")
+        return dx, dW, db
     sh = _lib.shim()
     if sh is not None:
         sh.linear_small_bwd(dy, yv, act, x, W, dx, dW, db, _stream_int())
@@ -666,15 +683,74 @@ def linear_small_bwd(dy, y_or_pre, act: int, x, W, want_dx: bool, want_dW: bool,
     return dx, dW, db
 
 
+class _GradBox:
+    """Mailbox between the node that PRODUCES a token-side tensor and the _FanOut node behind it: when the tensor has several
+    consumers, _FanOut.backward leaves all but one of their gradients here and the producer's backward kernel sums them while
+    it stages its operand (mil_linear_small_bwd_sum, mil_linear_small_ln_bwd3) - autograd would launch an elementwise add
+    per extra consumer (6 of the fusion step's 93 launches)."""
+    __slots__ = ("extras",)
+
+    def __init__(self):
+        self.extras = []
+
+    def take(self, like=None):
+        ex, self.extras = self.extras, []
+        return [e for e in ex if e is not None]
+
+
+def _sum_overflow(dy, extras, room: int):
+    """extras beyond what the kernel takes are added the plain way; returns (dy, extras that fit)."""
+    while len(extras) > room:
+        dy = dy + extras.pop()
+    return dy, extras
+
+
+def _ok_extra(e, like) -> bool:
+    return e.dtype == torch.float32 and e.is_contiguous() and e.shape == like.shape and e.data_ptr() % 16 == 0
+
+
+class _FanOut(torch.autograd.Function):
+    """n aliases of x, one per consumer.  Backward: the first gradient goes up the graph as x's gradient, the others into the
+    producer's mailbox (see _GradBox) - whatever autograd itself adds to the first one stays correct, sums commute."""
+
+    @staticmethod
+    def forward(ctx, x, box, n: int):
+        ctx.box = box
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None, None
+        first = gs[0]
+        for g in gs[1:]:
+            g = g if g.dtype == torch.float32 else g.float()
+            ctx.box.extras.append(g.contiguous())
+        return first, None, None
+
+
+def fan_out(x, n: int):
+    """n handles of x for n consumers.  When x came out of a token-side node that sums its output's gradients in-kernel
+    (linear_act's few-rows path, lin_ln_lin's xn), the consumers' gradients meet there instead of in autograd's add launches;
+    otherwise the handles are x itself."""
+    box = getattr(x, "_mil_box", None)
+    if n <= 1 or box is None or not torch.is_grad_enabled() or not x.requires_grad:
+        return (x,) * n
+    return _FanOut.apply(x, box, n)
+
+
 class _LinearAct(torch.autograd.Function):
     """y = act(x W^T + b) (+ residual): nn.Linear (+Tanh/ReLU) of aggregator.py:44-68, sam/transformer.py:413-416,
     sam/common.py:21-26.  x [M, K], W [N, K]."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act: int, residual, rows_dev=None):
+    def forward(ctx, x, W, b, act: int, residual, rows_dev=None, box=None, x2=None):
         x = _f32c(x, "x")
         W = _f32c(W, "W")
         M, K = x.shape
+        ctx.box = box
+        ctx.has_x2 = x2 is not None
         ctx.rows_dev = rows_dev             # capacity bucket: rows from rows_dev[0] on are padding (zero out, zero gradient)
         N = W.shape[0]
         res = _f32c(residual, "residual") if residual is not None else None
@@ -687,7 +763,10 @@ class _LinearAct(torch.autograd.Function):
         if ctx.mid:
             y = linear_mid_fwd(x, W, b, act, res)
         elif ctx.small and not (act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3])):
-            y = linear_small_fwd(x, W, b, act, res)
+            if x2 is not None:
+                y, x = linear_small_fwd(x, W, b, act, res, _f32c(x2, "x2"))      # x: the summed input, saved for the backward
+            else:
+                y = linear_small_fwd(x, W, b, act, res)
         elif act == ACT["quickgelu"] and any(ctx.needs_input_grad[:3]):
             # QuickGELU's derivative needs the pre-activation: keep it (learnable-prompt path only; the frozen
             # forward uses the fused epilogue)
@@ -702,6 +781,8 @@ class _LinearAct(torch.autograd.Function):
         ctx.b_param = b                     # only to look up its flat-gradient slot in backward
         ctx.has_res = residual is not None
         # with a residual the saved y is not the activation output; only act == none is used with residuals
+        if x2 is not None and not (ctx.small and not ctx.mid):
+            raise _lib.MilHipError("linear_act: x2 is only built for the few-rows path")
         ctx.save_for_backward(x, W, y if pre is None else pre)
         return y
 
@@ -713,27 +794,42 @@ class _LinearAct(torch.autograd.Function):
         N = W.shape[0]
         W_slot = grad_slot(W)
         b_slot = grad_slot(ctx.b_param) if ctx.b_param is not None else None
+        extras = ctx.box.take() if ctx.box is not None else []
+        if extras and not (ctx.small and not ctx.mid and dy.is_contiguous() and all(_ok_extra(e, dy) for e in extras)):
+            for e in extras:                    # another path, or an odd layout: the plain sums
+                dy = dy + e
+            extras = []
         if ctx.mid and ctx.act != ACT["quickgelu"]:
             if dy.data_ptr() % 16 or dy.stride(0) % 4:
                 dy = dy.clone()
             dx, dW, db = linear_mid_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                         ctx.has_b and ctx.needs_input_grad[2], W_slot, b_slot)
-            return dx, (dW if ctx.needs_input_grad[1] else None), db, None, (dy if ctx.has_res else None), None
+            return dx, (dW if ctx.needs_input_grad[1] else None), db, None, (dy if ctx.has_res else None), None, None, None
         if ctx.small:
             if dy.data_ptr() % 16:
                 dy = dy.clone()
+            dy, extras = _sum_overflow(dy, extras, 3)
+            want_dx = ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[7])
             want_dW, want_db = ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
-            if (deferred.enabled() and ctx.needs_input_grad[0] and want_dW and W_slot is not None and
+            if (deferred.enabled() and want_dx and want_dW and W_slot is not None and
                     (not want_db or b_slot is not None) and x.shape[1] % 4 == 0):
                 # the previous layer's backward waits for dx only: dx now, the weight / bias gradient with every other
                 # queued layer's in one grouped launch at the end of the pass (deferred.py), straight into the flat buffer.
                 # The queue holds aliases of its own: autograd adopts a returned gradient without a copy only while
                 # nothing else references that tensor object (see grad_slot)
-                dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False)
-                deferred.queue_dw(dy, y, x, W_slot.detach(), (b_slot.detach() if want_db else None), ctx.act)
-                return dx, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None), None
-            dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, ctx.needs_input_grad[0], want_dW, want_db, W_slot, b_slot)
-            return dx, dW, db, None, (dy if ctx.has_res else None), None
+                dysum = torch.empty((M, N), device=dy.device, dtype=torch.float32) if extras else None
+                dx, _, _ = linear_small_bwd(dy, y, ctx.act, x, W, True, False, False, extras=extras, dysum=dysum)
+                dyt = dysum if extras else dy
+                deferred.queue_dw(dyt, y, x, W_slot.detach(), (b_slot.detach() if want_db else None), ctx.act)
+                return (dx if ctx.needs_input_grad[0] else None, W_slot, (b_slot if want_db else None), None,
+                        (dyt if ctx.has_res else None), None, None, (dx if ctx.has_x2 else None))
+            if extras and ctx.has_res:
+                for e in extras:                # the residual branch wants the summed gradient as a tensor
+                    dy = dy + e
+                extras = []
+            dx, dW, db = linear_small_bwd(dy, y, ctx.act, x, W, want_dx, want_dW, want_db, W_slot, b_slot, extras=extras)
+            return (dx if ctx.needs_input_grad[0] else None, dW, db, None, (dy if ctx.has_res else None), None, None,
+                    (dx if ctx.has_x2 else None))
         if ctx.act == ACT["quickgelu"]:
             dpre = torch.empty_like(dy)
             rc = _lib.lib().mil_quickgelu(_p(y), _p(dy), _p(dpre), dy.numel(), _stream())     # y holds the pre-activation
@@ -745,17 +841,17 @@ class _LinearAct(torch.autograd.Function):
                 # for the weight-gradient product, which also yields the bias gradient - no dpre tensor at all
                 dW, db = linear_bwd_params(dy, y if ctx.act else None, ctx.act, x, W_slot, b_slot,
                                            ctx.has_b and ctx.needs_input_grad[2], rows_dev=ctx.rows_dev)
-                return None, dW, db, None, (dy if ctx.has_res else None), None
+                return None, dW, db, None, (dy if ctx.has_res else None), None, None, None
             dpre = act_bwd(dy, y, ctx.act)
             if fused:
                 dx = gemm(dpre, 0, W, 1, M, K, N)
                 dW, db = linear_bwd_params(dpre, None, 0, x, W_slot, b_slot, ctx.has_b and ctx.needs_input_grad[2])
-                return dx, dW, db, None, (dy if ctx.has_res else None), None
+                return dx, dW, db, None, (dy if ctx.has_res else None), None, None, None
         dx = gemm(dpre, 0, W, 1, M, K, N) if ctx.needs_input_grad[0] else None
         dW = gemm(dpre, 1, x, 1, N, K, M, out=W_slot, split_k=True) if ctx.needs_input_grad[1] else None
         db = colsum(dpre, out=b_slot) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res else None
-        return dx, dW, db, None, dres, None
+        return dx, dW, db, None, dres, None, None, None
 
 
 def _small_dw(dy, yv, x, W, b, act: int):
@@ -780,7 +876,8 @@ class _LinLnLin(torch.autograd.Function):
     consumers of the norm's output use xn, whose gradient arrives here.  Weight gradients join the grouped launch."""
 
     @staticmethod
-    def forward(ctx, z, Wp, bp, resp, gamma, beta, eps: float, x2, Wc, bc, actc: int):
+    def forward(ctx, z, Wp, bp, resp, gamma, beta, eps: float, x2, Wc, bc, actc: int, box=None):
+        ctx.box = box
         z, Wp, Wc = _f32c(z, "z"), _f32c(Wp, "Wp"), _f32c(Wc, "Wc")
         M = z.shape[0]
         dev = z.device
@@ -816,10 +913,14 @@ class _LinLnLin(torch.autograd.Function):
             dWc, dbc = _small_dw(dy, y, xin, Wc, bc, ctx.actc)                              # ... weight gradient grouped
         else:
             dxin, dWc, dbc = None, None, None
-        g1, g2 = (dxin, dxn) if dxin is not None else (dxn, None)
-        if g1 is None:
-            return (None,) * 11
-        g2 = _f32c(g2, "dxn") if g2 is not None else None
+        gs = [g for g in (dxin, dxn) if g is not None] + (ctx.box.take() if ctx.box is not None else [])
+        if not gs:
+            return (None,) * 12
+        gs = [_f32c(g, "dxn") for g in gs]
+        while len(gs) > 3 or (len(gs) > 1 and not (gs[-1].stride(1) == 1 and gs[-1].stride(0) % 4 == 0 and gs[-1].data_ptr() % 16 == 0)):
+            g = gs.pop()
+            gs[0] = gs[0] + g
+        g1, g2, g3 = (gs + [None, None])[:3]
         dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         du = torch.empty((M, E), device=dev, dtype=torch.float32)
         dg = grad_slot(gamma)
@@ -829,12 +930,13 @@ class _LinLnLin(torch.autograd.Function):
         if db is None:
             db = torch.empty(E, device=dev, dtype=torch.float32)
         K = z.shape[1]
-        rc = _lib.lib().mil_linear_small_ln_bwd(_p(g1), g1.stride(0), _p(g2), g2.stride(0) if g2 is not None else 0, _p(u),
-                                                u.stride(0), _p(stats), _p(gamma), _p(Wp), Wp.stride(0), _p(dz), K, _p(du),
-                                                _p(dg), _p(db), M, K, _stream())
-        _lib.check(rc, "mil_linear_small_ln_bwd")
+        rc = _lib.lib().mil_linear_small_ln_bwd3(_p(g1), g1.stride(0), _p(g2), g2.stride(0) if g2 is not None else 0, _p(g3),
+                                                 g3.stride(0) if g3 is not None else 0, _p(u), u.stride(0), _p(stats),
+                                                 _p(gamma), _p(Wp), Wp.stride(0), _p(dz), K, _p(du), _p(dg), _p(db), M, K,
+                                                 _stream())
+        _lib.check(rc, "mil_linear_small_ln_bwd3")
         dWp, dbp = _small_dw(du, None, z, Wp, bp, 0)
-        return (dz, dWp, dbp, (du if ctx.has_res else None), dg, db, None, (dxin if ctx.has_x2 else None), dWc, dbc, None)
+        return (dz, dWp, dbp, (du if ctx.has_res else None), dg, db, None, (dxin if ctx.has_x2 else None), dWc, dbc, None, None)
 
 
 def lin_ln_lin_ok(z, Wp, gamma, Wc) -> bool:
@@ -846,8 +948,11 @@ def lin_ln_lin_ok(z, Wp, gamma, Wc) -> bool:
 
 
 def lin_ln_lin(z, Wp, bp, resp, gamma, beta, eps, x2, Wc, bc, actc: str = "none"):
-    """(y, xn) of _LinLnLin; see there."""
-    return _LinLnLin.apply(z, Wp, bp, resp, gamma, beta, float(eps), x2, Wc, bc, ACT[actc])
+    """(y, xn) of _LinLnLin; see there.  xn carries the node's mailbox: hand it to several consumers through fan_out()."""
+    box = _GradBox()
+    y, xn = _LinLnLin.apply(z, Wp, bp, resp, gamma, beta, float(eps), x2, Wc, bc, ACT[actc], box)
+    xn._mil_box = box
+    return y, xn
 
 
 class _MlpQuickGelu(torch.autograd.Function):
@@ -897,13 +1002,28 @@ def mlp_quickgelu(x, W1, b1, W2, b2, residual=None):
     return _MlpQuickGelu.apply(x, W1, b1, W2, b2, residual)
 
 
-def linear_act(x, W, b=None, act: str = "none", residual=None, rows_dev=None):
+def linear_act(x, W, b=None, act: str = "none", residual=None, rows_dev=None, x2=None):
     """rows_dev: device int32 [1] with the true row count of a capacity bucket (x has the bucket's capacity rows; the rows behind
-    the count come out as zeros and carry no gradient) - tall layers only; the few-rows kernels ignore it."""
+    the count come out as zeros and carry no gradient) - tall layers only; the few-rows kernels ignore it.
+    x2: the layer's input is x + x2 (few-rows layers add it while the operand is staged; others through a plain add).
+    The result carries the node's gradient mailbox (see fan_out)."""
     lead = x.shape[:-1]
-    y = _LinearAct.apply(x.reshape(-1, x.shape[-1]), W, b, ACT[act],
-                         residual.reshape(-1, residual.shape[-1]) if residual is not None else None, rows_dev)
-    return y.reshape(*lead, W.shape[0])
+    x2d = x.reshape(-1, x.shape[-1])
+    if x2 is not None:
+        x2 = x2.reshape(-1, x2.shape[-1])
+        M, K = x2d.shape
+        N = W.shape[0]
+        few = (x2d.is_cuda and x2d.dtype == torch.float32 and x2.dtype == torch.float32 and x2d.is_contiguous() and x2.is_contiguous()
+               and W.dtype == torch.float32 and W.is_contiguous()
+               and _small_ok(M, N, K, x2d, W) and not _mid_ok(M, N, K, x2d, W, residual) and act != "quickgelu")
+        if not few:
+            x2d, x2 = x2d + x2, None
+    box = _GradBox()
+    y = _LinearAct.apply(x2d, W, b, ACT[act], residual.reshape(-1, residual.shape[-1]) if residual is not None else None, rows_dev,
+                         box, x2)
+    y = y.reshape(*lead, W.shape[0])
+    y._mil_box = box
+    return y
 
 
 # --------------------------------------------------------------------------- K2: attention cores, LayerNorm, PE
