@@ -488,6 +488,9 @@ int mil_linear_small_fwd_add(const float* x, int ldx, const float* x2, int ldx2,
 int mil_linear_small_bwd_sum(const float* dy, int lddy, const float* dy2, const float* dy3, const float* dy4, float* dysum,
                              const float* y_or_pre, int ldyv, int act, const float* x, int ldx, const float* W, int ldw,
                              float* dx, int lddx, float* dW, int lddw, float* db, int M, int N, int K, void* stream);
+/* out = a + b (+ c) (+ d) over n floats (n % 4 == 0, 16-byte aligned; c, d nullable, d needs c): one launch for a gradient
+ * sum that has no backward kernel to ride on. */
+int mil_sum4(const float* a, const float* b, const float* c, const float* d, float* out, int n, void* stream);
 int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3, const float* u,
                              int ldu, const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,
                              float* du, float* dgamma, float* dbeta, int M, int K, void* stream);

@@ -101,6 +101,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                          c_int, _P]),
     "mil_linear_small_bwd_sum": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P,
                                          c_int, _P, c_int, c_int, c_int, _P]),
+    "mil_sum4": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "mil_linear_small_ln_bwd3": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P,
                                          c_int, c_int, _P]),
     "mil_linear_small_dw_grouped": (c_int, [_P, c_int, _P]),

@@ -597,6 +597,27 @@ extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or
                                     dW, lddw, db, M, N, K, stream);
 }
 
+// out = a + b (+ c) (+ d), n floats (n % 4 == 0, 16-byte aligned): the one place a gradient sum of the token side is still
+// materialised - a layer whose input carries no gradient has no dx launch to ride on (the text projection in front of the
+// two-way transformer) - in ONE launch instead of autograd's one add per extra consumer.
+__global__ __launch_bounds__(256) void k_sum4(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                              const float* __restrict__ d, float wc, float wd, float* __restrict__ out, int n4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 va = reinterpret_cast<const f32x4*>(a)[i], vb = reinterpret_cast<const f32x4*>(b)[i];
+    const f32x4 vc = reinterpret_cast<const f32x4*>(c)[i], vd = reinterpret_cast<const f32x4*>(d)[i];
+    reinterpret_cast<f32x4*>(out)[i] = (va + vb) + (wc * vc + wd * vd);
+}
+extern "C" int mil_sum4(const float* a, const float* b, const float* c, const float* d, float* out, int n, void* stream) {
+    if (!a || !b || !out || n < 0 || (n & 3) || (d && !c)) return MIL_EINVAL;
+    if (!sl_aligned16(a) || !sl_aligned16(b) || (c && !sl_aligned16(c)) || (d && !sl_aligned16(d)) || !sl_aligned16(out)) return MIL_EINVAL;
+    if (n == 0) return MIL_OK;
+    hipLaunchKernelGGL(k_sum4, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, c ? c : a, d ? d : a, c ? 1.f : 0.f,
+                       d ? 1.f : 0.f, out, n / 4);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_linear_small_dw_grouped(const mil_small_dw_desc* descs, int n, void* stream) {
     if (n < 0 || n > MIL_SMALL_DW_MAX || (n > 0 && !descs)) return MIL_EINVAL;
     if (n == 0) return MIL_OK;

@@ -705,6 +705,24 @@ def _sum_overflow(dy, extras, room: int):
     return dy, extras
 
 
+def sum_n(ts):
+    """Sum of 2 .. 4 same-shape fp32 tensors in ONE launch (mil_sum4); more, or odd layouts: torch's adds."""
+    ts = list(ts)
+    a = ts[0]
+    ok = (2 <= len(ts) <= 4 and a.numel() % 4 == 0 and
+          all(t.dtype == torch.float32 and t.is_contiguous() and t.shape == a.shape and t.data_ptr() % 16 == 0 for t in ts))
+    if not ok:
+        out = ts[0]
+        for t in ts[1:]:
+            out = out + t
+        return out
+    out = torch.empty_like(a)
+    e = ts + [None] * (4 - len(ts))
+    rc = _lib.lib().mil_sum4(_p(e[0]), _p(e[1]), _p(e[2]), _p(e[3]), _p(out), a.numel(), _stream())
+    _lib.check(rc, "mil_sum4")
+    return out
+
+
 def _ok_extra(e, like) -> bool:
     return e.dtype == torch.float32 and e.is_contiguous() and e.shape == like.shape and e.data_ptr() % 16 == 0
 
@@ -810,7 +828,15 @@ class _LinearAct(torch.autograd.Function):
                 dy = dy.clone()
             dy, extras = _sum_overflow(dy, extras, 3)
             want_dx = ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[7])
+            if extras and not want_dx:
+                # no dx launch to ride on (the layer's input carries no gradient): one n-ary sum, then the deferred dW
+                dy, extras = sum_n([dy] + extras), []
             want_dW, want_db = ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
+            if (deferred.enabled() and not want_dx and want_dW and W_slot is not None and (not want_db or b_slot is not None)
+                    and x.shape[1] % 4 == 0 and dy.data_ptr() % 16 == 0):
+                # nothing upstream waits for this layer: its whole backward is the grouped weight-gradient launch
+                deferred.queue_dw(dy, y, x, W_slot.detach(), (b_slot.detach() if want_db else None), ctx.act)
+                return None, W_slot, (b_slot if want_db else None), None, (dy if ctx.has_res else None), None, None, None
             if (deferred.enabled() and want_dx and want_dW and W_slot is not None and
                     (not want_db or b_slot is not None) and x.shape[1] % 4 == 0):
                 # the previous layer's backward waits for dx only: dx now, the weight / bias gradient with every other

@@ -17,7 +17,8 @@ def short(n):
 def main():
     d, marker = sys.argv[1], sys.argv[2]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 15
-    f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+    import os
+    f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
     rows = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
     rows.sort(key=lambda r: r[1])
     idx = [i for i, r in enumerate(rows) if r[0].startswith(marker)]
