@@ -986,7 +986,7 @@ def run_rank(args):
             line["rccl_floor"] = rccl_floor(args)
         if world == 1 and not args.no_configs and args.dtype == "f32":
             cfgs = {}
-            jobs = [("cfg5", config5_bf16), ("cfg3", config3_fusion)]
+            jobs = [("cfg3", config3_fusion), ("cfg5", config5_bf16)]
             if not args.no_ragged:
                 jobs += [("ragged_image", lambda d: ragged_regime(d, "image")), ("ragged_fusion", lambda d: ragged_regime(d, "fusion")),
                          ("ragged_ct_pth", lambda d: ragged_regime(d, "ct_pth"))]
