@@ -491,6 +491,15 @@ int mil_linear_small_bwd_sum(const float* dy, int lddy, const float* dy2, const 
 /* out = a + b (+ c) (+ d) over n floats (n % 4 == 0, 16-byte aligned; c, d nullable, d needs c): one launch for a gradient
  * sum that has no backward kernel to ride on. */
 int mil_sum4(const float* a, const float* b, const float* c, const float* d, float* out, int n, void* stream);
+/*   mil_linear_small_bwd_split  the dx of mil_linear_small_bwd as nsplit (2 | 4) partial sums over n, N / nsplit a multiple
+ *                               of 512: dx_parts [nsplit][M][K] - a 2048-wide contraction (mlp.lin1) spread over 4 x the
+ *                               workgroups; the next backward kernel sums the parts while it stages them:
+ *   mil_linear_small_ln_bwd5    mil_linear_small_ln_bwd with up to five addends (g4, g5 [M, 512] contiguous, nullable). */
+int mil_linear_small_bwd_split(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* W, int ldw,
+                               float* dx_parts, int M, int N, int K, int nsplit, void* stream);
+int mil_linear_small_ln_bwd5(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3, const float* g4,
+                             const float* g5, const float* u, int ldu, const float* stats, const float* gamma, const float* W,
+                             int ldw, float* dx, int lddx, float* du, float* dgamma, float* dbeta, int M, int K, void* stream);
 int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3, const float* u,
                              int ldu, const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,
                              float* du, float* dgamma, float* dbeta, int M, int K, void* stream);

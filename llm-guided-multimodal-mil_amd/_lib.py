@@ -101,6 +101,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                          c_int, _P]),
     "mil_linear_small_bwd_sum": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P,
                                          c_int, _P, c_int, c_int, c_int, _P]),
+    "mil_linear_small_bwd_split": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "mil_linear_small_ln_bwd5": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P,
+                                         _P, c_int, c_int, _P]),
     "mil_sum4": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "mil_linear_small_ln_bwd3": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P,
                                          c_int, c_int, _P]),

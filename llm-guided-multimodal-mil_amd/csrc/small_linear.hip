@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x < nW) {
         // ---- dW[n][k] = sum_m dpre[m][n] x[m][k]: 64 (n) x 128 (k) per workgroup, one 32 x 32 tile per wave (0..7)
-        if (wave >= 8) return;
+        if (wave >= 8 || blockIdx.y != 0) return;
         const int r = lane & 31, h = lane >> 5;
         const int kt = blockIdx.x % nKt, nt = blockIdx.x / nKt;
         const int wn = wave >> 2, wk = wave & 3;
@@ -227,9 +227,14 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
             }
         }
     };
+    // gridDim.y > 1 (mil_linear_small_bwd_split): workgroup (.., s) contracts over n in [s N / S, (s + 1) N / S) only and writes
+    // the partial dx_s - the contraction of a 2048-wide layer (mlp.lin1) was a 17 us walk of four operand chunks per workgroup
+    // on 64 workgroups; the partials are summed by the next backward kernel while it stages them (mil_linear_small_ln_bwd5)
+    const int nsl = N / (int)gridDim.y, nbeg = (int)blockIdx.y * nsl, nend = nbeg + nsl;
+    dx += (size_t)blockIdx.y * M * lddx;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    gload(0);
-    for (int n0c = 0; n0c < N; n0c += SL_KCH) {
+    gload(nbeg);
+    for (int n0c = nbeg; n0c < nend; n0c += SL_KCH) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
             *reinterpret_cast<f32x4*>(opa + row * SL_LS + 4 * c) = g;
         }
         __syncthreads();
-        if (n0c + SL_KCH < N) gload(n0c + SL_KCH);
-        const int nblk = min(SL_KCH, N - n0c) >> 4, per = (nblk + NW - 1) / NW;
+        if (n0c + SL_KCH < nend) gload(n0c + SL_KCH);
+        const int nblk = min(SL_KCH, nend - n0c) >> 4, per = (nblk + NW - 1) / NW;
         const int b0 = wave * per, b1 = min(nblk, b0 + per);
         float fb[MAXPER][4];
 #pragma unroll
@@ -354,10 +359,15 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd_ln(const float* __restric
     sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, bias, act, residual, ldr, y, ldy);
 }
 
+struct SmallLnMore {          // addends four and five of the gradient at the norm's output ([M, 512] contiguous; weight 0: absent)
+    const float* g4;
+    const float* g5;
+    float w4, w5;
+};
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restrict__ g1, int ldg1, const float* __restrict__ g2,
                                                           int ldg2, const float* __restrict__ g3, int ldg3, float w2, float w3,
-                                                          const float* __restrict__ u, int ldu,
+                                                          SmallLnMore mo, const float* __restrict__ u, int ldu,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ W, int ldw, float* __restrict__ dx,
                                                           int lddx, float* __restrict__ du, float* __restrict__ dgamma,
@@ -381,6 +391,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
                 const int m = min(mb + 4 * e, M - 1);
                 gv[e] = g1[(size_t)m * ldg1 + c];
                 gv[e] += w2 * g2[(size_t)m * ldg2 + c] + w3 * g3[(size_t)m * ldg3 + c];
+                gv[e] += mo.w4 * mo.g4[(size_t)m * N + c] + mo.w5 * mo.g5[(size_t)m * N + c];
                 uv[e] = u[(size_t)m * ldu + c];
                 mu[e] = stats[2 * m];
                 rs[e] = stats[2 * m + 1];
@@ -414,6 +425,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
             f32x4 g = *reinterpret_cast<const f32x4*>(g1 + (size_t)grow * ldg1 + c);
             g += w2 * *reinterpret_cast<const f32x4*>(g2 + (size_t)grow * ldg2 + c) +
                  w3 * *reinterpret_cast<const f32x4*>(g3 + (size_t)grow * ldg3 + c);
+            g += mo.w4 * *reinterpret_cast<const f32x4*>(mo.g4 + (size_t)grow * N + c) +
+                 mo.w5 * *reinterpret_cast<const f32x4*>(mo.g5 + (size_t)grow * N + c);
             xh[j] = (*reinterpret_cast<const f32x4*>(u + (size_t)grow * ldu + c) - mean) * rstd;
             gg[j] = g * *reinterpret_cast<const f32x4*>(gamma + c);
             const f32x4 t = gg[j] * xh[j];
@@ -590,6 +603,28 @@ extern "C" int mil_linear_small_bwd_sum(const float* dy, int lddy, const float* 
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
+// dx of mil_linear_small_bwd as `nsplit` PARTIAL sums over n (nsplit in {2, 4}, N / nsplit a multiple of 512):
+// dx_parts [nsplit][M][K] contiguous, part s = dpre[:, s N / S : (s + 1) N / S] W[s N / S : .., :]; their sum is dx.
+extern "C" int mil_linear_small_bwd_split(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* W,
+                                          int ldw, float* dx_parts, int M, int N, int K, int nsplit, void* stream) {
+    if (!dy || !W || !dx_parts || M <= 0 || M > MIL_SMALL_ROWS || N <= 0 || K <= 0 || act < 0 || act > 4) return MIL_EINVAL;
+    if (act != SL_NONE && !y_or_pre) return MIL_EINVAL;
+    if ((nsplit != 2 && nsplit != 4) || (N % (nsplit * SL_KCH)) != 0) return MIL_EINVAL;
+    if ((lddy & 3) || (act != SL_NONE && (ldyv & 3)) || !sl_aligned16(dy) || (act != SL_NONE && !sl_aligned16(y_or_pre))) return MIL_EINVAL;
+    const int nX = ((K + 15) / 16) * ((M + 15) / 16);
+    const SmallDyExtra ex{dy, dy, dy, 0.f, 0.f, 0.f, nullptr};
+    const dim3 grid(nX, nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    if (N / nsplit >= 1024)
+        hipLaunchKernelGGL((k_small_bwd<SL_WAVES_DEEP, false>), grid, dim3(64 * SL_WAVES_DEEP), 0, st, dy, lddy, y_or_pre, ldyv, act,
+                           (const float*)nullptr, 0, W, ldw, dx_parts, K, (float*)nullptr, 0, (float*)nullptr, M, N, K, 0, 1, ex);
+    else
+        hipLaunchKernelGGL((k_small_bwd<SL_WAVES, false>), grid, dim3(64 * SL_WAVES), 0, st, dy, lddy, y_or_pre, ldyv, act,
+                           (const float*)nullptr, 0, W, ldw, dx_parts, K, (float*)nullptr, 0, (float*)nullptr, M, N, K, 0, 1, ex);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 extern "C" int mil_linear_small_bwd(const float* dy, int lddy, const float* y_or_pre, int ldyv, int act, const float* x,
                                     int ldx, const float* W, int ldw, float* dx, int lddx, float* dW, int lddw,
                                     float* db, int M, int N, int K, void* stream) {
@@ -662,12 +697,17 @@ extern "C" int mil_linear_small_ln_fwd(const float* u, int ldu, const float* gam
 // Input gradient of the layer P that FEEDS a LayerNorm, with the norm's backward applied on the way in (k_small_bwd_ln):
 // g1 (+ g2) [M, 512] = gradient at the norm's output, u = P's output (the norm's input), stats from the forward;
 // dx [M, K] = du W (W = P's weight [512, K]; NULL: du only), du [M, 512] (nullable), dgamma / dbeta [512] (both or neither).
-extern "C" int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3,
-                                        const float* u, int ldu, const float* stats, const float* gamma, const float* W,
-                                        int ldw, float* dx, int lddx, float* du, float* dgamma, float* dbeta, int M, int K,
-                                        void* stream) {
+extern "C" int mil_linear_small_ln_bwd5(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3,
+                                        const float* g4, const float* g5, const float* u, int ldu, const float* stats,
+                                        const float* gamma, const float* W, int ldw, float* dx, int lddx, float* du,
+                                        float* dgamma, float* dbeta, int M, int K, void* stream) {
     if (!g1 || !u || !stats || !gamma || M <= 0 || M > MIL_SMALL_ROWS) return MIL_EINVAL;
     if (g3 && ((ldg3 & 3) || !sl_aligned16(g3))) return MIL_EINVAL;
+    if ((g4 && !sl_aligned16(g4)) || (g5 && !sl_aligned16(g5))) return MIL_EINVAL;
+    const SmallLnMore mo{g4 ? g4 : g1, g5 ? g5 : g1, g4 ? 1.f : 0.f, g5 ? 1.f : 0.f};
+    if ((!g4 || !g5) && ldg1 != SLN_E) {                       // the stand-in is read with the extras' stride
+        if (ldg1 < SLN_E) return MIL_EINVAL;
+    }
     if ((dx != nullptr) && (!W || K <= 0)) return MIL_EINVAL;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return MIL_EINVAL;
     if ((ldg1 & 3) || (g2 && (ldg2 & 3)) || (ldu & 3) || !sl_aligned16(g1) || (g2 && !sl_aligned16(g2)) || !sl_aligned16(u) ||
@@ -676,10 +716,17 @@ extern "C" int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* 
     const int kt = dx ? (K + 15) / 16 : 1;
     const int nX = kt * ((M + 15) / 16);
     hipLaunchKernelGGL((k_small_bwd_ln<SL_WAVES>), dim3(nX + (dgamma ? 4 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
-                       g2 ? g2 : g1, g2 ? ldg2 : ldg1, g3 ? g3 : g1, g3 ? ldg3 : ldg1, g2 ? 1.f : 0.f, g3 ? 1.f : 0.f, u, ldu, stats, gamma,
+                       g2 ? g2 : g1, g2 ? ldg2 : ldg1, g3 ? g3 : g1, g3 ? ldg3 : ldg1, g2 ? 1.f : 0.f, g3 ? 1.f : 0.f, mo, u, ldu, stats, gamma,
                        W, ldw, dx, lddx, du, dgamma, dbeta, M, dx ? K : 16, nX);      // a missing addend: g1 again, weight 0 (no branch)
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+extern "C" int mil_linear_small_ln_bwd3(const float* g1, int ldg1, const float* g2, int ldg2, const float* g3, int ldg3,
+                                        const float* u, int ldu, const float* stats, const float* gamma, const float* W,
+                                        int ldw, float* dx, int lddx, float* du, float* dgamma, float* dbeta, int M, int K,
+                                        void* stream) {
+    return mil_linear_small_ln_bwd5(g1, ldg1, g2, ldg2, g3, ldg3, nullptr, nullptr, u, ldu, stats, gamma, W, ldw, dx, lddx, du,
+                                    dgamma, dbeta, M, K, stream);
 }
 extern "C" int mil_linear_small_ln_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* u, int ldu,
                                        const float* stats, const float* gamma, const float* W, int ldw, float* dx, int lddx,

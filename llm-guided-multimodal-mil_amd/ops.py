@@ -935,18 +935,38 @@ class _LinLnLin(torch.autograd.Function):
             dy = _f32c(dy, "dy")
             if dy.data_ptr() % 16:
                 dy = dy.clone()
-            dxin, _, _ = linear_small_bwd(dy, y, ctx.actc, xin, Wc, True, False, False)      # C: input gradient now ...
+            parts = None
+            Nc = Wc.shape[0]
+            if Nc >= 2048 and Nc % 2048 == 0 and not ctx.has_x2 and dy.stride(0) % 4 == 0 and y.stride(0) % 4 == 0:
+                # a wide C layer (mlp.lin1): its input gradient as four partial sums over n (4 x the workgroups, one operand
+                # chunk each); the norm's backward below adds them while it stages its operand
+                parts = torch.empty((4, M, E), device=dev, dtype=torch.float32)
+                rc = _lib.lib().mil_linear_small_bwd_split(_p(dy), dy.stride(0), _p(y if ctx.actc != 0 else None), y.stride(0),
+                                                           ctx.actc, _p(Wc), Wc.stride(0), _p(parts), M, Nc, E, 4, _stream())
+                _lib.check(rc, "mil_linear_small_bwd_split")
+                dxin = None
+            else:
+                dxin, _, _ = linear_small_bwd(dy, y, ctx.actc, xin, Wc, True, False, False)  # C: input gradient now ...
             dWc, dbc = _small_dw(dy, y, xin, Wc, bc, ctx.actc)                              # ... weight gradient grouped
         else:
-            dxin, dWc, dbc = None, None, None
+            dxin, dWc, dbc, parts = None, None, None, None
         gs = [g for g in (dxin, dxn) if g is not None] + (ctx.box.take() if ctx.box is not None else [])
+        if parts is not None:
+            gs = [parts[0], parts[1], parts[2]] + gs + [parts[3]]        # slots 4 and 5 take contiguous [M, 512] addends
         if not gs:
             return (None,) * 12
         gs = [_f32c(g, "dxn") for g in gs]
-        while len(gs) > 3 or (len(gs) > 1 and not (gs[-1].stride(1) == 1 and gs[-1].stride(0) % 4 == 0 and gs[-1].data_ptr() % 16 == 0)):
-            g = gs.pop()
-            gs[0] = gs[0] + g
-        g1, g2, g3 = (gs + [None, None])[:3]
+        def fits(i, g):           # addends 1-3 carry their own row stride, 4-5 are read as contiguous [M, 512]
+            return g.stride(1) == 1 and g.data_ptr() % 16 == 0 and (g.stride(0) % 4 == 0 if i < 3 else g.is_contiguous())
+        i = 1
+        while i < len(gs):        # whatever does not fit a slot is added the plain way
+            if i >= 5 or not fits(i, gs[i]):
+                gs[0] = gs[0] + gs.pop(i)
+            else:
+                i += 1
+        if not fits(0, gs[0]):
+            gs[0] = gs[0].contiguous()
+        g1, g2, g3, g4, g5 = (gs + [None] * 4)[:5]
         dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         du = torch.empty((M, E), device=dev, dtype=torch.float32)
         dg = grad_slot(gamma)
@@ -956,11 +976,11 @@ class _LinLnLin(torch.autograd.Function):
         if db is None:
             db = torch.empty(E, device=dev, dtype=torch.float32)
         K = z.shape[1]
-        rc = _lib.lib().mil_linear_small_ln_bwd3(_p(g1), g1.stride(0), _p(g2), g2.stride(0) if g2 is not None else 0, _p(g3),
-                                                 g3.stride(0) if g3 is not None else 0, _p(u), u.stride(0), _p(stats),
-                                                 _p(gamma), _p(Wp), Wp.stride(0), _p(dz), K, _p(du), _p(dg), _p(db), M, K,
-                                                 _stream())
-        _lib.check(rc, "mil_linear_small_ln_bwd3")
+        rc = _lib.lib().mil_linear_small_ln_bwd5(_p(g1), g1.stride(0), _p(g2), g2.stride(0) if g2 is not None else 0, _p(g3),
+                                                 g3.stride(0) if g3 is not None else 0, _p(g4), _p(g5), _p(u), u.stride(0),
+                                                 _p(stats), _p(gamma), _p(Wp), Wp.stride(0), _p(dz), K, _p(du), _p(dg), _p(db),
+                                                 M, K, _stream())
+        _lib.check(rc, "mil_linear_small_ln_bwd5")
         dWp, dbp = _small_dw(du, None, z, Wp, bp, 0)
         return (dz, dWp, dbp, (du if ctx.has_res else None), dg, db, None, (dxin if ctx.has_x2 else None), dWc, dbc, None, None)
 

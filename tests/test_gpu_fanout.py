@@ -84,3 +84,26 @@ def test_fan_out_of_a_plain_tensor_is_the_tensor():
     x = torch.randn(4, 16, device=DEV, requires_grad=True)
     a, b = ops.fan_out(x, 2)
     assert a is x and b is x
+
+
+@pytest.mark.parametrize("with_xn_consumer", [True, False])
+def test_wide_consumer_layer_input_gradient_in_partial_sums(with_xn_consumer):
+    """lin_ln_lin with a 2048-wide C layer (mlp.lin1, relu): C's input gradient comes as four partial sums over n
+    (mil_linear_small_bwd_split) that the norm's backward adds while staging (mil_linear_small_ln_bwd5)."""
+    g = torch.Generator().manual_seed(77)
+    M, E, N = 32, 512, 2048
+    z, Wp, bp, resp = _r(g, M, 256), _r(g, E, 256, sc=0.05), _r(g, E, sc=0.1), _r(g, M, E)
+    gamma, beta, Wc, bc = 1 + _r(g, E, sc=0.1), _r(g, E, sc=0.1), _r(g, N, E, sc=0.05), _r(g, N, sc=0.1)
+    cy, cx = _r(g, M, N), _r(g, M, E)
+    names = ("z", "Wp", "bp", "resp", "gamma", "beta", "Wc", "bc")
+    lv = [t.clone().requires_grad_(True) for t in (z, Wp, bp, resp, gamma, beta, Wc, bc)]
+    y, xn = ops.lin_ln_lin(lv[0], lv[1], lv[2], lv[3], lv[4], lv[5], 1e-5, None, lv[6], lv[7], "relu")
+    ((y * cy).sum() + ((xn * cx).sum() if with_xn_consumer else 0.0)).backward()
+    rf = [t.clone().requires_grad_(True) for t in (z, Wp, bp, resp, gamma, beta, Wc, bc)]
+    u = torch.nn.functional.linear(rf[0], rf[1], rf[2]) + rf[3]
+    xr = torch.nn.functional.layer_norm(u, (E,), rf[4], rf[5], 1e-5)
+    yr = torch.relu(torch.nn.functional.linear(xr, rf[6], rf[7]))
+    ((yr * cy).sum() + ((xr * cx).sum() if with_xn_consumer else 0.0)).backward()
+    assert rel_err(y.detach(), yr.detach()) <= 2e-6
+    for a, r_, nm in zip(lv, rf, names):
+        assert rel_err(a.grad, r_.grad) <= 5e-5, (nm, rel_err(a.grad, r_.grad))
