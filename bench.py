@@ -390,6 +390,7 @@ def config3_fusion(dev, steps=30, warmup=4):
     from mil_amd import synthetic as syn
     from mil_amd.model.utils import get_model
     from mil_amd.optim import FlatAdam
+    from mil_amd.ops import backward as ops_backward
     from oracle import mil_oracle as orc
     B, N = 32, 1024
     args = SimpleNamespace(modality=["pathology"], model_pathology="ABMIL", model_CI="CLIP", aggregator="ABMIL",
@@ -418,7 +419,7 @@ def config3_fusion(dev, steps=30, warmup=4):
     def gstep():
         model([x], ids, text_features=tfeat, labels=y)      # criterion(prob, y) of train_ddp.py:323-324 inside the module:
         loss = model.last_loss                              # pool + head + BCE run as one fused node
-        loss.backward()
+        ops_backward(loss)
         opt.step()
         return loss
 

@@ -364,7 +364,7 @@ struct SmallLnMore {          // addends four and five of the gradient at the no
     const float* g5;
     float w4, w5;
 };
-template <int NW>
+template <int NW, bool MORE>
 __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restrict__ g1, int ldg1, const float* __restrict__ g2,
                                                           int ldg2, const float* __restrict__ g3, int ldg3, float w2, float w3,
                                                           SmallLnMore mo, const float* __restrict__ u, int ldu,
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
                 const int m = min(mb + 4 * e, M - 1);
                 gv[e] = g1[(size_t)m * ldg1 + c];
                 gv[e] += w2 * g2[(size_t)m * ldg2 + c] + w3 * g3[(size_t)m * ldg3 + c];
-                gv[e] += mo.w4 * mo.g4[(size_t)m * N + c] + mo.w5 * mo.g5[(size_t)m * N + c];
+                if (MORE) gv[e] += mo.w4 * mo.g4[(size_t)m * N + c] + mo.w5 * mo.g5[(size_t)m * N + c];
                 uv[e] = u[(size_t)m * ldu + c];
                 mu[e] = stats[2 * m];
                 rs[e] = stats[2 * m + 1];
@@ -425,8 +425,9 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
             f32x4 g = *reinterpret_cast<const f32x4*>(g1 + (size_t)grow * ldg1 + c);
             g += w2 * *reinterpret_cast<const f32x4*>(g2 + (size_t)grow * ldg2 + c) +
                  w3 * *reinterpret_cast<const f32x4*>(g3 + (size_t)grow * ldg3 + c);
-            g += mo.w4 * *reinterpret_cast<const f32x4*>(mo.g4 + (size_t)grow * N + c) +
-                 mo.w5 * *reinterpret_cast<const f32x4*>(mo.g5 + (size_t)grow * N + c);
+            if (MORE)
+                g += mo.w4 * *reinterpret_cast<const f32x4*>(mo.g4 + (size_t)grow * N + c) +
+                     mo.w5 * *reinterpret_cast<const f32x4*>(mo.g5 + (size_t)grow * N + c);
             xh[j] = (*reinterpret_cast<const f32x4*>(u + (size_t)grow * ldu + c) - mean) * rstd;
             gg[j] = g * *reinterpret_cast<const f32x4*>(gamma + c);
             const f32x4 t = gg[j] * xh[j];
@@ -715,7 +716,8 @@ extern "C" int mil_linear_small_ln_bwd5(const float* g1, int ldg1, const float* 
         return MIL_EINVAL;
     const int kt = dx ? (K + 15) / 16 : 1;
     const int nX = kt * ((M + 15) / 16);
-    hipLaunchKernelGGL((k_small_bwd_ln<SL_WAVES>), dim3(nX + (dgamma ? 4 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
+    auto kern = (g4 || g5) ? k_small_bwd_ln<SL_WAVES, true> : k_small_bwd_ln<SL_WAVES, false>;
+    hipLaunchKernelGGL(kern, dim3(nX + (dgamma ? 4 : 0)), dim3(64 * SL_WAVES), 0, (hipStream_t)stream, g1, ldg1,
                        g2 ? g2 : g1, g2 ? ldg2 : ldg1, g3 ? g3 : g1, g3 ? ldg3 : ldg1, g2 ? 1.f : 0.f, g3 ? 1.f : 0.f, mo, u, ldu, stats, gamma,
                        W, ldw, dx, lddx, du, dgamma, dbeta, M, dx ? K : 16, nX);      // a missing addend: g1 again, weight 0 (no branch)
     MIL_CHECK_LAUNCH();

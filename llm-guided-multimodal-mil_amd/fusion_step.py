@@ -125,7 +125,8 @@ class RaggedFusionStepper:
             self.eager_only += 1
             self.gs._drop_grads()
             out = body()
-            out[0].backward()
+            from . import ops
+            ops.backward(out[0])
             self.opt.step()
             return tuple(o.detach() for o in out)
         key = ("fusion-bucket", slot.cap, self.model.training)

@@ -21,6 +21,8 @@ from typing import Callable, Dict, List, Sequence, Tuple
 
 import torch
 
+from . import ops
+
 from . import lifetime
 
 
@@ -53,7 +55,7 @@ class GraphedStep:
         with torch.cuda.stream(self.stream):
             self._drop_grads()
             out = body(*inputs)
-            out[0].backward()
+            ops.backward(out[0])
             if after_backward is not None:
                 after_backward()
             out = tuple(o.detach() for o in out)
@@ -73,13 +75,13 @@ class GraphedStep:
             with torch.cuda.stream(self.stream):
                 for _ in range(self.warmup):      # caches (segment maps, positional rows, split weights) fill here
                     self._drop_grads()
-                    body(*ent.inputs)[0].backward()
+                    ops.backward(body(*ent.inputs)[0])
             cur.wait_stream(self.stream)
             self._drop_grads()                    # backward inside the capture then allocates / adopts, never accumulates
             ent.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ent.graph, stream=self.stream):
                 out = body(*ent.inputs)
-                out[0].backward()
+                ops.backward(out[0])
                 if after_backward is not None:      # e.g. a counted FlatAdam step: the optimizer inside the graph (the
                     after_backward()                # warm-up passes above leave it out - they must not train)
         ent.keep = keep

@@ -23,6 +23,7 @@ if __package__ in (None, ""):
     import mil_amd  # noqa: F401
     __package__ = "mil_amd"
 
+from . import ops  # noqa: E402
 from .bags import BagLayout  # noqa: E402
 from .config import create_arg_parser  # noqa: E402
 from .dataset import collate_bags, load_cohort  # noqa: E402
@@ -317,7 +318,7 @@ def main_worker(local_rank: int, nprocs: int, args):
                         prob, toks = unpack(out)
                         loss = total_loss(prob, toks, y)                                  # loss_point 'Last' by default
                     optimizer.zero_grad()
-                    loss.backward()
+                    ops.backward(loss)
                     optimizer.step()
             if it % 10 == 0 or it == steps - 1:
                 losses.update(float(loss.detach()), x.shape[0])                                   # host sync only when logging

@@ -4,7 +4,7 @@ from types import SimpleNamespace
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mil_amd
-from mil_amd import synthetic as syn
+from mil_amd import synthetic as syn, ops
 from mil_amd.model.utils import get_model
 
 ap = argparse.ArgumentParser()
@@ -59,7 +59,7 @@ def fwd_loss(**kw):
 def step():
     loss = fwd_loss()
     opt.zero_grad(set_to_none=True)
-    loss.backward()
+    ops.backward(loss)
     opt.step()
     return loss
 
@@ -72,7 +72,7 @@ if a.graph:
             tfeat = model.clinic_extractor(ids)      # frozen tower: outside the graph (cached per note in training)
     def gstep():
         loss = fwd_loss(text_features=tfeat)
-        loss.backward()
+        ops.backward(loss)
         opt.step()
         return loss
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
