@@ -466,12 +466,12 @@ def config3_fusion(dev, steps=30, warmup=4):
     row = 512 * 4
     n_par = sum(p_.numel() for p_ in model.parameters() if p_.requires_grad)
     alg_bytes = (R * (768 + 512) * 4                              # fc_pathology forward: x in, xi out
-                 + 2 * (R * row + 2 * R * row)                    # per block: absorbed pool over the keys; LayerNorm(keys + row) in / out
-                 + R * row                                        # final token -> image pool
+                 + R * row                                        # first block: absorbed pool over the keys
+                 + 2 * (2 * R * row)                              # LayerNorm(keys + row) fused with the NEXT site's pool (round 4): x in, keys out
                  + R * row + R * 384 * 4 + R * row                # gate forward (x0 in, gates out) + pool pass
                  + (R * row + R * 384 * 4) + (R * 384 * 4 + R * row)      # gate dW (x0, gates in); gate dx (gates in, dx out)
-                 + 3 * (R * row + 3 * R * row)                    # absorbed pool backward x 3: dots (keys), apply (keys, dkeys in, dkeys out)
-                 + 2 * (3 * R * row)                              # LayerNorm-with-bag-row backward x 2: x, dy in, dx out
+                 + (R * row + 3 * R * row)                        # first block's pool backward: dots (keys), apply (keys, dkeys in, dkeys out)
+                 + 2 * (3 * R * row)                              # fused pair backward x 2, ONE pass: x, dy in, dx out (keys recomputed)
                  + R * (512 + 512 + 768) * 4                      # fc_pathology parameter backward: dy, y (tanh'), x
                  + n_par * 28)                                    # Adam: p, m, v in and out + g in
     return {"workload": f"{B} bags x {N} x 768 + one 77-token note per bag, aggregator(args) fwd+BCE+bwd+Adam "

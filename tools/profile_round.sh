@@ -15,7 +15,9 @@ OUT=$ROOT/gpurun_out/prof_round
 # PART=A: the profiled runs (kernel traces + PMC passes); PART=B: the un-profiled bench.py lines; PART=C: the tools/ lines;
 # unset: all (a gpurun call is limited to 20 minutes - run the parts as separate calls)
 PART=${PART:-ABC}
-if [[ "$PART" == *A* ]]; then rm -rf "$OUT"; fi
+# ONLY="cfg3" (with PART=A): re-profile just these workloads, keeping the other raw runs of the round
+WL=${ONLY:-cfg2 pool cfg5 cfg3}
+if [[ "$PART" == *A* && -z "$ONLY" ]]; then rm -rf "$OUT"; fi
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --no-configs --no-cpu-baseline --no-breakdown"
@@ -35,16 +37,18 @@ if [ "${QUICK:-0}" = "1" ]; then
 fi
 export STEPS=60
 if [[ "$PART" == *A* ]]; then
-for w in cfg2 pool cfg5 cfg3; do
+for w in $WL; do
+  rm -rf $OUT/stats_$w $OUT/fetch_$w $OUT/write_$w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- ${CMD[$w]} > $OUT/stats_$w.log 2>&1
   echo "stats $w done"
 done
-for w in cfg2 pool cfg5 cfg3; do
+for w in $WL; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$w -- ${CMD[$w]} > $OUT/fetch_$w.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$w -- ${CMD[$w]} > $OUT/write_$w.log 2>&1
   echo "traffic $w done"
 done
 for w in cfg2 cfg5; do
+  [[ " $WL " == *" $w "* ]] || continue
   timeout -k 10 300 rocprofv3 --pmc $MFMA --output-format csv -d $OUT/mfma_$w -- ${CMD[$w]} > $OUT/mfma_$w.log 2>&1
   echo "mfma $w done"
 done
