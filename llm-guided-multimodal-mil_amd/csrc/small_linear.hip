@@ -561,9 +561,20 @@ __global__ __launch_bounds__(512) void k_small_dw_grouped(const SmallDwBatch bat
         const int nbase = 64 * nt + 32 * wn;
         const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)d.dW, 0, ((N - 1) * d.lddw + K) * 4, MIL_SRD_FLAGS);
         const int voff_w = 4 * ((nbase + 4 * h) * d.lddw + k);
+#if defined(DWG_PLAIN_STORES)
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[i]), srd_w, voff_w, 4 * ((i & 3) + 8 * (i >> 2)) * d.lddw, 0);
+        for (int i = 0; i < 16; ++i) {
+            const int nn = nbase + mfma32_row(i, h);
+            if (nn < N) d.dW[(size_t)nn * d.lddw + k] = acc[i];
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[i];
+            asm volatile("" : "+v"(v));          // (hipcc 7.2 stored register 0 of the accumulator sixteen times without this)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_w, voff_w, 4 * ((i & 3) + 8 * (i >> 2)) * d.lddw, 0);
+        }
+#endif
     }
     if (d.db != nullptr && kt == 0 && wk == 0) {
         const float tot = bsum + __shfl_xor(bsum, 32);
