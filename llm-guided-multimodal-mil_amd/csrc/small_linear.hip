@@ -42,11 +42,27 @@ __device__ __forceinline__ float sl_dact(float g, float yv, int act) {
 }
 
 // Fold the waves' 16 x 16 partial tiles (lane l holds column l & 15 of rows 4 (l >> 4) + i) and store with epilogue.
+// The epilogue's two operands (bias and residual of the thread's output element) are fetched by sl_epi_prefetch at the START
+// of the kernel: loaded after the last barrier they were one more exposed L2 round trip per launch of the token-side chain.
+struct SlEpi {
+    float b, r;
+};
+__device__ __forceinline__ SlEpi sl_epi_prefetch(int tid, int M, int N, int m0, int n0, const float* __restrict__ bias,
+                                                 const float* __restrict__ residual, int ldr) {
+    SlEpi e{0.f, 0.f};
+    if (tid < 256) {
+        const int i = tid >> 6, l = tid & 63;
+        const int row = m0 + 4 * (l >> 4) + i, col = n0 + (l & 15);
+        if (row < M && col < N) {
+            if (bias != nullptr) e.b = bias[col];
+            if (residual != nullptr) e.r = residual[(size_t)row * ldr + col];
+        }
+    }
+    return e;
+}
 template <int NW>
 __device__ __forceinline__ void sl_fold_store(float (*red)[4][64], const f32x4 acc, int tid, int M, int N, int m0, int n0,
-                                              const float* __restrict__ bias, int act,
-                                              const float* __restrict__ residual, int ldr, float* __restrict__ out,
-                                              int ldo) {
+                                              const SlEpi epi, int act, float* __restrict__ out, int ldo) {
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
@@ -57,12 +73,7 @@ __device__ __forceinline__ void sl_fold_store(float (*red)[4][64], const f32x4 a
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][i][l];
         const int row = m0 + 4 * (l >> 4) + i, col = n0 + (l & 15);
-        if (row < M && col < N) {
-            if (bias != nullptr) v += bias[col];
-            v = sl_act(v, act);
-            if (residual != nullptr) v += residual[(size_t)row * ldr + col];
-            out[(size_t)row * ldo + col] = v;
-        }
+        if (row < M && col < N) out[(size_t)row * ldo + col] = sl_act(v + epi.b, act) + epi.r;
     }
 }
 
@@ -90,6 +101,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd(const float* __restrict__
     const int r = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     constexpr int NT = 64 * NW, LPT = (16 * SL_KCH / 4) / NT;          // 16-byte loads per thread, operand and chunk
+    const SlEpi epi = sl_epi_prefetch(tid, M, N, m0, n0, bias, residual, ldr);
     f32x4 rx[LPT], rw[LPT];
     auto gload = [&](int k0) {
 #pragma unroll
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd(const float* __restrict__
         }
         __syncthreads();
     }
-    sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, bias, act, residual, ldr, y, ldy);
+    sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, epi, act, y, ldy);
 }
 
 // The gradient of a layer's output that SEVERAL consumers wrote (round 4): dy + dy2 + dy3 + dy4 (each [M, N] contiguous,
@@ -239,20 +251,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     gload(nbeg);
     for (int n0c = nbeg; n0c < nend; n0c += SL_KCH) {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
-            f32x4 g = rg[i];
-            if (EX && ex.dysum != nullptr && k0 == 0 && m0 + row < M && n0c + 4 * c < N)
-                *reinterpret_cast<f32x4*>(ex.dysum + (size_t)(m0 + row) * N + n0c + 4 * c) = g;      // the summed dy, before act'
-            if (act != SL_NONE) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) g[jj] = sl_dact(g[jj], ry[i][jj], act);
-            }
-            *reinterpret_cast<f32x4*>(opa + row * SL_LS + 4 * c) = g;
-        }
-        __syncthreads();
-        if (n0c + SL_KCH < nend) gload(n0c + SL_KCH);
+        // the chunk's W^T fragments are requested BEFORE the staging barrier (they depend on nothing in LDS): behind it they
+        // were a second exposed L2 round trip per launch
         const int nblk = min(SL_KCH, nend - n0c) >> 4, per = (nblk + NW - 1) / NW;
         const int b0 = wave * per, b1 = min(nblk, b0 + per);
         float fb[MAXPER][4];
@@ -260,8 +260,31 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
         for (int u = 0; u < MAXPER; ++u) {
             const int nb = n0c + 16 * min(b0 + u, max(b1 - 1, 0)) + 4 * kq;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) fb[u][jj] = (b0 + u < b1) ? W[(size_t)(nb + jj) * ldw + kc] : 0.f;
+            for (int jj = 0; jj < 4; ++jj) fb[u][jj] = W[(size_t)(nb + jj) * ldw + kc];      // clamped block: unused where b0 + u >= b1
         }
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
+            f32x4 g = rg[i];
+            if (EX && ex.dysum != nullptr && k0 == 0 && m0 + row < M && n0c + 4 * c < N)
+                *reinterpret_cast<f32x4*>(ex.dysum + (size_t)(m0 + row) * N + n0c + 4 * c) = g;      // the summed dy, before act'
+            switch (act) {              // wave-uniform: one branch per 16-byte piece, not one per element and activation
+            case SL_NONE: break;
+            case SL_TANH: g = g * (1.0f - ry[i] * ry[i]); break;
+            case SL_RELU:
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) g[jj] = ry[i][jj] > 0.f ? g[jj] : 0.f;
+                break;
+            case SL_SIGMOID: g = g * ry[i] * (1.0f - ry[i]); break;
+            default:
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) g[jj] = sl_dact(g[jj], ry[i][jj], SL_QUICKGELU);
+                break;
+            }
+            *reinterpret_cast<f32x4*>(opa + row * SL_LS + 4 * c) = g;
+        }
+        __syncthreads();
+        if (n0c + SL_KCH < nend) gload(n0c + SL_KCH);
 #pragma unroll
         for (int u = 0; u < MAXPER; ++u) {
             if (b0 + u < b1) {
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
         }
         __syncthreads();
     }
-    sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, nullptr, SL_NONE, nullptr, 0, dx, lddx);
+    sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, SlEpi{0.f, 0.f}, SL_NONE, dx, lddx);
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm folded into its neighbours
@@ -304,6 +327,19 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd_ln(const float* __restric
     const int r = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     constexpr int K = SLN_E, NT = 64 * NW, LPT = (16 * SL_KCH / 4) / NT;
+    const SlEpi epi = sl_epi_prefetch(tid, M, N, m0, n0, bias, residual, ldr);
+    // the norm's own operands (gamma, beta, the second addend) requested with the staging loads, not behind the first barrier
+    f32x4 pg[4], pbt[4], px2[4];
+    {
+        const int p = tid & 31, grow = m0 + (tid >> 5);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * p + 128 * j;
+            pg[j] = *reinterpret_cast<const f32x4*>(gamma + c);
+            pbt[j] = *reinterpret_cast<const f32x4*>(beta + c);
+            px2[j] = x2 != nullptr ? *reinterpret_cast<const f32x4*>(x2 + (size_t)min(grow, M - 1) * ldx2 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int idx = tid + i * NT, row = idx >> 7, c = idx & 127;
@@ -340,11 +376,10 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd_ln(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = 4 * p + 128 * j;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
-            f32x4 o = v[j] * rstd * g + bt;
+            f32x4 o = v[j] * rstd * pg[j] + pbt[j];
             if (wr) *reinterpret_cast<f32x4*>(xn + (size_t)grow * K + c) = o;
             if (x2 != nullptr) {
-                o += *reinterpret_cast<const f32x4*>(x2 + (size_t)min(grow, M - 1) * ldx2 + c);
+                o += px2[j];
                 if (wr) *reinterpret_cast<f32x4*>(xin + (size_t)grow * K + c) = o;
             }
             *reinterpret_cast<f32x4*>(opx + row * SL_LS + c) = o;
@@ -360,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_fwd_ln(const float* __restric
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[jj], fb[jj], acc, 0, 0, 0);
     }
-    sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, bias, act, residual, ldr, y, ldy);
+    sl_fold_store<NW>(red, acc, tid, M, N, m0, n0, epi, act, y, ldy);
 }
 
 struct SmallLnMore {          // addends four and five of the gradient at the norm's output ([M, 512] contiguous; weight 0: absent)
@@ -418,6 +453,18 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
     const int nK16 = (K + 15) >> 4;
     const int k0 = ((int)blockIdx.x % nK16) * 16, m0 = ((int)blockIdx.x / nK16) * 16;
     const int kc = min(k0 + r, K - 1);
+    // W^T fragments of this wave's n blocks: requested with the staging loads, not behind the barrier (one L2 round trip less)
+    constexpr int per = (N / 16) / NW;
+    const int b0 = wave * per;
+    float fb[per][4];
+    if (dx != nullptr) {
+#pragma unroll
+        for (int uu = 0; uu < per; ++uu) {
+            const int nb = 16 * (b0 + uu) + 4 * kq;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fb[uu][jj] = W[(size_t)(nb + jj) * ldw + kc];
+        }
+    }
     {
         const int row = tid >> 5, p = tid & 31, grow = min(m0 + row, M - 1);
         const float mean = stats[2 * grow], rstd = stats[2 * grow + 1];
@@ -453,15 +500,6 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
     }
     __syncthreads();
     if (dx == nullptr) return;
-    constexpr int per = (N / 16) / NW;
-    const int b0 = wave * per;
-    float fb[per][4];
-#pragma unroll
-    for (int uu = 0; uu < per; ++uu) {
-        const int nb = 16 * (b0 + uu) + 4 * kq;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) fb[uu][jj] = W[(size_t)(nb + jj) * ldw + kc];
-    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int uu = 0; uu < per; ++uu) {
@@ -469,7 +507,7 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd_ln(const float* __restric
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[jj], fb[uu][jj], acc, 0, 0, 0);
     }
-    sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, nullptr, SL_NONE, nullptr, 0, dx, lddx);
+    sl_fold_store<NW>(red, acc, tid, M, K, m0, k0, SlEpi{0.f, 0.f}, SL_NONE, dx, lddx);
 }
 
 // Weight / bias gradients of up to MIL_SMALL_DW_MAX few-rows layers in ONE launch (grid.y = layer): the dW role of
