@@ -156,6 +156,120 @@ struct SmallDyExtra {
     float w2, w3, w4;
     float* dysum;
 };
+// The dW role, shared by k_small_bwd (workgroups [0, nW)) and k_small_dw_grouped: dW[n][k] = sum_m dpre[m][n] x[m][k] on a
+// 64 (n) x 128 (k) tile per workgroup of 8 waves, one 32 x 32 MFMA tile per wave, + the bias gradient (kt == 0).
+struct SlDwArgs {
+    const float* dy;
+    const float* yv;
+    const float* x;
+    float* dW;
+    float* db;
+    int lddy, ldyv, ldx, lddw, act, M, N, K;
+};
+template <bool EX>
+__device__ __forceinline__ void sl_dw_role(const SlDwArgs& d, const int wg, const SmallDyExtra& ex) {
+    const int M = d.M, N = d.N, K = d.K, act = d.act;
+    const int nKt = (K + 127) / 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int kt = wg % nKt, nt = wg / nKt;
+    const int wn = wave >> 2, wk = wave & 3;
+    const int n = 64 * nt + 32 * wn + r, k = 128 * kt + 32 * wk + r;
+    const int nc = min(n, N - 1), kc = min(k, K - 1);
+    const float* __restrict__ dy = d.dy;
+    const float* __restrict__ yv = d.yv;
+    const float* __restrict__ x = d.x;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    const __amdgpu_buffer_rsrc_t srd_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, ((M - 1) * d.lddy + N) * 4, MIL_SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, ((M - 1) * d.ldx + K) * 4, MIL_SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srd_yv =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(yv != nullptr ? yv : dy), 0, ((M - 1) * d.ldyv + N) * 4, MIL_SRD_FLAGS);
+    const int voff_dy = 4 * (h * d.lddy + nc), voff_x = 4 * (h * d.ldx + kc), voff_yv = 4 * (h * d.ldyv + nc);
+    const int voff_ex = 4 * (h * N + nc);
+    const __amdgpu_buffer_rsrc_t srd_e2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EX ? ex.dy2 : dy), 0, M * N * 4, MIL_SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srd_e3 = __builtin_amdgcn_make_buffer_rsrc((void*)(EX ? ex.dy3 : dy), 0, M * N * 4, MIL_SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srd_e4 = __builtin_amdgcn_make_buffer_rsrc((void*)(EX ? ex.dy4 : dy), 0, M * N * 4, MIL_SRD_FLAGS);
+    const int steps = (M + 1) >> 1;
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+        // every load of the trip first, unconditionally (clamped rows, masked afterwards), THEN the activation derivative under
+        // one wave-uniform switch: with the per-element `if (act ..)` / `m < M` forms the compiler emitted a load - wait -
+        // compute sequence per u, 16 dependent L2 round trips per workgroup (8.4 us for ONE 512 x 512 layer, 30 us for the 19
+        // layers of the fusion step against 7 us of write time)
+        // Buffer loads: ONE address register per operand (lane part: row parity h and the column; the row pair of trip u is a
+        // scalar offset), rows >= M read as zero through the resource's bounds check - 64-bit addresses per load held the kernel
+        // at 145 VGPRs = one workgroup per CU.
+        float fa[16], fb[16], yy[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            fa[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_dy, voff_dy, 8 * (s0 + u) * d.lddy, 0));
+            if (EX) {            // the other consumers' gradients ([M, N] contiguous; a missing one: dy again with weight 0)
+                const float e2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_e2, voff_ex, 8 * (s0 + u) * N, 0));
+                const float e3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_e3, voff_ex, 8 * (s0 + u) * N, 0));
+                const float e4 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_e4, voff_ex, 8 * (s0 + u) * N, 0));
+                fa[u] += ex.w2 * e2 + ex.w3 * e3 + ex.w4 * e4;
+            }
+            fb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, voff_x, 8 * (s0 + u) * d.ldx, 0));
+        }
+        if (act != SL_NONE) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                yy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_yv, voff_yv, 8 * (s0 + u) * d.ldyv, 0));
+            switch (act) {
+            case SL_TANH:
+#pragma unroll
+                for (int u = 0; u < 16; ++u) fa[u] *= 1.0f - yy[u] * yy[u];
+                break;
+            case SL_RELU:
+#pragma unroll
+                for (int u = 0; u < 16; ++u) fa[u] = yy[u] > 0.f ? fa[u] : 0.f;
+                break;
+            case SL_SIGMOID:
+#pragma unroll
+                for (int u = 0; u < 16; ++u) fa[u] *= yy[u] * (1.0f - yy[u]);
+                break;
+            default:
+#pragma unroll
+                for (int u = 0; u < 16; ++u) fa[u] = sl_dact(fa[u], yy[u], SL_QUICKGELU);
+                break;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            bsum += fa[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
+        }
+    }
+    if (d.dW != nullptr && k < K) {
+        // buffer stores: lane part (column k, the half's 4 rows) in one register, the register's row as a scalar offset; rows
+        // >= N fall outside the resource and are dropped by the bounds check
+        const int nbase = 64 * nt + 32 * wn;
+        const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)d.dW, 0, ((N - 1) * d.lddw + K) * 4, MIL_SRD_FLAGS);
+        const int voff_w = 4 * ((nbase + 4 * h) * d.lddw + k);
+#if defined(DWG_PLAIN_STORES)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int nn = nbase + mfma32_row(i, h);
+            if (nn < N) d.dW[(size_t)nn * d.lddw + k] = acc[i];
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[i];
+            asm volatile("" : "+v"(v));          // (hipcc 7.2 stored register 0 of the accumulator sixteen times without this)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_w, voff_w, 4 * ((i & 3) + 8 * (i >> 2)) * d.lddw, 0);
+        }
+#endif
+    }
+    if (d.db != nullptr && kt == 0 && wk == 0) {
+        const float tot = bsum + __shfl_xor(bsum, 32);
+        if (h == 0 && n < N) d.db[n] = tot;
+    }
+}
+
 template <int NW, bool EX>
 __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__ dy, int lddy, const float* __restrict__ yv,
                                                        int ldyv, int act, const float* __restrict__ x, int ldx,
@@ -168,48 +282,8 @@ __global__ __launch_bounds__(64 * NW) void k_small_bwd(const float* __restrict__
     if ((int)blockIdx.x < nW) {
         // ---- dW[n][k] = sum_m dpre[m][n] x[m][k]: 64 (n) x 128 (k) per workgroup, one 32 x 32 tile per wave (0..7)
         if (wave >= 8 || blockIdx.y != 0) return;
-        const int r = lane & 31, h = lane >> 5;
-        const int kt = blockIdx.x % nKt, nt = blockIdx.x / nKt;
-        const int wn = wave >> 2, wk = wave & 3;
-        const int n = 64 * nt + 32 * wn + r, k = 128 * kt + 32 * wk + r;
-        const int nc = min(n, N - 1), kc = min(k, K - 1);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        float bsum = 0.f;
-        const int steps = (M + 1) >> 1;
-        for (int s0 = 0; s0 < steps; s0 += 16) {
-            float fa[16], fb[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int m = 2 * (s0 + u) + h;
-                const int mm = min(m, M - 1);
-                float g = dy[(size_t)mm * lddy + nc];
-                if (EX)
-                    g += ex.w2 * ex.dy2[(size_t)mm * N + nc] + ex.w3 * ex.dy3[(size_t)mm * N + nc] + ex.w4 * ex.dy4[(size_t)mm * N + nc];
-                if (act != SL_NONE) g = sl_dact(g, yv[(size_t)mm * ldyv + nc], act);
-                fa[u] = m < M ? g : 0.f;
-                fb[u] = m < M ? x[(size_t)mm * ldx + kc] : 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                bsum += fa[u];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
-            }
-        }
-        if (dW != nullptr && k < K) {
-            const int nbase = 64 * nt + 32 * wn;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int nn = nbase + mfma32_row(i, h);
-                if (nn < N) dW[(size_t)nn * lddw + k] = acc[i];
-            }
-        }
-        if (db != nullptr && kt == 0 && wk == 0) {
-            const float tot = bsum + __shfl_xor(bsum, 32);
-            if (h == 0 && n < N) db[n] = tot;
-        }
+        const SlDwArgs d{dy, yv, x, dW, db, lddy, ldyv, ldx, lddw, act, M, N, K};
+        sl_dw_role<EX>(d, (int)blockIdx.x, ex);
         return;
     }
     // ---- dx[m][k] = sum_n dpre[m][n] W[n][k]: one 16 x 16 tile per workgroup, the waves split n.  dpre = dy * act'(.) of
@@ -526,98 +600,9 @@ __global__ __launch_bounds__(512) void k_small_dw_grouped(const SmallDwBatch bat
 #pragma unroll
     for (int stp = MIL_SMALL_DW_MAX / 2; stp >= 1; stp >>= 1)                                // 5 dependent scalar loads, not <= 31
         if (layer + stp < batch.n && (int)blockIdx.x >= batch.first[layer + stp]) layer += stp;
-    const mil_small_dw_desc& d = batch.d[layer];
-    const int wg = (int)blockIdx.x - batch.first[layer];
-    const int M = d.M, N = d.N, K = d.K, act = d.act;
-    const int nKt = (K + 127) / 128;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int kt = wg % nKt, nt = wg / nKt;
-    const int wn = wave >> 2, wk = wave & 3;
-    const int n = 64 * nt + 32 * wn + r, k = 128 * kt + 32 * wk + r;
-    const int nc = min(n, N - 1), kc = min(k, K - 1);
-    const float* __restrict__ dy = d.dy;
-    const float* __restrict__ yv = d.yv;
-    const float* __restrict__ x = d.x;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float bsum = 0.f;
-    const __amdgpu_buffer_rsrc_t srd_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, ((M - 1) * d.lddy + N) * 4, MIL_SRD_FLAGS);
-    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, ((M - 1) * d.ldx + K) * 4, MIL_SRD_FLAGS);
-    const __amdgpu_buffer_rsrc_t srd_yv =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(yv != nullptr ? yv : dy), 0, ((M - 1) * d.ldyv + N) * 4, MIL_SRD_FLAGS);
-    const int voff_dy = 4 * (h * d.lddy + nc), voff_x = 4 * (h * d.ldx + kc), voff_yv = 4 * (h * d.ldyv + nc);
-    const int steps = (M + 1) >> 1;
-    for (int s0 = 0; s0 < steps; s0 += 16) {
-        // every load of the trip first, unconditionally (clamped rows, masked afterwards), THEN the activation derivative under
-        // one wave-uniform switch: with the per-element `if (act ..)` / `m < M` forms the compiler emitted a load - wait -
-        // compute sequence per u, 16 dependent L2 round trips per workgroup (8.4 us for ONE 512 x 512 layer, 30 us for the 19
-        // layers of the fusion step against 7 us of write time)
-        // Buffer loads: ONE address register per operand (lane part: row parity h and the column; the row pair of trip u is a
-        // scalar offset), rows >= M read as zero through the resource's bounds check - 64-bit addresses per load held the kernel
-        // at 145 VGPRs = one workgroup per CU.
-        float fa[16], fb[16], yy[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            fa[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_dy, voff_dy, 8 * (s0 + u) * d.lddy, 0));
-            fb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, voff_x, 8 * (s0 + u) * d.ldx, 0));
-        }
-        if (act != SL_NONE) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                yy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_yv, voff_yv, 8 * (s0 + u) * d.ldyv, 0));
-            switch (act) {
-            case SL_TANH:
-#pragma unroll
-                for (int u = 0; u < 16; ++u) fa[u] *= 1.0f - yy[u] * yy[u];
-                break;
-            case SL_RELU:
-#pragma unroll
-                for (int u = 0; u < 16; ++u) fa[u] = yy[u] > 0.f ? fa[u] : 0.f;
-                break;
-            case SL_SIGMOID:
-#pragma unroll
-                for (int u = 0; u < 16; ++u) fa[u] *= yy[u] * (1.0f - yy[u]);
-                break;
-            default:
-#pragma unroll
-                for (int u = 0; u < 16; ++u) fa[u] = sl_dact(fa[u], yy[u], SL_QUICKGELU);
-                break;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            bsum += fa[u];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
-        }
-    }
-    if (d.dW != nullptr && k < K) {
-        // buffer stores: lane part (column k, the half's 4 rows) in one register, the register's row as a scalar offset; rows
-        // >= N fall outside the resource and are dropped by the bounds check
-        const int nbase = 64 * nt + 32 * wn;
-        const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)d.dW, 0, ((N - 1) * d.lddw + K) * 4, MIL_SRD_FLAGS);
-        const int voff_w = 4 * ((nbase + 4 * h) * d.lddw + k);
-#if defined(DWG_PLAIN_STORES)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int nn = nbase + mfma32_row(i, h);
-            if (nn < N) d.dW[(size_t)nn * d.lddw + k] = acc[i];
-        }
-#else
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = acc[i];
-            asm volatile("" : "+v"(v));          // (hipcc 7.2 stored register 0 of the accumulator sixteen times without this)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_w, voff_w, 4 * ((i & 3) + 8 * (i >> 2)) * d.lddw, 0);
-        }
-#endif
-    }
-    if (d.db != nullptr && kt == 0 && wk == 0) {
-        const float tot = bsum + __shfl_xor(bsum, 32);
-        if (h == 0 && n < N) d.db[n] = tot;
-    }
+    const mil_small_dw_desc& dd = batch.d[layer];
+    const SlDwArgs d{dd.dy, dd.yv, dd.x, dd.dW, dd.db, dd.lddy, dd.ldyv, dd.ldx, dd.lddw, dd.act, dd.M, dd.N, dd.K};
+    sl_dw_role<false>(d, (int)blockIdx.x - batch.first[layer], SmallDyExtra{});
 }
 
 static inline bool sl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
