@@ -1163,6 +1163,18 @@ __global__ __launch_bounds__(1024) void k_apool_merge_value(const float* __restr
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, H = AP_H, I = H * C;
     const int j4 = tid & 127, q = tid >> 7;                   // E == 512: 128 column threads per group
     const int g0 = bag_tile_off[b], g1 = bag_tile_off[b + 1];
+    // the value projection's weights (first 256 threads: `per` threads per output, 512 / per floats each) depend on nothing:
+    // requested now, they arrive under the merge - behind the last barrier they were four more round trips
+    const int per = 256 / C, vc = (tid & 255) / per, vpart = (tid & 255) % per;
+    f32x4 wvr[16];                                             // C = 32: 16 pieces of 16 bytes per thread, C = 64: 8
+    if (tid < 256) {
+        const float* w = Wv + (size_t)(h * C + vc) * E;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = 4 * vpart + 4 * per * u;
+            wvr[u] = j < E ? *reinterpret_cast<const f32x4*>(w + j) : f32x4{0, 0, 0, 0};
+        }
+    }
     float m = -INFINITY;
     for (int g = g0 + tid; g < g1; g += 1024) m = fmaxf(m, pml[((size_t)g * AP_H + h) * 2]);
     m = wave_allmax(m);
@@ -1212,20 +1224,31 @@ __global__ __launch_bounds__(1024) void k_apool_merge_value(const float* __restr
     }
     __syncthreads();
     if (tid >= 256) return;
-    const int per = 256 / C, c = tid / per, part = tid % per;
-    const float* w = Wv + (size_t)(h * C + c) * E;
+    const int c = vc, part = vpart;
     float v = 0.f;
-    for (int j0 = 4 * part; j0 < E; j0 += 16 * per) {
-        f32x4 gv[4], wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = min(j0 + 4 * per * u, E - 4);
-            gv[u] = *reinterpret_cast<const f32x4*>(&pl[0][j]);
-            wv[u] = *reinterpret_cast<const f32x4*>(w + j);
+    for (int u = 0; u < 16; ++u) {                              // same pieces in the same order as the four-at-a-time loop
+        const int j = 4 * part + 4 * per * u;
+        if (j < E) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(&pl[0][j]);
+            v += gv[0] * wvr[u][0] + gv[1] * wvr[u][1] + gv[2] * wvr[u][2] + gv[3] * wvr[u][3];
+        }
+    }
+    if (4 * per * 16 < E) {                                     // C = 64: the second half of the row, one batch
+        const float* w = Wv + (size_t)(h * C + c) * E;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = 4 * part + 4 * per * (16 + u);
+            wvr[u] = j < E ? *reinterpret_cast<const f32x4*>(w + j) : f32x4{0, 0, 0, 0};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (j0 + 4 * per * u < E) v += gv[u][0] * wv[u][0] + gv[u][1] * wv[u][1] + gv[u][2] * wv[u][2] + gv[u][3] * wv[u][3];
+        for (int u = 0; u < 16; ++u) {
+            const int j = 4 * part + 4 * per * (16 + u);
+            if (j < E) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(&pl[0][j]);
+                v += gv[0] * wvr[u][0] + gv[1] * wvr[u][1] + gv[2] * wvr[u][2] + gv[3] * wvr[u][3];
+            }
+        }
     }
     for (int m2 = per >> 1; m2 >= 1; m2 >>= 1) v += __shfl_xor(v, m2);
     if (part == 0) o[(size_t)b * I + h * C + c] = v + bv[h * C + c];
