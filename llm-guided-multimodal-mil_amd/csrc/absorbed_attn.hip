@@ -738,6 +738,10 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_bwd_r16(const float* __restrict
 // site where the three kernels moved 5 (and the round-3 form 7).  The bag's 16 vectors [scale Qp | dpooled] live in LDS
 // (32 KB, 16-byte reads, conflict-free; 64 KB per row and wave = 14 us of LDS time per site next to 37 us of HBM time); the
 // same 32 KB fold the four waves' dQp partials afterwards.
+// LN = false: the plain absorbed pool (the first block: its keys are the image projection, no norm in front): x holds the
+// keys themselves, dx = dy_acc + the rank-16 update, no dgamma / dbeta / do partials - the one-pass form of k_apool_dots +
+// k_apool_bwd_apply<true>.
+template <bool LN>
 __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __restrict__ x, const float* __restrict__ o,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ stats, const float* __restrict__ dy_acc,
@@ -804,9 +808,11 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
     f32x4 gm[NQ], bt[NQ], ov[NQ], dg[NQ], db[NQ], d0[NQ], dq[AP_H][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        gm[q] = *reinterpret_cast<const f32x4*>(gamma + 256 * q + 4 * lane);
-        bt[q] = *reinterpret_cast<const f32x4*>(beta + 256 * q + 4 * lane);
-        ov[q] = *reinterpret_cast<const f32x4*>(o + (size_t)b * E + 256 * q + 4 * lane);
+        if (LN) {
+            gm[q] = *reinterpret_cast<const f32x4*>(gamma + 256 * q + 4 * lane);
+            bt[q] = *reinterpret_cast<const f32x4*>(beta + 256 * q + 4 * lane);
+            ov[q] = *reinterpret_cast<const f32x4*>(o + (size_t)b * E + 256 * q + 4 * lane);
+        }
         dg[q] = db[q] = d0[q] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int h = 0; h < AP_H; ++h) dq[h][q] = f32x4{0, 0, 0, 0};
@@ -819,12 +825,17 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
     const float* Vl = V + 4 * lane;
     auto one_row = [&](int rr, f32x4 (&xn)[NQ], f32x4 (&dn)[NQ], f32x4 (&pn)[NQ]) {
         const size_t row = (size_t)(key0 + rr);
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float mean = 0.f, rstd = 1.f;
+        if (LN) { mean = stats[2 * row]; rstd = stats[2 * row + 1]; }
         f32x4 xh[NQ], y[NQ], kin[NQ], d[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            xh[q] = (xn[q] + ov[q] - mean) * rstd;
-            y[q] = xh[q] * gm[q] + bt[q];
+            if (LN) {
+                xh[q] = (xn[q] + ov[q] - mean) * rstd;
+                y[q] = xh[q] * gm[q] + bt[q];
+            } else {
+                y[q] = xn[q];
+            }
             kin[q] = y[q] + pn[q];
             d[q] = dn[q];
         }
@@ -859,6 +870,11 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
             dq[h][0] += th[h] * kin[0];
             dq[h][1] += th[h] * kin[1];
         }
+        if (!LN) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dx + row * E + 256 * q + 4 * lane) = d[q];
+            return;
+        }
         f32x4 gg[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -881,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
         if (rr + 4 < nkeys) one_row(rr + 4, xb, db_, pb);
     }
     // fold of the four waves: dgamma / dbeta / do through red3; dQp through the 32 KB of V in two rounds (3, 2 -> 1, 0; 1 -> 0)
-    if (wave > 0) {
+    if (LN && wave > 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             *reinterpret_cast<f32x4*>(&red3[wave - 1][0][256 * q + 4 * lane]) = dg[q];
@@ -919,17 +935,19 @@ __global__ __launch_bounds__(256, 2) void k_lnbr_apool_bwd_one(const float* __re
                 const f32x4 v = dq[h][q] + *reinterpret_cast<const f32x4*>(V + h * E + 256 * q + 4 * lane);
                 *reinterpret_cast<f32x4*>(pdq + ((size_t)g * AP_H + h) * E + 256 * q + 4 * lane) = v * scale;
             }
+        if (LN) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                dg[q] += *reinterpret_cast<const f32x4*>(&red3[w][0][256 * q + 4 * lane]);
-                db[q] += *reinterpret_cast<const f32x4*>(&red3[w][1][256 * q + 4 * lane]);
-                d0[q] += *reinterpret_cast<const f32x4*>(&red3[w][2][256 * q + 4 * lane]);
+                for (int w = 0; w < 3; ++w) {
+                    dg[q] += *reinterpret_cast<const f32x4*>(&red3[w][0][256 * q + 4 * lane]);
+                    db[q] += *reinterpret_cast<const f32x4*>(&red3[w][1][256 * q + 4 * lane]);
+                    d0[q] += *reinterpret_cast<const f32x4*>(&red3[w][2][256 * q + 4 * lane]);
+                }
+                *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 0) * E + 256 * q + 4 * lane) = dg[q];
+                *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 1) * E + 256 * q + 4 * lane) = db[q];
+                *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 2) * E + 256 * q + 4 * lane) = d0[q];
             }
-            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 0) * E + 256 * q + 4 * lane) = dg[q];
-            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 1) * E + 256 * q + 4 * lane) = db[q];
-            *reinterpret_cast<f32x4*>(part + ((size_t)g * 3 + 2) * E + 256 * q + 4 * lane) = d0[q];
         }
     }
 }
@@ -1627,6 +1645,11 @@ extern "C" int mil_value_proj_bwd(const float* dO, const float* Wv, const float*
     return MIL_OK;
 }
 
+static bool lnbr_bwd_one_pass() {
+    const char* e = getenv("MIL_LNBR_BWD");            // read per call (a call is a capture-time event under a hipGraph)
+    return e == nullptr || strcmp(e, "r16") != 0;
+}
+
 extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const float* Qp, const float* lse,
                                      const float* dpooled, const float* pooled, const int32_t* k_off,
                                      const int32_t* tile_map, const int32_t* bag_tile_off, int ntiles, int n_keys, int B,
@@ -1639,7 +1662,13 @@ extern "C" int mil_absorbed_pool_bwd(const float* keys, const float* pe, const f
     const float scale = 1.0f / sqrtf((float)C);
     float* pdq = workspace;                                    // [ntiles][H][E]
     float* ad = workspace + (size_t)ntiles * AP_H * E;         // [n_keys][16]
-    if (ntiles > 0) {
+    if (ntiles > 0 && lnbr_bwd_one_pass()) {
+        // one pass over the rows (round 4; MIL_LNBR_BWD=r16 keeps the dots + apply pair): keys, dkeys_acc in, dkeys out
+        hipLaunchKernelGGL(k_lnbr_apool_bwd_one<false>, dim3(ntiles), dim3(256), 0, st, keys, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, dkeys_acc, pe, Qp, dpooled, pooled, lse, k_off, tile_map, scale,
+                           dkeys, (float*)nullptr, pdq);
+        MIL_CHECK_LAUNCH();
+    } else if (ntiles > 0) {
         hipLaunchKernelGGL(k_apool_dots, dim3(ntiles), dim3(256), 0, st, keys, pe, Qp, lse, dpooled, pooled, k_off, tile_map,
                            scale, ad);
         MIL_CHECK_LAUNCH();
@@ -1682,11 +1711,6 @@ extern "C" int mil_lnbr_absorbed_pool_value_fwd(const float* x, const float* o, 
 // one fold of all partials (MIL_LNBR_BWD=r16: the three-kernel form it replaces - per-row dots, per-tile dQp partials, the
 // LayerNorm backward with the pool's rank-16 update folded into its load - kept as the cross-check of the tests).
 // workspace: ntiles H E + 16 n_keys + 3 ntiles E floats.
-static bool lnbr_bwd_one_pass() {
-    const char* e = getenv("MIL_LNBR_BWD");            // read per call (a call is a capture-time event under a hipGraph)
-    return e == nullptr || strcmp(e, "r16") != 0;
-}
-
 extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const float* gamma, const float* beta, const float* stats, const float* y,
                                           const float* pe, const float* Qp, const float* lse, const float* dpooled,
                                           const float* pooled, const int32_t* k_off, const int32_t* tile_map,
@@ -1702,7 +1726,7 @@ extern "C" int mil_lnbr_absorbed_pool_bwd(const float* x, const float* o, const 
     float* ad = pdq + (size_t)ntiles * AP_H * E;               // [n_keys][16]
     float* part = ad + (size_t)16 * n_keys;                    // [ntiles][3][E]
     if (ntiles > 0 && lnbr_bwd_one_pass()) {
-        hipLaunchKernelGGL(k_lnbr_apool_bwd_one, dim3(ntiles), dim3(256), 0, st, x, o, gamma, beta, stats, dy_acc, pe, Qp, dpooled, pooled,
+        hipLaunchKernelGGL(k_lnbr_apool_bwd_one<true>, dim3(ntiles), dim3(256), 0, st, x, o, gamma, beta, stats, dy_acc, pe, Qp, dpooled, pooled,
                            lse, k_off, tile_map, scale, dx, part, pdq);
         MIL_CHECK_LAUNCH();
     } else if (ntiles > 0) {

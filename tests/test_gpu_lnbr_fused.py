@@ -157,3 +157,23 @@ def test_transformer_with_and_without_the_fused_pairs():
     assert set(a[4]) == set(b[4])
     for nm in a[4]:
         assert rel_err(a[4][nm], b[4][nm]) <= 1e-4, (nm, rel_err(a[4][nm], b[4][nm]))
+
+
+def test_plain_pool_backward_one_pass_matches_the_two_kernel_form(monkeypatch):
+    """ops.one_token_attention (no norm in front: the first block's site): k_lnbr_apool_bwd_one<false> (default) against
+    k_apool_dots + k_apool_bwd_apply (MIL_LNBR_BWD=r16), with a second consumer's gradient on the keys."""
+    lengths, C = [300, 77, 512, 129], 32
+    t, pe, do, dy = _inputs(lengths, C, seed=31)
+    B = len(lengths)
+    s_ti = AttnSegs.make([1] * B, lengths, torch.device(DEV))
+
+    def run():
+        lv = {k: t[k].clone().requires_grad_(True) for k in ("x", "qp", "Wk", "Wv", "bv")}
+        o, keys = ops.one_token_attention(None, lv["x"], pe, s_ti, None, None, lv["Wk"], lv["Wv"], lv["bv"], H, qp=lv["qp"])
+        ((o * do).sum() + (keys * dy).sum()).backward()
+        return {k: v.grad for k, v in lv.items()}
+    g1 = run()
+    monkeypatch.setenv("MIL_LNBR_BWD", "r16")
+    g0 = run()
+    for name in g0:
+        assert rel_err(g1[name], g0[name]) <= 1e-5, (name, rel_err(g1[name], g0[name]))
