@@ -82,8 +82,18 @@ extern "C" int mil_dropout_keep_bits(uint32_t* bits, int rows, int cols, float p
 __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __restrict__ xbits, size_t nx, uint32_t xs_lo,
                                                                 uint32_t xs_hi, uint32_t* __restrict__ mbits, size_t nm,
                                                                 uint32_t ms_lo, uint32_t ms_hi, uint64_t offset,
-                                                                const int32_t* __restrict__ offset_dev, unsigned xblocks) {
+                                                                const int32_t* __restrict__ offset_dev, unsigned xblocks,
+                                                                int32_t* __restrict__ advance, int32_t* __restrict__ done) {
     if (offset_dev != nullptr) offset += (uint64_t)(uint32_t)offset_dev[0];
+    if (advance != nullptr && threadIdx.x == 0) {
+        // every workgroup has read the counter before it signs off; the last one to do so advances it (the module route's
+        // separate counter launch rides here: mil_dropout_keep_bits_pair)
+        const int prev = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == (int)gridDim.x - 1) {
+            __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(advance, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     const uint32_t o_lo = (uint32_t)offset, o_hi = (uint32_t)(offset >> 32);
     if (blockIdx.x < xblocks) {
         const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x, w0 = blk * 4;
@@ -104,17 +114,31 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
 }
 
 // Internal (step.hip, gated_pool.hip): mil_dropout_keep_bits(xbits, R, L, 0.5, seed ..) + (mbits, B, L, 0.25, mseed ..)
-int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
-                           const int32_t* offset_dev, void* stream) {
-    if (!xbits || !mbits || R < 0 || B < 0 || L <= 0 || (L % 32) != 0) return MIL_EINVAL;
+static int keep_bits_pair_impl(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
+                               uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done, void* stream) {
+    if ((R > 0 && !xbits) || (B > 0 && !mbits) || R < 0 || B < 0 || L <= 0 || (L % 32) != 0) return MIL_EINVAL;
+    if ((advance != nullptr) != (done != nullptr)) return MIL_EINVAL;
     const size_t nx = (size_t)R * (L / 32), nm = (size_t)B * (L / 32);
     if (nx + nm == 0) return MIL_OK;
     const unsigned xblocks = (unsigned)(((nx + 3) / 4 + 255) / 256), mblocks = (unsigned)(((nm + 1) / 2 + 255) / 256);
     hipLaunchKernelGGL(k_dropout_keep_bits_pair, dim3(xblocks + mblocks), dim3(256), 0, (hipStream_t)stream, xbits, nx,
                        (uint32_t)seed, (uint32_t)(seed >> 32), mbits, nm, (uint32_t)mseed, (uint32_t)(mseed >> 32), offset,
-                       offset_dev, xblocks);
+                       offset_dev, xblocks, advance, done);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
+                           const int32_t* offset_dev, void* stream) {
+    if (!xbits || !mbits) return MIL_EINVAL;
+    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, nullptr, nullptr, stream);
+}
+// The module route's three launches (patch keep bits, the pass counter's increment, the head's keep words) as one: both
+// tensors drawn at stream position offset + offset_dev[0] (keys seed / mseed), then - by the last workgroup to sign off -
+// advance[0] += 1 (advance, done: both or neither; done: a zero word between launches).  R == 0 or B == 0: that tensor only.
+extern "C" int mil_dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
+                                          uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done,
+                                          void* stream) {
+    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, advance, done, stream);
 }
 
 // dx[row][col] = keep ? dx * scale : 0 in place (autograd route: backward through the patch dropout when the gradient

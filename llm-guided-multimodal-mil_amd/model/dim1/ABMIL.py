@@ -27,19 +27,23 @@ class ABMIL(nn.Module):
         self.last_xbits: Optional[torch.Tensor] = None
         self._drop_seed: Optional[int] = None
         self._drop_ctr: Optional[torch.Tensor] = None
+        self._drop_done: Optional[torch.Tensor] = None
 
     def _keep_bits(self, x: torch.Tensor):
         """Keep bits of Dropout(0.5) on the patch features (ABMIL.py:49: the dropped x is also what gets pooled).  No dropped
         copy: a Philox keep-bit tensor (1/32 of x) that the gate, pool and backward kernels read x through
         (csrc/dropout.hip).  seed: torch's generator, so torch.manual_seed governs the masks; offset: a per-module pass
         counter kept ON THE DEVICE, so a step replayed from a hipGraph (graph_step.py) draws a fresh mask every replay."""
-        if self._drop_seed is None or self._drop_ctr is None or self._drop_ctr.device != x.device:
-            self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            self._drop_ctr = torch.zeros(1, device=x.device, dtype=torch.int32)
-        xbits = ops.dropout_keep_bits(x.shape[0], x.shape[1], ops.X_DROP_P, self._drop_seed, 0, x.device,
-                                      offset_dev=self._drop_ctr)
-        ops.counter_add(self._drop_ctr, 1)
+        self._drop_state(x.device)
+        xbits, _ = ops.dropout_keep_bits_pair(x.shape[0], 0, x.shape[1], self._drop_seed, 0, self._drop_ctr, self._drop_done)
         return xbits
+
+    def _drop_state(self, device):
+        if self._drop_seed is None:
+            self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if self._drop_ctr is None or self._drop_ctr.device != device:
+            self._drop_ctr = torch.zeros(1, device=device, dtype=torch.int32)
+            self._drop_done = torch.zeros(1, device=device, dtype=torch.int32)     # sign-off word of the generator launch
 
     def _gate_params(self):
         return (self.attention_V[0].weight, self.attention_V[0].bias, self.attention_U[0].weight, self.attention_U[0].bias,
@@ -66,18 +70,14 @@ class ABMIL(nn.Module):
                        head_train: bool = False):
         """Pool + Dropout(.25) + head + sigmoid + loss in one autograd node (ops.gated_pool_head_loss): rows x [R, L] of all
         bags, labels y [B, C] -> (loss, prob, logits).  Used by aggregator.forward(labels=...)."""
-        xbits = self._keep_bits(x) if self.training else None
-        mbits = None
-        if head_train:
-            # the head's Dropout(.25) (aggregator.py:129) inside the fused tail: [B, L/32] keep words, same generator
-            if self._drop_seed is None:
-                self._drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            if self._drop_ctr is None or self._drop_ctr.device != x.device:
-                self._drop_ctr = torch.zeros(1, device=x.device, dtype=torch.int32)
-            mbits = ops.dropout_keep_bits(layout.B, x.shape[1], ops.M_DROP_P, self._drop_seed ^ 0x9E3779B97F4A7C15, 0,
-                                          x.device, offset_dev=self._drop_ctr)
-            if xbits is None:
-                ops.counter_add(self._drop_ctr, 1)
+        xbits = mbits = None
+        if self.training or head_train:
+            # patch keep bits (Dropout(.5), ABMIL.py:49) and the head's keep words (Dropout(.25), aggregator.py:129: inside
+            # the fused tail) from one generator launch at the same stream position, which also advances the pass counter
+            self._drop_state(x.device)
+            xbits, mbits = ops.dropout_keep_bits_pair(x.shape[0] if self.training else 0, layout.B if head_train else 0,
+                                                      x.shape[1], self._drop_seed, self._drop_seed ^ 0x9E3779B97F4A7C15,
+                                                      self._drop_ctr, self._drop_done)
         self.last_xbits, self.last_mbits = xbits, mbits
         loss, prob, z, M = ops.gated_pool_head_loss(x, *self._gate_params(), fc_weight, fc_bias, y, layout, scale, loss_kind,
                                                     xbits, mbits)

@@ -53,6 +53,19 @@ def dropout_keep_bits(rows: int, cols: int, p_drop: float, seed: int, offset: in
     return out
 
 
+def dropout_keep_bits_pair(rows: int, bags: int, cols: int, seed: int, mseed: int, counter, done):
+    """(xbits [rows, cols/32] at p = 0.5, mbits [bags, cols/32] at p = 0.25) drawn at stream position counter[0] in ONE launch
+    that also advances the counter (mil_dropout_keep_bits_pair); rows == 0 / bags == 0: that tensor is None."""
+    dev = counter.device
+    xb = torch.empty((rows, cols // 32), device=dev, dtype=torch.int32) if rows else None
+    mb = torch.empty((bags, cols // 32), device=dev, dtype=torch.int32) if bags else None
+    m64 = 2 ** 64 - 1
+    rc = _lib.lib().mil_dropout_keep_bits_pair(_p(xb), rows, _p(mb), bags, cols, int(seed) & m64, int(mseed) & m64, 0,
+                                               _p(counter), _p(counter), _p(done), _stream())
+    _lib.check(rc, "mil_dropout_keep_bits_pair")
+    return xb, mb
+
+
 def counter_add(counter, v: int = 1):
     """counter[0] += v on the current stream (device int32)."""
     rc = _lib.lib().mil_counter_add(_p(counter), int(v), _stream())
