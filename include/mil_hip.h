@@ -75,11 +75,12 @@ int mil_abi_version(void);   /* 6 */
 int mil_dropout_keep_bits(uint32_t* bits, int rows, int cols, float p_drop, uint64_t seed, uint64_t offset,
                           const int32_t* offset_dev, void* stream);
 /* Round 4 - the fusion model's route: patch keep bits [R, L/32] (p = 0.5, key seed) and the head's keep words [B, L/32]
- * (p = 0.25, key mseed) at the SAME stream position offset + offset_dev[0] in one launch whose last workgroup advances
+ * (p = 0.25, key mseed; mdelta >= 0 stream positions further) at stream position offset + offset_dev[0] in one launch whose last workgroup advances
  * advance[0] by one (advance / done both or neither; done = a zero int32 between launches) - the counter launch and the
  * second generator launch of a captured train-mode step are gone.  R == 0 or B == 0: the other tensor alone. */
 int mil_dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
-                               uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done, void* stream);
+                               uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done, int mdelta,
+                               void* stream);
 /* counter[0] += v on the stream (a device-side pass counter that a replayed hipGraph advances: dropout offsets). */
 int mil_counter_add(int32_t* counter, int v, void* stream);
 /* dst[0..n) = values_host[0..n), n <= 8, the values travelling as kernel arguments of one tiny launch (no staging copy): the

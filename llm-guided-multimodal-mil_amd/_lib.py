@@ -21,7 +21,7 @@ _P = c_void_p
 SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "mil_abi_version": (c_int, []),
     "mil_dropout_keep_bits": (c_int, [_P, c_int, c_int, c_float, c_uint64, c_uint64, _P, _P]),
-    "mil_dropout_keep_bits_pair": (c_int, [_P, c_int, _P, c_int, c_int, c_uint64, c_uint64, c_uint64, _P, _P, _P, _P]),
+    "mil_dropout_keep_bits_pair": (c_int, [_P, c_int, _P, c_int, c_int, c_uint64, c_uint64, c_uint64, _P, _P, _P, c_int, _P]),
     "mil_dropout_apply_bits": (c_int, [_P, _P, c_int, c_int, c_float, _P]),
     "mil_counter_add": (c_int, [_P, c_int, _P]),
     "mil_gate_scores_fwd": (c_int, [_P] * 9 + [c_int, c_int, c_int, _P, c_float, _P]),

@@ -83,8 +83,18 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
                                                                 uint32_t xs_hi, uint32_t* __restrict__ mbits, size_t nm,
                                                                 uint32_t ms_lo, uint32_t ms_hi, uint64_t offset,
                                                                 const int32_t* __restrict__ offset_dev, unsigned xblocks,
-                                                                int32_t* __restrict__ advance, int32_t* __restrict__ done) {
-    if (offset_dev != nullptr) offset += (uint64_t)(uint32_t)offset_dev[0];
+                                                                int32_t* __restrict__ advance, int32_t* __restrict__ done,
+                                                                uint32_t mdelta) {
+    if (advance != nullptr) {
+        // the counter is read by ONE thread and handed to the others through LDS: that thread signs off only after its own
+        // read has returned, so no wave of a workgroup can see the value the last workgroup to sign off writes
+        __shared__ uint32_t off_lds;
+        if (threadIdx.x == 0) off_lds = offset_dev != nullptr ? (uint32_t)offset_dev[0] : 0u;
+        __syncthreads();
+        offset += (uint64_t)off_lds;
+    } else if (offset_dev != nullptr) {
+        offset += (uint64_t)(uint32_t)offset_dev[0];
+    }
     if (advance != nullptr && threadIdx.x == 0) {
         // every workgroup has read the counter before it signs off; the last one to do so advances it (the module route's
         // separate counter launch rides here: mil_dropout_keep_bits_pair)
@@ -107,7 +117,8 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
     } else {
         const size_t blk = (size_t)(blockIdx.x - xblocks) * 256 + threadIdx.x, w0 = blk * 2;
         if (w0 >= nm) return;
-        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), o_lo, o_hi, ms_lo, ms_hi);
+        const uint64_t mo = offset + mdelta;              // the head's words mdelta stream positions behind the patch bits
+        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)mo, (uint32_t)(mo >> 32), ms_lo, ms_hi);
         mbits[w0] = ~(r.v[0] & r.v[1]);
         if (w0 + 1 < nm) mbits[w0 + 1] = ~(r.v[2] & r.v[3]);
     }
@@ -115,7 +126,8 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
 
 // Internal (step.hip, gated_pool.hip): mil_dropout_keep_bits(xbits, R, L, 0.5, seed ..) + (mbits, B, L, 0.25, mseed ..)
 static int keep_bits_pair_impl(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
-                               uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done, void* stream) {
+                               uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done, uint32_t mdelta,
+                               void* stream) {
     if ((R > 0 && !xbits) || (B > 0 && !mbits) || R < 0 || B < 0 || L <= 0 || (L % 32) != 0) return MIL_EINVAL;
     if ((advance != nullptr) != (done != nullptr)) return MIL_EINVAL;
     const size_t nx = (size_t)R * (L / 32), nm = (size_t)B * (L / 32);
@@ -123,22 +135,24 @@ static int keep_bits_pair_impl(uint32_t* xbits, int R, uint32_t* mbits, int B, i
     const unsigned xblocks = (unsigned)(((nx + 3) / 4 + 255) / 256), mblocks = (unsigned)(((nm + 1) / 2 + 255) / 256);
     hipLaunchKernelGGL(k_dropout_keep_bits_pair, dim3(xblocks + mblocks), dim3(256), 0, (hipStream_t)stream, xbits, nx,
                        (uint32_t)seed, (uint32_t)(seed >> 32), mbits, nm, (uint32_t)mseed, (uint32_t)(mseed >> 32), offset,
-                       offset_dev, xblocks, advance, done);
+                       offset_dev, xblocks, advance, done, mdelta);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
                            const int32_t* offset_dev, void* stream) {
     if (!xbits || !mbits) return MIL_EINVAL;
-    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, nullptr, nullptr, stream);
+    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, nullptr, nullptr, 0u, stream);
 }
 // The module route's three launches (patch keep bits, the pass counter's increment, the head's keep words) as one: both
-// tensors drawn at stream position offset + offset_dev[0] (keys seed / mseed), then - by the last workgroup to sign off -
-// advance[0] += 1 (advance, done: both or neither; done: a zero word between launches).  R == 0 or B == 0: that tensor only.
+// tensors drawn at stream position offset + offset_dev[0] (keys seed / mseed; the head's words mdelta positions further: 1 =
+// where the module route's separate launch drew them, behind the counter's increment), then - by the last workgroup to sign
+// off - advance[0] += 1 (advance, done: both or neither; done: a zero word between launches).  R == 0 or B == 0: that tensor only.
 extern "C" int mil_dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
                                           uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done,
-                                          void* stream) {
-    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, advance, done, stream);
+                                          int mdelta, void* stream) {
+    if (mdelta < 0) return MIL_EINVAL;
+    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, advance, done, (uint32_t)mdelta, stream);
 }
 
 // dx[row][col] = keep ? dx * scale : 0 in place (autograd route: backward through the patch dropout when the gradient

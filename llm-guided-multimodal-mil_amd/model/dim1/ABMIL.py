@@ -73,7 +73,7 @@ class ABMIL(nn.Module):
         xbits = mbits = None
         if self.training or head_train:
             # patch keep bits (Dropout(.5), ABMIL.py:49) and the head's keep words (Dropout(.25), aggregator.py:129: inside
-            # the fused tail) from one generator launch at the same stream position, which also advances the pass counter
+            # the fused tail) from one generator launch (the words one stream position behind the bits, where the separate launch drew them), which also advances the pass counter
             self._drop_state(x.device)
             xbits, mbits = ops.dropout_keep_bits_pair(x.shape[0] if self.training else 0, layout.B if head_train else 0,
                                                       x.shape[1], self._drop_seed, self._drop_seed ^ 0x9E3779B97F4A7C15,

@@ -60,8 +60,9 @@ def dropout_keep_bits_pair(rows: int, bags: int, cols: int, seed: int, mseed: in
     xb = torch.empty((rows, cols // 32), device=dev, dtype=torch.int32) if rows else None
     mb = torch.empty((bags, cols // 32), device=dev, dtype=torch.int32) if bags else None
     m64 = 2 ** 64 - 1
+    # mdelta = 1: the head's words at the position the separate launch drew them (behind the counter's increment)
     rc = _lib.lib().mil_dropout_keep_bits_pair(_p(xb), rows, _p(mb), bags, cols, int(seed) & m64, int(mseed) & m64, 0,
-                                               _p(counter), _p(counter), _p(done), _stream())
+                                               _p(counter), _p(counter), _p(done), 1, _stream())
     _lib.check(rc, "mil_dropout_keep_bits_pair")
     return xb, mb
 
