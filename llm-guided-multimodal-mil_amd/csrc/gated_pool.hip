@@ -2263,7 +2263,15 @@ __global__ __launch_bounds__(256) void k_gate_bwd_dx(const float* __restrict__ g
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int NJ = L / 128;
-    const int jt = blockIdx.x % NJ, rt = blockIdx.x / NJ;
+    // XCD-aware order (as the weight-gradient kernels): the NJ column tiles of a row tile read the same 128 x 384 gates; with
+    // the hardware's round-robin of workgroup ids over the 8 XCDs they sat on NJ different L2s (PMC: 200 MiB fetched for 48 MiB
+    // of gates).  logical = (id % 8) * share + id / 8 puts them on consecutive slots of ONE XCD.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int jt = bid % NJ, rt = bid / NJ;
     const int row0 = rt * 128, j0 = jt * 128;
 
     // A producer: thread -> unit quad dq = tid & 3 (d = 16 kk + 4 dq ..+3), rows (tid >> 2) + 64 i (i < 2)

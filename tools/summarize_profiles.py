@@ -132,6 +132,14 @@ with open(os.path.join(DST, f"{TAG}_hbm_traffic_pmc.csv"), "w") as o:
             tot3[name] += sum(vals) * mult * 1024.0
             if k.startswith("k_gemm_nt2"):
                 steps3[name] = len(vals)
+    # per-kernel rows of config 3's heavy launches (the fused LayerNorm + pool pairs are HBM-bound streams: their bytes per
+    # launch against the algorithmic x + dy in, dx out are what DESIGN 4.4 quotes)
+    for name, sub, mult in (("FETCH_SIZE", "fetch_cfg3", 2.0), ("WRITE_SIZE", "write_cfg3", 1.0)):
+        for k, v in sorted(pmc(sub).items()):
+            vals = v.get(name, [])
+            if vals and k.startswith(("k_lnbr_", "k_apool_partial", "k_gemm_nt2", "k_gemm_tn2", "k_gate_fwd2", "k_gate_bwd_d", "k_adam_segs")):
+                m = sum(vals) / len(vals)
+                o.write(f"cfg3,{k},{name},{len(vals)},{m:.1f},{m * mult / 1024:.1f}\n")
     if steps3["FETCH_SIZE"] and steps3["WRITE_SIZE"]:
         rd, wr = tot3["FETCH_SIZE"] / steps3["FETCH_SIZE"], tot3["WRITE_SIZE"] / steps3["WRITE_SIZE"]
         traffic["cfg3:step"] = rd + wr
