@@ -84,7 +84,13 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
                                                                 uint32_t ms_lo, uint32_t ms_hi, uint64_t offset,
                                                                 const int32_t* __restrict__ offset_dev, unsigned xblocks,
                                                                 int32_t* __restrict__ advance, int32_t* __restrict__ done,
-                                                                uint32_t mdelta) {
+                                                                uint32_t mdelta, TileMapJob tm) {
+    if (tm.bag_len != nullptr && blockIdx.x == gridDim.x - 1) {
+        // the LAST workgroup of the launch is not a generator block: it builds the step's tile map (a 5 us launch of its own
+        // in front of every one-ragged-bag step otherwise)
+        build_tile_map_block(tm.bag_len, tm.B, tm.tile_map, tm.bag_tile_off, tm.rows_out, tm.T_cap);
+        return;
+    }
     if (advance != nullptr) {
         // the counter is read by ONE thread and handed to the others through LDS: that thread signs off only after its own
         // read has returned, so no wave of a workgroup can see the value the last workgroup to sign off writes
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
         // every workgroup has read the counter before it signs off; the last one to do so advances it (the module route's
         // separate counter launch rides here: mil_dropout_keep_bits_pair)
         const int prev = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == (int)gridDim.x - 1) {
+        if (prev == (int)gridDim.x - 1 - (tm.bag_len != nullptr ? 1 : 0)) {
             __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(advance, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -127,15 +133,15 @@ __global__ __launch_bounds__(256) void k_dropout_keep_bits_pair(uint32_t* __rest
 // Internal (step.hip, gated_pool.hip): mil_dropout_keep_bits(xbits, R, L, 0.5, seed ..) + (mbits, B, L, 0.25, mseed ..)
 static int keep_bits_pair_impl(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
                                uint64_t offset, const int32_t* offset_dev, int32_t* advance, int32_t* done, uint32_t mdelta,
-                               void* stream) {
+                               void* stream, TileMapJob tm = TileMapJob{nullptr, 0, nullptr, nullptr, nullptr, 0}) {
     if ((R > 0 && !xbits) || (B > 0 && !mbits) || R < 0 || B < 0 || L <= 0 || (L % 32) != 0) return MIL_EINVAL;
     if ((advance != nullptr) != (done != nullptr)) return MIL_EINVAL;
     const size_t nx = (size_t)R * (L / 32), nm = (size_t)B * (L / 32);
-    if (nx + nm == 0) return MIL_OK;
+    if (nx + nm == 0 && tm.bag_len == nullptr) return MIL_OK;
     const unsigned xblocks = (unsigned)(((nx + 3) / 4 + 255) / 256), mblocks = (unsigned)(((nm + 1) / 2 + 255) / 256);
-    hipLaunchKernelGGL(k_dropout_keep_bits_pair, dim3(xblocks + mblocks), dim3(256), 0, (hipStream_t)stream, xbits, nx,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), mbits, nm, (uint32_t)mseed, (uint32_t)(mseed >> 32), offset,
-                       offset_dev, xblocks, advance, done, mdelta);
+    hipLaunchKernelGGL(k_dropout_keep_bits_pair, dim3(xblocks + mblocks + (tm.bag_len != nullptr ? 1 : 0)), dim3(256), 0,
+                       (hipStream_t)stream, xbits, nx, (uint32_t)seed, (uint32_t)(seed >> 32), mbits, nm, (uint32_t)mseed,
+                       (uint32_t)(mseed >> 32), offset, offset_dev, xblocks, advance, done, mdelta, tm);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
@@ -143,6 +149,14 @@ int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L
                            const int32_t* offset_dev, void* stream) {
     if (!xbits || !mbits) return MIL_EINVAL;
     return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, nullptr, nullptr, 0u, stream);
+}
+// Internal (step.hip): dropout_keep_bits_pair + mil_build_tile_map in ONE launch (the map is built by an extra workgroup).
+int dropout_keep_bits_pair_tilemap(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
+                                   uint64_t offset, const int32_t* offset_dev, const TileMapJob& tm, void* stream) {
+    if (!xbits || !mbits || !tm.bag_len || !tm.tile_map || !tm.bag_tile_off || !tm.rows_out || tm.B <= 0 || tm.B > 1024 ||
+        tm.T_cap < 0)
+        return MIL_EINVAL;
+    return keep_bits_pair_impl(xbits, R, mbits, B, L, seed, mseed, offset, offset_dev, nullptr, nullptr, 0u, stream, tm);
 }
 // The module route's three launches (patch keep bits, the pass counter's increment, the head's keep words) as one: both
 // tensors drawn at stream position offset + offset_dev[0] (keys seed / mseed; the head's words mdelta positions further: 1 =

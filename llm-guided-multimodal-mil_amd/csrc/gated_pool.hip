@@ -1709,16 +1709,29 @@ static int launch_gate_fwd_r32(const float* x, const float* Wv, const float* bv,
 }
 
 int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
-                           const int32_t* offset_dev, void* stream);      // dropout.hip
+                           const int32_t* offset_dev, void* stream);
+int dropout_keep_bits_pair_tilemap(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
+                                   uint64_t offset, const int32_t* offset_dev, const TileMapJob& tm, void* stream);
+extern "C" int mil_build_tile_map(const int32_t* bag_len, int B, int32_t* tile_map, int32_t* bag_tile_off, int32_t* rows_out,
+                                  int T_cap, void* stream);      // dropout.hip
 
 static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                 const float* w, const float* b, float* scores, float* gates, int R, int L, int D,
                                 const uint32_t* xbits, float xscale, const GateFwdGen* gen, void* stream,
-                                const GateFwdPool* pool = nullptr, int* fused = nullptr, const int32_t* rows_dev = nullptr) {
+                                const GateFwdPool* pool = nullptr, int* fused = nullptr, const int32_t* rows_dev = nullptr,
+                                const TileMapJob* tmap = nullptr) {
     if (!x || !Wv || !bv || !Wu || !bu || !w || !b || !scores) return MIL_EINVAL;
     if (D != MIL_GATE_D || L <= 0 || (L % GF_BK) != 0 || R < 0) return MIL_EINVAL;
     if (R == 0) return MIL_OK;
     hipStream_t st = (hipStream_t)stream;
+    // tmap: the step's tile map is still to be built (it writes rows_dev, which this launch reads): it rides on the generator
+    // launch where there is one, and is a launch of its own in front of the forward otherwise
+    bool tmap_done = tmap == nullptr;
+    auto tmap_alone = [&]() -> int {
+        if (tmap_done) return MIL_OK;
+        tmap_done = true;
+        return mil_build_tile_map(tmap->bag_len, tmap->B, tmap->tile_map, tmap->bag_tile_off, tmap->rows_out, tmap->T_cap, stream);
+    };
     const bool r32 = (R + GF_TM - 1) / GF_TM < (3 * MIL_NUM_CU) / 4;
     int tail = (!r32 && gates != nullptr) ? gate_tail_rows(R, MIL_NUM_CU) : 0;   // the tail path keeps V, U in `gates`
     if (!r32 && tail == 0) {
@@ -1747,6 +1760,7 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
         // [128][L/32] words fit its LDS slot; otherwise the stand-alone generator runs first
         const bool in_kernel = !r32 && tail == 0 && fwd2 && L <= 1024 && (L % 128) == 0;
         if (in_kernel) {
+            { const int rc_ = tmap_alone(); if (rc_ != MIL_OK) return rc_; }
             const int grid = (R + GF_TM - 1) / GF_TM;
             if (pool_in && gen->mbits_out != nullptr) {
                 hipLaunchKernelGGL((k_gate_fwd2<true, true, 2>), dim3(grid), dim3(512), 0, st, x, Wv, bv, Wu, bu, w, b, scores, gates,
@@ -1760,7 +1774,13 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
             return MIL_OK;
         }
         int rc;
-        if (gen->mbits_out != nullptr)
+        if (gen->mbits_out != nullptr && !tmap_done) {
+            rc = dropout_keep_bits_pair_tilemap(gen->xbits_out, R, gen->mbits_out, gen->B, L,
+                                                ((uint64_t)gen->seed_hi << 32) | gen->seed_lo,
+                                                ((uint64_t)gen->mseed_hi << 32) | gen->mseed_lo, gen->offset, gen->offset_dev, *tmap,
+                                                stream);
+            tmap_done = true;
+        } else if (gen->mbits_out != nullptr)
             rc = dropout_keep_bits_pair(gen->xbits_out, R, gen->mbits_out, gen->B, L, ((uint64_t)gen->seed_hi << 32) | gen->seed_lo,
                                         ((uint64_t)gen->mseed_hi << 32) | gen->mseed_lo, gen->offset, gen->offset_dev, stream);
         else
@@ -1769,6 +1789,7 @@ static int gate_scores_fwd_impl(const float* x, const float* Wv, const float* bv
         if (rc != MIL_OK) return rc;
         xbits = gen->xbits_out;
     }
+    { const int rc_ = tmap_alone(); if (rc_ != MIL_OK) return rc_; }
     if (r32) {
         // fewer 128-row tiles than 3/4 of the CUs: 32-row tiles (4x the workgroups, each a quarter of the time)
         return launch_gate_fwd_r32(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, xbits, xscale, st, rows_dev);
@@ -1845,7 +1866,7 @@ extern "C" int mil_gate_scores_fwd_draw(const float* x, const float* Wv, const f
 int gate_fwd_rows_dev(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* w,
                       const float* b, float* scores, float* gates, int R, int L, int draw, uint32_t* xbits, float xscale,
                       uint32_t* mbits, int B, uint64_t seed, uint64_t mseed, uint64_t offset, const int32_t* offset_dev,
-                      const int32_t* rows_dev, void* stream) {
+                      const int32_t* rows_dev, void* stream, const TileMapJob* tmap) {
     if (draw) {
         if (!xbits || (L % 64) != 0 || (mbits && B <= 0)) return MIL_EINVAL;
         GateFwdGen g{};
@@ -1859,10 +1880,10 @@ int gate_fwd_rows_dev(const float* x, const float* Wv, const float* bv, const fl
         g.offset = offset;
         g.offset_dev = offset_dev;
         return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, MIL_GATE_D, nullptr, xscale, &g, stream, nullptr,
-                                    nullptr, rows_dev);
+                                    nullptr, rows_dev, tmap);
     }
     return gate_scores_fwd_impl(x, Wv, bv, Wu, bu, w, b, scores, gates, R, L, MIL_GATE_D, xbits, xscale, nullptr, stream, nullptr,
-                                nullptr, rows_dev);
+                                nullptr, rows_dev, tmap);
 }
 
 // Internal (step.hip): gate forward with the pool partial pass in its epilogue when the batch allows it; *fused says
@@ -1924,32 +1945,7 @@ static int launch_pool_partial(const float* x, const float* scores, const int32_
 __global__ __launch_bounds__(256) void k_build_tile_map(const int32_t* __restrict__ bag_len, int B, int32_t* __restrict__ tile_map,
                                                         int32_t* __restrict__ bag_tile_off, int32_t* __restrict__ rows_out,
                                                         int T_cap) {
-    __shared__ int s_row[1025], s_tile[1025];
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int r = 0, t = 0;
-        for (int b = 0; b < B; ++b) {
-            s_row[b] = r;
-            s_tile[b] = t;
-            const int n = max(bag_len[b], 0);
-            r += n;
-            t += (n + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
-        }
-        s_row[B] = r;
-        s_tile[B] = min(t, T_cap);
-        rows_out[0] = r;
-    }
-    __syncthreads();
-    for (int b = tid; b <= B; b += 256) bag_tile_off[b] = min(s_tile[b], T_cap);
-    const int T = s_tile[B];
-    for (int b = 0; b < B; ++b) {
-        const int t0 = s_tile[b], t1 = min(s_tile[b + 1], T_cap), r0 = s_row[b], r1 = s_row[b + 1];
-        for (int t = t0 + tid; t < t1; t += 256) {
-            const int row0 = r0 + (t - t0) * MIL_POOL_TILE;
-            reinterpret_cast<int4*>(tile_map)[t] = make_int4(b, row0, min(MIL_POOL_TILE, r1 - row0), 0);
-        }
-    }
-    for (int t = T + tid; t < T_cap; t += 256) reinterpret_cast<int4*>(tile_map)[t] = make_int4(0, 0, 0, 0);
+    build_tile_map_block(bag_len, B, tile_map, bag_tile_off, rows_out, T_cap);
 }
 
 extern "C" int mil_build_tile_map(const int32_t* bag_len, int B, int32_t* tile_map, int32_t* bag_tile_off, int32_t* rows_out,

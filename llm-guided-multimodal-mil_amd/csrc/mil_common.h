@@ -247,3 +247,45 @@ __device__ __forceinline__ f32x4 adam_fused4(const AdamFuse& ad, const float* gp
 // Row of a 32x32 MFMA accumulator register: C/D layout col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (dtype independent on gfx950).
 __device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+struct TileMapJob {            // mil_build_tile_map's arguments as an optional rider of another launch (bag_len == NULL: none)
+    const int32_t* bag_len;
+    int B;
+    int32_t* tile_map;
+    int32_t* bag_tile_off;
+    int32_t* rows_out;
+    int T_cap;
+};
+
+// Tile map of a batch whose bag lengths live on the device (one workgroup of 256 threads; see k_build_tile_map in
+// gated_pool.hip): shared by that kernel and by the generator launch that carries it as an extra workgroup (dropout.hip).
+__device__ __forceinline__ void build_tile_map_block(const int32_t* __restrict__ bag_len, int B, int32_t* __restrict__ tile_map,
+                                                     int32_t* __restrict__ bag_tile_off, int32_t* __restrict__ rows_out,
+                                                     int T_cap) {
+    __shared__ int s_row[1025], s_tile[1025];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int r = 0, t = 0;
+        for (int b = 0; b < B; ++b) {
+            s_row[b] = r;
+            s_tile[b] = t;
+            const int n = max(bag_len[b], 0);
+            r += n;
+            t += (n + MIL_POOL_TILE - 1) / MIL_POOL_TILE;
+        }
+        s_row[B] = r;
+        s_tile[B] = min(t, T_cap);
+        rows_out[0] = r;
+    }
+    __syncthreads();
+    for (int b = tid; b <= B; b += 256) bag_tile_off[b] = min(s_tile[b], T_cap);
+    const int T = s_tile[B];
+    for (int b = 0; b < B; ++b) {
+        const int t0 = s_tile[b], t1 = min(s_tile[b + 1], T_cap), r0 = s_row[b], r1 = s_row[b + 1];
+        for (int t = t0 + tid; t < t1; t += 256) {
+            const int row0 = r0 + (t - t0) * MIL_POOL_TILE;
+            reinterpret_cast<int4*>(tile_map)[t] = make_int4(b, row0, min(MIL_POOL_TILE, r1 - row0), 0);
+        }
+    }
+    for (int t = T + tid; t < T_cap; t += 256) reinterpret_cast<int4*>(tile_map)[t] = make_int4(0, 0, 0, 0);
+}

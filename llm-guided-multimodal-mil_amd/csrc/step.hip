@@ -19,7 +19,7 @@ int gate_fwd_with_pool(const float* x, const float* Wv, const float* bv, const f
 int gate_fwd_rows_dev(const float* x, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* w,
                       const float* b, float* scores, float* gates, int R, int L, int draw, uint32_t* xbits, float xscale,
                       uint32_t* mbits, int B, uint64_t seed, uint64_t mseed, uint64_t offset, const int32_t* offset_dev,
-                      const int32_t* rows_dev, void* stream);
+                      const int32_t* rows_dev, void* stream, const TileMapJob* tmap);
 
 // gated_pool.hip: split-K fold + head gradients + Adam in one launch, the step number on the host or in a device counter
 int gate_bwd_reduce_head_adam_impl(const float* workspace, int R, int L, float* dWv, float* dbv, float* dWu, float* dbu,
@@ -48,6 +48,8 @@ int gate_fwd_bf16_with_pool(const uint16_t* x, const uint16_t* Wv, const float* 
 // dropout.hip: both keep-bit tensors of a step in one launch
 int dropout_keep_bits_pair(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed, uint64_t offset,
                            const int32_t* offset_dev, void* stream);
+int dropout_keep_bits_pair_tilemap(uint32_t* xbits, int R, uint32_t* mbits, int B, int L, uint64_t seed, uint64_t mseed,
+                                   uint64_t offset, const int32_t* offset_dev, const TileMapJob& tm, void* stream);
 
 static int step_check(const mil_image_only_step* a) {
     if (!a || a->struct_bytes != sizeof(mil_image_only_step)) return MIL_EINVAL;
@@ -96,14 +98,26 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
     bool adam_in_reduce = false;
     int pool_fused = 0;
 
-    if ((st & MIL_STAGE_TILEMAP) && a->bag_len_dev) {
+    // keep bits drawn by the forward kernel itself (no generator launches) when both stages run in this call
+    const bool draw_in_fwd = (st & MIL_STAGE_DROPBITS) && (st & MIL_STAGE_GATE_FWD) && train && !a->x_bf16;
+    const bool gen_launch = (st & MIL_STAGE_DROPBITS) && train && !draw_in_fwd;
+    const bool want_tmap = (st & MIL_STAGE_TILEMAP) && a->bag_len_dev;
+    const TileMapJob tmj{a->bag_len_dev, a->B, const_cast<int32_t*>(a->tile_map), const_cast<int32_t*>(a->bag_tile_off), a->rows_dev,
+                         a->T};
+    // the fp32 bucketed forward (gate_fwd_rows_dev) takes the tile map along: on its generator launch when it has one
+    const bool tmap_with_fwd = want_tmap && (st & MIL_STAGE_GATE_FWD) && !a->x_bf16 && a->rows_dev != nullptr && !gen_launch;
+    if (want_tmap && gen_launch) {
+        // one launch: the generator's workgroups + one more that builds the tile map (round 4: a bucketed one-bag step began
+        // with two launches of 5 us each)
+        rc = dropout_keep_bits_pair_tilemap(a->xbits, a->R, a->mbits, a->B, a->L, a->seed, a->seed ^ 0x9E3779B97F4A7C15ull,
+                                            a->offset, a->offset_dev, tmj, stream);
+        if (rc != MIL_OK) return rc;
+    } else if (want_tmap && !tmap_with_fwd) {
         rc = mil_build_tile_map(a->bag_len_dev, a->B, const_cast<int32_t*>(a->tile_map), const_cast<int32_t*>(a->bag_tile_off),
                                 a->rows_dev, a->T, stream);
         if (rc != MIL_OK) return rc;
     }
-    // keep bits drawn by the forward kernel itself (no generator launches) when both stages run in this call
-    const bool draw_in_fwd = (st & MIL_STAGE_DROPBITS) && (st & MIL_STAGE_GATE_FWD) && train && !a->x_bf16;
-    if ((st & MIL_STAGE_DROPBITS) && train && !draw_in_fwd) {
+    if (gen_launch && !((st & MIL_STAGE_TILEMAP) && a->bag_len_dev)) {
         // patch bits and (a second key, same stream position) the head's mask, one launch
         rc = dropout_keep_bits_pair(a->xbits, a->R, a->mbits, a->B, a->L, a->seed, a->seed ^ 0x9E3779B97F4A7C15ull, a->offset,
                                     a->offset_dev, stream);
@@ -132,7 +146,7 @@ extern "C" int mil_image_only_step_run(const mil_image_only_step* a, void* strea
         else if (a->bag_len_dev && a->rows_dev)
             rc = gate_fwd_rows_dev((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R, a->L,
                                    draw_in_fwd ? 1 : 0, a->xbits, xscale, a->mbits, a->B, a->seed, a->seed ^ 0x9E3779B97F4A7C15ull,
-                                   a->offset, a->offset_dev, a->rows_dev, stream);
+                                   a->offset, a->offset_dev, a->rows_dev, stream, tmap_with_fwd ? &tmj : nullptr);
         else if (draw_in_fwd)
             rc = mil_gate_scores_fwd_draw((const float*)a->x, a->Wv, a->bv, a->Wu, a->bu, a->w, a->b, a->scores, gates, a->R,
                                           a->L, MIL_GATE_D, a->xbits, xscale, a->mbits, a->B, a->seed,
