@@ -793,7 +793,7 @@ def run_rank(args):
     # per resident batch, [forward .. fold -> all_reduce -> Adam] as one captured segment (trainer.capture)
     graph_coll = use_dist and os.environ.get("MIL_GRAPH_COLLECTIVE") == "1" and args.accum == 1 and not rehearsal
     tr = ImageOnlyTrainer(params, dev, world_size=world, train_mode=bool(args.train_mode), accum=args.accum,
-                          counted=bool(graph_coll))
+                          counted=bool(graph_coll) or bool(args.graph))      # a captured step keeps its step number / mask position on the device
     nb = max(1, args.batches) if not args.graph else 1       # a captured step replays its static buffers
     xs = [syn.make_bags(4321 + rank + 1000 * i, B, N, L).reshape(B * N, L).to(dev) for i in range(nb)]   # resident in HBM before timing
     if args.dtype == "bf16":
